@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd Mpix/s of the differentiable Gaussian rasterizer on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run,
+one rank per GPU over RCCL).  One STEP = one pass of the hot path over one batch of synthetic input:
+for each of this rank's 4 views of SynthScene-v1 (100 000 Gaussians, 800x800, BASELINE.json configs[2])
+parameter activation -> ``GaussianRasterizer`` forward -> autograd backward with a fixed seeded
+dL/dcolour; for N>1 the step ends with ONE all-reduce of the flat Gaussian-gradient bucket (RCCL).
+Weak scaling: every rank renders 4 views (rank r takes cameras 4r..4r+3 of a 4N-camera ring), so
+value = 4*N*H*W / t_step.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 with the contract's keys plus
+  "roofline":     dominant kernel, algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  "cpu_baseline": the CPU oracle (kind "port": the reference has no CPU path and its CUDA extension is absent)
+                  timed on this box's host cores on ONE view fwd+bwd of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "gs-dynamics_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+P_GAUSS, W, H, VIEWS_PER_RANK = 100_000, 800, 800, 4
+HBM_PEAK = 8.0e12       # B/s, MI355X spec (MI355X_MICROARCH.md)
+VALU_PEAK = 78.6e12     # fp32 lane-instructions/s (157.3 TFLOP/s / 2)
+
+
+def algorithmic_bytes(P, D, Npx):
+    """SURVEY.md section 8d compulsory traffic per view, per kernel group (bytes)."""
+    return {
+        "preprocess_fwd": 116 * P, "scan": 8 * P, "emit_entries": 24 * P + 12 * D, "sort": 24 * D,
+        "tile_ranges": 8 * D, "render_fwd": 44 * D + 24 * Npx, "render_bwd": 76 * D + 20 * Npx,
+        "preprocess_bwd": 140 * P,
+        "fwd": 148 * P + 88 * D + 24 * Npx, "bwd": 140 * P + 76 * D + 20 * Npx,
+        "total": 288 * P + 164 * D + 44 * Npx,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    from gsdyn.dp import GradBucket
+
+    params = synth_scene_params(P_GAUSS, seed=0, device=dev)
+    cams = synth_ring_cameras(VIEWS_PER_RANK * world, W, H, device=dev, first=VIEWS_PER_RANK * rank,
+                              count=VIEWS_PER_RANK)
+    rng = np.random.default_rng(1234 + rank)
+    dLs = [torch.tensor(rng.uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev) for _ in cams]
+    bucket = GradBucket(params)
+    num_rendered = []
+
+    def step(record=False):
+        bucket.zero()
+        for cam, dL in zip(cams, dLs):
+            rv = params2rendervar(params)
+            im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
+            if not args.forward_only:
+                im.backward(gradient=dL)
+        if world > 1 and not args.forward_only:
+            bucket.all_reduce()
+
+    # capture num_rendered per view once (spy on the backend call; not in the timed region)
+    orig = _hip.rasterize_forward
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        num_rendered.append(out[3].num_rendered)
+        return out
+    _hip.rasterize_forward = spy
+    step()
+    _hip.rasterize_forward = orig
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_step = dt / args.steps
+    if world > 1:
+        t = torch.tensor([t_step], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_step = float(t.item())
+
+    # ---- per-kernel HIP-event pass (outside the timed region)
+    _hip.profile_begin()
+    prof_steps = max(3, min(10, args.steps))
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _hip.profile_end()
+    per_launch_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}
+    per_view_us = {k: 1e3 * ms / (prof_steps * VIEWS_PER_RANK) for k, (ms, n) in prof.items()}
+
+    D = float(np.mean(num_rendered)) if num_rendered else 0.0
+    Npx = H * W
+    ab = algorithmic_bytes(P_GAUSS, D, Npx)
+    mpix = VIEWS_PER_RANK * world * Npx / t_step / 1e6
+    path_bytes = VIEWS_PER_RANK * (ab["fwd"] if args.forward_only else ab["total"])
+    dom = "render_fwd" if args.forward_only else max(
+        (k for k in per_view_us if k in ("render_fwd", "render_bwd")), key=lambda k: per_view_us[k], default="render_bwd")
+    dom_us = per_launch_us.get(dom, float("nan"))
+    dom_achieved = ab[dom] / (dom_us * 1e-6) / 1e9 if dom_us == dom_us and dom_us > 0 else None
+    pairs = 256.0 * D
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": dom_achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": (dom_achieved / (HBM_PEAK / 1e9)) if dom_achieved else None, "traffic": None,
+        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": dom_us,
+        "path": {"algorithmic_bytes_per_step_per_gpu": path_bytes, "achieved_GBps": path_bytes / t_step / 1e9,
+                 "frac_of_hbm_peak": path_bytes / t_step / HBM_PEAK},
+        "valu": {"pixel_gaussian_pairs_per_view": pairs,
+                 "render_fwd_lane_instr_per_s": (pairs * 25 / (per_launch_us["render_fwd"] * 1e-6)) if "render_fwd" in per_launch_us else None,
+                 "peak_lane_instr_per_s": VALU_PEAK},
+        "per_kernel_us_per_view": {k: round(v, 2) for k, v in sorted(per_view_us.items())},
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(params, cams[0], dLs[0], params2rendervar)
+
+    if rank == 0:
+        line = {
+            "metric": "fwd Mpix/s (forward-only, extra)" if args.forward_only else
+                      "fwd+bwd Mpix/s at 100k Gaussians, 4x800^2 views",
+            "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: SynthScene-v1, 100k Gaussians, 4 views 800x800 per GPU, "
+                                   "colour render fwd+bwd per view" + ("" if world == 1 else ", 1 RCCL all-reduce of the flat grad bucket per step"),
+                       "gaussians": P_GAUSS, "views_per_gpu": VIEWS_PER_RANK, "image": [H, W],
+                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(params, cam, dL, params2rendervar):
+    """Oracle O2 (C, OpenMP over tiles) on the host cores: ONE view fwd+bwd of the same workload."""
+    try:
+        from oracle import OracleCamera, TiledOracle
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"oracle unavailable: {e}"}
+    with torch.no_grad():
+        rv = {k: v.detach().cpu().numpy() for k, v in params2rendervar(params).items()}
+    ocam = OracleCamera(H, W, cam.tanfovx, cam.tanfovy, cam.bg.cpu().numpy(), 1.0,
+                        cam.viewmatrix.cpu().numpy().reshape(-1), cam.projmatrix.cpu().numpy().reshape(-1), 0,
+                        cam.campos.cpu().numpy())
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    g = dL.cpu().numpy()
+    t0 = time.perf_counter()
+    o2 = TiledOracle(ocam, rv["means3D"], rv["opacities"], colors_precomp=rv["colors_precomp"], scales=rv["scales"],
+                     rotations=rv["rotations"], nthreads=threads)
+    o2.backward(g)
+    dt = time.perf_counter() - t0
+    return {"value": H * W / dt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": "1 view (800x800, 100k Gaussians) fwd+bwd, oracle/gsr_oracle.c with OpenMP over tiles",
+            "seconds": dt, "host_cpu_count": cores}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,252 @@
+// gsr_api.hip -- extern "C" entry points of libgsr_hip.so (declared in include/gsr.h) and the
+// device self-test.  Host-side orchestration only: buffer carving, kernel sequencing, the one
+// device->host read of num_rendered.  No allocation, no global state beyond a thread-local error string.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "gsr_common.h"
+
+static thread_local char g_err[512] = "";
+
+// ---- profiling state (process-wide; benches are single-threaded per process)
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+GsrProfScope::GsrProfScope(const char* name, hipStream_t s) : slot(-1), st(s) {
+  if (!g_prof_on) return;
+  ProfRec r; r.name = name;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+GsrProfScope::~GsrProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
+void gsr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+static int make_cam(const gsr_settings* s, GsrCam* c) {
+  if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
+  if (s->image_height <= 0 || s->image_width <= 0) { gsr_set_error("gsr: image size must be positive"); return -2; }
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) {
+    gsr_set_error("gsr: bg/viewmatrix/projmatrix/campos must be device pointers");
+    return -2;
+  }
+  c->H = s->image_height; c->W = s->image_width;
+  c->gx = (c->W + GSR_TILE - 1) / GSR_TILE; c->gy = (c->H + GSR_TILE - 1) / GSR_TILE;
+  c->T = c->gx * c->gy;
+  if (c->gx > 65535 || c->gy > 65535) { gsr_set_error("gsr: image too large (tile grid exceeds 65535)"); return -2; }
+  c->tanfovx = s->tanfovx; c->tanfovy = s->tanfovy; c->scale_modifier = s->scale_modifier;
+  c->sh_degree = s->sh_degree; c->M = s->sh_coeffs;
+  c->bg = s->bg; c->view = s->viewmatrix; c->proj = s->projmatrix; c->campos = s->campos;
+  return 0;
+}
+
+extern "C" {
+
+int gsr_version(void) { return GSR_VERSION; }
+const char* gsr_last_error(void) { return g_err; }
+
+size_t gsr_geom_bytes(int32_t P) { GeomState g; return gsr_carve_geom(nullptr, P, &g); }
+size_t gsr_image_bytes(int32_t H, int32_t W) { ImageState im; return gsr_carve_image(nullptr, H, W, &im); }
+size_t gsr_binning_bytes(uint32_t D, int32_t, int32_t) { BinningState b; return gsr_carve_binning(nullptr, D, &b); }
+size_t gsr_backward_scratch_bytes(int32_t, uint32_t D) { return gsr_align((size_t)(D ? D : 1) * GSR_PARTIAL_F4 * 16); }
+
+int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                           const float* rotations, const float* opacities, const float* colors_precomp,
+                           const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
+                           uint32_t* num_rendered_host, void* stream) {
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (num_rendered_host) *num_rendered_host = 0;
+  if (P <= 0) return 0;
+  if (!means3D || !opacities || !geom_state || !radii) { gsr_set_error("gsr_forward_preprocess: NULL argument"); return -2; }
+  if ((colors_precomp == nullptr) == (shs == nullptr)) {
+    gsr_set_error("gsr_forward_preprocess: provide exactly one of colors_precomp / shs");
+    return -2;
+  }
+  if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    gsr_set_error("gsr_forward_preprocess: provide exactly one of scales+rotations / cov3D_precomp");
+    return -2;
+  }
+  if (shs && (cam.M < (cam.sh_degree + 1) * (cam.sh_degree + 1) || cam.sh_degree > 3 || cam.sh_degree < 0 || cam.M > 16)) {
+    gsr_set_error("gsr_forward_preprocess: sh_degree %d needs (deg+1)^2 <= sh_coeffs (%d) <= 16", cam.sh_degree, cam.M);
+    return -2;
+  }
+  GeomState g;
+  gsr_carve_geom(geom_state, P, &g);
+  if (int rc = gsr_launch_preprocess(cam, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
+                                     g, radii, st))
+    return rc;
+  if (int rc = gsr_launch_scan_exclusive(g.tiles_touched, g.offsets, (uint32_t)P, g.counters, st)) return rc;
+  uint32_t D = 0;
+  GSR_HIP_CHECK(hipMemcpyAsync(&D, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GSR_HIP_CHECK(hipStreamSynchronize(st));
+  if (num_rendered_host) *num_rendered_host = D;
+  return 0;
+}
+
+int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state,
+                       void* binning_state, void* image_state, float* out_color, float* out_depth, void* stream) {
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (!image_state || !out_color || !out_depth) { gsr_set_error("gsr_forward_render: NULL argument"); return -2; }
+  GeomState g; ImageState im; BinningState bs;
+  gsr_carve_geom(const_cast<void*>(geom_state), P, &g);
+  gsr_carve_image(image_state, cam.H, cam.W, &im);
+  gsr_carve_binning(binning_state, num_rendered, &bs);
+  if (num_rendered > 0 && (!geom_state || !binning_state)) { gsr_set_error("gsr_forward_render: NULL state"); return -2; }
+  if (int rc = gsr_launch_binning(cam, P, num_rendered, g, bs, im, st)) return rc;
+  return gsr_launch_render_fwd(cam, g, bs, im, out_color, out_depth, st);
+}
+
+int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,
+                 const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                 const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
+                 const void* binning_state, const void* image_state, const float* dL_dcolor, void* scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dsh, void* stream) {
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (P <= 0) return 0;
+  if (!means3D || !radii || !geom_state || !image_state || !dL_dcolor || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) {
+    gsr_set_error("gsr_backward: NULL argument");
+    return -2;
+  }
+  if (num_rendered > 0 && (!binning_state || !scratch)) { gsr_set_error("gsr_backward: NULL binning/scratch"); return -2; }
+  GeomState g; ImageState im; BinningState bs;
+  gsr_carve_geom(const_cast<void*>(geom_state), P, &g);
+  gsr_carve_image(const_cast<void*>(image_state), cam.H, cam.W, &im);
+  gsr_carve_binning(const_cast<void*>(binning_state), num_rendered, &bs);
+  float4* partials = (float4*)scratch;
+  if (int rc = gsr_launch_render_bwd(cam, num_rendered, g, bs, im, dL_dcolor, partials, st)) return rc;
+  return gsr_launch_preprocess_bwd(cam, P, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g,
+                                   partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales,
+                                   dL_drotations, dL_dcov3D, dL_dsh, st);
+}
+
+int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {
+  if (P <= 0) return 0;
+  if (!viewmatrix || !means3D || !present) { gsr_set_error("gsr_mark_visible: NULL argument"); return -2; }
+  return gsr_launch_mark_visible(viewmatrix, P, means3D, present, (hipStream_t)stream);
+}
+
+int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t H, int32_t W, const void* geom_state,
+                        const void* binning_state, const void* image_state, gsr_debug_views* out) {
+  if (!out) return -2;
+  memset(out, 0, sizeof *out);
+  GeomState g; ImageState im; BinningState bs;
+  if (geom_state) {
+    gsr_carve_geom(const_cast<void*>(geom_state), P, &g);
+    out->recA = (const float*)g.recA; out->recB = (const float*)g.recB; out->recC = (const float*)g.recC;
+    out->rect = (const uint32_t*)g.rect; out->tiles_touched = g.tiles_touched; out->offsets = g.offsets;
+  }
+  if (binning_state) {
+    gsr_carve_binning(const_cast<void*>(binning_state), num_rendered, &bs);
+    out->point_list = bs.point_list;
+  }
+  if (image_state) {
+    gsr_carve_image(const_cast<void*>(image_state), H, W, &im);
+    out->ranges = (const uint32_t*)im.ranges; out->final_T = im.final_T; out->n_contrib = im.n_contrib;
+  }
+  return 0;
+}
+
+int gsr_selftest(void* stream) { return gsr_run_selftest((hipStream_t)stream); }
+
+int gsr_profile_begin(void) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+
+int gsr_profile_end(gsr_kernel_time* out, int32_t max_entries, int32_t* n_out) {
+  g_prof_on = false;
+  int n = 0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      int k = 0;
+      for (; k < n; ++k) if (strcmp(out[k].name, r.name) == 0) break;
+      if (k == n) {
+        if (n >= max_entries) continue;
+        memset(&out[n], 0, sizeof out[n]);
+        strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
+        ++n;
+      }
+      out[k].total_ms += ms;
+      out[k].launches += 1;
+    }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  if (n_out) *n_out = n;
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------ self-test
+namespace {
+__global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_ref) {
+  float v = in[threadIdx.x];
+  float a = gsr_wave_sum_to_lane63(v);
+  float b = gsr_wave_sum_shfl(v);
+  if ((threadIdx.x & 63) == 63) { out_dpp[threadIdx.x >> 6] = a; out_ref[threadIdx.x >> 6] = b; }
+}
+}  // namespace
+
+int gsr_run_selftest(hipStream_t st) {
+  int fail = 0;
+  // 1. DPP wave reduction vs shuffle reduction vs host sum
+  {
+    const int n = 256;
+    std::vector<float> h(n);
+    for (int i = 0; i < n; ++i) h[i] = (float)((i * 37) % 101) - 50.0f;  // small integers: sums are exact
+    float *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    GSR_HIP_CHECK(hipMalloc(&d_in, n * 4)); GSR_HIP_CHECK(hipMalloc(&d_a, 16)); GSR_HIP_CHECK(hipMalloc(&d_b, 16));
+    GSR_HIP_CHECK(hipMemcpyAsync(d_in, h.data(), n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(st_wave_sum_kernel, dim3(1), dim3(n), 0, st, d_in, d_a, d_b);
+    float a[4], b[4];
+    GSR_HIP_CHECK(hipMemcpyAsync(a, d_a, 16, hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipMemcpyAsync(b, d_b, 16, hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+    for (int w = 0; w < 4; ++w) {
+      float ref = 0.f;
+      for (int l = 0; l < 64; ++l) ref += h[w * 64 + l];
+      if (a[w] != ref) fail |= 1;
+      if (b[w] != ref) fail |= 2;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_a); (void)hipFree(d_b);
+  }
+  // 2. exclusive scan
+  {
+    const uint32_t n = 20011;
+    std::vector<uint32_t> h(n), ref(n + 1), got(n + 1);
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < n; ++i) { h[i] = (i * 2654435761u) >> 28; ref[i] = acc; acc += h[i]; }
+    ref[n] = acc;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    GSR_HIP_CHECK(hipMalloc(&d_in, n * 4)); GSR_HIP_CHECK(hipMalloc(&d_out, (n + 1) * 4));
+    GSR_HIP_CHECK(hipMemcpyAsync(d_in, h.data(), n * 4, hipMemcpyHostToDevice, st));
+    if (int rc = gsr_launch_scan_exclusive(d_in, d_out, n, nullptr, st)) return rc;
+    GSR_HIP_CHECK(hipMemcpyAsync(got.data(), d_out, (n + 1) * 4, hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+    if (memcmp(ref.data(), got.data(), (n + 1) * 4) != 0) fail |= 4;
+    (void)hipFree(d_in); (void)hipFree(d_out);
+  }
+  return fail;
+}

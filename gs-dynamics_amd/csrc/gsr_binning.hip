@@ -1,0 +1,308 @@
+// gsr_binning.hip -- duplicates ("duplicateWithKeys"), sort and tile ranges for gfx950
+// (replaces the reference extension's scan / duplicateWithKeys / radix sort /
+// identifyTileRanges stage).
+//
+// The reference semantics: every (Gaussian, touched tile) pair becomes an entry keyed
+// (tile_id << 32 | depth_bits) and the entries are sorted with a STABLE LSD radix sort, so each tile's
+// list is ordered by fp32 depth bits with ties in ascending Gaussian index.  The same order is produced
+// here with a hybrid MSD/LSD radix sort laid out for CDNA4:
+//   1. emit_entries     entries written in Gaussian-major order, fully coalesced (one entry per lane,
+//                       owner Gaussian found by an 8-step binary search in LDS), so emission is
+//                       load-balanced no matter how many tiles a single Gaussian covers;
+//   2. radix passes     stable LSD passes over the TILE-ID bits only (ceil(log2 T) bits, <= 8 per pass:
+//                       2 passes at 800x800 instead of the 6 a full 44-bit key sort needs); ranks inside a
+//                       wave come from wave-64 __ballot peer masks, histograms live in LDS, and no global
+//                       atomics are used anywhere, so the result is deterministic;
+//   3. tile_ranges      run boundaries of the tile id -> ranges[tile];
+//   4. tile_sort        one workgroup per tile sorts its segment by the 64-bit unique key
+//                       (depth_bits << 32 | gaussian_id) with a compare-exchange network in LDS
+//                       (global-memory network for segments above the LDS capacity).  Because the key is
+//                       unique and includes the Gaussian id, the result is exactly the stable-sort order.
+// HBM traffic: emit 12 B/entry written; each radix pass 12 B read (hist) + 12 B read + 12 B written
+// (scatter); tile_sort 8 B read + 4 B written per entry.
+#include "gsr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ exclusive scan, single workgroup
+// out[i] = sum_{j<i} in[j], out[n] = total.  1024 threads x 8 items per round, carry between rounds.
+// Used for per-Gaussian offsets (n = P) and radix block histograms (n = bins * blocks).
+#define SCAN_THREADS 1024
+#define SCAN_ITEMS 8
+__global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint32_t* __restrict__ in,
+                                                                      uint32_t* __restrict__ out, uint32_t n,
+                                                                      uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t wave_tot[SCAN_THREADS / GSR_WAVE];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  const uint32_t per_round = SCAN_THREADS * SCAN_ITEMS;
+  for (uint32_t base = 0; base < n; base += per_round) {
+    uint32_t v[SCAN_ITEMS];
+    uint32_t first = base + (uint32_t)tid * SCAN_ITEMS;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      uint32_t idx = first + k;
+      v[k] = idx < n ? in[idx] : 0u;
+      sum += v[k];
+    }
+    // inclusive scan of `sum` across the wave
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wv; ++w) wave_off += wave_tot[w];
+    uint32_t carry = carry_s;
+    uint32_t run = carry + wave_off + inc - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      uint32_t idx = first + k;
+      if (idx < n) out[idx] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == SCAN_THREADS - 1) carry_s = run;  // last thread holds carry + round total
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t tot = carry_s;
+    out[n] = tot;
+    if (total_out) *total_out = tot;
+  }
+}
+
+// ------------------------------------------------------------------ emit (duplicateWithKeys)
+__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float2* __restrict__ recC,
+                                                                 const uint2* __restrict__ rect,
+                                                                 const uint32_t* __restrict__ offsets,
+                                                                 uint32_t* __restrict__ tkey,
+                                                                 uint64_t* __restrict__ dg) {
+  __shared__ uint32_t soff[GSR_BLOCK + 1];
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * GSR_BLOCK;
+  soff[tid] = offsets[min(g0 + tid, P)];
+  if (tid == 0) soff[GSR_BLOCK] = offsets[min(g0 + GSR_BLOCK, P)];
+  __syncthreads();
+  const uint32_t begin = soff[0], end = soff[GSR_BLOCK];
+  for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
+    int lo = 0, hi = GSR_BLOCK;  // invariant: soff[lo] <= e < soff[hi]
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      int mid = (lo + hi) >> 1;
+      if (soff[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int g = g0 + lo;
+    const uint32_t k = e - soff[lo];
+    const uint2 r = rect[g];
+    const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu;
+    const uint32_t w = maxx - minx;
+    const uint32_t ty = miny + k / w, tx = minx + k % w;
+    tkey[e] = ty * (uint32_t)gx + tx;
+    dg[e] = ((uint64_t)__float_as_uint(recC[g].y) << 32) | (uint32_t)g;
+  }
+}
+
+// ------------------------------------------------------------------ stable radix pass on tile-id digits
+__device__ __forceinline__ uint64_t match_peers(uint32_t digit, bool valid, int bits) {
+  uint64_t peers = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (digit >> b) & 1u;
+    const uint64_t m = __ballot(valid && bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+// Per-block digit histogram, written bin-major: block_hist[bin * nblocks + block].
+__global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
+                                                               int shift, int bits, uint32_t nblocks,
+                                                               uint32_t* __restrict__ block_hist) {
+  __shared__ uint32_t hist[256];
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  __syncthreads();
+  const uint32_t mask = (1u << bits) - 1u;
+  const uint32_t start = blockIdx.x * GSR_RADIX_EPB;
+  const uint32_t stop = min(D, start + GSR_RADIX_EPB);
+  for (uint32_t i = start + tid; i < stop; i += GSR_BLOCK) atomicAdd(&hist[(tkey[i] >> shift) & mask], 1u);
+  __syncthreads();
+  if (tid < (1 << bits)) block_hist[(uint32_t)tid * nblocks + blockIdx.x] = hist[tid];
+}
+
+// Stable scatter.  Wave w of the block owns the w-th quarter of the block's chunk and walks it in order,
+// 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
+__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
+    const uint32_t* __restrict__ tkey_in, const uint64_t* __restrict__ dg_in, uint32_t* __restrict__ tkey_out,
+    uint64_t* __restrict__ dg_out, uint32_t D, int shift, int bits, uint32_t nblocks,
+    const uint32_t* __restrict__ block_base) {
+  __shared__ uint32_t wcount[4][256];
+  volatile uint32_t(*wbase)[256] = wcount;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t mask = (1u << bits) - 1u;
+  const int nb = 1 << bits;
+  for (int i = tid; i < 4 * 256; i += GSR_BLOCK) (&wcount[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t chunk0 = blockIdx.x * GSR_RADIX_EPB;
+  const uint32_t per_wave = GSR_RADIX_EPB / 4;
+  const uint32_t wstart = chunk0 + wv * per_wave;
+  const uint32_t wstop = min(D, wstart + per_wave);
+  // A: per-wave digit histogram
+  for (uint32_t i = wstart + lane; i < wstop; i += 64) atomicAdd(&wcount[wv][(tkey_in[i] >> shift) & mask], 1u);
+  __syncthreads();
+  // B: wave bases = global base of (bin, block) + counts of earlier waves
+  if (tid < nb) {
+    uint32_t base = block_base[(uint32_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      uint32_t c = wcount[w][tid];
+      wcount[w][tid] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  // C: ordered walk
+  for (uint32_t i0 = wstart; i0 < wstop; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool valid = i < wstop;
+    uint32_t key = 0;
+    uint64_t pay = 0;
+    if (valid) { key = tkey_in[i]; pay = dg_in[i]; }
+    const uint32_t digit = (key >> shift) & mask;
+    const uint64_t peers = match_peers(digit, valid, bits);
+    const uint32_t rank = (uint32_t)__popcll(peers & gsr_lanemask_lt());
+    uint32_t pos = 0;
+    if (valid) pos = wbase[wv][digit] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) wbase[wv][digit] = pos + (uint32_t)__popcll(peers);  // group leader advances
+    __builtin_amdgcn_wave_barrier();
+    if (valid) { tkey_out[pos] = key; dg_out[pos] = pay; }
+  }
+}
+
+// ------------------------------------------------------------------ tile ranges
+__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
+                                                                uint2* __restrict__ ranges) {
+  uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= D) return;
+  uint32_t t = tkey[i];
+  if (i == 0) ranges[t].x = 0;
+  else {
+    uint32_t pt = tkey[i - 1];
+    if (pt != t) { ranges[pt].y = i; ranges[t].x = i; }
+  }
+  if (i == D - 1) ranges[t].y = D;
+}
+
+// ------------------------------------------------------------------ per-tile depth sort
+// Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
+// +inf padding above n never moves and pairs touching it are skipped.
+#define TILE_SORT_LDS_CAP 4096
+template <typename PTR>
+__device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
+  uint32_t np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const uint32_t npairs = np2 >> 1;
+  for (uint32_t k = 2; k <= np2; k <<= 1) {
+    const uint32_t hk = k >> 1;
+    for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {  // mirror step
+      const uint32_t blk = p / hk, off = p % hk;
+      const uint32_t l = blk * k + off, r = blk * k + (k - 1 - off);
+      if (r < n) {
+        uint64_t x = a[l], y = a[r];
+        if (y < x) { a[l] = y; a[r] = x; }
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+      for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {
+        const uint32_t l = 2 * j * (p / j) + (p % j), r = l + j;
+        if (r < n) {
+          uint64_t x = a[l], y = a[r];
+          if (y < x) { a[l] = y; a[r] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                              uint64_t* __restrict__ dg,
+                                                              uint32_t* __restrict__ point_list) {
+  __shared__ uint64_t skeys[TILE_SORT_LDS_CAP];
+  const int tid = threadIdx.x;
+  const uint2 rg = ranges[blockIdx.x];
+  const uint32_t n = rg.y - rg.x;
+  if (n == 0) return;
+  uint64_t* seg = dg + rg.x;
+  if (n <= TILE_SORT_LDS_CAP) {
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) skeys[i] = seg[i];
+    __syncthreads();
+    if (n > 1) tile_sort_network(skeys, n, tid);
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)skeys[i];
+  } else {
+    __syncthreads();
+    tile_sort_network((volatile uint64_t*)seg, n, tid);
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)seg[i];
+  }
+}
+
+}  // namespace
+
+int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st) {
+  { GSR_PROF("scan", st);
+  hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, total_out); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int ceil_log2_u32(uint32_t n) {
+  int b = 0;
+  while (((uint64_t)1 << b) < n) ++b;
+  return b;
+}
+
+int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
+                       const ImageState& im, hipStream_t st) {
+  GSR_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.T, st));
+  if (D == 0 || P <= 0) return 0;
+  { GSR_PROF("emit_entries", st);
+  hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
+                     g.recC, g.rect, g.offsets, bs.tkey[0], bs.dg[0]); }
+  GSR_HIP_CHECK(hipGetLastError());
+  const int tbits = ceil_log2_u32((uint32_t)cam.T);
+  const int npass = (tbits + 7) / 8;
+  const int bpp = npass ? (tbits + npass - 1) / npass : 0;
+  const uint32_t nblocks = gsr_radix_blocks(D);
+  int cur = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int shift = pass * bpp;
+    const int bits = (tbits - shift) < bpp ? (tbits - shift) : bpp;
+    { GSR_PROF("radix_hist", st);
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D, shift, bits, nblocks,
+                       bs.block_hist); }
+    GSR_HIP_CHECK(hipGetLastError());
+    int rc = gsr_launch_scan_exclusive(bs.block_hist, bs.block_base, (uint32_t)(1u << bits) * nblocks, nullptr, st);
+    if (rc) return rc;
+    { GSR_PROF("radix_scatter", st);
+  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], bs.dg[cur],
+                       bs.tkey[cur ^ 1], bs.dg[cur ^ 1], D, shift, bits, nblocks, bs.block_base); }
+    GSR_HIP_CHECK(hipGetLastError());
+    cur ^= 1;
+  }
+  { GSR_PROF("tile_ranges", st);
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D,
+                     im.ranges); }
+  GSR_HIP_CHECK(hipGetLastError());
+  { GSR_PROF("tile_sort", st);
+  hipLaunchKernelGGL(tile_sort_kernel, dim3(cam.T), dim3(GSR_BLOCK), 0, st, im.ranges, bs.dg[cur], bs.point_list); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}

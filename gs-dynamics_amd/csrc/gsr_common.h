@@ -1,0 +1,178 @@
+// gsr_common.h -- shared declarations of the gfx950 Gaussian rasterizer kernels.
+// Wave = 64 lanes everywhere; workgroups are 256 threads (4 waves) unless stated.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsr.h"
+
+#define GSR_WAVE 64
+#define GSR_BLOCK 256
+#define GSR_NEAR_Z 0.2f
+#define GSR_ALPHA_MIN (1.0f / 255.0f)
+#define GSR_ALPHA_MAX 0.99f
+#define GSR_T_EPS 0.0001f
+
+// ---------------------------------------------------------------- state layouts (HBM)
+// Geometry state: per-Gaussian records written by preprocess, read (gathered) by the blend kernels.
+//   recA float4 {mean2D.x, mean2D.y, conicA, conicB}
+//   recB float4 {conicC, opacity, r, g}
+//   recC float2 {b, depth}
+// 40 B per Gaussian in three arrays so that every gather is one aligned 16/16/8-byte load.
+struct GeomState {
+  float4* recA;
+  float4* recB;
+  float2* recC;
+  uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
+  uint32_t* tiles_touched;
+  uint32_t* offsets;      // [P+1]
+  uint32_t* clamped;      // [P] bit ch set when SH colour channel was clamped at 0
+  uint32_t* counters;     // [0] = num_rendered
+};
+struct ImageState {
+  float* final_T;         // [H*W]
+  uint32_t* n_contrib;    // [H*W]
+  uint2* ranges;          // [T]
+};
+// Binning state: tile-key / (depth,gid) entries, double-buffered for the radix passes.
+struct BinningState {
+  uint32_t* tkey[2];      // [D] tile id of each duplicate
+  uint64_t* dg[2];        // [D] depth_bits << 32 | gaussian id
+  uint32_t* point_list;   // [D] final per-tile depth-sorted Gaussian ids
+  uint32_t* block_hist;   // [256 * nblocks] radix block histograms (bin-major)
+  uint32_t* block_base;   // [256 * nblocks + 1] their exclusive scan
+};
+
+static inline __host__ __device__ size_t gsr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+#define GSR_RADIX_ITEMS 8                      // keys per thread per radix block
+#define GSR_RADIX_EPB (GSR_BLOCK * GSR_RADIX_ITEMS)  // keys per radix block
+
+static inline uint32_t gsr_radix_blocks(uint32_t D) { return D == 0 ? 1u : (D + GSR_RADIX_EPB - 1) / GSR_RADIX_EPB; }
+
+static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
+  size_t off = 0, Pn = (size_t)(P > 0 ? P : 1);
+  char* b = (char*)base;
+  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
+  g->recA = (float4*)take(Pn * 16);
+  g->recB = (float4*)take(Pn * 16);
+  g->recC = (float2*)take(Pn * 8);
+  g->rect = (uint2*)take(Pn * 8);
+  g->tiles_touched = (uint32_t*)take(Pn * 4);
+  g->offsets = (uint32_t*)take((Pn + 1) * 4);
+  g->clamped = (uint32_t*)take(Pn * 4);
+  g->counters = (uint32_t*)take(64);
+  return off;
+}
+static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageState* im) {
+  size_t off = 0, N = (size_t)H * W;
+  size_t T = (size_t)((H + GSR_TILE - 1) / GSR_TILE) * ((W + GSR_TILE - 1) / GSR_TILE);
+  char* b = (char*)base;
+  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
+  im->final_T = (float*)take((N ? N : 1) * 4);
+  im->n_contrib = (uint32_t*)take((N ? N : 1) * 4);
+  im->ranges = (uint2*)take((T ? T : 1) * 8);
+  return off;
+}
+static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs) {
+  size_t off = 0, Dn = D ? D : 1;
+  size_t nb = gsr_radix_blocks(D);
+  char* b = (char*)base;
+  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
+  bs->tkey[0] = (uint32_t*)take(Dn * 4);
+  bs->tkey[1] = (uint32_t*)take(Dn * 4);
+  bs->dg[0] = (uint64_t*)take(Dn * 8);
+  bs->dg[1] = (uint64_t*)take(Dn * 8);
+  bs->point_list = (uint32_t*)take(Dn * 4);
+  bs->block_hist = (uint32_t*)take(256 * nb * 4);
+  bs->block_base = (uint32_t*)take((256 * nb + 1) * 4);
+  return off;
+}
+
+// Backward scratch: one 48-byte record per duplicate, Gaussian-major (entry e = offsets[g] + k,
+// k = row-major rank of the tile inside the Gaussian's rect):
+//   float4 {d mean2D.x, d mean2D.y, dA, dB}, float4 {dC, d opacity, dr, dg}, float4 {db, 0, 0, 0}
+#define GSR_PARTIAL_F4 3
+
+// ---------------------------------------------------------------- error plumbing (gsr_api.hip)
+void gsr_set_error(const char* fmt, ...);
+#define GSR_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      gsr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return (int)_e ? (int)_e : -1;                                                          \
+    }                                                                                         \
+  } while (0)
+
+// ---------------------------------------------------------------- per-kernel HIP-event timing (gsr_api.hip)
+// When profiling is enabled (gsr_profile_begin) every launch site brackets its kernel with two events
+// recorded on the launch stream; gsr_profile_end turns them into per-kernel totals.  Off by default:
+// no events are created or recorded in normal operation.
+struct GsrProfScope {
+  GsrProfScope(const char* name, hipStream_t st);
+  ~GsrProfScope();
+  int slot;
+  hipStream_t st;
+};
+#define GSR_PROF_CAT2(a, b) a##b
+#define GSR_PROF_CAT(a, b) GSR_PROF_CAT2(a, b)
+#define GSR_PROF(name, st) GsrProfScope GSR_PROF_CAT(_gsr_prof_, __LINE__)(name, st)
+
+// ---------------------------------------------------------------- launchers (one per .hip file)
+struct GsrCam {  // host copy of the scalar settings; matrices stay on the device
+  int H, W, gx, gy, T;
+  float tanfovx, tanfovy, scale_modifier;
+  int sh_degree, M;
+  const float *bg, *view, *proj, *campos;
+};
+
+int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const float* scales,
+                          const float* rotations, const float* opacities, const float* colors_precomp,
+                          const float* shs, const float* cov3D_precomp, const GeomState& g, int32_t* radii,
+                          hipStream_t st);
+int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
+int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
+                       const ImageState& im, hipStream_t st);
+int gsr_launch_render_fwd(const GsrCam& cam, const GeomState& g, const BinningState& bs, const ImageState& im,
+                          float* out_color, float* out_depth, hipStream_t st);
+int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, const BinningState& bs,
+                          const ImageState& im, const float* dL_dcolor, float4* partials, hipStream_t st);
+int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
+                              const float* rotations, const float* colors_precomp, const float* shs,
+                              const float* cov3D_precomp, const int32_t* radii, const GeomState& g,
+                              const float4* partials, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                              float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                              float* dL_dsh, hipStream_t st);
+int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
+int gsr_run_selftest(hipStream_t st);
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+__device__ __forceinline__ int gsr_lane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t gsr_lanemask_lt() { return (1ull << gsr_lane()) - 1ull; }
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float gsr_dpp_add(float v) {
+  // v + (v read through the DPP crossbar); lanes whose source is masked read 0.
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 (all of row 3).
+// quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror (each row of 16 now
+// holds its row sum) -> row_bcast:15 into rows 1,3 -> row_bcast:31 into rows 2,3.
+__device__ __forceinline__ float gsr_wave_sum_to_lane63(float v) {
+  v = gsr_dpp_add<0xB1>(v);
+  v = gsr_dpp_add<0x4E>(v);
+  v = gsr_dpp_add<0x141>(v);
+  v = gsr_dpp_add<0x140>(v);
+  v = gsr_dpp_add<0x142, 0xA>(v);
+  v = gsr_dpp_add<0x143, 0xC>(v);
+  return v;
+}
+// Reference (slow, LDS-crossbar) version used by the self-test.
+__device__ __forceinline__ float gsr_wave_sum_shfl(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+#endif

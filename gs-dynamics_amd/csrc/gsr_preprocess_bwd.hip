@@ -1,0 +1,281 @@
+// gsr_preprocess_bwd.hip -- per-Gaussian backward for gfx950 (replaces the
+// reference extension's computeCov2D-backward + preprocess-backward kernels, fused into one).
+//
+// One lane per Gaussian:
+//   1. reduce its entry records (one 48-byte record per touched tile, contiguous, written by
+//      render_bwd) in ascending tile order -> dL/d{mean2D_pix, conic(A,B,C), opacity, rgb};
+//   2. conic -> cov2D -> (cov3D, view-space mean) -> (scale, rotation, mean3D);  the 3D covariance is
+//      recomputed from scale/rotation rather than stored by the forward (saves 24 B/Gaussian each way);
+//   3. 2D mean -> 3D mean through the 4x4 projection; SH backward when colours came from SH.
+// Every output element is written (zeros for culled Gaussians): callers need no memset.
+// HBM per Gaussian: reads 48*tiles + 12 + 12 + 16 + 8 + 4 + 4, writes 12+12+12+4+12+16+24 = 92 B.
+#include "gsr_common.h"
+
+namespace {
+
+__constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                             -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// SH backward for one Gaussian: writes dL_dsh (all M coefficients; inactive ones get 0) and returns
+// the gradient w.r.t. the mean through the view direction.
+__device__ void sh_backward(int deg, int M, const float* __restrict__ sh, float3 p, const float* __restrict__ campos,
+                            uint32_t clamped, float g0, float g1, float g2, float* __restrict__ dsh, float dmean[3]) {
+  float dL[3] = {(clamped & 1u) ? 0.f : g0, (clamped & 2u) ? 0.f : g1, (clamped & 4u) ? 0.f : g2};
+  const float ox = p.x - campos[0], oy = p.y - campos[1], oz = p.z - campos[2];
+  const float len = sqrtf(ox * ox + oy * oy + oz * oz), inv = 1.0f / len;
+  const float x = ox * inv, y = oy * inv, z = oz * inv;
+  float basis[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+  float dRdx[3] = {0.f, 0.f, 0.f}, dRdy[3] = {0.f, 0.f, 0.f}, dRdz[3] = {0.f, 0.f, 0.f};
+  basis[0] = SH_C0;
+  if (deg > 0) {
+    basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      dRdx[ch] = -SH_C1 * sh[3 * 3 + ch]; dRdy[ch] = -SH_C1 * sh[1 * 3 + ch]; dRdz[ch] = SH_C1 * sh[2 * 3 + ch];
+    }
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      basis[4] = kC2[0] * xy; basis[5] = kC2[1] * yz; basis[6] = kC2[2] * (2.0f * zz - xx - yy);
+      basis[7] = kC2[3] * xz; basis[8] = kC2[4] * (xx - yy);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+#define S(k) sh[(k)*3 + ch]
+        dRdx[ch] += kC2[0] * y * S(4) - 2.0f * kC2[2] * x * S(6) + kC2[3] * z * S(7) + 2.0f * kC2[4] * x * S(8);
+        dRdy[ch] += kC2[0] * x * S(4) + kC2[1] * z * S(5) - 2.0f * kC2[2] * y * S(6) - 2.0f * kC2[4] * y * S(8);
+        dRdz[ch] += kC2[1] * y * S(5) + 4.0f * kC2[2] * z * S(6) + kC2[3] * x * S(7);
+#undef S
+      }
+      if (deg > 2) {
+        basis[9] = kC3[0] * y * (3.0f * xx - yy); basis[10] = kC3[1] * xy * z;
+        basis[11] = kC3[2] * y * (4.0f * zz - xx - yy); basis[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        basis[13] = kC3[4] * x * (4.0f * zz - xx - yy); basis[14] = kC3[5] * z * (xx - yy);
+        basis[15] = kC3[6] * x * (xx - 3.0f * yy);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+#define S(k) sh[(k)*3 + ch]
+          dRdx[ch] += kC3[0] * S(9) * 6.0f * xy + kC3[1] * S(10) * yz - kC3[2] * S(11) * 2.0f * xy -
+                      kC3[3] * S(12) * 6.0f * xz + kC3[4] * S(13) * (-3.0f * xx + 4.0f * zz - yy) +
+                      kC3[5] * S(14) * 2.0f * xz + kC3[6] * S(15) * 3.0f * (xx - yy);
+          dRdy[ch] += kC3[0] * S(9) * 3.0f * (xx - yy) + kC3[1] * S(10) * xz +
+                      kC3[2] * S(11) * (-3.0f * yy + 4.0f * zz - xx) - kC3[3] * S(12) * 6.0f * yz -
+                      kC3[4] * S(13) * 2.0f * xy - kC3[5] * S(14) * 2.0f * yz - kC3[6] * S(15) * 6.0f * xy;
+          dRdz[ch] += kC3[1] * S(10) * xy + kC3[2] * S(11) * 8.0f * yz +
+                      kC3[3] * S(12) * 3.0f * (2.0f * zz - xx - yy) + kC3[4] * S(13) * 8.0f * xz +
+                      kC3[5] * S(14) * (xx - yy);
+#undef S
+        }
+      }
+    }
+  }
+  const int ncoef = (deg + 1) * (deg + 1);
+  for (int k = 0; k < M; ++k) {
+    const float bk = k < ncoef ? basis[k < 16 ? k : 15] : 0.f;
+    dsh[k * 3 + 0] = bk * dL[0]; dsh[k * 3 + 1] = bk * dL[1]; dsh[k * 3 + 2] = bk * dL[2];
+  }
+  const float ddx = dRdx[0] * dL[0] + dRdx[1] * dL[1] + dRdx[2] * dL[2];
+  const float ddy = dRdy[0] * dL[0] + dRdy[1] * dL[1] + dRdy[2] * dL[2];
+  const float ddz = dRdz[0] * dL[0] + dRdz[1] * dL[1] + dRdz[2] * dL[2];
+  const float sum2 = ox * ox + oy * oy + oz * oz;
+  const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  dmean[0] = ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+  dmean[1] = (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+  dmean[2] = (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+}
+
+template <bool USE_SH>
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
+    int P, int W, int H, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ colors_precomp, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ clamped,
+    const float4* __restrict__ partials, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh) {
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  float gm3[3] = {0.f, 0.f, 0.f}, gm2[2] = {0.f, 0.f}, gcol[3] = {0.f, 0.f, 0.f}, gop = 0.f;
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool alive = radii[i] > 0;
+  if (USE_SH && !alive && dL_dsh) {
+    for (int k = 0; k < M * 3; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
+  }
+  if (alive) {
+    // 1. reduce entry records
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    float r2x = 0.f;
+    const uint32_t e0 = offsets[i], e1 = offsets[i + 1];
+    for (uint32_t e = e0; e < e1; ++e) {
+      const float4 q0 = partials[(size_t)e * GSR_PARTIAL_F4 + 0];
+      const float4 q1 = partials[(size_t)e * GSR_PARTIAL_F4 + 1];
+      const float4 q2 = partials[(size_t)e * GSR_PARTIAL_F4 + 2];
+      r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
+      r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
+      r2x += q2.x;
+    }
+    const float gmx = r0.x, gmy = r0.y, gA = r0.z, gB = r0.w, gC = r1.x;
+    gop = r1.y;
+    float drgb[3] = {r1.z, r1.w, r2x};
+    const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    float dmean_sh[3] = {0.f, 0.f, 0.f};
+    if (USE_SH) {
+      sh_backward(sh_degree, M, shs + (size_t)i * M * 3, p, campos, clamped[i], drgb[0], drgb[1], drgb[2],
+                  dL_dsh + (size_t)i * M * 3, dmean_sh);
+    } else {
+      gcol[0] = drgb[0]; gcol[1] = drgb[1]; gcol[2] = drgb[2];
+    }
+    // 2. geometry chain
+    const float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
+    const float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
+    const float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
+    float R[3][3] = {{0}}, s[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float c0, c1, c2, c3, c4, c5;
+    if (cov3D_precomp) {
+      c0 = cov3D_precomp[6 * i]; c1 = cov3D_precomp[6 * i + 1]; c2 = cov3D_precomp[6 * i + 2];
+      c3 = cov3D_precomp[6 * i + 3]; c4 = cov3D_precomp[6 * i + 4]; c5 = cov3D_precomp[6 * i + 5];
+    } else {
+      const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+      q4[0] = r; q4[1] = x; q4[2] = y; q4[3] = z;
+      R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+      R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+      R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+      s[0] = mod * scales[3 * i]; s[1] = mod * scales[3 * i + 1]; s[2] = mod * scales[3 * i + 2];
+      float Mm[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Mm[a][b] = R[a][b] * s[b];
+      c0 = Mm[0][0] * Mm[0][0] + Mm[0][1] * Mm[0][1] + Mm[0][2] * Mm[0][2];
+      c1 = Mm[0][0] * Mm[1][0] + Mm[0][1] * Mm[1][1] + Mm[0][2] * Mm[1][2];
+      c2 = Mm[0][0] * Mm[2][0] + Mm[0][1] * Mm[2][1] + Mm[0][2] * Mm[2][2];
+      c3 = Mm[1][0] * Mm[1][0] + Mm[1][1] * Mm[1][1] + Mm[1][2] * Mm[1][2];
+      c4 = Mm[1][0] * Mm[2][0] + Mm[1][1] * Mm[2][1] + Mm[1][2] * Mm[2][2];
+      c5 = Mm[2][0] * Mm[2][0] + Mm[2][1] * Mm[2][1] + Mm[2][2] * Mm[2][2];
+    }
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float tz = pvz;
+    const float txtz = pvx / tz, tytz = pvy / tz;
+    const float xm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float ym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float tx = clampf(txtz, -limx, limx) * tz, ty = clampf(tytz, -limy, limy) * tz;
+    const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+    const float T0[3] = {J00 * view[0] + J02 * view[2], J00 * view[4] + J02 * view[6], J00 * view[8] + J02 * view[10]};
+    const float T1[3] = {J11 * view[1] + J12 * view[2], J11 * view[5] + J12 * view[6], J11 * view[9] + J12 * view[10]};
+    const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
+    float U0[3], U1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      U0[k] = S[k][0] * T0[0] + S[k][1] * T0[1] + S[k][2] * T0[2];
+      U1[k] = S[k][0] * T1[0] + S[k][1] * T1[1] + S[k][2] * T1[2];
+    }
+    const float a = U0[0] * T0[0] + U0[1] * T0[1] + U0[2] * T0[2] + 0.3f;
+    const float b = U0[0] * T1[0] + U0[1] * T1[1] + U0[2] * T1[2];
+    const float cc = U1[0] * T1[0] + U1[1] * T1[1] + U1[2] * T1[2] + 0.3f;
+    const float det = a * cc - b * b;
+    const float d2inv = 1.0f / (det * det + 0.0000001f);
+    const float dL_da = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
+    const float dL_dc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
+    const float dL_db = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+    gcov[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+    gcov[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+    gcov[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+    gcov[1] = 2.0f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.0f * T1[0] * T1[1] * dL_dc;
+    gcov[2] = 2.0f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.0f * T1[0] * T1[2] * dL_dc;
+    gcov[4] = 2.0f * T0[1] * T0[2] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.0f * T1[1] * T1[2] * dL_dc;
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dT0[j] = 2.0f * U0[j] * dL_da + U1[j] * dL_db;
+      dT1[j] = 2.0f * U1[j] * dL_dc + U0[j] * dL_db;
+    }
+    const float dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
+    const float dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
+    const float dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
+    const float dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
+    const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    const float dtx = xm * -fx * itz2 * dJ02;
+    const float dty = ym * -fy * itz2 * dJ12;
+    const float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
+    gm3[0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
+    gm3[1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
+    gm3[2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
+    // 3. 2D mean -> 3D mean
+    gm2[0] = gmx * 0.5f * (float)W;
+    gm2[1] = gmy * 0.5f * (float)H;
+    const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
+    const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
+    const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
+    const float mw = 1.0f / (hw + 0.0000001f);
+    const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+    gm3[0] += (proj[0] * mw - proj[3] * mul1) * gm2[0] + (proj[1] * mw - proj[3] * mul2) * gm2[1] + dmean_sh[0];
+    gm3[1] += (proj[4] * mw - proj[7] * mul1) * gm2[0] + (proj[5] * mw - proj[7] * mul2) * gm2[1] + dmean_sh[1];
+    gm3[2] += (proj[8] * mw - proj[11] * mul1) * gm2[0] + (proj[9] * mw - proj[11] * mul2) * gm2[1] + dmean_sh[2];
+    // 4. cov3D -> scale, rotation
+    if (!cov3D_precomp) {
+      const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                              {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                              {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+      float G[3][3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        float dM0 = 2.0f * (dS[0][0] * R[0][jj] + dS[0][1] * R[1][jj] + dS[0][2] * R[2][jj]) * s[jj];
+        float dM1 = 2.0f * (dS[1][0] * R[0][jj] + dS[1][1] * R[1][jj] + dS[1][2] * R[2][jj]) * s[jj];
+        float dM2 = 2.0f * (dS[2][0] * R[0][jj] + dS[2][1] * R[1][jj] + dS[2][2] * R[2][jj]) * s[jj];
+        gs[jj] = mod * (R[0][jj] * dM0 + R[1][jj] * dM1 + R[2][jj] * dM2);
+        G[0][jj] = dM0 * s[jj]; G[1][jj] = dM1 * s[jj]; G[2][jj] = dM2 * s[jj];
+      }
+      const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+      gq[0] = 2.0f * (-z * G[0][1] + y * G[0][2] + z * G[1][0] - x * G[1][2] - y * G[2][0] + x * G[2][1]);
+      gq[1] = 2.0f * (y * G[0][1] + z * G[0][2] + y * G[1][0] - 2.0f * x * G[1][1] - r * G[1][2] + z * G[2][0] + r * G[2][1] - 2.0f * x * G[2][2]);
+      gq[2] = 2.0f * (-2.0f * y * G[0][0] + x * G[0][1] + r * G[0][2] + x * G[1][0] + z * G[1][2] - r * G[2][0] + z * G[2][1] - 2.0f * y * G[2][2]);
+      gq[3] = 2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]);
+    }
+  }
+  dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
+  dL_dmeans2D[3 * i] = gm2[0]; dL_dmeans2D[3 * i + 1] = gm2[1]; dL_dmeans2D[3 * i + 2] = 0.f;
+  if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
+  dL_dopacity[i] = gop;
+  if (dL_dscales) { dL_dscales[3 * i] = gs[0]; dL_dscales[3 * i + 1] = gs[1]; dL_dscales[3 * i + 2] = gs[2]; }
+  if (dL_drot) { dL_drot[4 * i] = gq[0]; dL_drot[4 * i + 1] = gq[1]; dL_drot[4 * i + 2] = gq[2]; dL_drot[4 * i + 3] = gq[3]; }
+  if (dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = gcov[k];
+  }
+}
+
+}  // namespace
+
+int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
+                              const float* rotations, const float* colors_precomp, const float* shs,
+                              const float* cov3D_precomp, const int32_t* radii, const GeomState& g,
+                              const float4* partials, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                              float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                              float* dL_dsh, hipStream_t st) {
+  if (P <= 0) return 0;
+  const dim3 grid((P + GSR_BLOCK - 1) / GSR_BLOCK), block(GSR_BLOCK);
+#define GSR_PBWD_ARGS                                                                                              \
+  P, cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,       \
+      cam.campos, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g.offsets, g.clamped,  \
+      partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dsh
+  if (shs) {
+    if (!dL_dsh) { gsr_set_error("gsr_backward: shs given but dL_dsh is NULL"); return -2; }
+    { GSR_PROF("preprocess_bwd", st);
+  hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, st, GSR_PBWD_ARGS); }
+  } else {
+    { GSR_PROF("preprocess_bwd", st);
+  hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, st, GSR_PBWD_ARGS); }
+  }
+#undef GSR_PBWD_ARGS
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,197 @@
+// gsr_preprocess_fwd.hip -- per-Gaussian forward preprocess for gfx950 (replaces the reference
+// extension's preprocess stage).  One lane per Gaussian.
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: every fp32 op is separately rounded, in the same
+// order as oracle/gsr_oracle.c::preprocess_one, so radii / tile rects / depth keys are bit-identical
+// to the CPU oracle (integer parity is exact, not "within tolerance").
+//
+// HBM traffic per Gaussian: reads 12 (mean) + 12 (scale) + 16 (rot) + 4 (opacity) + 12 (colour) = 56 B
+// (+48 M-coefficient SH when used), writes 16 + 16 + 8 (records) + 8 (rect) + 4 (tiles) + 4 (radii) = 56 B.
+// The 4x4 matrices are read through uniform (scalar) loads: they never occupy VGPRs.
+#include "gsr_common.h"
+
+namespace {
+
+__constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                             -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void sh_to_rgb(int deg, int M, const float* __restrict__ sh, float3 p,
+                                          const float* __restrict__ campos, float out[3], uint32_t& clamped) {
+  float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
+  float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  float inv = 1.0f / len;
+  float x = dx * inv, y = dy * inv, z = dz * inv;
+  clamped = 0;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+#define S(k) sh[(k)*3 + ch]
+    float r = SH_C0 * S(0);
+    if (deg > 0) {
+      r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+      if (deg > 1) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r = r + kC2[0] * xy * S(4) + kC2[1] * yz * S(5) + kC2[2] * (2.0f * zz - xx - yy) * S(6) +
+            kC2[3] * xz * S(7) + kC2[4] * (xx - yy) * S(8);
+        if (deg > 2) {
+          r = r + kC3[0] * y * (3.0f * xx - yy) * S(9) + kC3[1] * xy * z * S(10) +
+              kC3[2] * y * (4.0f * zz - xx - yy) * S(11) +
+              kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) +
+              kC3[4] * x * (4.0f * zz - xx - yy) * S(13) + kC3[5] * z * (xx - yy) * S(14) +
+              kC3[6] * x * (xx - 3.0f * yy) * S(15);
+        }
+      }
+    }
+#undef S
+    r += 0.5f;
+    if (r < 0.0f) { clamped |= (1u << ch); r = 0.0f; }
+    out[ch] = r;
+  }
+  (void)M;
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
+    int P, int W, int H, int gx, int gy, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ recA,
+    float4* __restrict__ recB, float2* __restrict__ recC, uint2* __restrict__ rect,
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii) {
+  int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  // defaults for a culled Gaussian
+  int32_t radius_i = 0;
+  uint32_t tiles = 0;
+  uint2 rc = make_uint2(0u, 0u);
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+  float2 c2 = make_float2(0.f, 0.f);
+  uint32_t clamp_bits = 0;
+
+  float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+  float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
+  float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
+  float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
+  if (pvz > GSR_NEAR_Z) {
+    float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
+    float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
+    float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
+    float pw = 1.0f / (hw + 0.0000001f);
+    float ndcx = hx * pw, ndcy = hy * pw;
+    // 3D covariance
+    float c0, c1, c2_, c3, c4, c5;
+    if (cov3D_precomp) {
+      c0 = cov3D_precomp[6 * i]; c1 = cov3D_precomp[6 * i + 1]; c2_ = cov3D_precomp[6 * i + 2];
+      c3 = cov3D_precomp[6 * i + 3]; c4 = cov3D_precomp[6 * i + 4]; c5 = cov3D_precomp[6 * i + 5];
+    } else {
+      float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+      float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+      float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+      float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+      float s0 = mod * scales[3 * i], s1 = mod * scales[3 * i + 1], s2 = mod * scales[3 * i + 2];
+      float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
+      float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
+      float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
+      c0 = M00 * M00 + M01 * M01 + M02 * M02;
+      c1 = M00 * M10 + M01 * M11 + M02 * M12;
+      c2_ = M00 * M20 + M01 * M21 + M02 * M22;
+      c3 = M10 * M10 + M11 * M11 + M12 * M12;
+      c4 = M10 * M20 + M11 * M21 + M12 * M22;
+      c5 = M20 * M20 + M21 * M21 + M22 * M22;
+    }
+    // EWA projection with the frustum clamp
+    float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    float tz = pvz;
+    float txtz = pvx / tz, tytz = pvy / tz;
+    float tx = clampf(txtz, -limx, limx) * tz;
+    float ty = clampf(tytz, -limy, limy) * tz;
+    float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+    float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+    float T00 = J00 * view[0] + J02 * view[2], T01 = J00 * view[4] + J02 * view[6], T02 = J00 * view[8] + J02 * view[10];
+    float T10 = J11 * view[1] + J12 * view[2], T11 = J11 * view[5] + J12 * view[6], T12 = J11 * view[9] + J12 * view[10];
+    float U00 = T00 * c0 + T01 * c1 + T02 * c2_, U01 = T00 * c1 + T01 * c3 + T02 * c4, U02 = T00 * c2_ + T01 * c4 + T02 * c5;
+    float U10 = T10 * c0 + T11 * c1 + T12 * c2_, U11 = T10 * c1 + T11 * c3 + T12 * c4, U12 = T10 * c2_ + T11 * c4 + T12 * c5;
+    float a = U00 * T00 + U01 * T01 + U02 * T02;
+    float b = U00 * T10 + U01 * T11 + U02 * T12;
+    float cc = U10 * T10 + U11 * T11 + U12 * T12;
+    a += 0.3f; cc += 0.3f;
+    float det = a * cc - b * b;
+    if (det != 0.0f) {
+      float det_inv = 1.0f / det;
+      float cA = cc * det_inv, cB = -b * det_inv, cC = a * det_inv;
+      float mid = 0.5f * (a + cc);
+      float disc = mid * mid - det;
+      float sq = sqrtf(disc > 0.1f ? disc : 0.1f);
+      float l1 = mid + sq, l2 = mid - sq;
+      float radius = ceilf(3.0f * sqrtf(l1 > l2 ? l1 : l2));
+      float px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+      float py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+      int minx = min(gx, max(0, (int)((px - radius) / (float)GSR_TILE)));
+      int miny = min(gy, max(0, (int)((py - radius) / (float)GSR_TILE)));
+      int maxx = min(gx, max(0, (int)((px + radius + (float)(GSR_TILE - 1)) / (float)GSR_TILE)));
+      int maxy = min(gy, max(0, (int)((py + radius + (float)(GSR_TILE - 1)) / (float)GSR_TILE)));
+      int area = (maxx - minx) * (maxy - miny);
+      if (area != 0) {
+        float rgb[3];
+        if (colors_precomp) {
+          rgb[0] = colors_precomp[3 * i]; rgb[1] = colors_precomp[3 * i + 1]; rgb[2] = colors_precomp[3 * i + 2];
+        } else {
+          sh_to_rgb(sh_degree, M, shs + (size_t)i * M * 3, p, campos, rgb, clamp_bits);
+        }
+        radius_i = (int32_t)radius;
+        tiles = (uint32_t)area;
+        rc = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
+        a4 = make_float4(px, py, cA, cB);
+        b4 = make_float4(cC, opacities[i], rgb[0], rgb[1]);
+        c2 = make_float2(rgb[2], pvz);
+      }
+    }
+  }
+  recA[i] = a4; recB[i] = b4; recC[i] = c2;
+  rect[i] = rc;
+  tiles_touched[i] = tiles;
+  clamped_out[i] = clamp_bits;
+  radii[i] = radius_i;
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float* __restrict__ view,
+                                                                 const float* __restrict__ means3D,
+                                                                 uint8_t* __restrict__ present) {
+  int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  float z = view[2] * means3D[3 * i] + view[6] * means3D[3 * i + 1] + view[10] * means3D[3 * i + 2] + view[14];
+  present[i] = z > GSR_NEAR_Z ? 1 : 0;
+}
+
+}  // namespace
+
+int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const float* scales,
+                          const float* rotations, const float* opacities, const float* colors_precomp,
+                          const float* shs, const float* cov3D_precomp, const GeomState& g, int32_t* radii,
+                          hipStream_t st) {
+  if (P <= 0) return 0;
+  int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+  { GSR_PROF("preprocess_fwd", st);
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
+                     cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
+                     cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.recA,
+                     g.recB, g.recC, g.rect, g.tiles_touched, g.clamped, radii); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st) {
+  if (P <= 0) return 0;
+  int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+  { GSR_PROF("mark_visible", st);
+  hipLaunchKernelGGL(mark_visible_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, view, means3D, present); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,130 @@
+"""``diff_gaussian_rasterization`` -- MI355X-native drop-in for the rasterizer package gs-dynamics imports.
+
+Same import surface the reference uses:
+
+    from diff_gaussian_rasterization import GaussianRasterizer                          # render/renderer.py:3
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera     # tracking/helpers.py:5
+    im, radius, depth = GaussianRasterizer(raster_settings=cam)(**rendervar)            # tracking/train_utils.py:178
+
+(paths relative to /root/reference/src).  The compute path is ``libgsr_hip.so`` (hand-written gfx950
+kernels behind the C-ABI of ``include/gsr.h``); this module is the thin host mirror: argument checks,
+allocation through torch's caching allocator, and the autograd glue.  There is no CPU implementation.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _hip
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Per-view camera record; the 11 fields (names and order) the reference constructs at
+    /root/reference/src/tracking/helpers.py:20-32."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+def _prep(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """None for absent/empty inputs, else a contiguous fp32 tensor (no copy when already so)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """forward -> (color, radii, depth); backward -> grads for the 8 tensor inputs, None for settings."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        m3 = _prep(means3D)
+        if m3 is None:
+            if means3D is not None and means3D.dim() == 2 and means3D.shape[1] == 3:
+                # P = 0: zero-filled outputs without launching anything
+                dev = means3D.device
+                H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+                ctx.empty = True
+                return (torch.zeros((3, H, W), device=dev), torch.zeros((0,), dtype=torch.int32, device=dev),
+                        torch.zeros((1, H, W), device=dev))
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        if m3.dim() != 2 or m3.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        ctx.empty = False
+        sh_, col_, op_ = _prep(sh), _prep(colors_precomp), _prep(opacities)
+        sc_, rot_, cov_ = _prep(scales), _prep(rotations), _prep(cov3Ds_precomp)
+        color, radii, depth, state = _hip.rasterize_forward(raster_settings, m3, op_, col_, sh_, sc_, rot_, cov_)
+        ctx.state = state
+        ctx.has = (sh_ is not None, col_ is not None, sc_ is not None, cov_ is not None)
+        empty = m3.new_empty(0)
+        ctx.save_for_backward(m3, radii, col_ if col_ is not None else empty, sh_ if sh_ is not None else empty,
+                              sc_ if sc_ is not None else empty, rot_ if rot_ is not None else empty,
+                              cov_ if cov_ is not None else empty)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth):  # grad_radii / grad_depth: accepted, ignored
+        if ctx.empty:
+            return (None,) * 9
+        m3, radii, col_, sh_, sc_, rot_, cov_ = ctx.saved_tensors
+        has_sh, has_col, has_sc, has_cov = ctx.has
+        if grad_color is None:
+            grad_color = torch.zeros((3, ctx.state.H, ctx.state.W), device=m3.device)
+        d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh = _hip.rasterize_backward(
+            ctx.state, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
+            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
+        ctx.state = None
+        return (d_means3D, d_means2D, d_sh if has_sh else None, d_colors if has_col else None, d_opacity,
+                d_scales if has_sc else None, d_rot if has_sc else None, d_cov if has_cov else None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Constructed per call by the reference (``Renderer(raster_settings=cam)(**rendervar)``,
+    /root/reference/src/tracking/train_utils.py:178): construction does no work."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            return _hip.mark_visible(positions, self.raster_settings.viewmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

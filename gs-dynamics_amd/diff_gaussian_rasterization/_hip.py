@@ -1,0 +1,249 @@
+"""ctypes binding of ``libgsr_hip.so`` (C-ABI in ``include/gsr.h``) -- the ONLY compute backend.
+
+There is no CPU path and no fallback: if the shared library is missing, or the tensors are not on
+a HIP device, the calls below raise.  PyTorch is used for device memory (caching allocator), the
+current stream handle, and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.environ.get("GSR_HIP_LIB", os.path.join(_CSRC, "libgsr_hip.so"))
+
+_lib = None
+
+
+class GsrSettings(C.Structure):
+    """struct gsr_settings (include/gsr.h)."""
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("prefiltered", C.c_int32),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class GsrDebugViews(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("recA", "recB", "recC", "rect", "tiles_touched", "offsets",
+                                          "point_list", "ranges", "final_T", "n_contrib")]
+
+
+class GsrKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
+           "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
+           "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end")
+
+
+def load_library():
+    """dlopen libgsr_hip.so and declare the prototypes.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"diff_gaussian_rasterization: HIP extension not found at {LIB_PATH}. "
+            "Build it with `make -C gs-dynamics_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
+    lib.gsr_version.restype = C.c_int
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_geom_bytes.restype = sz; lib.gsr_geom_bytes.argtypes = [i32]
+    lib.gsr_image_bytes.restype = sz; lib.gsr_image_bytes.argtypes = [i32, i32]
+    lib.gsr_binning_bytes.restype = sz; lib.gsr_binning_bytes.argtypes = [u32, i32, i32]
+    lib.gsr_backward_scratch_bytes.restype = sz; lib.gsr_backward_scratch_bytes.argtypes = [i32, u32]
+    lib.gsr_forward_preprocess.restype = C.c_int
+    lib.gsr_forward_preprocess.argtypes = [C.POINTER(GsrSettings), i32] + [vp] * 7 + [vp, vp, C.POINTER(u32), vp]
+    lib.gsr_forward_render.restype = C.c_int
+    lib.gsr_forward_render.argtypes = [C.POINTER(GsrSettings), i32, u32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_backward.restype = C.c_int
+    lib.gsr_backward.argtypes = [C.POINTER(GsrSettings), i32, u32] + [vp] * 20 + [vp]
+    lib.gsr_mark_visible.restype = C.c_int
+    lib.gsr_mark_visible.argtypes = [vp, i32, vp, vp, vp]
+    lib.gsr_debug_get_views.restype = C.c_int
+    lib.gsr_debug_get_views.argtypes = [i32, u32, i32, i32, vp, vp, vp, C.POINTER(GsrDebugViews)]
+    lib.gsr_selftest.restype = C.c_int
+    lib.gsr_selftest.argtypes = [vp]
+    lib.gsr_profile_begin.restype = C.c_int
+    lib.gsr_profile_end.restype = C.c_int
+    lib.gsr_profile_end.argtypes = [C.POINTER(GsrKernelTime), i32, C.POINTER(i32)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().gsr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Tensor:
+    """Settings tensors: n contiguous fp32 values on the render device (viewmatrix may be [1,4,4])."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.float32)
+    t = t.to(device=dev, dtype=torch.float32).contiguous()
+    if t.numel() < n:
+        raise ValueError(f"raster_settings.{name} must hold {n} floats, got shape {tuple(t.shape)}")
+    return t
+
+
+class RasterState:
+    """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
+    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W")
+
+
+def _make_settings(rs, dev, sh_coeffs: int):
+    keep = (_dev_f32(rs.bg, dev, 3, "bg"), _dev_f32(rs.viewmatrix, dev, 16, "viewmatrix"),
+            _dev_f32(rs.projmatrix, dev, 16, "projmatrix"), _dev_f32(rs.campos, dev, 3, "campos"))
+    s = GsrSettings()
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    s.scale_modifier = float(rs.scale_modifier)
+    s.sh_degree, s.sh_coeffs, s.prefiltered = int(rs.sh_degree), int(sh_coeffs), int(bool(rs.prefiltered))
+    s.bg, s.viewmatrix, s.projmatrix, s.campos = (k.data_ptr() for k in keep)
+    return s, keep
+
+
+def _require_device(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "diff_gaussian_rasterization (MI355X build) runs on a HIP device only; got a tensor on "
+            f"'{t.device}'. There is no CPU fallback.")
+
+
+def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, RasterState]:
+    """K1..K6.  Returns (color[3,H,W], radii[P] int32, depth[1,H,W], state)."""
+    lib = load_library()
+    _require_device(means3D)
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(rs.image_height), int(rs.image_width)
+    M = 0 if shs is None else int(shs.shape[1])
+    with torch.cuda.device(dev):
+        s, keep = _make_settings(rs, dev, M)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((lib.gsr_geom_bytes(P),), **u8)
+        image = torch.empty((lib.gsr_image_bytes(H, W),), **u8)
+        D = C.c_uint32(0)
+        st = _stream(dev)
+        _check(lib.gsr_forward_preprocess(C.byref(s), P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                          _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr(geom),
+                                          _ptr(radii), C.byref(D), st), "gsr_forward_preprocess")
+        binning = torch.empty((lib.gsr_binning_bytes(D.value, H, W),), **u8)
+        _check(lib.gsr_forward_render(C.byref(s), P, D.value, _ptr(geom), _ptr(binning), _ptr(image), _ptr(color),
+                                      _ptr(depth), st), "gsr_forward_render")
+    state = RasterState()
+    state.settings, state.keep, state.P, state.num_rendered = s, keep, P, int(D.value)
+    state.geom, state.binning, state.image, state.H, state.W = geom, binning, image, H, W
+    return color, radii, depth, state
+
+
+def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_precomp, shs, scales, rotations,
+                       cov3D_precomp):
+    """K7..K9.  Returns (dmeans3D, dmeans2D, dcolors, dopacity[P,1], dscales, drotations, dcov3D, dsh)."""
+    lib = load_library()
+    dev = means3D.device
+    P, D = state.P, state.num_rendered
+    M = 0 if shs is None else int(shs.shape[1])
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        g = grad_color.to(**f32).contiguous()
+        d_means3D = torch.empty((P, 3), **f32)
+        d_means2D = torch.empty((P, 3), **f32)
+        d_colors = torch.empty((P, 3), **f32) if shs is None else None
+        d_opacity = torch.empty((P, 1), **f32)
+        d_scales = torch.empty((P, 3), **f32) if cov3D_precomp is None else None
+        d_rot = torch.empty((P, 4), **f32) if cov3D_precomp is None else None
+        d_cov = torch.empty((P, 6), **f32)
+        d_sh = torch.empty((P, M, 3), **f32) if shs is not None else None
+        scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, D),), dtype=torch.uint8, device=dev)
+        _check(lib.gsr_backward(C.byref(state.settings), P, D, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr(radii), _ptr(state.geom),
+                                _ptr(state.binning), _ptr(state.image), _ptr(g), _ptr(scratch), _ptr(d_means3D),
+                                _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot),
+                                _ptr(d_cov), _ptr(d_sh), _stream(dev)), "gsr_backward")
+    return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
+
+
+def mark_visible(positions, viewmatrix) -> torch.Tensor:
+    lib = load_library()
+    _require_device(positions)
+    dev = positions.device
+    P = int(positions.shape[0])
+    with torch.cuda.device(dev):
+        pos = positions.to(dtype=torch.float32).contiguous()
+        vm = _dev_f32(viewmatrix, dev, 16, "viewmatrix")
+        present = torch.zeros((P,), dtype=torch.uint8, device=dev)
+        _check(lib.gsr_mark_visible(_ptr(vm), P, _ptr(pos), _ptr(present), _stream(dev)), "gsr_mark_visible")
+    return present.bool()
+
+
+def debug_views(state: RasterState):
+    """Tensors copied out of the opaque state buffers (tests / benches only)."""
+    lib = load_library()
+    v = GsrDebugViews()
+    _check(lib.gsr_debug_get_views(state.P, state.num_rendered, state.H, state.W, _ptr(state.geom),
+                                   _ptr(state.binning), _ptr(state.image), C.byref(v)), "gsr_debug_get_views")
+    P, D, H, W = state.P, state.num_rendered, state.H, state.W
+    T = ((H + 15) // 16) * ((W + 15) // 16)
+
+    def view(buf: torch.Tensor, addr, dtype, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device=buf.device)
+        off = addr - buf.data_ptr()
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype).reshape(shape).clone()
+
+    i32 = torch.int32  # torch has no uint32 arithmetic; values here are < 2^31
+    return dict(
+        recA=view(state.geom, v.recA, torch.float32, (P, 4)), recB=view(state.geom, v.recB, torch.float32, (P, 4)),
+        recC=view(state.geom, v.recC, torch.float32, (P, 2)), rect=view(state.geom, v.rect, i32, (P, 2)),
+        tiles_touched=view(state.geom, v.tiles_touched, i32, (P,)), offsets=view(state.geom, v.offsets, i32, (P + 1,)),
+        point_list=view(state.binning, v.point_list, i32, (D,)), ranges=view(state.image, v.ranges, i32, (T, 2)),
+        final_T=view(state.image, v.final_T, torch.float32, (H, W)),
+        n_contrib=view(state.image, v.n_contrib, i32, (H, W)))
+
+
+def selftest(device=None) -> int:
+    lib = load_library()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        return int(lib.gsr_selftest(_stream(dev)))
+
+
+def profile_begin():
+    """Arm per-kernel HIP-event timing inside libgsr_hip.so (bench.py's roofline leg)."""
+    _check(load_library().gsr_profile_begin(), "gsr_profile_begin")
+
+
+def profile_end():
+    """Returns {kernel name: (total_ms, launches)} for every kernel launched since profile_begin()."""
+    lib = load_library()
+    arr = (GsrKernelTime * 64)()
+    n = C.c_int32(0)
+    _check(lib.gsr_profile_end(arr, 64, C.byref(n)), "gsr_profile_end")
+    return {arr[i].name.decode(): (float(arr[i].total_ms), int(arr[i].launches)) for i in range(n.value)}

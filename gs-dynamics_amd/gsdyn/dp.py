@@ -1,0 +1,107 @@
+"""View-sharded data parallelism for the tracking step (SURVEY.md section 8e -- new design, the reference
+is single-GPU: no torch.distributed anywhere under /root/reference/src).
+
+One process per GPU.  Gaussian parameters are replicated; the views of a step are sharded over ranks
+(rank r renders views r, r+world, ...).  The only exchange per optimiser step is ONE all-reduce(SUM) of
+a flat fp32 bucket that IS the parameters' ``.grad`` storage (gradients are views into the bucket, so
+there is no gather/scatter copy), plus one small bucket of densification statistics
+(/root/reference/src/tracking/external.py:138-142, /root/reference/src/tracking/train_utils.py:243-245).
+On ROCm the ``nccl`` backend is RCCL; the 6.8 MB bucket at 100k Gaussians is latency-bound on the
+fully-connected xGMI mesh, so a single call per step is the right shape (no per-tensor collectives).
+Every rank then applies the identical Adam update, so replicas stay bit-identical without a broadcast.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .step import LossWeights, get_loss
+
+
+def shard_views(num_views: int, rank: int, world: int) -> List[int]:
+    """Round-robin view -> rank assignment: views rank, rank+world, ..."""
+    return list(range(rank, num_views, world))
+
+
+class GradBucket:
+    """Flat fp32 buffer holding the gradients of all trainable parameters, in dict order."""
+
+    def __init__(self, params: Dict[str, torch.nn.Parameter]):
+        self.names = [k for k, p in params.items() if p.requires_grad]
+        self.params = [params[k] for k in self.names]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slices = {}
+        off = 0
+        for k, p in zip(self.names, self.params):
+            n = p.numel()
+            self.slices[k] = (off, off + n)
+            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into the bucket
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+        for k, p in zip(self.names, self.params):  # re-attach if an optimizer dropped the views
+            s, e = self.slices[k]
+            if p.grad is None or p.grad.data_ptr() != self.flat[s:e].data_ptr():
+                p.grad = self.flat[s:e].view_as(p)
+
+    def all_reduce(self, group=None, async_op: bool = False):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
+
+
+class ViewShardedStep:
+    """One optimiser step over a set of views, sharded over the ranks of ``group``."""
+
+    def __init__(self, params, optimizer: Optional[torch.optim.Optimizer], weights: LossWeights = LossWeights(),
+                 group=None):
+        self.params, self.optimizer, self.weights, self.group = params, optimizer, weights, group
+        self.bucket = GradBucket(params)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def __call__(self, views: Sequence[dict], variables: dict, is_initial_timestep: bool = True,
+                 local_only: bool = False):
+        """``views``: all views of the step (every rank passes the same list) unless ``local_only``, in
+        which case ``views`` is already this rank's shard.  Returns (sum of local losses, variables)."""
+        mine = list(views) if local_only else [views[i] for i in shard_views(len(views), self.rank, self.world)]
+        P = self.params["means3D"].shape[0]
+        dev = self.params["means3D"].device
+        self.bucket.zero()
+        stat = torch.zeros((2, P), dtype=torch.float32, device=dev)   # [grad-norm * seen, seen]
+        rad = torch.zeros((P,), dtype=torch.float32, device=dev)
+        total = torch.zeros((), dtype=torch.float32, device=dev)
+        for data in mine:
+            loss, variables = get_loss(self.params, data, variables, is_initial_timestep, self.weights)
+            loss.backward()
+            total += loss.detach()
+            with torch.no_grad():
+                seen = variables["seen"]
+                g2 = variables["means2D"].grad
+                if g2 is not None:
+                    stat[0] += torch.norm(g2[:, :2], dim=-1) * seen
+                stat[1] += seen
+                rad = torch.maximum(rad, variables["max_2D_radius"])
+        self.bucket.all_reduce(self.group)
+        if self.world > 1:
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group)
+        with torch.no_grad():
+            if "means2D_gradient_accum" in variables:
+                variables["means2D_gradient_accum"] += stat[0]
+                variables["denom"] += stat[1]
+            variables["max_2D_radius"] = rad
+            variables["seen"] = stat[1] > 0
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return total, variables
+
+
+def init_variables(P: int, device) -> dict:
+    z = lambda: torch.zeros(P, dtype=torch.float32, device=device)  # noqa: E731
+    return {"max_2D_radius": z(), "means2D_gradient_accum": z(), "denom": z()}

@@ -1,0 +1,94 @@
+"""Loss terms used by the tracking step, restated from the reference's formulas.
+
+Pinned by golden vectors captured from the imported reference (tests/golden/gen_reference_goldens.py):
+  l1_loss_v1 / l1_loss_v2 / weighted_l2_loss_v1 / weighted_l2_loss_v2 / quat_mult
+      <- /root/reference/src/tracking/helpers.py:71-94
+  build_rotation, calc_ssim, calc_psnr
+      <- /root/reference/src/tracking/external.py:25-42, 54-135
+All plain torch ops (device-agnostic); none of this is on the rasterizer hot path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def l1_loss_v1(x, y):
+    return (x - y).abs().mean()
+
+
+def l1_loss_v2(x, y):
+    return (x - y).abs().sum(-1).mean()
+
+
+def weighted_l2_loss_v1(x, y, w):
+    return torch.sqrt((x - y) ** 2 * w + 1e-20).mean()
+
+
+def weighted_l2_loss_v2(x, y, w):
+    return torch.sqrt(((x - y) ** 2).sum(-1) * w + 1e-20).mean()
+
+
+def quat_mult(q1, q2):
+    """Hamilton product of (w,x,y,z) quaternions, batched over rows."""
+    w1, x1, y1, z1 = q1.unbind(-1)
+    w2, x2, y2, z2 = q2.unbind(-1)
+    return torch.stack([
+        w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+        w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+
+def build_rotation(q):
+    """Rotation matrices [N,3,3] of (w,x,y,z) quaternions (normalised inside, as the reference does)."""
+    q = q / q.norm(dim=1, keepdim=True)
+    r, x, y, z = q.unbind(-1)
+    rows = [1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]
+    return torch.stack(rows, dim=-1).reshape(-1, 3, 3)
+
+
+def calc_psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+_WINDOW_CACHE = {}
+
+
+def _ssim_window(size: int, channels: int, like: torch.Tensor) -> torch.Tensor:
+    key = (size, channels, like.device, like.dtype)
+    w = _WINDOW_CACHE.get(key)
+    if w is None:
+        g = torch.tensor([math.exp(-(i - size // 2) ** 2 / (2 * 1.5 ** 2)) for i in range(size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2d = (g @ g.t()).float()[None, None]
+        w = w2d.expand(channels, 1, size, size).contiguous().to(device=like.device, dtype=like.dtype)
+        _WINDOW_CACHE[key] = w
+    return w
+
+
+def calc_ssim(img1, img2, window_size: int = 11, size_average: bool = True):
+    """SSIM with an 11x11 Gaussian window (sigma 1.5), zero-padded depthwise convolutions."""
+    ch = img1.size(-3)
+    win = _ssim_window(window_size, ch, img1)
+    pad = window_size // 2
+    a = img1 if img1.dim() == 4 else img1.unsqueeze(0)
+    b = img2 if img2.dim() == 4 else img2.unsqueeze(0)
+
+    def blur(t):
+        return F.conv2d(t, win, padding=pad, groups=ch)
+    mu1, mu2 = blur(a), blur(b)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = blur(a * a) - mu1_sq
+    s2 = blur(b * b) - mu2_sq
+    s12 = blur(a * b) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+    if img1.dim() != 4:
+        m = m.squeeze(0)
+    return m.mean() if size_average else m.mean(-1).mean(-1).mean(-1)

@@ -1,0 +1,130 @@
+"""The per-iteration tracking step: activation, two renders, losses -- the caller side of the hot path.
+
+Mirrors, call for call, /root/reference/src/tracking/train_utils.py:167-246 (``get_loss``) and
+/root/reference/src/tracking/helpers.py:36-45 (``params2rendervar``), with the shipped defects of the
+reference's driver worked around as SURVEY.md Appendix C records (weights passed explicitly, views
+sampled uniformly with replacement).  Every render goes through ``GaussianRasterizer``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+
+from .losses import (build_rotation, calc_psnr, calc_ssim, l1_loss_v1, l1_loss_v2, quat_mult, weighted_l2_loss_v1,
+                     weighted_l2_loss_v2)
+
+
+@dataclass
+class LossWeights:
+    """Defaults of /root/reference/src/tracking/train_gs.py:54-61."""
+    soft_col_cons: float = 0.01
+    im: float = 50.0
+    seg: float = 200.0
+    rigid: float = 200.0
+    bg: float = 200.0
+    iso: float = 1000.0
+    rot: float = 4.0
+    floor: float = 2.0
+
+
+def params2rendervar(params, colors_key: str = "rgb_colors"):
+    return {
+        "means3D": params["means3D"],
+        "colors_precomp": params[colors_key],
+        "rotations": torch.nn.functional.normalize(params["unnorm_rotations"]),
+        "opacities": torch.sigmoid(params["logit_opacities"]),
+        "scales": torch.exp(params["log_scales"]),
+        "means2D": torch.zeros_like(params["means3D"], requires_grad=True) + 0,
+    }
+
+
+def initialize_optimizer(params, scene_radius: float):
+    """Adam, one group per parameter, lrs of /root/reference/src/tracking/train_utils.py:152-164."""
+    lrs = {"means3D": 0.00016 * scene_radius, "rgb_colors": 0.0, "seg_colors": 0.0, "unnorm_rotations": 0.001,
+           "logit_opacities": 0.05, "log_scales": 0.001, "cam_m": 1e-4, "cam_c": 1e-4}
+    groups = [{"params": [v], "name": k, "lr": lrs[k]} for k, v in params.items()]
+    return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+
+def _image_term(pred, target):
+    return 0.8 * l1_loss_v1(pred, target) + 0.2 * (1.0 - calc_ssim(pred, target))
+
+
+def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWeights):
+    """Returns (loss, variables).  ``curr_data``: dict(cam=settings, im=[3,H,W], seg=[3,H,W], id=int)."""
+    losses = {}
+    rendervar = params2rendervar(params)
+    rendervar["means2D"].retain_grad()
+    im, radius, _ = Renderer(raster_settings=curr_data["cam"])(**rendervar)
+    cid = curr_data["id"]
+    im = torch.exp(params["cam_m"][cid])[:, None, None] * im + params["cam_c"][cid][:, None, None]
+    losses["im"] = _image_term(im, curr_data["im"])
+    variables["means2D"] = rendervar["means2D"]  # densification reads the colour render's gradient only
+
+    segrendervar = params2rendervar(params, colors_key="seg_colors")
+    seg, _, _ = Renderer(raster_settings=curr_data["cam"])(**segrendervar)
+    losses["seg"] = _image_term(seg, curr_data["seg"])
+
+    if not is_initial_timestep:
+        is_fg = (params["seg_colors"][:, 0] > 0.5).detach()
+        fg_pts = rendervar["means3D"][is_fg]
+        fg_rot = rendervar["rotations"][is_fg]
+        rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
+        rot = build_rotation(rel_rot)
+        nbr = variables["neighbor_indices"]
+        curr_offset = fg_pts[nbr] - fg_pts[:, None]
+        offset_prev_frame = (rot.transpose(2, 1)[:, None] @ curr_offset[:, :, :, None]).squeeze(-1)
+        nw = variables["neighbor_weight"]
+        losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
+        losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
+        offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
+        losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
+        losses["floor"] = torch.clamp(fg_pts[:, 1], min=0).mean()
+        bg_pts = rendervar["means3D"][~is_fg]
+        bg_rot = rendervar["rotations"][~is_fg]
+        losses["bg"] = l1_loss_v2(bg_pts, variables["init_bg_pts"]) + l1_loss_v2(bg_rot, variables["init_bg_rot"])
+        losses["soft_col_cons"] = 0.0
+
+    weights = {"im": w.im, "seg": w.seg, "rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg,
+               "soft_col_cons": w.soft_col_cons}
+    loss = sum(weights[k] * v for k, v in losses.items())
+    seen = radius > 0
+    variables["max_2D_radius"][seen] = torch.max(radius[seen], variables["max_2D_radius"][seen])
+    variables["seen"] = seen
+    return loss, variables
+
+
+@torch.no_grad()
+def report_psnr(params, data):
+    """The extra forward render of /root/reference/src/tracking/train_utils.py:377-384."""
+    im, _, _ = Renderer(raster_settings=data["cam"])(**params2rendervar(params))
+    cid = data["id"]
+    im = torch.exp(params["cam_m"][cid])[:, None, None] * im + params["cam_c"][cid][:, None, None]
+    return calc_psnr(im, data["im"]).mean()
+
+
+def make_rigidity_variables(params, num_knn: int = 20, device=None):
+    """Neighbour tensors for the t>0 loss terms (/root/reference/src/tracking/train_utils.py:354-374).
+    The reference builds the kNN with Open3D on the CPU; here a dense torch.cdist top-k (fg points only)."""
+    with torch.no_grad():
+        is_fg = params["seg_colors"][:, 0] > 0.5
+        fg = params["means3D"][is_fg]
+        rot = torch.nn.functional.normalize(params["unnorm_rotations"])
+        n = fg.shape[0]
+        k = min(num_knn, max(n - 1, 1))
+        idx_chunks, d_chunks = [], []
+        for s in range(0, n, 4096):
+            d = torch.cdist(fg[s:s + 4096], fg)
+            dk, ik = torch.topk(d, k + 1, dim=1, largest=False)
+            idx_chunks.append(ik[:, 1:]); d_chunks.append(dk[:, 1:] ** 2)
+        nbr = torch.cat(idx_chunks) if idx_chunks else torch.zeros((0, k), dtype=torch.long, device=fg.device)
+        sq = torch.cat(d_chunks) if d_chunks else torch.zeros((0, k), device=fg.device)
+        inv = rot[is_fg].clone()
+        inv[:, 1:] = -inv[:, 1:]
+        return dict(neighbor_indices=nbr.long().contiguous(), neighbor_weight=torch.exp(-2000 * sq).contiguous(),
+                    neighbor_dist=torch.sqrt(sq).contiguous(), init_bg_pts=params["means3D"][~is_fg].detach().clone(),
+                    init_bg_rot=rot[~is_fg].detach().clone(), prev_inv_rot_fg=inv.detach(),
+                    prev_offset=(fg[nbr] - fg[:, None]).detach())

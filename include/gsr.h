@@ -1,0 +1,134 @@
+/*
+ * gsr.h -- C-ABI of libgsr_hip.so: the MI355X (gfx950) differentiable 3D-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of robo-alex/gs-dynamics: the rasterizer behind
+ * `diff_gaussian_rasterization.GaussianRasterizer / GaussianRasterizationSettings`.  In the reference
+ * that package is an un-vendored third-party CUDA extension (/root/reference/README.md:28-32) whose
+ * native binding exposes three functions to its own Python wrapper -- `rasterize_gaussians`,
+ * `rasterize_gaussians_backward`, `mark_visible` -- none of which is visible to any reference caller.
+ * The reference-visible contract is the Python API used at
+ *     /root/reference/src/tracking/helpers.py:20-32      (settings record, 11 fields)
+ *     /root/reference/src/tracking/train_utils.py:174-192 (forward + autograd backward, twice per step)
+ *     /root/reference/src/render/renderer.py:18-23       (forward only, no_grad)
+ * The entry points below are what a ctypes / pybind binding for that package binds instead
+ * (see INTEGRATION.md); plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *   - every `const float*` / `void*` data pointer is a DEVICE pointer unless the name ends in _host;
+ *   - all float tensors are fp32, row-major, contiguous; radii is int32; images are CHW;
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream); all work is enqueued on it;
+ *   - functions return 0 on success, non-zero on error (message via gsr_last_error());
+ *   - no global state, no hidden allocations: the caller owns every buffer (sizes from gsr_*_bytes).
+ */
+#ifndef GSR_H_
+#define GSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
+
+/* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
+ * bg / viewmatrix / projmatrix / campos stay device tensors exactly as the reference passes them
+ * (viewmatrix = w2c transposed, [1,4,4] or [4,4]: 16 contiguous floats). */
+typedef struct gsr_settings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  int32_t sh_degree;   /* active SH degree (0..3) */
+  int32_t sh_coeffs;   /* M: coefficients per Gaussian in `shs` ([P,M,3]); 0 when colors_precomp is used */
+  int32_t prefiltered; /* accepted for API parity; reference call sites always pass False */
+  const float* bg;         /* [3]  device */
+  const float* viewmatrix; /* [16] device */
+  const float* projmatrix; /* [16] device */
+  const float* campos;     /* [3]  device */
+} gsr_settings;
+
+/* ---- buffer sizes (bytes).  The three opaque state buffers play the role of the reference
+ * extension's geomBuffer / binningBuffer / imgBuffer, but are sized by the caller up front. */
+size_t gsr_geom_bytes(int32_t P);
+size_t gsr_image_bytes(int32_t image_height, int32_t image_width);
+size_t gsr_binning_bytes(uint32_t num_rendered, int32_t image_height, int32_t image_width);
+size_t gsr_backward_scratch_bytes(int32_t P, uint32_t num_rendered);
+
+/* ---- forward, stage 1  (replaces the first half of `rasterize_gaussians`: preprocess + offsets scan)
+ * Per Gaussian: frustum cull, projection, 3D->2D covariance, conic, radius, tile rect, colour
+ * (colors_precomp or SH->RGB).  Writes radii[P] and the geometry state, and returns the number of
+ * (Gaussian,tile) duplicates in *num_rendered_host (this call synchronises `stream` once to do so).
+ * Exactly one of {colors_precomp, shs} and exactly one of {scales+rotations, cov3D_precomp} non-NULL. */
+int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                           const float* rotations, const float* opacities, const float* colors_precomp,
+                           const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
+                           uint32_t* num_rendered_host, void* stream);
+
+/* ---- forward, stage 2  (replaces the second half of `rasterize_gaussians`: duplicateWithKeys,
+ * sort, identifyTileRanges, render).  out_color[3,H,W], out_depth[1,H,W].  `binning_state` must hold
+ * gsr_binning_bytes(num_rendered,...) bytes, `image_state` gsr_image_bytes(...). */
+int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state,
+                       void* binning_state, void* image_state, float* out_color, float* out_depth,
+                       void* stream);
+
+/* ---- backward  (replaces `rasterize_gaussians_backward`).
+ * dL_dcolor[3,H,W] in; gradients out (every output is fully written, no pre-zeroing needed):
+ *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y = dL/d(NDC), z = 0) dL_dcolors[P,3] dL_dopacity[P]
+ *   dL_dscales[P,3] dL_drotations[P,4] dL_dcov3D[P,6] dL_dsh[P,M,3]
+ * Pointers for unused outputs (dL_dsh without shs; dL_dcolors with shs) may be NULL.
+ * Incoming gradients for radii and depth do not exist in this ABI: they are ignored by contract
+ * (no reference call site differentiates them, /root/reference/src/tracking/train_utils.py:178,192). */
+int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,
+                 const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                 const float* cov3D_precomp, const int32_t* radii, const void* geom_state,
+                 const void* binning_state, const void* image_state, const float* dL_dcolor, void* scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dsh, void* stream);
+
+/* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
+int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);
+
+/* ---- introspection for tests / benches (copies of internal state, device -> caller's DEVICE buffers) */
+typedef struct gsr_debug_views {
+  const float* recA;          /* [P,4] mean2D.x, mean2D.y, conic A, conic B */
+  const float* recB;          /* [P,4] conic C, opacity, r, g */
+  const float* recC;          /* [P,2] b, depth */
+  const uint32_t* rect;       /* [P,2] minx|miny<<16, maxx|maxy<<16 */
+  const uint32_t* tiles_touched; /* [P] */
+  const uint32_t* offsets;    /* [P+1] exclusive prefix of tiles_touched */
+  const uint32_t* point_list; /* [D] sorted Gaussian ids   (binning state) */
+  const uint32_t* ranges;     /* [T,2]                      (image state)   */
+  const float* final_T;       /* [H*W] */
+  const uint32_t* n_contrib;  /* [H*W] */
+} gsr_debug_views;
+int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t image_height, int32_t image_width,
+                        const void* geom_state, const void* binning_state, const void* image_state,
+                        gsr_debug_views* out);
+
+/* Device self-test of the wave-64 building blocks (DPP reduction, ballot match, scan, sorts).
+ * Returns 0 when all pass, else a bitmask of failed checks. */
+int gsr_selftest(void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * gsr_profile_begin() arms it; every kernel launched by gsr_* calls after that is bracketed by two events;
+ * gsr_profile_end() waits for them and returns one (name, total ms, launches) row per kernel name.
+ * Not thread-safe; off by default (no events exist in normal operation). */
+typedef struct gsr_kernel_time {
+  char name[32];
+  double total_ms;
+  int64_t launches;
+} gsr_kernel_time;
+int gsr_profile_begin(void);
+int gsr_profile_end(gsr_kernel_time* out, int32_t max_entries, int32_t* n_out);
+
+const char* gsr_last_error(void);
+int gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_ */

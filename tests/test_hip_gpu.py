@@ -1,0 +1,302 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the drop-in API and
+hence through the C-ABI, against the CPU oracle on the same seeded inputs and the committed goldens.
+
+Bars (DESIGN.md section 'Parity'):
+  * integers -- radii, tile lists (point_list), tile ranges: bit-exact;
+  * n_contrib: exact on pixels the oracle does not flag as threshold-ambiguous;
+  * colour / depth / final_T: |a-b| <= 1e-4 * (|b| + max|b|*1e-4 ...) on non-ambiguous pixels (mixed_err);
+  * gradients: max|a-b| <= 1e-4 * max|b| per tensor (rel_err; sums with cancellation).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import mixed_err, oracle_camera, random_gaussians, rel_err, ring_camera
+from oracle import OracleCamera, TiledOracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _settings(cam: OracleCamera, dev, sh_degree=None):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)  # noqa: E731
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=t(cam.bg), scale_modifier=cam.scale_modifier, viewmatrix=t(cam.viewmatrix).reshape(1, 4, 4),
+        projmatrix=t(cam.projmatrix).reshape(1, 4, 4), sh_degree=cam.sh_degree if sh_degree is None else sh_degree,
+        campos=t(cam.campos), prefiltered=False)
+
+
+def _run_hip(cam, g, dev, dL=None, want_state=False):
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip
+    t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+    means2D = torch.zeros((g["means3D"].shape[0], 3), device=dev, requires_grad=True)
+    rs = _settings(cam, dev)
+    state = {}
+    if want_state:
+        orig = _hip.rasterize_forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            state["s"] = out[3]
+            return out
+        _hip.rasterize_forward = spy
+    try:
+        color, radii, depth = GaussianRasterizer(raster_settings=rs)(
+            means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t.get("shs"),
+            colors_precomp=t.get("colors_precomp"), scales=t.get("scales"), rotations=t.get("rotations"),
+            cov3D_precomp=t.get("cov3D_precomp"))
+    finally:
+        if want_state:
+            _hip.rasterize_forward = orig
+    views = _hip.debug_views(state["s"]) if want_state else None
+    grads = None
+    if dL is not None:
+        (color * torch.tensor(dL, device=dev)).sum().backward()
+        grads = {k: v.grad.detach().cpu().numpy() for k, v in t.items() if v.grad is not None}
+        grads["means2D"] = means2D.grad.detach().cpu().numpy()
+    torch.cuda.synchronize()
+    return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), grads, views
+
+
+def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True):
+    H, W = cam.image_height, cam.image_width
+    dL = np.random.default_rng(seed).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
+    o2 = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g.get("colors_precomp"), shs=g.get("shs"),
+                     scales=g.get("scales"), rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"),
+                     nthreads=nthreads)
+    ok = ~o2.ambiguous
+    assert ok.mean() > 0.995, "too many threshold-ambiguous pixels for a meaningful comparison"
+    assert np.array_equal(radii, o2.radii), "radii differ"
+    if check_lists:
+        assert int(views["offsets"][-1]) == o2.num_rendered
+        assert np.array_equal(views["tiles_touched"].cpu().numpy().astype(np.uint32), o2.tiles_touched)
+        assert np.array_equal(views["point_list"].cpu().numpy().astype(np.uint32), o2.point_list), "tile lists differ"
+        assert np.array_equal(views["ranges"].cpu().numpy().astype(np.uint32), o2.ranges), "tile ranges differ"
+        assert np.array_equal(views["n_contrib"].cpu().numpy().astype(np.uint32)[ok], o2.n_contrib[ok])
+        assert mixed_err(views["final_T"].cpu().numpy()[ok], o2.final_T[ok]) < TOL
+    assert mixed_err(color[:, ok], o2.color[:, ok]) < TOL, "colour"
+    assert mixed_err(depth[:, ok], o2.depth[:, ok]) < TOL, "depth"
+    gr = o2.backward(dL)
+    for k, v in grads.items():
+        ref = gr["colors_precomp" if k == "colors_precomp" else k]
+        e = rel_err(v, ref)
+        assert e < TOL, f"grad {k}: rel err {e:.3e}"
+    return o2
+
+
+def test_device_selftest(dev):
+    from diff_gaussian_rasterization import _hip
+    assert _hip.selftest(dev) == 0
+
+
+def test_committed_goldens(dev, golden_dir):
+    z = np.load(os.path.join(golden_dir, "raster_cases.npz"))
+    for n in [str(x) for x in z["names"]]:
+        v = z[f"{n}/cam"]
+        cam = OracleCamera(int(v[0]), int(v[1]), float(v[2]), float(v[3]), v[4:7].astype(np.float32), 1.0,
+                           v[7:23].astype(np.float32), v[23:39].astype(np.float32), 0, v[39:42].astype(np.float32))
+        g = {k: z[f"{n}/in_{k}"] for k in ("means3D", "scales", "rotations", "opacities", "colors_precomp")}
+        color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=z[f"{n}/dL_dcolor"], want_state=True)
+        ok = ~z[f"{n}/ambiguous"]
+        assert np.array_equal(radii, z[f"{n}/radii"]), n
+        assert np.array_equal(views["point_list"].cpu().numpy().astype(np.uint32), z[f"{n}/point_list"]), n
+        assert np.array_equal(views["ranges"].cpu().numpy().astype(np.uint32), z[f"{n}/ranges"]), n
+        assert np.array_equal(views["n_contrib"].cpu().numpy().astype(np.uint32)[ok], z[f"{n}/n_contrib"][ok]), n
+        assert mixed_err(color[:, ok], z[f"{n}/color"][:, ok]) < TOL, n
+        assert mixed_err(depth[:, ok], z[f"{n}/depth"][:, ok]) < TOL, n
+        for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"):
+            assert rel_err(grads[k], z[f"{n}/grad_{k}"]) < TOL, (n, k)
+
+
+@pytest.mark.parametrize("P,W,H,seed", [(1, 16, 16, 1), (37, 33, 17, 2), (700, 130, 94, 3), (5000, 256, 192, 4)])
+def test_random_scenes_vs_oracle(dev, P, W, H, seed):
+    g = random_gaussians(P, seed=seed, scale_lo=0.02, scale_hi=0.25)
+    _check_against_oracle(ring_camera(W, H, v=seed, bg=(0.1, 0.3, 0.5)), g, dev, seed=seed)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colours_vs_oracle(dev, deg):
+    g = random_gaussians(400, seed=10 + deg, scale_lo=0.03, scale_hi=0.3, sh_M=16)
+    del g["colors_precomp"]
+    _check_against_oracle(ring_camera(96, 80, v=deg, sh_degree=deg), g, dev, seed=deg)
+
+
+def test_cov3d_precomp_vs_oracle(dev):
+    g = random_gaussians(300, seed=21, scale_lo=0.03, scale_hi=0.3)
+    cam = ring_camera(80, 64)
+    probe = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"],
+                        rotations=g["rotations"])
+    g2 = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=g["colors_precomp"], cov3D_precomp=probe.cov3D)
+    _check_against_oracle(cam, g2, dev, seed=5)
+
+
+def test_huge_tile_lists_take_the_global_sort_path(dev):
+    """> 4096 entries per tile: the per-tile sort leaves LDS and runs its network in global memory."""
+    P = 6000
+    g = random_gaussians(P, seed=33, scale_lo=0.5, scale_hi=0.9, spread=0.5)
+    g["opacities"][:] = 0.004  # nearly transparent: nothing terminates early, every entry matters
+    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6)
+    assert (o2.ranges[:, 1] - o2.ranges[:, 0]).max() > 4096
+
+
+def test_early_termination_dense_scene(dev):
+    g = random_gaussians(3000, seed=34, scale_lo=0.1, scale_hi=0.5, spread=0.6)
+    g["opacities"][:] = 0.95
+    _check_against_oracle(ring_camera(120, 88, bg=(1, 1, 1)), g, dev, seed=7)
+
+
+def test_edge_cases(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cam = ring_camera(40, 24, bg=(0.3, 0.6, 0.9))
+    rs = _settings(cam, dev)
+    # P = 0
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    color, radii, depth = GaussianRasterizer(raster_settings=rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1),
+                                                                 colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, 24, 40) and radii.numel() == 0
+    # everything culled (behind the camera): background only, zero gradients, zero depth
+    g = random_gaussians(50, seed=1)
+    g["means3D"] = (g["means3D"] * 0.1 + np.array([40.0, 8.0, 12.0], np.float32)).astype(np.float32)  # behind the ring camera
+    color, radii, depth, grads, _ = _run_hip(cam, g, dev, dL=np.ones((3, 24, 40), np.float32))
+    assert np.all(radii == 0) and np.all(depth == 0)
+    np.testing.assert_allclose(color[:, 5, 7], [0.3, 0.6, 0.9], atol=1e-6)
+    assert all(np.all(v == 0) for v in grads.values())
+    # argument validation (same exceptions as the reference extension's Python wrapper)
+    r = GaussianRasterizer(raster_settings=rs)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=z(3, 3), means2D=z(3, 3), opacities=z(3, 1), scales=z(3, 3), rotations=z(3, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=z(3, 3), means2D=z(3, 3), opacities=z(3, 1), colors_precomp=z(3, 3))
+
+
+def test_mark_visible(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle.tiled import mark_visible
+    cam = ring_camera(32, 32)
+    pts = np.random.default_rng(0).uniform(-6, 6, (1000, 3)).astype(np.float32)
+    got = GaussianRasterizer(raster_settings=_settings(cam, dev)).markVisible(torch.tensor(pts, device=dev))
+    assert np.array_equal(got.cpu().numpy(), mark_visible(cam.viewmatrix, pts))
+
+
+def test_reference_call_pattern_get_loss(dev):
+    """The literal call sequence of /root/reference/src/tracking/train_utils.py:174-192, 243-245 and
+    /root/reference/src/tracking/external.py:138-142 runs against the HIP backend."""
+    from gsdyn import get_loss, LossWeights, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    W, H, P = 160, 128, 3000
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, W, H, device=dev)[0]
+    im, seg = synth_targets(W, H, device=dev)
+    variables = init_variables(P, dev)
+    loss, variables = get_loss(params, dict(cam=cam, im=im, seg=seg, id=0), variables, True, LossWeights())
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "seg_colors", "cam_m", "cam_c"):
+        assert params[k].grad is not None and torch.isfinite(params[k].grad).all(), k
+    g2 = variables["means2D"].grad
+    assert g2.shape == (P, 3) and torch.all(g2[:, 2] == 0)
+    seen = variables["seen"]
+    accum = torch.norm(g2[seen, :2], dim=-1)
+    assert seen.any() and torch.isfinite(accum).all()
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+@pytest.fixture(scope="module")
+def full_scene(dev):
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H = 100_000, 800, 800
+    params = synth_scene_params(P, device=dev)
+    cams = synth_ring_cameras(4, W, H, device=dev)
+    return params, cams, params2rendervar
+
+
+def test_full_size_matches_oracle_one_view(dev, full_scene):
+    """BASELINE config 3 sizes (100k Gaussians, 800x800), view 0, against the (threaded) oracle."""
+    params, cams, p2r = full_scene
+    with torch.no_grad():
+        rv = {k: v.detach().cpu().numpy() for k, v in p2r(params).items()}
+    cam = cams[0]
+    ocam = OracleCamera(800, 800, cam.tanfovx, cam.tanfovy, cam.bg.cpu().numpy(), 1.0,
+                        cam.viewmatrix.cpu().numpy().reshape(-1), cam.projmatrix.cpu().numpy().reshape(-1), 0,
+                        cam.campos.cpu().numpy())
+    g = dict(means3D=rv["means3D"], scales=rv["scales"], rotations=rv["rotations"], opacities=rv["opacities"],
+             colors_precomp=rv["colors_precomp"])
+    o2 = _check_against_oracle(ocam, g, dev, seed=11, nthreads=os.cpu_count() or 8)
+    print("num_rendered", o2.num_rendered, "ambiguous px", int(o2.ambiguous.sum()))
+
+
+def test_full_size_properties(dev, full_scene):
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip
+    params, cams, p2r = full_scene
+    W = H = 800
+    dL = torch.tensor(np.random.default_rng(5).uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev)
+
+    def run(cam, scale=1.0, colors=None, bg=None):
+        rv = p2r(params)
+        rv = {k: v.detach().requires_grad_(True) for k, v in rv.items()}
+        if colors is not None:
+            rv["colors_precomp"] = colors
+        if bg is not None:
+            cam = cam._replace(bg=torch.tensor(bg, device=dev, dtype=torch.float32))
+        im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
+        (im * (dL * scale)).sum().backward()
+        return im.detach(), radii, depth.detach(), {k: v.grad for k, v in rv.items() if v.grad is not None}
+
+    im1, rad1, dep1, g1 = run(cams[1])
+    im2, rad2, dep2, g2 = run(cams[1])
+    # determinism: no atomics anywhere -> bit-identical reruns
+    assert torch.equal(im1, im2) and torch.equal(dep1, dep2) and torch.equal(rad1, rad2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    # linearity of the backward in the incoming gradient (exact for a power-of-two scale)
+    _, _, _, g4 = run(cams[1], scale=4.0)
+    for k in g1:
+        assert torch.equal(g1[k] * 4.0, g4[k]), k
+    # partition of unity: colours == 1 and background == 1  =>  every pixel renders 1
+    ones = torch.ones_like(params["rgb_colors"])
+    im_one, _, _, _ = run(cams[2], colors=ones, bg=(1.0, 1.0, 1.0))
+    assert (im_one - 1.0).abs().max().item() < 2e-5
+    # sortedness / partition of the tile lists
+    rv = p2r(params)
+    orig = _hip.rasterize_forward
+    st = {}
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        st["s"] = out[3]
+        return out
+    _hip.rasterize_forward = spy
+    try:
+        with torch.no_grad():
+            GaussianRasterizer(raster_settings=cams[3])(**rv)
+    finally:
+        _hip.rasterize_forward = orig
+    v = _hip.debug_views(st["s"])
+    ranges, pl, depth_g = v["ranges"].long(), v["point_list"].long(), v["recC"][:, 1]
+    D = st["s"].num_rendered
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == D and int(v["offsets"][-1]) == D
+    nz = lens > 0
+    starts = ranges[nz, 0].sort().values
+    assert starts[0] == 0 and torch.equal(starts[1:], (ranges[nz, 1].sort().values)[:-1])
+    tile_of = torch.repeat_interleave(torch.arange(ranges.shape[0], device=dev), lens.clamp(min=0))
+    order = torch.argsort(ranges[:, 0].masked_fill(~nz, 2 ** 40), stable=True)
+    tile_sorted = torch.repeat_interleave(order[: int(nz.sum())], lens[order[: int(nz.sum())]])
+    d = depth_g[pl]
+    same = tile_sorted[1:] == tile_sorted[:-1]
+    assert torch.all((d[1:] >= d[:-1]) | ~same), "per-tile depth order violated"
+    tie = same & (d[1:] == d[:-1])
+    assert torch.all((pl[1:] > pl[:-1]) | ~tie), "depth ties must keep ascending Gaussian index"
+    del tile_of
