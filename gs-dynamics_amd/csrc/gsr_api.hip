@@ -88,7 +88,8 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
   if (int rc = gsr_launch_preprocess(cam, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
                                      g, radii, st))
     return rc;
-  if (int rc = gsr_launch_scan_exclusive(g.tiles_touched, g.offsets, (uint32_t)P, g.counters, st)) return rc;
+  const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
+  if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
   uint32_t D = 0;
   GSR_HIP_CHECK(hipMemcpyAsync(&D, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   GSR_HIP_CHECK(hipStreamSynchronize(st));

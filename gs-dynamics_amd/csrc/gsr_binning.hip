@@ -18,8 +18,9 @@
 //                       (depth_bits << 32 | gaussian_id) with a compare-exchange network in LDS
 //                       (global-memory network for segments above the LDS capacity).  Because the key is
 //                       unique and includes the Gaussian id, the result is exactly the stable-sort order.
-// HBM traffic: emit 12 B/entry written; each radix pass 12 B read (hist) + 12 B read + 12 B written
-// (scatter); tile_sort 8 B read + 4 B written per entry.
+// HBM traffic: emit 12 B/entry written; each radix pass 4 B read (hist) + 12 B read + 12 B written
+// (scatter) per entry; tile_sort 8 B read + 4 B written per entry.
+// Launches per view: emit, 2 x (hist, scatter), ranges, tile_sort = 7 (no scan kernels in the sort).
 #include "gsr_common.h"
 
 namespace {
@@ -79,23 +80,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
 }
 
 // ------------------------------------------------------------------ emit (duplicateWithKeys)
+// Block b owns Gaussians [256b, 256b+256).  Its first entry offset comes from the scan of the preprocess
+// block sums; the per-Gaussian offsets inside the block are scanned here in LDS and written out once
+// (offsets[] is what render_bwd / preprocess_bwd use to address the Gaussian-major partial records).
 __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float2* __restrict__ recC,
                                                                  const uint2* __restrict__ rect,
-                                                                 const uint32_t* __restrict__ offsets,
+                                                                 const uint32_t* __restrict__ tiles_touched,
+                                                                 const uint32_t* __restrict__ block_offsets,
+                                                                 uint32_t* __restrict__ offsets,
                                                                  uint32_t* __restrict__ tkey,
                                                                  uint64_t* __restrict__ dg) {
   __shared__ uint32_t soff[GSR_BLOCK + 1];
-  const int tid = threadIdx.x;
+  __shared__ uint32_t swave[GSR_BLOCK / GSR_WAVE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = blockIdx.x * GSR_BLOCK;
-  soff[tid] = offsets[min(g0 + tid, P)];
-  if (tid == 0) soff[GSR_BLOCK] = offsets[min(g0 + GSR_BLOCK, P)];
+  const uint32_t mine = (g0 + tid < P) ? tiles_touched[g0 + tid] : 0u;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) swave[wv] = inc;
+  __syncthreads();
+  uint32_t base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wv; ++w) base += swave[w];
+  const uint32_t excl = base + inc - mine;
+  soff[tid] = excl;
+  if (tid == GSR_BLOCK - 1) soff[GSR_BLOCK] = excl + mine;
+  if (g0 + tid < P) offsets[g0 + tid] = excl;
+  if (g0 + tid == P - 1) offsets[P] = excl + mine;
   __syncthreads();
   const uint32_t begin = soff[0], end = soff[GSR_BLOCK];
   for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
     int lo = 0, hi = GSR_BLOCK;  // invariant: soff[lo] <= e < soff[hi]
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      int mid = (lo + hi) >> 1;
+      const int mid = (lo + hi) >> 1;
       if (soff[mid] <= e) lo = mid; else hi = mid;
     }
     const int g = g0 + lo;
@@ -120,7 +141,7 @@ __device__ __forceinline__ uint64_t match_peers(uint32_t digit, bool valid, int 
   return peers;
 }
 
-// Per-block digit histogram, written bin-major: block_hist[bin * nblocks + block].
+// Per-block digit histogram, block-major: block_hist[block * nbins + bin] (a coalesced row per block).
 __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
                                                                int shift, int bits, uint32_t nblocks,
                                                                uint32_t* __restrict__ block_hist) {
@@ -133,22 +154,60 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* _
   const uint32_t stop = min(D, start + GSR_RADIX_EPB);
   for (uint32_t i = start + tid; i < stop; i += GSR_BLOCK) atomicAdd(&hist[(tkey[i] >> shift) & mask], 1u);
   __syncthreads();
-  if (tid < (1 << bits)) block_hist[(uint32_t)tid * nblocks + blockIdx.x] = hist[tid];
+  if (tid < (1 << bits)) block_hist[blockIdx.x * (uint32_t)(1 << bits) + tid] = hist[tid];
 }
 
-// Stable scatter.  Wave w of the block owns the w-th quarter of the block's chunk and walks it in order,
-// 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
+// Stable scatter.  No separate scan launch: every block derives its own bases from the histogram matrix
+// (nblocks x nbins, L2-resident): base(bin) = sum of all counts of lower bins + counts of this bin in
+// earlier blocks.  Then wave w of the block owns the w-th quarter of the block's chunk and walks it in
+// order, 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
 __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     const uint32_t* __restrict__ tkey_in, const uint64_t* __restrict__ dg_in, uint32_t* __restrict__ tkey_out,
     uint64_t* __restrict__ dg_out, uint32_t D, int shift, int bits, uint32_t nblocks,
-    const uint32_t* __restrict__ block_base) {
+    const uint32_t* __restrict__ block_hist) {
   __shared__ uint32_t wcount[4][256];
+  __shared__ uint32_t s_tot[4][256];   // per-wave partial: total count of each bin over all blocks
+  __shared__ uint32_t s_pre[4][256];   // per-wave partial: count of each bin in blocks before this one
+  __shared__ uint32_t s_binbase[256];
   volatile uint32_t(*wbase)[256] = wcount;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t mask = (1u << bits) - 1u;
   const int nb = 1 << bits;
   for (int i = tid; i < 4 * 256; i += GSR_BLOCK) (&wcount[0][0])[i] = 0;
+  // column sums of the histogram matrix: wave w takes blocks w, w+4, ...; lane l takes bins l, l+64, ...
+  for (int bin = lane; bin < nb; bin += 64) {
+    uint32_t tot = 0, pre = 0;
+    for (uint32_t b = wv; b < nblocks; b += 4) {
+      const uint32_t v = block_hist[b * (uint32_t)nb + bin];
+      tot += v;
+      pre += (b < blockIdx.x) ? v : 0u;
+    }
+    s_tot[wv][bin] = tot;
+    s_pre[wv][bin] = pre;
+  }
   __syncthreads();
+  if (wv == 0) {  // exclusive scan over the bin totals: lane l owns bins 4l .. 4l+3
+    uint32_t t4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bin = lane * 4 + q;
+      t4[q] = bin < nb ? (s_tot[0][bin] + s_tot[1][bin] + s_tot[2][bin] + s_tot[3][bin]) : 0u;
+      sum += t4[q];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bin = lane * 4 + q;
+      if (bin < nb) s_binbase[bin] = run;
+      run += t4[q];
+    }
+  }
   const uint32_t chunk0 = blockIdx.x * GSR_RADIX_EPB;
   const uint32_t per_wave = GSR_RADIX_EPB / 4;
   const uint32_t wstart = chunk0 + wv * per_wave;
@@ -158,10 +217,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
   __syncthreads();
   // B: wave bases = global base of (bin, block) + counts of earlier waves
   if (tid < nb) {
-    uint32_t base = block_base[(uint32_t)tid * nblocks + blockIdx.x];
+    uint32_t base = s_binbase[tid] + s_pre[0][tid] + s_pre[1][tid] + s_pre[2][tid] + s_pre[3][tid];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      uint32_t c = wcount[w][tid];
+      const uint32_t c = wcount[w][tid];
       wcount[w][tid] = base;
       base += c;
     }
@@ -275,7 +334,7 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
   if (D == 0 || P <= 0) return 0;
   { GSR_PROF("emit_entries", st);
   hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
-                     g.recC, g.rect, g.offsets, bs.tkey[0], bs.dg[0]); }
+                     g.recC, g.rect, g.tiles_touched, g.block_offsets, g.offsets, bs.tkey[0], bs.dg[0]); }
   GSR_HIP_CHECK(hipGetLastError());
   const int tbits = ceil_log2_u32((uint32_t)cam.T);
   const int npass = (tbits + 7) / 8;
@@ -289,11 +348,9 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
   hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D, shift, bits, nblocks,
                        bs.block_hist); }
     GSR_HIP_CHECK(hipGetLastError());
-    int rc = gsr_launch_scan_exclusive(bs.block_hist, bs.block_base, (uint32_t)(1u << bits) * nblocks, nullptr, st);
-    if (rc) return rc;
     { GSR_PROF("radix_scatter", st);
   hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], bs.dg[cur],
-                       bs.tkey[cur ^ 1], bs.dg[cur ^ 1], D, shift, bits, nblocks, bs.block_base); }
+                       bs.tkey[cur ^ 1], bs.dg[cur ^ 1], D, shift, bits, nblocks, bs.block_hist); }
     GSR_HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }

@@ -25,7 +25,9 @@ struct GeomState {
   float2* recC;
   uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
   uint32_t* tiles_touched;
-  uint32_t* offsets;      // [P+1]
+  uint32_t* offsets;      // [P+1] exclusive prefix of tiles_touched (written by emit_entries)
+  uint32_t* block_sums;   // [ceil(P/256)] per-preprocess-block totals of tiles_touched
+  uint32_t* block_offsets;// [ceil(P/256)+1] their exclusive scan
   uint32_t* clamped;      // [P] bit ch set when SH colour channel was clamped at 0
   uint32_t* counters;     // [0] = num_rendered
 };
@@ -39,8 +41,7 @@ struct BinningState {
   uint32_t* tkey[2];      // [D] tile id of each duplicate
   uint64_t* dg[2];        // [D] depth_bits << 32 | gaussian id
   uint32_t* point_list;   // [D] final per-tile depth-sorted Gaussian ids
-  uint32_t* block_hist;   // [256 * nblocks] radix block histograms (bin-major)
-  uint32_t* block_base;   // [256 * nblocks + 1] their exclusive scan
+  uint32_t* block_hist;   // [nblocks * 256] radix block histograms (block-major: hist[block][bin])
 };
 
 static inline __host__ __device__ size_t gsr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -60,6 +61,9 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->rect = (uint2*)take(Pn * 8);
   g->tiles_touched = (uint32_t*)take(Pn * 4);
   g->offsets = (uint32_t*)take((Pn + 1) * 4);
+  const size_t nblk = (Pn + GSR_BLOCK - 1) / GSR_BLOCK;
+  g->block_sums = (uint32_t*)take(nblk * 4);
+  g->block_offsets = (uint32_t*)take((nblk + 1) * 4);
   g->clamped = (uint32_t*)take(Pn * 4);
   g->counters = (uint32_t*)take(64);
   return off;
@@ -85,7 +89,6 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
   bs->dg[1] = (uint64_t*)take(Dn * 8);
   bs->point_list = (uint32_t*)take(Dn * 4);
   bs->block_hist = (uint32_t*)take(256 * nb * 4);
-  bs->block_base = (uint32_t*)take((256 * nb + 1) * 4);
   return off;
 }
 

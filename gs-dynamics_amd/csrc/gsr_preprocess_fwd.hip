@@ -63,9 +63,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ recA,
     float4* __restrict__ recB, float2* __restrict__ recC, uint2* __restrict__ rect,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii) {
-  int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  if (i >= P) return;
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii,
+    uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  const bool in_range = i < P;
   // defaults for a culled Gaussian
   int32_t radius_i = 0;
   uint32_t tiles = 0;
@@ -74,11 +76,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   float2 c2 = make_float2(0.f, 0.f);
   uint32_t clamp_bits = 0;
 
-  float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+  float3 p = make_float3(0.f, 0.f, 0.f);
+  if (in_range) p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
   float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
   float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
   float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
-  if (pvz > GSR_NEAR_Z) {
+  if (in_range && pvz > GSR_NEAR_Z) {
     float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
     float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
     float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
@@ -154,11 +157,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
       }
     }
   }
-  recA[i] = a4; recB[i] = b4; recC[i] = c2;
-  rect[i] = rc;
-  tiles_touched[i] = tiles;
-  clamped_out[i] = clamp_bits;
-  radii[i] = radius_i;
+  if (in_range) {
+    recA[i] = a4; recB[i] = b4; recC[i] = c2;
+    rect[i] = rc;
+    tiles_touched[i] = tiles;
+    clamped_out[i] = clamp_bits;
+    radii[i] = radius_i;
+  }
+  // per-block total of tiles_touched: feeds the two-level offsets scan (no full-length scan kernel)
+  uint32_t wsum = tiles;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m, 64);
+  if ((threadIdx.x & 63) == 0) s_wave_sum[threadIdx.x >> 6] = wsum;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float* __restrict__ view,
@@ -182,7 +194,7 @@ int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const 
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
                      cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
                      cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.recA,
-                     g.recB, g.recC, g.rect, g.tiles_touched, g.clamped, radii); }
+                     g.recB, g.recC, g.rect, g.tiles_touched, g.clamped, radii, g.block_sums); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
