@@ -173,6 +173,18 @@ __device__ __forceinline__ float gsr_wave_sum_to_lane63(float v) {
   v = gsr_dpp_add<0x143, 0xC>(v);
   return v;
 }
+// exp(x) for x <= 0 to ~1-2 ulp: v_exp_f32 on a compensated x*log2(e).  The plain `__expf` form rounds
+// x*log2e once (relative error |x| * 6e-8 in the result); alpha feeds T/(1-alpha) in the backward,
+// which amplifies alpha's error by up to 100x near the 0.99 clamp, so the extra 4 VALU ops buy parity.
+__device__ __forceinline__ float gsr_exp(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;     // fp32(log2 e)
+  const float L2E_LO = 1.925963033500817e-08f;         // log2 e - L2E_HI
+  const float th = x * L2E_HI;
+  float tl = __builtin_fmaf(x, L2E_HI, -th);           // rounding error of the product, exact
+  tl = __builtin_fmaf(x, L2E_LO, tl);
+  const float e = __builtin_amdgcn_exp2f(th);
+  return __builtin_fmaf(e, tl * 0.693147182464599609375f, e);  // e * 2^tl, |tl| <= 1e-5
+}
 // Reference (slow, LDS-crossbar) version used by the self-test.
 __device__ __forceinline__ float gsr_wave_sum_shfl(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_kernel(
         const float2 c = sC[j];
         const float dx = a.x - pxf, dy = a.y - pyf;
         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float alpha = fminf(GSR_ALPHA_MAX, b.y * __expf(power));
+        const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
         const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;
         const float test_T = T * (1.0f - alpha);
         if (hit) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_kernel(
       const float blue = sBlue[j];
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float G = __expf(power);
+      const float G = gsr_exp(power);
       const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
       const bool hit = (k < last) && power <= 0.0f && alpha >= GSR_ALPHA_MIN;
       if (__ballot(hit) == 0ull) continue;  // wave-uniform: nothing to add for this entry

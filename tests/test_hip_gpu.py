@@ -69,19 +69,28 @@ def _run_hip(cam, g, dev, dL=None, want_state=False):
     return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), grads, views
 
 
-def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True):
+def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min_ok=0.995):
+    """Forward + backward of the HIP path vs oracle O2 on the same inputs.
+
+    Pixels where the oracle saw a threshold decision (alpha >= 1/255, T >= 1e-4) within 1e-5 relative of
+    flipping are 'ambiguous': two correct fp32 implementations may legitimately decide differently there,
+    and one flipped pair changes a pixel by up to ~4e-3 * colour.  They are excluded from the image
+    comparison, and the upstream gradient is zeroed on them (for both sides) so they cannot leak into
+    the per-Gaussian gradient comparison through the 1/(1-alpha) amplification."""
     H, W = cam.image_height, cam.image_width
-    dL = np.random.default_rng(seed).uniform(-1, 1, (3, H, W)).astype(np.float32)
-    color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
     o2 = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g.get("colors_precomp"), shs=g.get("shs"),
                      scales=g.get("scales"), rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"),
                      nthreads=nthreads)
     ok = ~o2.ambiguous
-    assert ok.mean() > 0.995, "too many threshold-ambiguous pixels for a meaningful comparison"
+    assert ok.mean() > min_ok, "too many threshold-ambiguous pixels for a meaningful comparison"
+    dL = np.random.default_rng(seed).uniform(-1, 1, (3, H, W)).astype(np.float32)
+    dL[:, ~ok] = 0.0
+    color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
     assert np.array_equal(radii, o2.radii), "radii differ"
     if check_lists:
         assert int(views["offsets"][-1]) == o2.num_rendered
         assert np.array_equal(views["tiles_touched"].cpu().numpy().astype(np.uint32), o2.tiles_touched)
+        assert np.array_equal(views["offsets"].cpu().numpy().astype(np.uint32), o2.offsets)
         assert np.array_equal(views["point_list"].cpu().numpy().astype(np.uint32), o2.point_list), "tile lists differ"
         assert np.array_equal(views["ranges"].cpu().numpy().astype(np.uint32), o2.ranges), "tile ranges differ"
         assert np.array_equal(views["n_contrib"].cpu().numpy().astype(np.uint32)[ok], o2.n_contrib[ok])
@@ -90,8 +99,7 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True):
     assert mixed_err(depth[:, ok], o2.depth[:, ok]) < TOL, "depth"
     gr = o2.backward(dL)
     for k, v in grads.items():
-        ref = gr["colors_precomp" if k == "colors_precomp" else k]
-        e = rel_err(v, ref)
+        e = rel_err(v, gr[k])
         assert e < TOL, f"grad {k}: rel err {e:.3e}"
     return o2
 
@@ -147,7 +155,8 @@ def test_huge_tile_lists_take_the_global_sort_path(dev):
     P = 6000
     g = random_gaussians(P, seed=33, scale_lo=0.5, scale_hi=0.9, spread=0.5)
     g["opacities"][:] = 0.02  # nearly transparent: nothing terminates early, every entry matters
-    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6)
+    # 6000 faint Gaussians x every pixel: a few % of pixels graze the 1/255 threshold within 1e-5 (excluded)
+    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6, min_ok=0.9)
     assert (o2.ranges[:, 1] - o2.ranges[:, 0]).max() > 4096
 
 

@@ -16,12 +16,12 @@ def find(d, pat):
 
 
 def short(name):
-    name = name.split("(")[0]
     for tag in ("render_fwd", "render_bwd", "preprocess_fwd", "preprocess_bwd", "emit_entries", "radix_hist", "radix_scatter",
                 "tile_ranges", "tile_sort", "scan_exclusive", "mark_visible"):
         if tag in name:
             return tag
-    return name[-60:]
+    name = name.replace("void ", "").replace("at::native::", "")
+    return name[:60]
 
 
 def stats(d):
