@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the views of a step are spread over")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,13 +81,28 @@ def main():
     bucket = GradBucket(params)
     num_rendered = []
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+
+    def one_view(cam, dL):
+        rv = params2rendervar(params)
+        im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
+        if not args.forward_only:
+            im.backward(gradient=dL)
+
     def step(record=False):
         bucket.zero()
-        for cam, dL in zip(cams, dLs):
-            rv = params2rendervar(params)
-            im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
-            if not args.forward_only:
-                im.backward(gradient=dL)
+        if streams is None:
+            for cam, dL in zip(cams, dLs):
+                one_view(cam, dL)
+        else:
+            main = torch.cuda.current_stream(dev)
+            for i, (cam, dL) in enumerate(zip(cams, dLs)):
+                st = streams[i % len(streams)]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    one_view(cam, dL)
+            for st in streams:
+                main.wait_stream(st)
         if world > 1 and not args.forward_only:
             bucket.all_reduce()
 

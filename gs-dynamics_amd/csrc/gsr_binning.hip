@@ -259,6 +259,48 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* 
   if (i == D - 1) ranges[t].y = D;
 }
 
+// ------------------------------------------------------------------ LPT work queue
+// Tiles bucketed by list length (8 entries per bucket, 256 buckets), longest first.  The blend kernels'
+// persistent workgroups pop tickets from this order, so heavy tiles start first and the tail of the
+// kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
+// is arbitrary: per-tile results do not depend on it.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int T,
+                                                          uint32_t* __restrict__ tile_order,
+                                                          uint32_t* __restrict__ queue) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t start[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 256) cnt[tid] = 0;
+  if (tid < 8) queue[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const uint2 r = ranges[t];
+    const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
+    atomicAdd(&cnt[bucket], 1u);
+  }
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 256 bucket counts: lane l owns buckets 4l .. 4l+3
+    uint32_t c4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c4[q] = cnt[lane * 4 + q]; sum += c4[q]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { start[lane * 4 + q] = run; run += c4[q]; }
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const uint2 r = ranges[t];
+    const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
+    tile_order[atomicAdd(&start[bucket], 1u)] = (uint32_t)t;
+  }
+}
+
 // ------------------------------------------------------------------ per-tile depth sort
 // Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
 // +inf padding above n never moves and pairs touching it are skipped.
@@ -331,7 +373,12 @@ static int ceil_log2_u32(uint32_t n) {
 int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
                        const ImageState& im, hipStream_t st) {
   GSR_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.T, st));
-  if (D == 0 || P <= 0) return 0;
+  if (D == 0 || P <= 0) {
+    { GSR_PROF("tile_order", st);
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   { GSR_PROF("emit_entries", st);
   hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
                      g.recC, g.rect, g.tiles_touched, g.block_offsets, g.offsets, bs.tkey[0], bs.dg[0]); }
@@ -357,6 +404,9 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
   { GSR_PROF("tile_ranges", st);
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D,
                      im.ranges); }
+  GSR_HIP_CHECK(hipGetLastError());
+  { GSR_PROF("tile_order", st);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
   GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("tile_sort", st);
   hipLaunchKernelGGL(tile_sort_kernel, dim3(cam.T), dim3(GSR_BLOCK), 0, st, im.ranges, bs.dg[cur], bs.point_list); }

@@ -24,6 +24,7 @@ struct GeomState {
   float4* recB;
   float2* recC;
   uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
+  uint2* abox;            // {xmin | xmax<<16, ymin | ymax<<16}: int16 pixel box outside which alpha < 1/255
   uint32_t* tiles_touched;
   uint32_t* offsets;      // [P+1] exclusive prefix of tiles_touched (written by emit_entries)
   uint32_t* block_sums;   // [ceil(P/256)] per-preprocess-block totals of tiles_touched
@@ -35,6 +36,8 @@ struct ImageState {
   float* final_T;         // [H*W]
   uint32_t* n_contrib;    // [H*W]
   uint2* ranges;          // [T]
+  uint32_t* tile_order;   // [T] tile ids sorted by list length, longest first (LPT work queue)
+  uint32_t* queue;        // [8] work-queue heads: [0] render_fwd, [1] render_bwd
 };
 // Binning state: tile-key / (depth,gid) entries, double-buffered for the radix passes.
 struct BinningState {
@@ -59,6 +62,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->recB = (float4*)take(Pn * 16);
   g->recC = (float2*)take(Pn * 8);
   g->rect = (uint2*)take(Pn * 8);
+  g->abox = (uint2*)take(Pn * 8);
   g->tiles_touched = (uint32_t*)take(Pn * 4);
   g->offsets = (uint32_t*)take((Pn + 1) * 4);
   const size_t nblk = (Pn + GSR_BLOCK - 1) / GSR_BLOCK;
@@ -76,6 +80,8 @@ static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageStat
   im->final_T = (float*)take((N ? N : 1) * 4);
   im->n_contrib = (uint32_t*)take((N ? N : 1) * 4);
   im->ranges = (uint2*)take((T ? T : 1) * 8);
+  im->tile_order = (uint32_t*)take((T ? T : 1) * 4);
+  im->queue = (uint32_t*)take(64);
   return off;
 }
 static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs) {

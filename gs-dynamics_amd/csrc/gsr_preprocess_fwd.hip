@@ -62,7 +62,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ recA,
-    float4* __restrict__ recB, float2* __restrict__ recC, uint2* __restrict__ rect,
+    float4* __restrict__ recB, float2* __restrict__ recC, uint2* __restrict__ rect, uint2* __restrict__ abox,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii,
     uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   int32_t radius_i = 0;
   uint32_t tiles = 0;
   uint2 rc = make_uint2(0u, 0u);
+  uint2 box = make_uint2(0x00000001u, 0x00000001u);  // empty: min = 1 > max = 0
   float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
   float2 c2 = make_float2(0.f, 0.f);
   uint32_t clamp_bits = 0;
@@ -151,6 +152,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
         radius_i = (int32_t)radius;
         tiles = (uint32_t)area;
         rc = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
+        // Conservative pixel box of {alpha >= 1/255}: the ellipse d^T Sigma^-1 d <= 2 ln(255 o) has half-extents
+        // sqrt(2 ln(255 o) * Sigma_xx), sqrt(.. * Sigma_yy).  The +0.02 on the log (2 % slack on alpha) and the
+        // outward rounding make it safe against any fp32 difference with the per-pixel evaluation; pixels
+        // outside the box would be skipped by the alpha test anyway, so using it cannot change a result.
+        const float tau2 = 2.0f * (__logf(255.0f * opacities[i]) + 0.02f);
+        if (tau2 > 0.0f) {
+          const float hx = sqrtf(tau2 * a) + 0.01f, hy = sqrtf(tau2 * cc) + 0.01f;
+          const int xmin = max(-32768, min(32767, (int)floorf(px - hx)));
+          const int xmax = max(-32768, min(32767, (int)ceilf(px + hx)));
+          const int ymin = max(-32768, min(32767, (int)floorf(py - hy)));
+          const int ymax = max(-32768, min(32767, (int)ceilf(py + hy)));
+          box = make_uint2(((uint32_t)xmin & 0xffffu) | ((uint32_t)xmax << 16),
+                           ((uint32_t)ymin & 0xffffu) | ((uint32_t)ymax << 16));
+        }
         a4 = make_float4(px, py, cA, cB);
         b4 = make_float4(cC, opacities[i], rgb[0], rgb[1]);
         c2 = make_float2(rgb[2], pvz);
@@ -160,6 +175,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   if (in_range) {
     recA[i] = a4; recB[i] = b4; recC[i] = c2;
     rect[i] = rc;
+    abox[i] = box;
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;
@@ -194,7 +210,7 @@ int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const 
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
                      cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
                      cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.recA,
-                     g.recB, g.recC, g.rect, g.tiles_touched, g.clamped, radii, g.block_sums); }
+                     g.recB, g.recC, g.rect, g.abox, g.tiles_touched, g.clamped, radii, g.block_sums); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
