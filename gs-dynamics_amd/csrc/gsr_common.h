@@ -179,6 +179,36 @@ __device__ __forceinline__ float gsr_wave_sum_to_lane63(float v) {
   v = gsr_dpp_add<0x143, 0xC>(v);
   return v;
 }
+// Nine wave sums at once (the backward's per-entry gradient partials), totals valid in lane 63.
+// Written as ONE stage-major block of 54 fused v_add_f32_dpp: hipcc otherwise SLP-packs the adds into
+// v_pk_add_f32, which blocks the mov_dpp+add fusion (2.5 instructions per step instead of 1), and cannot
+// fuse the row_bcast steps at all.  Stage-major order keeps every DPP read 9 instructions behind the
+// VALU write of its source (the ISA wants >= 2 wait states); the leading s_nop covers the first stage.
+// Rows not enabled by row_mask keep their value because dst == src1.
+#define GSR_DPP9(CTRL)                              \
+  "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"           \
+  "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"           \
+  "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"           \
+  "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"           \
+  "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"           \
+  "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"           \
+  "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"           \
+  "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"           \
+  "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"
+__device__ __forceinline__ void gsr_wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4,
+                                                        float& v5, float& v6, float& v7, float& v8) {
+  asm volatile(
+      "s_nop 1\n\t"
+      GSR_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      GSR_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      GSR_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      GSR_DPP9("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      GSR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      GSR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 0"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+}
+
 // exp(x) for x <= 0 to ~1-2 ulp: v_exp_f32 on a compensated x*log2(e).  The plain `__expf` form rounds
 // x*log2e once (relative error |x| * 6e-8 in the result); alpha feeds T/(1-alpha) in the backward,
 // which amplifies alpha's error by up to 100x near the 0.99 clamp, so the extra 4 VALU ops buy parity.

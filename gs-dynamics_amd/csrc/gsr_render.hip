@@ -38,16 +38,45 @@ namespace {
 
 __device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(v & 0xffffu); }
 
-// Which of the tile's four 16x4 strips can the Gaussian's alpha >= 1/255 box reach?  (bit w = strip w)
-__device__ __forceinline__ uint32_t strip_mask(uint2 box, int tx0, int ty0) {
+// q(d) = A dx^2 + 2 B dx dy + C dy^2 restricted to a vertical (dx fixed) or horizontal (dy fixed) edge,
+// minimised over the edge's extent.
+__device__ __forceinline__ float qmin_on_vertical_edge(float A, float B, float C, float invC, float dx, float dylo, float dyhi) {
+  const float dy = fminf(fmaxf(-B * dx * invC, dylo), dyhi);
+  return A * dx * dx + (2.0f * B * dx + C * dy) * dy;
+}
+__device__ __forceinline__ float qmin_on_horizontal_edge(float A, float B, float C, float invA, float dy, float dxlo, float dxhi) {
+  const float dx = fminf(fmaxf(-B * dy * invA, dxlo), dxhi);
+  return C * dy * dy + (2.0f * B * dy + A * dx) * dx;
+}
+
+// Which of the tile's four 16x4 strips can this Gaussian reach with alpha >= 1/255?  (bit w = strip w)
+// Level 1: the integer pixel box from preprocess.  Level 2, for strips that pass: the exact minimum of the
+// quadratic form over the strip rectangle (0 when the mean is inside, else the least edge minimum -- the
+// form is convex) against 2 ln(255 o) + 0.04.  Both are conservative: a pair they drop fails the alpha
+// test at every pixel of the strip, so results are unchanged.
+__device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC, float opacity, int tx0, int ty0) {
   const int xmin = sext16(box.x), xmax = sext16(box.x >> 16), ymin = sext16(box.y), ymax = sext16(box.y >> 16);
+  if (xmax < tx0 || xmin > tx0 + 15 || xmin > xmax) return 0u;
+  const float mx = a.x, my = a.y, A = a.z, B = a.w, C = conicC;
+  const float tau2 = 2.0f * (__logf(255.0f * opacity) + 0.02f);
+  const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(C);
+  const float dxlo = (float)tx0 - mx, dxhi = (float)(tx0 + 15) - mx;
+  const bool x_inside = dxlo <= 0.0f && dxhi >= 0.0f;
   uint32_t m = 0;
-  if (!(xmax < tx0 || xmin > tx0 + 15)) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int y0 = ty0 + 4 * w;
-      if (!(ymax < y0 || ymin > y0 + 3)) m |= 1u << w;
+  for (int w = 0; w < 4; ++w) {
+    const int y0 = ty0 + 4 * w;
+    if (ymax < y0 || ymin > y0 + 3) continue;
+    const float dylo = (float)y0 - my, dyhi = (float)(y0 + 3) - my;
+    bool keep = x_inside && dylo <= 0.0f && dyhi >= 0.0f;
+    if (!keep) {
+      float q = qmin_on_vertical_edge(A, B, C, invC, dxlo, dylo, dyhi);
+      q = fminf(q, qmin_on_vertical_edge(A, B, C, invC, dxhi, dylo, dyhi));
+      q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dylo, dxlo, dxhi));
+      q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dyhi, dxlo, dxhi));
+      keep = q <= tau2;
     }
+    if (keep) m |= 1u << w;
   }
   return m;
 }
@@ -90,7 +119,7 @@ __device__ __forceinline__ void fwd_tile(
       b = recB[g];
       const float2 c2 = recC[g];
       c = make_float4(c2.x, c2.y, __uint_as_float((uint32_t)(idx + 1)), 0.f);
-      mask = strip_mask(abox[g], tx0, ty0);
+      mask = strip_mask(abox[g], a, b.x, b.y, tx0, ty0);
     }
     uint64_t bal[4];
 #pragma unroll
@@ -220,7 +249,7 @@ __device__ __forceinline__ void bwd_tile(
       a = recA[g];
       b = recB[g];
       c = make_float2(recC[g].x, __uint_as_float((uint32_t)tid));
-      mask = strip_mask(abox[g], tx0, ty0);
+      mask = strip_mask(abox[g], a, b.x, b.y, tx0, ty0);
     }
     uint64_t bal[4];
 #pragma unroll
@@ -282,9 +311,7 @@ __device__ __forceinline__ void bwd_tile(
         v5 = G * dL_dalpha;
         v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;
       }
-      v0 = gsr_wave_sum_to_lane63(v0); v1 = gsr_wave_sum_to_lane63(v1); v2 = gsr_wave_sum_to_lane63(v2);
-      v3 = gsr_wave_sum_to_lane63(v3); v4 = gsr_wave_sum_to_lane63(v4); v5 = gsr_wave_sum_to_lane63(v5);
-      v6 = gsr_wave_sum_to_lane63(v6); v7 = gsr_wave_sum_to_lane63(v7); v8 = gsr_wave_sum_to_lane63(v8);
+      gsr_wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
       if (lane == 63) {
         L.sRed[wv][j][0] = make_float4(v0, v1, v2, v3);
         L.sRed[wv][j][1] = make_float4(v4, v5, v6, v7);
