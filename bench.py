@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the views of a step are spread over")
+    ap.add_argument("--per-view-calls", action="store_true",
+                    help="one GaussianRasterizer call per view (reference call pattern) instead of the batched multi-view call")
     ap.add_argument("--with-activations", action="store_true",
                     help="include params2rendervar (normalize/sigmoid/exp) and its backward in the timed step")
     args = ap.parse_args()
@@ -101,9 +103,22 @@ def main():
         if not args.forward_only:
             im.backward(gradient=dL)
 
+    from diff_gaussian_rasterization import rasterize_gaussians_views
+    dL_all = torch.stack(dLs)
+    m2_views = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True)
+
     def step(record=False):
+        nonlocal streams
         (bucket if args.with_activations else leaf_bucket).zero()
-        if streams is None:
+        if not args.per_view_calls:
+            rv = params2rendervar(params) if args.with_activations else rv_leaf
+            im, radii, depth = rasterize_gaussians_views(
+                cams, rv["means3D"], m2_views, rv["opacities"], colors_precomp=rv["colors_precomp"], scales=rv["scales"],
+                rotations=rv["rotations"])
+            if not args.forward_only:
+                im.backward(gradient=dL_all)
+                m2_views.grad = None
+        elif streams is None:
             for cam, dL in zip(cams, dLs):
                 one_view(cam, dL)
         else:
@@ -125,9 +140,15 @@ def main():
         out = orig(*a, **k)
         num_rendered.append(out[3].num_rendered)
         return out
-    _hip.rasterize_forward = spy
+    orig_b = _hip.rasterize_forward_batch
+
+    def spy_b(*a, **k):
+        out = orig_b(*a, **k)
+        num_rendered.extend(st.num_rendered for st in out[3])
+        return out
+    _hip.rasterize_forward, _hip.rasterize_forward_batch = spy, spy_b
     step()
-    _hip.rasterize_forward = orig
+    _hip.rasterize_forward, _hip.rasterize_forward_batch = orig, orig_b
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -150,13 +171,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_step = float(t.item())
 
-    # ---- per-kernel HIP-event pass (outside the timed region)
+    # ---- per-kernel HIP-event pass (outside the timed region).  Kernel durations are only meaningful when
+    # the kernels of different views do not overlap, so this pass always uses one call per view on one stream.
+    saved = (args.per_view_calls, streams)
+    args.per_view_calls, streams = True, None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     _hip.profile_begin()
     prof_steps = max(3, min(10, args.steps))
     for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     prof = _hip.profile_end()
+    args.per_view_calls, streams = saved
     per_launch_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}
     per_view_us = {k: 1e3 * ms / (prof_steps * VIEWS_PER_RANK) for k, (ms, n) in prof.items()}
 
@@ -180,6 +208,7 @@ def main():
                  "render_fwd_lane_instr_per_s": (pairs * 25 / (per_launch_us["render_fwd"] * 1e-6)) if "render_fwd" in per_launch_us else None,
                  "peak_lane_instr_per_s": VALU_PEAK},
         "per_kernel_us_per_view": {k: round(v, 2) for k, v in sorted(per_view_us.items())},
+        "per_kernel_timing": "HIP events around every launch, per-view sequential pass after the timed region",
     }
 
     cpu_baseline = None
@@ -196,7 +225,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: SynthScene-v1, 100k Gaussians, 4 views 800x800 per GPU, "
                                    "colour render fwd+bwd per view" + ("" if world == 1 else ", 1 RCCL all-reduce of the flat grad bucket per step"),
                        "gaussians": P_GAUSS, "views_per_gpu": VIEWS_PER_RANK, "image": [H, W],
-                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}"},
+                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}",
+                       "call_pattern": "per-view GaussianRasterizer calls" if args.per_view_calls else
+                                       "one rasterize_gaussians_views call per step (per-view chains on internal streams)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -138,6 +138,133 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
                                    dL_drotations, dL_dcov3D, dL_dsh, st);
 }
 
+
+// ------------------------------------------------------------------------------------------ multi-view batch
+// The views of one optimisation step share the Gaussians and are independent until the gradients are
+// summed, and a single 800x800 view cannot fill 256 CUs (most binning kernels are launch/latency bound).
+// The *_batch entry points run view v's kernel chain on internal stream v (forked from / joined to the
+// caller's stream with events), so the chains of different views overlap on the GPU, and stage 1 does
+// ONE host synchronisation for all views' duplicate counts instead of one per view.
+namespace {
+struct StreamPool {
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> done;
+  hipEvent_t fork = nullptr;
+  uint32_t* host_counts = nullptr;  // pinned
+  int device = -1;
+};
+StreamPool g_pools[16];
+
+int get_pool(int V, StreamPool** out) {
+  int dev = 0;
+  GSR_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) { gsr_set_error("gsr batch: device index %d out of range", dev); return -2; }
+  StreamPool& p = g_pools[dev];
+  p.device = dev;
+  if (!p.fork) GSR_HIP_CHECK(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+  if (!p.host_counts) GSR_HIP_CHECK(hipHostMalloc((void**)&p.host_counts, sizeof(uint32_t) * GSR_MAX_BATCH, hipHostMallocDefault));
+  while ((int)p.streams.size() < V) {
+    hipStream_t st; hipEvent_t ev;
+    GSR_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    p.streams.push_back(st); p.done.push_back(ev);
+  }
+  *out = &p;
+  return 0;
+}
+int fork_streams(StreamPool& p, int V, hipStream_t caller) {
+  GSR_HIP_CHECK(hipEventRecord(p.fork, caller));
+  for (int v = 0; v < V; ++v) GSR_HIP_CHECK(hipStreamWaitEvent(p.streams[v], p.fork, 0));
+  return 0;
+}
+int join_streams(StreamPool& p, int V, hipStream_t caller) {
+  for (int v = 0; v < V; ++v) {
+    GSR_HIP_CHECK(hipEventRecord(p.done[v], p.streams[v]));
+    GSR_HIP_CHECK(hipStreamWaitEvent(caller, p.done[v], 0));
+  }
+  return 0;
+}
+}  // namespace
+
+int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                 const float* rotations, const float* opacities, const float* colors_precomp,
+                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
+                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s || !geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
+  for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
+  if (P <= 0) return 0;
+  if ((colors_precomp == nullptr) == (shs == nullptr) || ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    gsr_set_error("gsr_forward_preprocess_batch: provide exactly one of colors_precomp/shs and of scales+rotations/cov3D_precomp");
+    return -2;
+  }
+  StreamPool* pool = nullptr;
+  if (int rc = get_pool(V, &pool)) return rc;
+  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  for (int v = 0; v < V; ++v) {
+    GsrCam cam;
+    if (int rc = make_cam(&s[v], &cam)) return rc;
+    hipStream_t st = pool->streams[v];
+    GeomState g;
+    gsr_carve_geom(geom_states[v], P, &g);
+    if (int rc = gsr_launch_preprocess(cam, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
+                                       g, radii[v], st))
+      return rc;
+    const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
+    if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
+    GSR_HIP_CHECK(hipMemcpyAsync(&pool->host_counts[v], g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  for (int v = 0; v < V; ++v) GSR_HIP_CHECK(hipStreamSynchronize(pool->streams[v]));
+  for (int v = 0; v < V; ++v) num_rendered_host[v] = pool->host_counts[v];
+  return 0;
+}
+
+int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
+                             void* const* geom_states, void* const* binning_states, void* const* image_states,
+                             float* const* out_color, float* const* out_depth, void* stream) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s || !num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
+    gsr_set_error("gsr_forward_render_batch: NULL argument");
+    return -2;
+  }
+  StreamPool* pool = nullptr;
+  if (int rc = get_pool(V, &pool)) return rc;
+  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  for (int v = 0; v < V; ++v) {
+    if (int rc = gsr_forward_render(&s[v], P, num_rendered[v], geom_states[v], binning_states[v], image_states[v],
+                                    out_color[v], out_depth[v], pool->streams[v]))
+      return rc;
+  }
+  return join_streams(*pool, V, (hipStream_t)stream);
+}
+
+int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
+                       const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                       const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
+                       void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
+                       void* const* scratch, float* const* dL_dmeans3D, float* const* dL_dmeans2D,
+                       float* const* dL_dcolors, float* const* dL_dopacity, float* const* dL_dscales,
+                       float* const* dL_drotations, float* const* dL_dcov3D, float* const* dL_dsh, void* stream) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s || !num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
+      !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) {
+    gsr_set_error("gsr_backward_batch: NULL argument");
+    return -2;
+  }
+  StreamPool* pool = nullptr;
+  if (int rc = get_pool(V, &pool)) return rc;
+  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  for (int v = 0; v < V; ++v) {
+    if (int rc = gsr_backward(&s[v], P, num_rendered[v], means3D, scales, rotations, colors_precomp, shs, cov3D_precomp,
+                              radii[v], geom_states[v], binning_states[v], image_states[v], dL_dcolor[v], scratch[v],
+                              dL_dmeans3D[v], dL_dmeans2D[v], dL_dcolors ? dL_dcolors[v] : nullptr, dL_dopacity[v],
+                              dL_dscales ? dL_dscales[v] : nullptr, dL_drotations ? dL_drotations[v] : nullptr,
+                              dL_dcov3D ? dL_dcov3D[v] : nullptr, dL_dsh ? dL_dsh[v] : nullptr, pool->streams[v]))
+      return rc;
+  }
+  return join_streams(*pool, V, (hipStream_t)stream);
+}
+
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {
   if (P <= 0) return 0;
   if (!viewmatrix || !means3D || !present) { gsr_set_error("gsr_mark_visible: NULL argument"); return -2; }

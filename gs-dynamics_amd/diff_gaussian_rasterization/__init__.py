@@ -19,7 +19,7 @@ from torch import nn
 
 from . import _hip
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_views"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -92,6 +92,60 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.state = None
         return (d_means3D, d_means2D, d_sh if has_sh else None, d_colors if has_col else None, d_opacity,
                 d_scales if has_sc else None, d_rot if has_sc else None, d_cov if has_cov else None, None)
+
+
+class _RasterizeGaussiansViews(torch.autograd.Function):
+    """V views of the same Gaussians in one call (extension of the reference API, which renders one view
+    per call): forward -> (color[V,3,H,W], radii[V,P], depth[V,1,H,W]); backward sums the per-view input
+    gradients.  ``means2D`` is a [V,P,3] holder so each view's screen-space gradient stays separate
+    (densification accumulates their norms per view, /root/reference/src/tracking/external.py:138-142)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+        m3 = _prep(means3D)
+        if m3 is None or m3.dim() != 2 or m3.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        sh_, col_, op_ = _prep(sh), _prep(colors_precomp), _prep(opacities)
+        sc_, rot_, cov_ = _prep(scales), _prep(rotations), _prep(cov3Ds_precomp)
+        color, radii, depth, states = _hip.rasterize_forward_batch(list(settings_list), m3, op_, col_, sh_, sc_, rot_, cov_)
+        ctx.states = states
+        ctx.has = (sh_ is not None, col_ is not None, sc_ is not None, cov_ is not None)
+        empty = m3.new_empty(0)
+        ctx.save_for_backward(m3, radii, col_ if col_ is not None else empty, sh_ if sh_ is not None else empty,
+                              sc_ if sc_ is not None else empty, rot_ if rot_ is not None else empty,
+                              cov_ if cov_ is not None else empty)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth):
+        m3, radii, col_, sh_, sc_, rot_, cov_ = ctx.saved_tensors
+        has_sh, has_col, has_sc, has_cov = ctx.has
+        V = len(ctx.states)
+        if grad_color is None:
+            grad_color = torch.zeros((V, 3, ctx.states[0].H, ctx.states[0].W), device=m3.device)
+        d3, d2, dc, do, ds, dr, dcov, dsh = _hip.rasterize_backward_batch(
+            ctx.states, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
+            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
+        ctx.states = None
+        sm = lambda t: None if t is None else t.sum(0)  # noqa: E731
+        return (sm(d3), d2, sm(dsh) if has_sh else None, sm(dc) if has_col else None, sm(do), sm(ds) if has_sc else None,
+                sm(dr) if has_sc else None, sm(dcov) if has_cov else None, None)
+
+
+def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                              rotations=None, cov3D_precomp=None):
+    """Render ``len(settings_list)`` views of one set of Gaussians.  ``means2D``: [V,P,3] gradient holder."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    empty = torch.Tensor([])
+    return _RasterizeGaussiansViews.apply(
+        means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
+        empty if scales is None else scales, empty if rotations is None else rotations,
+        empty if cov3D_precomp is None else cov3D_precomp, tuple(settings_list))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

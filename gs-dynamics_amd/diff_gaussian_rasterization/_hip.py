@@ -40,7 +40,8 @@ class GsrKernelTime(C.Structure):
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
-           "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end")
+           "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
+           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_backward_batch")
 
 
 def load_library():
@@ -67,6 +68,14 @@ def load_library():
     lib.gsr_forward_render.argtypes = [C.POINTER(GsrSettings), i32, u32, vp, vp, vp, vp, vp, vp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_backward.argtypes = [C.POINTER(GsrSettings), i32, u32] + [vp] * 20 + [vp]
+    PS = C.POINTER(GsrSettings)
+    PV = C.POINTER(C.c_void_p)
+    lib.gsr_forward_preprocess_batch.restype = C.c_int
+    lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, C.POINTER(u32), vp]
+    lib.gsr_forward_render_batch.restype = C.c_int
+    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, PV, PV, vp]
+    lib.gsr_backward_batch.restype = C.c_int
+    lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 6 + [PV] * 14 + [vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [vp, i32, vp, vp, vp]
     lib.gsr_debug_get_views.restype = C.c_int
@@ -183,6 +192,97 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
                                 _ptr(state.binning), _ptr(state.image), _ptr(g), _ptr(scratch), _ptr(d_means3D),
                                 _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot),
                                 _ptr(d_cov), _ptr(d_sh), _stream(dev)), "gsr_backward")
+    return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
+
+
+def _ptr_array(tensors):
+    """Host array of device pointers (void* const*) for the *_batch entry points."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp):
+    """All views of a step in one call: per-view kernel chains on the library's internal streams, one host
+    sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V])."""
+    lib = load_library()
+    _require_device(means3D)
+    dev = means3D.device
+    V = len(settings_list)
+    P = int(means3D.shape[0])
+    H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+    if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
+        raise ValueError("rasterize_forward_batch: all views must share the image size")
+    M = 0 if shs is None else int(shs.shape[1])
+    with torch.cuda.device(dev):
+        sarr = (GsrSettings * V)()
+        keeps = []
+        for v, rs in enumerate(settings_list):
+            s, keep = _make_settings(rs, dev, M)
+            sarr[v] = s
+            keeps.append(keep)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((V, P), dtype=torch.int32, device=dev)
+        geoms = [torch.empty((lib.gsr_geom_bytes(P),), **u8) for _ in range(V)]
+        images = [torch.empty((lib.gsr_image_bytes(H, W),), **u8) for _ in range(V)]
+        Ds = (C.c_uint32 * V)()
+        st = _stream(dev)
+        _check(lib.gsr_forward_preprocess_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                                _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
+                                                _ptr_array([radii[v] for v in range(V)]), Ds, st),
+               "gsr_forward_preprocess_batch")
+        binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) for v in range(V)]
+        _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
+                                            _ptr_array([color[v] for v in range(V)]),
+                                            _ptr_array([depth[v] for v in range(V)]), st), "gsr_forward_render_batch")
+    states = []
+    for v in range(V):
+        state = RasterState()
+        state.settings, state.keep, state.P, state.num_rendered = sarr[v], keeps[v], P, int(Ds[v])
+        state.geom, state.binning, state.image, state.H, state.W = geoms[v], binnings[v], images[v], H, W
+        states.append(state)
+    return color, radii, depth, states
+
+
+def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
+    """Backward of all views; returns per-view gradient stacks [V, P, ...] (the caller sums over views) and
+    the per-view means2D gradients [V, P, 3]."""
+    lib = load_library()
+    dev = means3D.device
+    V = len(states)
+    P = states[0].P
+    M = 0 if shs is None else int(shs.shape[1])
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        g = grad_color.to(**f32).contiguous()
+        sarr = (GsrSettings * V)()
+        Ds = (C.c_uint32 * V)()
+        for v, stt in enumerate(states):
+            sarr[v] = stt.settings
+            Ds[v] = stt.num_rendered
+        d_means3D = torch.empty((V, P, 3), **f32)
+        d_means2D = torch.empty((V, P, 3), **f32)
+        d_colors = torch.empty((V, P, 3), **f32) if shs is None else None
+        d_opacity = torch.empty((V, P, 1), **f32)
+        d_scales = torch.empty((V, P, 3), **f32) if cov3D_precomp is None else None
+        d_rot = torch.empty((V, P, 4), **f32) if cov3D_precomp is None else None
+        d_cov = torch.empty((V, P, 6), **f32)
+        d_sh = torch.empty((V, P, M, 3), **f32) if shs is not None else None
+        scratch = [torch.empty((lib.gsr_backward_scratch_bytes(P, stt.num_rendered),), dtype=torch.uint8, device=dev)
+                   for stt in states]
+
+        def per_view(t):
+            return None if t is None else _ptr_array([t[v] for v in range(V)])
+        _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(colors_precomp),
+                                      _ptr(shs), _ptr(cov3D_precomp), per_view(radii),
+                                      _ptr_array([stt.geom for stt in states]), _ptr_array([stt.binning for stt in states]),
+                                      _ptr_array([stt.image for stt in states]), per_view(g), _ptr_array(scratch),
+                                      per_view(d_means3D), per_view(d_means2D), per_view(d_colors), per_view(d_opacity),
+                                      per_view(d_scales), per_view(d_rot), per_view(d_cov), per_view(d_sh), _stream(dev)),
+               "gsr_backward_batch")
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
 
 

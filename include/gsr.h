@@ -18,7 +18,8 @@
  *   - all float tensors are fp32, row-major, contiguous; radii is int32; images are CHW;
  *   - `stream` is a hipStream_t passed as void* (0 = null stream); all work is enqueued on it;
  *   - functions return 0 on success, non-zero on error (message via gsr_last_error());
- *   - no global state, no hidden allocations: the caller owns every buffer (sizes from gsr_*_bytes).
+ *   - no hidden allocations on the data path: the caller owns every buffer (sizes from gsr_*_bytes);
+ *     the only persistent state is the stream/event pool of the *_batch entry points.
  */
 #ifndef GSR_H_
 #define GSR_H_
@@ -88,6 +89,29 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
                  const void* binning_state, const void* image_state, const float* dL_dcolor, void* scratch,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dsh, void* stream);
+
+/* ---- multi-view batch (new design, no counterpart in the reference: its training loop renders one view per
+ * optimiser step, /root/reference/src/tracking/train_gs.py:25-39).  The V views of a sharded step share the
+ * Gaussian inputs; view v's kernel chain runs on internal stream v, forked from / joined to `stream` with
+ * events, so the chains overlap on the GPU, and stage 1 synchronises ONCE for all V duplicate counts.
+ * Array arguments have V entries (host arrays of device pointers).  Per-view gradient outputs are NOT summed
+ * here: the caller reduces over views.  The library keeps a small per-device pool of streams/events and one
+ * pinned host word per view for this (the only persistent state in the library). */
+#define GSR_MAX_BATCH 16
+int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                 const float* rotations, const float* opacities, const float* colors_precomp,
+                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
+                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream);
+int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
+                             void* const* geom_states, void* const* binning_states, void* const* image_states,
+                             float* const* out_color, float* const* out_depth, void* stream);
+int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
+                       const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                       const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
+                       void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
+                       void* const* scratch, float* const* dL_dmeans3D, float* const* dL_dmeans2D,
+                       float* const* dL_dcolors, float* const* dL_dopacity, float* const* dL_dscales,
+                       float* const* dL_drotations, float* const* dL_dcov3D, float* const* dL_dsh, void* stream);
 
 /* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);
