@@ -278,7 +278,7 @@ int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t H, int32_t W, 
   GeomState g; ImageState im; BinningState bs;
   if (geom_state) {
     gsr_carve_geom(const_cast<void*>(geom_state), P, &g);
-    out->recA = (const float*)g.recA; out->recB = (const float*)g.recB; out->recC = (const float*)g.recC;
+    out->rec = (const float*)g.rec;
     out->rect = (const uint32_t*)g.rect; out->tiles_touched = g.tiles_touched; out->offsets = g.offsets;
   }
   if (binning_state) {

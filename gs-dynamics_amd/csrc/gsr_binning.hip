@@ -83,7 +83,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
 // Block b owns Gaussians [256b, 256b+256).  Its first entry offset comes from the scan of the preprocess
 // block sums; the per-Gaussian offsets inside the block are scanned here in LDS and written out once
 // (offsets[] is what render_bwd / preprocess_bwd use to address the Gaussian-major partial records).
-__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float2* __restrict__ recC,
+__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float4* __restrict__ rec,
                                                                  const uint2* __restrict__ rect,
                                                                  const uint32_t* __restrict__ tiles_touched,
                                                                  const uint32_t* __restrict__ block_offsets,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, 
     const uint32_t w = maxx - minx;
     const uint32_t ty = miny + k / w, tx = minx + k % w;
     tkey[e] = ty * (uint32_t)gx + tx;
-    dg[e] = ((uint64_t)__float_as_uint(recC[g].y) << 32) | (uint32_t)g;
+    dg[e] = ((uint64_t)__float_as_uint(rec[3 * g + 2].y) << 32) | (uint32_t)g;
   }
 }
 
@@ -381,7 +381,7 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
   }
   { GSR_PROF("emit_entries", st);
   hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
-                     g.recC, g.rect, g.tiles_touched, g.block_offsets, g.offsets, bs.tkey[0], bs.dg[0]); }
+                     g.rec, g.rect, g.tiles_touched, g.block_offsets, g.offsets, bs.tkey[0], bs.dg[0]); }
   GSR_HIP_CHECK(hipGetLastError());
   const int tbits = ceil_log2_u32((uint32_t)cam.T);
   const int npass = (tbits + 7) / 8;

@@ -15,16 +15,15 @@
 
 // ---------------------------------------------------------------- state layouts (HBM)
 // Geometry state: per-Gaussian records written by preprocess, read (gathered) by the blend kernels.
-//   recA float4 {mean2D.x, mean2D.y, conicA, conicB}
-//   recB float4 {conicC, opacity, r, g}
-//   recC float2 {b, depth}
-// 40 B per Gaussian in three arrays so that every gather is one aligned 16/16/8-byte load.
+// ONE 48-byte AoS record per Gaussian (3 x float4), so that a blend-kernel gather touches one or two
+// cache lines instead of four separate arrays:
+//   rec[3g+0] {mean2D.x, mean2D.y, conicA, conicB}
+//   rec[3g+1] {conicC, opacity, r, g}
+//   rec[3g+2] {b, depth, bits(alpha-box x: xmin | xmax<<16), bits(alpha-box y: ymin | ymax<<16)}
+// The alpha-box is the int16 pixel box outside which alpha < 1/255.
 struct GeomState {
-  float4* recA;
-  float4* recB;
-  float2* recC;
+  float4* rec;            // [3P]
   uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
-  uint2* abox;            // {xmin | xmax<<16, ymin | ymax<<16}: int16 pixel box outside which alpha < 1/255
   uint32_t* tiles_touched;
   uint32_t* offsets;      // [P+1] exclusive prefix of tiles_touched (written by emit_entries)
   uint32_t* block_sums;   // [ceil(P/256)] per-preprocess-block totals of tiles_touched
@@ -58,11 +57,8 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   size_t off = 0, Pn = (size_t)(P > 0 ? P : 1);
   char* b = (char*)base;
   auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
-  g->recA = (float4*)take(Pn * 16);
-  g->recB = (float4*)take(Pn * 16);
-  g->recC = (float2*)take(Pn * 8);
+  g->rec = (float4*)take(Pn * 48);
   g->rect = (uint2*)take(Pn * 8);
-  g->abox = (uint2*)take(Pn * 8);
   g->tiles_touched = (uint32_t*)take(Pn * 4);
   g->offsets = (uint32_t*)take((Pn + 1) * 4);
   const size_t nblk = (Pn + GSR_BLOCK - 1) / GSR_BLOCK;

@@ -6,7 +6,7 @@
 // to the CPU oracle (integer parity is exact, not "within tolerance").
 //
 // HBM traffic per Gaussian: reads 12 (mean) + 12 (scale) + 16 (rot) + 4 (opacity) + 12 (colour) = 56 B
-// (+48 M-coefficient SH when used), writes 16 + 16 + 8 (records) + 8 (rect) + 4 (tiles) + 4 (radii) = 56 B.
+// (+48 M-coefficient SH when used), writes 48 (record) + 8 (rect) + 4 (tiles) + 4 (clamp) + 4 (radii) = 68 B.
 // The 4x4 matrices are read through uniform (scalar) loads: they never occupy VGPRs.
 #include "gsr_common.h"
 
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
-    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ recA,
-    float4* __restrict__ recB, float2* __restrict__ recC, uint2* __restrict__ rect, uint2* __restrict__ abox,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ rec,
+    uint2* __restrict__ rect,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii,
     uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
@@ -173,9 +173,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     }
   }
   if (in_range) {
-    recA[i] = a4; recB[i] = b4; recC[i] = c2;
+    rec[3 * i + 0] = a4;
+    rec[3 * i + 1] = b4;
+    rec[3 * i + 2] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
     rect[i] = rc;
-    abox[i] = box;
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;
@@ -209,8 +210,8 @@ int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const 
   { GSR_PROF("preprocess_fwd", st);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
                      cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
-                     cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.recA,
-                     g.recB, g.recC, g.rect, g.abox, g.tiles_touched, g.clamped, radii, g.block_sums); }
+                     cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.rec,
+                     g.rect, g.tiles_touched, g.clamped, radii, g.block_sums); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -83,16 +83,15 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
 
 // Per-strip compacted entry lists of one staged batch (stable: list order is preserved).
 struct FwdLds {
-  float4 sA[4][FWD_BATCH];   // mean2D.x, mean2D.y, conic A, conic B
-  float4 sB[4][FWD_BATCH];   // conic C, opacity, r, g
-  float4 sC[4][FWD_BATCH];   // b, depth, bits(1-based list position), -
+  float4 sA[4][FWD_BATCH + 1];   // mean2D.x, mean2D.y, conic A, conic B   (+1: the loop prefetches entry j+1)
+  float4 sB[4][FWD_BATCH + 1];   // conic C, opacity, r, g
+  float4 sC[4][FWD_BATCH + 1];   // b, depth, bits(1-based list position), -
   uint32_t cnt[4][4];        // [staging wave][strip]
 };
 
 __device__ __forceinline__ void fwd_tile(
     const int tile, FwdLds& L, int W, int H, int gx, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ recA, const float4* __restrict__ recB,
-    const float2* __restrict__ recC, const uint2* __restrict__ abox, const float* __restrict__ bg,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_depth) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -107,19 +106,31 @@ __device__ __forceinline__ void fwd_tile(
   uint32_t last = 0;
   bool done = !inside;
 
+  // Software-pipelined staging: the gathers of batch b+1 are issued before batch b is walked, so their
+  // latency (point_list -> record arrays, two dependent trips to L2/HBM) hides behind the blend loop.
+  float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+  float2 nc = make_float2(0.f, 0.f);
+  uint2 nbox = make_uint2(1u, 1u);
+  if (tid < FWD_BATCH && tid < n) {
+    const uint32_t g = point_list[rg.x + tid];
+    { const float4 t2 = rec[3 * g + 2]; na = rec[3 * g]; nb = rec[3 * g + 1]; nc = make_float2(t2.x, t2.y);
+      nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+  }
   for (int base = 0; base < n; base += FWD_BATCH) {
     if (__syncthreads_count(done) == GSR_BLOCK) break;  // also fences the previous batch's LDS reads
-    // ---- stage: threads 0..127 each fetch one entry and classify it against the four strips
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
-    uint32_t mask = 0;
+    // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
+    const float4 a = na, b = nb;
     const int idx = base + tid;
-    if (tid < FWD_BATCH && idx < n) {
-      const uint32_t g = point_list[rg.x + idx];
-      a = recA[g];
-      b = recB[g];
-      const float2 c2 = recC[g];
-      c = make_float4(c2.x, c2.y, __uint_as_float((uint32_t)(idx + 1)), 0.f);
-      mask = strip_mask(abox[g], a, b.x, b.y, tx0, ty0);
+    const float4 c = make_float4(nc.x, nc.y, __uint_as_float((uint32_t)(idx + 1)), 0.f);
+    uint32_t mask = 0;
+    if (tid < FWD_BATCH && idx < n) mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
+    {
+      const int nidx = idx + FWD_BATCH;
+      if (tid < FWD_BATCH && nidx < n) {
+        const uint32_t g = point_list[rg.x + nidx];
+        { const float4 t2 = rec[3 * g + 2]; na = rec[3 * g]; nb = rec[3 * g + 1]; nc = make_float2(t2.x, t2.y);
+      nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+      }
     }
     uint64_t bal[4];
 #pragma unroll
@@ -137,33 +148,33 @@ __device__ __forceinline__ void fwd_tile(
         L.sA[w][pos] = a; L.sB[w][pos] = b; L.sC[w][pos] = c;
       }
     }
-    const int m = (int)(L.cnt[0][wv] + L.cnt[1][wv]);  // staging threads live in waves 0 and 1 only
+    // staging threads live in waves 0 and 1 only; readfirstlane makes the trip count a scalar
+    const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
     __syncthreads();
-    // ---- blend: wave wv walks only the entries that can reach its strip
+    // ---- blend: wave wv walks only the entries that can reach its strip.  Straight-line body: the next
+    // entry's record is fetched from LDS while this one is evaluated, and the blend itself is predicated
+    // (w = 0 when the pair does not contribute) instead of branched, so consecutive iterations overlap.
     if (__ballot(!done) != 0ull) {
       const float4* __restrict__ wA = L.sA[wv];
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
+      float4 ea = wA[0], eb = wB[0], ec = wC[0];
       for (int j = 0; j < m; ++j) {
-        const float4 ea = wA[j];
-        const float4 eb = wB[j];
+        const float4 xa = wA[j + 1], xb = wB[j + 1], xc = wC[j + 1];
         const float dx = ea.x - pxf, dy = ea.y - pyf;
         const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
         const float alpha = fminf(GSR_ALPHA_MAX, eb.y * gsr_exp(power));
         const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;
         const float test_T = T * (1.0f - alpha);
-        if (hit) {
-          if (test_T < GSR_T_EPS) {
-            done = true;
-          } else {
-            const float4 ec = wC[j];
-            const float w = alpha * T;
-            C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);
-            C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);
-            T = test_T;
-            last = __float_as_uint(ec.z);
-          }
-        }
+        const bool stop = hit && test_T < GSR_T_EPS;
+        const bool blend = hit && !stop;
+        done = done || stop;
+        const float w = blend ? alpha * T : 0.0f;
+        C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);
+        C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);
+        T = blend ? test_T : T;
+        last = blend ? __float_as_uint(ec.z) : last;
+        ea = xa; eb = xb; ec = xc;
         if ((j & 7) == 7 && __ballot(!done) == 0ull) break;
       }
     }
@@ -182,9 +193,9 @@ __device__ __forceinline__ void fwd_tile(
 
 // ------------------------------------------------------------------------------------------ backward
 struct BwdLds {
-  float4 sA[4][BWD_BATCH];                     // mx, my, A, B            (per-strip compacted)
-  float4 sB[4][BWD_BATCH];                     // C, opacity, r, g
-  float2 sC[4][BWD_BATCH];                     // b, bits(batch index j)
+  float4 sA[4][BWD_BATCH + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
+  float4 sB[4][BWD_BATCH + 1];                 // C, opacity, r, g
+  float2 sC[4][BWD_BATCH + 1];                 // b, bits(batch index j)
   float4 sRed[4][BWD_BATCH][GSR_PARTIAL_F4];   // per-wave totals, indexed by batch index
   uint64_t sActive[4][BWD_BATCH / 64];         // which (wave, entry) totals are valid
   uint32_t sG[BWD_BATCH];                      // gaussian id by batch index
@@ -194,8 +205,7 @@ struct BwdLds {
 
 __device__ __forceinline__ void bwd_tile(
     const int tile, BwdLds& L, int W, int H, int gx, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float4* __restrict__ recA, const float4* __restrict__ recB,
-    const float2* __restrict__ recC, const uint2* __restrict__ abox, const float* __restrict__ bg,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -236,20 +246,33 @@ __device__ __forceinline__ void bwd_tile(
     partials[(size_t)e * GSR_PARTIAL_F4 + 2] = z;
   }
 
+  // Software-pipelined staging (see fwd_tile): batch b+1 is fetched while batch b is processed.
+  float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+  float nblue = 0.f;
+  uint2 nbox = make_uint2(1u, 1u);
+  uint32_t ng = 0;
+  if (tid < BWD_BATCH && tid < max_last) {
+    ng = point_list[rg.x + (max_last - 1 - tid)];
+    { const float4 t2 = rec[3 * ng + 2]; na = rec[3 * ng]; nb = rec[3 * ng + 1]; nblue = t2.x;
+      nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+  }
   for (int base = 0; base < max_last; base += BWD_BATCH) {
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
     const int m_all = min(BWD_BATCH, max_last - base);
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    float2 c = make_float2(0.f, 0.f);
+    const float4 a = na, b = nb;
+    const float2 c = make_float2(nblue, __uint_as_float((uint32_t)tid));
     uint32_t mask = 0;
     if (tid < m_all) {
-      const int pos = max_last - 1 - (base + tid);
-      const uint32_t g = point_list[rg.x + pos];
-      L.sG[tid] = g;
-      a = recA[g];
-      b = recB[g];
-      c = make_float2(recC[g].x, __uint_as_float((uint32_t)tid));
-      mask = strip_mask(abox[g], a, b.x, b.y, tx0, ty0);
+      L.sG[tid] = ng;
+      mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
+    }
+    {
+      const int nj = base + BWD_BATCH + tid;
+      if (tid < BWD_BATCH && nj < max_last) {
+        ng = point_list[rg.x + (max_last - 1 - nj)];
+        { const float4 t2 = rec[3 * ng + 2]; na = rec[3 * ng]; nb = rec[3 * ng + 1]; nblue = t2.x;
+      nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+      }
     }
     uint64_t bal[4];
 #pragma unroll
@@ -267,16 +290,18 @@ __device__ __forceinline__ void bwd_tile(
         L.sA[w][p] = a; L.sB[w][p] = b; L.sC[w][p] = c;
       }
     }
-    const int m = (int)(L.cnt[0][wv] + L.cnt[1][wv]);
+    const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
     __syncthreads();
     uint64_t active_lo = 0ull, active_hi = 0ull;
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
+    float4 xa = wA[0], xb = wB[0];
+    float2 xc = wC[0];
     for (int jj = 0; jj < m; ++jj) {
-      const float4 ea = wA[jj];
-      const float4 eb = wB[jj];
-      const float2 ec = wC[jj];
+      const float4 ea = xa, eb = xb;
+      const float2 ec = xc;
+      xa = wA[jj + 1]; xb = wB[jj + 1]; xc = wC[jj + 1];  // next entry, in flight during this one
       const int j = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ec.y));  // batch index (wave-uniform)
       const int pos = max_last - 1 - (base + j);
       const float blue = ec.x;
@@ -347,10 +372,9 @@ __device__ __forceinline__ void bwd_tile(
 // ------------------------------------------------------------------------------------------ kernels
 #define GSR_FWD_ARGS                                                                                          \
   int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-      const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,      \
-      const uint2* __restrict__ abox, const float* __restrict__ bg, float* __restrict__ final_T,              \
+      const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,              \
       uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth
-#define GSR_FWD_PASS W, H, gx, ranges, point_list, recA, recB, recC, abox, bg, final_T, n_contrib, out_color, out_depth
+#define GSR_FWD_PASS W, H, gx, ranges, point_list, rec, bg, final_T, n_contrib, out_color, out_depth
 
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GSR_FWD_ARGS) {
   __shared__ FwdLds L;
@@ -371,14 +395,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint32_
   }
 }
 
+
 #define GSR_BWD_ARGS                                                                                          \
   int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-      const float4* __restrict__ recA, const float4* __restrict__ recB, const float2* __restrict__ recC,      \
-      const uint2* __restrict__ abox, const float* __restrict__ bg, const float* __restrict__ final_T,        \
+      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,        \
       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const uint2* __restrict__ rect, \
       const uint32_t* __restrict__ offsets, float4* __restrict__ partials
 #define GSR_BWD_PASS \
-  W, H, gx, ranges, point_list, recA, recB, recC, abox, bg, final_T, n_contrib, dL_dcolor, rect, offsets, partials
+  W, H, gx, ranges, point_list, rec, bg, final_T, n_contrib, dL_dcolor, rect, offsets, partials
 
 __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GSR_BWD_ARGS) {
   __shared__ BwdLds L;
@@ -419,11 +443,11 @@ int gsr_launch_render_fwd(const GsrCam& cam, const GeomState& g, const BinningSt
   { GSR_PROF("render_fwd", st);
     if (use_static) {
       hipLaunchKernelGGL(render_fwd_static, dim3(cam.T), dim3(GSR_BLOCK), 0, st, cam.W, cam.H, cam.gx, cam.T, im.ranges,
-                         bs.point_list, g.recA, g.recB, g.recC, g.abox, cam.bg, im.final_T, im.n_contrib, out_color, out_depth);
+                         bs.point_list, g.rec, cam.bg, im.final_T, im.n_contrib, out_color, out_depth);
     } else {
       const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
       hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue + 0, cam.W,
-                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.recA, g.recB, g.recC, g.abox, cam.bg, im.final_T,
+                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
                          im.n_contrib, out_color, out_depth);
     }
   }
@@ -440,12 +464,12 @@ int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, con
   { GSR_PROF("render_bwd", st);
     if (use_static) {
       hipLaunchKernelGGL(render_bwd_static, dim3(cam.T), dim3(GSR_BLOCK), 0, st, cam.W, cam.H, cam.gx, cam.T, im.ranges,
-                         bs.point_list, g.recA, g.recB, g.recC, g.abox, cam.bg, im.final_T, im.n_contrib, dL_dcolor, g.rect,
+                         bs.point_list, g.rec, cam.bg, im.final_T, im.n_contrib, dL_dcolor, g.rect,
                          g.offsets, partials);
     } else {
       const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
       hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue + 1, cam.W,
-                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.recA, g.recB, g.recC, g.abox, cam.bg, im.final_T,
+                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
                          im.n_contrib, dL_dcolor, g.rect, g.offsets, partials);
     }
   }

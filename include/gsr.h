@@ -118,9 +118,7 @@ int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, u
 
 /* ---- introspection for tests / benches (copies of internal state, device -> caller's DEVICE buffers) */
 typedef struct gsr_debug_views {
-  const float* recA;          /* [P,4] mean2D.x, mean2D.y, conic A, conic B */
-  const float* recB;          /* [P,4] conic C, opacity, r, g */
-  const float* recC;          /* [P,2] b, depth */
+  const float* rec;           /* [P,12] mean2D.xy, conic A,B | conic C, opacity, r, g | b, depth, alpha-box bits x2 */
   const uint32_t* rect;       /* [P,2] minx|miny<<16, maxx|maxy<<16 */
   const uint32_t* tiles_touched; /* [P] */
   const uint32_t* offsets;    /* [P+1] exclusive prefix of tiles_touched */

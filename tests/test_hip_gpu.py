@@ -293,7 +293,7 @@ def test_full_size_properties(dev, full_scene):
     finally:
         _hip.rasterize_forward = orig
     v = _hip.debug_views(st["s"])
-    ranges, pl, depth_g = v["ranges"].long(), v["point_list"].long(), v["recC"][:, 1]
+    ranges, pl, depth_g = v["ranges"].long(), v["point_list"].long(), v["rec"][:, 9]
     D = st["s"].num_rendered
     lens = ranges[:, 1] - ranges[:, 0]
     assert int(lens.sum()) == D and int(v["offsets"][-1]) == D
