@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the get_loss-shaped step and forward-only timings")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the views of a step are spread over")
     ap.add_argument("--per-view-calls", action="store_true",
@@ -211,6 +212,21 @@ def main():
         "per_kernel_timing": "HIP events around every launch, per-view sequential pass after the timed region",
     }
 
+    # measured HBM traffic of the dominant kernel, if a PMC summary of this round is committed (tools/prof_traffic.sh)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if dom in tj:
+                roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
+        except Exception:  # noqa: BLE001
+            pass
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(params, cams[0], dLs[0], params2rendervar)
@@ -228,11 +244,65 @@ def main():
                        "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}",
                        "call_pattern": "per-view GaussianRasterizer calls" if args.per_view_calls else
                                        "one rasterize_gaussians_views call per step (per-view chains on internal streams)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _time_ms(fn, iters, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / iters
+
+
+def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
+    """Reported beside the headline: the full get_loss-shaped step of train_gs.py
+    (2 renders + SSIM/L1 + rigidity terms + backward, per view) and BASELINE configs[1] (forward only)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import LossWeights, get_loss, params2rendervar, synth_targets
+    from gsdyn.dp import init_variables
+    from gsdyn.step import make_rigidity_variables
+    out = {}
+    try:
+        im_gt, seg_gt = synth_targets(W, H, device=dev)
+        variables = init_variables(P_GAUSS, dev)
+        variables.update(make_rigidity_variables(params, num_knn=20))
+        w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)  # assets/datasets.md weights
+        views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
+
+        def getloss_step():
+            for p in params.values():
+                p.grad = None
+            for d in views:
+                loss, _ = get_loss(params, d, variables, False, w)
+                loss.backward()
+        ms = _time_ms(getloss_step, 5, 2)
+        out["getloss_step"] = {"ms_per_step": ms, "ms_per_view": ms / len(views), "views": len(views),
+                               "what": "train_gs.py get_loss (colour+seg renders, 0.8 L1 + 0.2 (1-SSIM), rigid/rot/iso/floor/bg) + backward, t>0"}
+    except Exception as e:  # noqa: BLE001
+        out["getloss_step"] = {"error": repr(e)}
+    try:
+        p2 = synth_scene_params(50_000, seed=0, device=dev)
+        with torch.no_grad():
+            rv = {k: v.detach() for k, v in params2rendervar(p2).items()}
+        cam = cams[0]
+
+        def fwd():
+            with torch.no_grad():
+                GaussianRasterizer(raster_settings=cam)(**rv)
+        ms = _time_ms(fwd, 20, 5)
+        out["forward_only_cfg2"] = {"ms_per_view": ms, "Mpix_per_s": H * W / ms / 1e3,
+                                    "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only"}
+    except Exception as e:  # noqa: BLE001
+        out["forward_only_cfg2"] = {"error": repr(e)}
+    return out
 
 
 def run_cpu_baseline(params, cam, dL, params2rendervar):
