@@ -336,8 +336,13 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   // the nine-at-once asm form must agree too: feed it v, 2v, ..., 9v
   float q0 = v, q1 = 2.f * v, q2 = 3.f * v, q3 = 4.f * v, q4 = 5.f * v, q5 = 6.f * v, q6 = 7.f * v, q7 = 8.f * v, q8 = 9.f * v;
   gsr_wave_sum9_to_lane63(q0, q1, q2, q3, q4, q5, q6, q7, q8);
+  // packed form: lane with (lane & 15) = i < 8 holds the total of value i, lanes with bit 3 set the total of value 8
+  const float z = gsr_wave_sum9_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v, 9.f * v);
+  const int l = threadIdx.x & 63;
+  const float zexp = ((l & 8) == 0) ? (float)((l & 7) + 1) * b : 9.f * b;
+  const bool okz = __ballot(z != zexp) == 0ull;
   if ((threadIdx.x & 63) == 63) {
-    const bool ok9 = q0 == b && q1 == 2.f * b && q2 == 3.f * b && q3 == 4.f * b && q4 == 5.f * b && q5 == 6.f * b &&
+    const bool ok9 = okz && q0 == b && q1 == 2.f * b && q2 == 3.f * b && q3 == 4.f * b && q4 == 5.f * b && q5 == 6.f * b &&
                      q6 == 7.f * b && q7 == 8.f * b && q8 == 9.f * b;
     out_dpp[threadIdx.x >> 6] = ok9 ? a : -1e30f;
     out_ref[threadIdx.x >> 6] = b;

@@ -177,7 +177,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
   // column sums of the histogram matrix: wave w takes blocks w, w+4, ...; lane l takes bins l, l+64, ...
   for (int bin = lane; bin < nb; bin += 64) {
     uint32_t tot = 0, pre = 0;
-    for (uint32_t b = wv; b < nblocks; b += 4) {
+    uint32_t b = wv;
+    for (; b + 28 < nblocks; b += 32) {  // 8 independent loads in flight per lane
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = block_hist[(b + 4 * u) * (uint32_t)nb + bin];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { tot += v[u]; pre += (b + 4 * u < blockIdx.x) ? v[u] : 0u; }
+    }
+    for (; b < nblocks; b += 4) {
       const uint32_t v = block_hist[b * (uint32_t)nb + bin];
       tot += v;
       pre += (b < blockIdx.x) ? v : 0u;
@@ -307,23 +315,24 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 #define TILE_SORT_LDS_CAP 4096
 template <typename PTR>
 __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
-  uint32_t np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  const uint32_t npairs = np2 >> 1;
-  for (uint32_t k = 2; k <= np2; k <<= 1) {
-    const uint32_t hk = k >> 1;
+  uint32_t lg = 1;  // log2 of the padded size
+  while ((1u << lg) < n) ++lg;
+  const uint32_t npairs = (1u << lg) >> 1;
+  for (uint32_t lk = 1; lk <= lg; ++lk) {  // merge size k = 2^lk; all index maths are shifts and masks
+    const uint32_t k = 1u << lk, hk = k >> 1;
     for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {  // mirror step
-      const uint32_t blk = p / hk, off = p % hk;
-      const uint32_t l = blk * k + off, r = blk * k + (k - 1 - off);
+      const uint32_t base = (p >> (lk - 1)) << lk, off = p & (hk - 1);
+      const uint32_t l = base + off, r = base + (k - 1 - off);
       if (r < n) {
         uint64_t x = a[l], y = a[r];
         if (y < x) { a[l] = y; a[r] = x; }
       }
     }
     __syncthreads();
-    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+    for (int lj = (int)lk - 2; lj >= 0; --lj) {
+      const uint32_t j = 1u << lj;
       for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {
-        const uint32_t l = 2 * j * (p / j) + (p % j), r = l + j;
+        const uint32_t l = ((p >> lj) << (lj + 1)) + (p & (j - 1)), r = l + j;
         if (r < n) {
           uint64_t x = a[l], y = a[r];
           if (y < x) { a[l] = y; a[r] = x; }
@@ -335,11 +344,12 @@ __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ tile_order,
                                                               uint64_t* __restrict__ dg,
                                                               uint32_t* __restrict__ point_list) {
   __shared__ uint64_t skeys[TILE_SORT_LDS_CAP];
   const int tid = threadIdx.x;
-  const uint2 rg = ranges[blockIdx.x];
+  const uint2 rg = ranges[tile_order[blockIdx.x]];  // longest lists are dispatched first
   const uint32_t n = rg.y - rg.x;
   if (n == 0) return;
   uint64_t* seg = dg + rg.x;
@@ -409,7 +419,8 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
   GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("tile_sort", st);
-  hipLaunchKernelGGL(tile_sort_kernel, dim3(cam.T), dim3(GSR_BLOCK), 0, st, im.ranges, bs.dg[cur], bs.point_list); }
+  hipLaunchKernelGGL(tile_sort_kernel, dim3(cam.T), dim3(GSR_BLOCK), 0, st, im.ranges, im.tile_order, bs.dg[cur],
+                     bs.point_list); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

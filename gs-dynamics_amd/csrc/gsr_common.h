@@ -205,6 +205,45 @@ __device__ __forceinline__ void gsr_wave_sum9_to_lane63(float& v0, float& v1, fl
       : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
+// Packed ("transposition") form of the nine wave sums: 33 instructions instead of 54.  At butterfly level
+// xor-1 the nine values are folded pairwise by lane parity (each lane keeps one value of a pair, sends the
+// other to its partner: 2 selects + 1 fused DPP add per pair), so the register count goes 9 -> 5 -> 3 -> 2 -> 1
+// across the xor-1 / xor-2 / xor-4 / xor-8 levels; the two row levels then run on ONE register (33 instructions).
+// Result z (in every row): lane with (lane & 15) = i < 8 holds the wave total of v_i, lanes with bit 3 set the total of v8.
+template <int CTRL>
+__device__ __forceinline__ float gsr_dpp_get(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float gsr_swz_xor4(float x) {  // ds_swizzle bit mode: src lane = lane ^ 4
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101F));
+}
+__device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float v2, float v3, float v4, float v5,
+                                                      float v6, float v7, float v8) {
+  const int lane = gsr_lane();
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  // xor 1 (quad_perm [1,0,3,2]): 9 -> 5
+  const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
+  const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
+  const float r45 = (b0 ? v5 : v4) + gsr_dpp_get<0xB1>(b0 ? v4 : v5);
+  const float r67 = (b0 ? v7 : v6) + gsr_dpp_get<0xB1>(b0 ? v6 : v7);
+  const float r8 = v8 + gsr_dpp_get<0xB1>(v8);
+  // xor 2 (quad_perm [2,3,0,1]): 5 -> 3   (lane & 3 now indexes v0..v3 / v4..v7)
+  const float q03 = (b1 ? r23 : r01) + gsr_dpp_get<0x4E>(b1 ? r01 : r23);
+  const float q47 = (b1 ? r67 : r45) + gsr_dpp_get<0x4E>(b1 ? r45 : r67);
+  const float q8 = r8 + gsr_dpp_get<0x4E>(r8);
+  // xor 4 (ds_swizzle): 3 -> 2   (lane & 7 indexes v0..v7)
+  const float p07 = (b2 ? q47 : q03) + gsr_swz_xor4(b2 ? q03 : q47);
+  const float p8 = q8 + gsr_swz_xor4(q8);
+  // xor 8 (row_ror:8): 2 -> 1   (lanes with bit 3 clear: v_(lane&7); bit 3 set: v8)
+  float z = (b3 ? p8 : p07) + gsr_dpp_get<0x128>(b3 ? p07 : p8);
+  // rows: the packed layout differs per lane, so the row levels must be lane-wise exchanges (row_bcast would
+  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  Every lane ends up
+  // with the total of "its" value: lane & 15 in 0..7 -> v_(lane & 7), lane & 8 set -> v8.
+  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
+  z += __shfl_xor(z, 32, 64);
+  return z;
+}
+
 // exp(x) for x <= 0 to ~1-2 ulp: v_exp_f32 on a compensated x*log2(e).  The plain `__expf` form rounds
 // x*log2e once (relative error |x| * 6e-8 in the result); alpha feeds T/(1-alpha) in the backward,
 // which amplifies alpha's error by up to 100x near the 0.99 clamp, so the extra 4 VALU ops buy parity.

@@ -336,12 +336,8 @@ __device__ __forceinline__ void bwd_tile(
         v5 = G * dL_dalpha;
         v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;
       }
-      gsr_wave_sum9_to_lane63(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-      if (lane == 63) {
-        L.sRed[wv][j][0] = make_float4(v0, v1, v2, v3);
-        L.sRed[wv][j][1] = make_float4(v4, v5, v6, v7);
-        L.sRed[wv][j][2] = make_float4(v8, 0.f, 0.f, 0.f);
-      }
+      const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);
+      if (lane >= 48 && lane <= 56) reinterpret_cast<float*>(&L.sRed[wv][j][0])[lane - 48] = z;  // one ds_write_b32
       if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
     }
     if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
