@@ -294,6 +294,8 @@ int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t H, int32_t W, 
 
 int gsr_selftest(void* stream) { return gsr_run_selftest((hipStream_t)stream); }
 
+int gsr_debug_phase_timing(uint64_t* out16) { return gsr_debug_fwd_timing((unsigned long long*)out16); }
+
 int gsr_profile_begin(void) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* 
 // kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
 // is arbitrary: per-tile results do not depend on it.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int T,
-                                                          uint32_t* __restrict__ tile_order,
+                                                          uint4* __restrict__ tile_order,
                                                           uint32_t* __restrict__ queue) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t start[256];
@@ -305,8 +305,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
   for (int t = tid; t < T; t += 1024) {
     const uint2 r = ranges[t];
     const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
-    tile_order[atomicAdd(&start[bucket], 1u)] = (uint32_t)t;
+    tile_order[atomicAdd(&start[bucket], 1u)] = make_uint4((uint32_t)t, r.x, r.y, 0u);
   }
+  if (tid == 0) queue[4] = (uint32_t)T - cnt[255];  // bucket 255 = empty tiles (sorted last)
 }
 
 // ------------------------------------------------------------------ per-tile depth sort
@@ -344,12 +345,13 @@ __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ tile_order,
+                                                              const uint4* __restrict__ tile_order,
                                                               uint64_t* __restrict__ dg,
                                                               uint32_t* __restrict__ point_list) {
   __shared__ uint64_t skeys[TILE_SORT_LDS_CAP];
   const int tid = threadIdx.x;
-  const uint2 rg = ranges[tile_order[blockIdx.x]];  // longest lists are dispatched first
+  const uint4 ord = tile_order[blockIdx.x];  // longest lists are dispatched first
+  const uint2 rg = make_uint2(ord.y, ord.z);
   const uint32_t n = rg.y - rg.x;
   if (n == 0) return;
   uint64_t* seg = dg + rg.x;

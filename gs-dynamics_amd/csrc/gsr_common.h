@@ -35,8 +35,8 @@ struct ImageState {
   float* final_T;         // [H*W]
   uint32_t* n_contrib;    // [H*W]
   uint2* ranges;          // [T]
-  uint32_t* tile_order;   // [T] tile ids sorted by list length, longest first (LPT work queue)
-  uint32_t* queue;        // [8] work-queue heads: [0] render_fwd, [1] render_bwd
+  uint4* tile_order;      // [T] {tile id, list start, list end, 0} sorted by list length, longest first (LPT queue)
+  uint32_t* queue;        // [8] work-queue heads: [0] render_fwd, [1] render_bwd; [4] = number of non-empty tiles
 };
 // Binning state: tile-key / (depth,gid) entries, double-buffered for the radix passes.
 struct BinningState {
@@ -76,7 +76,7 @@ static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageStat
   im->final_T = (float*)take((N ? N : 1) * 4);
   im->n_contrib = (uint32_t*)take((N ? N : 1) * 4);
   im->ranges = (uint2*)take((T ? T : 1) * 8);
-  im->tile_order = (uint32_t*)take((T ? T : 1) * 4);
+  im->tile_order = (uint4*)take((T ? T : 1) * 16);
   im->queue = (uint32_t*)take(64);
   return off;
 }
@@ -151,6 +151,7 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
                               float* dL_dsh, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
+int gsr_debug_fwd_timing(unsigned long long* out16);
 
 // ---------------------------------------------------------------- device helpers
 #ifdef __HIPCC__

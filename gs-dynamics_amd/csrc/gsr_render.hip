@@ -31,6 +31,19 @@
 #include <stdlib.h>
 #include "gsr_common.h"
 
+// Optional phase timing of the forward tile loop (debug build only: make TIMING=1).  Wave 0 lane 0 of every
+// workgroup accumulates s_memtime deltas per phase and adds them to g_fwd_timing at kernel end.
+#ifdef GSR_TILE_TIMING
+__device__ unsigned long long g_fwd_timing[16];
+#define GSR_T0() unsigned long long _t_prev = __builtin_readcyclecounter(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GSR_TP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); _t_acc[i] += _t - _t_prev; _t_prev = _t; } while (0)
+#define GSR_TFLUSH() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_fwd_timing[_i], _t_acc[_i]); atomicAdd(&g_fwd_timing[15], 1ull); } } while (0)
+#else
+#define GSR_T0() do {} while (0)
+#define GSR_TP(i) do {} while (0)
+#define GSR_TFLUSH() do {} while (0)
+#endif
+
 namespace {
 
 #define FWD_BATCH 128
@@ -90,7 +103,7 @@ struct FwdLds {
 };
 
 __device__ __forceinline__ void fwd_tile(
-    const int tile, FwdLds& L, int W, int H, int gx, const uint2* __restrict__ ranges,
+    const int tile, const uint2 rg, FwdLds& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_depth) {
@@ -99,12 +112,12 @@ __device__ __forceinline__ void fwd_tile(
   const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 rg = ranges[tile];
   const int n = (int)(rg.y - rg.x);
 
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
   uint32_t last = 0;
   bool done = !inside;
+  GSR_T0();
 
   // Software-pipelined staging: the gathers of batch b+1 are issued before batch b is walked, so their
   // latency (point_list -> record arrays, two dependent trips to L2/HBM) hides behind the blend loop.
@@ -116,8 +129,10 @@ __device__ __forceinline__ void fwd_tile(
     { const float4 t2 = rec[3 * g + 2]; na = rec[3 * g]; nb = rec[3 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
   }
+  GSR_TP(0);
   for (int base = 0; base < n; base += FWD_BATCH) {
     if (__syncthreads_count(done) == GSR_BLOCK) break;  // also fences the previous batch's LDS reads
+    GSR_TP(1);
     // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
     const float4 a = na, b = nb;
     const int idx = base + tid;
@@ -139,7 +154,9 @@ __device__ __forceinline__ void fwd_tile(
 #pragma unroll
       for (int w = 0; w < 4; ++w) L.cnt[wv][w] = (uint32_t)__popcll(bal[w]);
     }
+    GSR_TP(2);
     __syncthreads();
+    GSR_TP(3);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if ((mask >> w) & 1u) {
@@ -148,9 +165,10 @@ __device__ __forceinline__ void fwd_tile(
         L.sA[w][pos] = a; L.sB[w][pos] = b; L.sC[w][pos] = c;
       }
     }
-    // staging threads live in waves 0 and 1 only; readfirstlane makes the trip count a scalar
-    const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
+    // readfirstlane makes the trip count a scalar
+    const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv] + L.cnt[2][wv] + L.cnt[3][wv]));
     __syncthreads();
+    GSR_TP(4);
     // ---- blend: wave wv walks only the entries that can reach its strip.  Straight-line body: the next
     // entry's record is fetched from LDS while this one is evaluated, and the blend itself is predicated
     // (w = 0 when the pair does not contribute) instead of branched, so consecutive iterations overlap.
@@ -178,7 +196,9 @@ __device__ __forceinline__ void fwd_tile(
         if ((j & 7) == 7 && __ballot(!done) == 0ull) break;
       }
     }
+    GSR_TP(5);
   }
+  GSR_TP(1);
   if (inside) {
     const int pix = py * W + px;
     const size_t N = (size_t)H * W;
@@ -189,6 +209,8 @@ __device__ __forceinline__ void fwd_tile(
     out_color[2 * N + pix] = C2 + T * bg[2];
     out_depth[pix] = Dp;
   }
+  GSR_TP(6);
+  GSR_TFLUSH();
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -204,7 +226,7 @@ struct BwdLds {
 };
 
 __device__ __forceinline__ void bwd_tile(
-    const int tile, BwdLds& L, int W, int H, int gx, const uint2* __restrict__ ranges,
+    const int tile, const uint2 rg, BwdLds& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials) {
@@ -214,7 +236,6 @@ __device__ __forceinline__ void bwd_tile(
   const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 rg = ranges[tile];
   const int n = (int)(rg.y - rg.x);
   if (n == 0) return;  // uniform: nothing to differentiate in an empty tile
   const size_t N = (size_t)H * W;
@@ -370,27 +391,53 @@ __device__ __forceinline__ void bwd_tile(
   int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
       const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,              \
       uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth
-#define GSR_FWD_PASS W, H, gx, ranges, point_list, rec, bg, final_T, n_contrib, out_color, out_depth
+#define GSR_FWD_PASS W, H, gx, point_list, rec, bg, final_T, n_contrib, out_color, out_depth
 
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GSR_FWD_ARGS) {
   __shared__ FwdLds L;
-  fwd_tile((int)blockIdx.x, L, GSR_FWD_PASS);
+  fwd_tile((int)blockIdx.x, ranges[blockIdx.x], L, GSR_FWD_PASS);
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint32_t* __restrict__ tile_order,
-                                                                  uint32_t* __restrict__ queue_head, GSR_FWD_ARGS) {
+// Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
+// (grid-stride over the tail of the order array), then pop busy tiles longest-first.
+__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint4* __restrict__ tile_order,
+                                                                  uint32_t* __restrict__ queue, GSR_FWD_ARGS) {
   __shared__ FwdLds L;
   __shared__ uint32_t s_ticket;
-  for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(queue_head, 1u);
+  const uint32_t n_busy = queue[4];
+  // Tickets: the first one is implicit (blockIdx.x, no atomic: no thundering herd at kernel start); later ones
+  // are gridDim.x + atomicAdd(head), popped after the tile.  (Popping the next ticket early was measured
+  // slower: the in-flight returning atomic sits in front of the wave's gather waits -- vmcnt retires in order.)
+  {  // background of the empty tiles
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    const size_t N = (size_t)H * W;
+    for (uint32_t i = n_busy + blockIdx.x; i < (uint32_t)T_tiles; i += gridDim.x) {
+      const int tile = (int)tile_order[i].x;
+      const int px = (tile % gx) * GSR_TILE + (threadIdx.x & 15), py = (tile / gx) * GSR_TILE + (threadIdx.x >> 4);
+      if (px < W && py < H) {
+        const int pix = py * W + px;
+        final_T[pix] = 1.0f; n_contrib[pix] = 0u;
+        out_color[pix] = b0; out_color[N + pix] = b1; out_color[2 * N + pix] = b2;
+        out_depth[pix] = 0.0f;
+      }
+    }
+  }
+  uint32_t ticket = blockIdx.x;
+  while (ticket < n_busy) {
+    const uint4 ord = tile_order[ticket];
+    fwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS);
+#ifdef GSR_TILE_TIMING
+    const unsigned long long tq0 = __builtin_readcyclecounter();
+#endif
+    if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[0], 1u);
     __syncthreads();
-    const uint32_t ticket = s_ticket;
-    __syncthreads();  // every wave has its copy before lane 0 overwrites the slot
-    if (ticket >= (uint32_t)T_tiles) break;
-    fwd_tile((int)tile_order[ticket], L, GSR_FWD_PASS);
+    ticket = s_ticket;
+    __syncthreads();  // every wave has its copy before thread 0 overwrites the slot
+#ifdef GSR_TILE_TIMING
+    if (threadIdx.x == 0) atomicAdd(&g_fwd_timing[7], __builtin_readcyclecounter() - tq0);
+#endif
   }
 }
-
 
 #define GSR_BWD_ARGS                                                                                          \
   int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
@@ -398,29 +445,46 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint32_
       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const uint2* __restrict__ rect, \
       const uint32_t* __restrict__ offsets, float4* __restrict__ partials
 #define GSR_BWD_PASS \
-  W, H, gx, ranges, point_list, rec, bg, final_T, n_contrib, dL_dcolor, rect, offsets, partials
+  W, H, gx, point_list, rec, bg, final_T, n_contrib, dL_dcolor, rect, offsets, partials
 
 __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GSR_BWD_ARGS) {
   __shared__ BwdLds L;
-  bwd_tile((int)blockIdx.x, L, GSR_BWD_PASS);
+  bwd_tile((int)blockIdx.x, ranges[blockIdx.x], L, GSR_BWD_PASS);
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(const uint32_t* __restrict__ tile_order,
-                                                                  uint32_t* __restrict__ queue_head, GSR_BWD_ARGS) {
+__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(const uint4* __restrict__ tile_order,
+                                                                  uint32_t* __restrict__ queue, GSR_BWD_ARGS) {
   __shared__ BwdLds L;
   __shared__ uint32_t s_ticket;
-  for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(queue_head, 1u);
+  const uint32_t n_busy = queue[4];  // empty tiles have nothing to differentiate: they never enter the queue
+  // First ticket implicit (blockIdx.x); later ones popped after the tile.  (No ticket prefetch here: every wave
+  // of bwd_tile issues global loads right at tile start, and they would queue behind the in-flight atomic.)
+  uint32_t ticket = blockIdx.x;
+  while (ticket < n_busy) {
+    const uint4 ord = tile_order[ticket];
+    bwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS);
+    if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
+    __syncthreads();  // also: the tile's LDS (incl. sMaxLast) is dead before the next tile reuses it
+    ticket = s_ticket;
     __syncthreads();
-    const uint32_t ticket = s_ticket;
-    __syncthreads();
-    if (ticket >= (uint32_t)T_tiles) break;
-    bwd_tile((int)tile_order[ticket], L, GSR_BWD_PASS);
-    __syncthreads();  // the tile's LDS (incl. sMaxLast) is dead before the next tile reuses it
   }
 }
 
 }  // namespace
+
+// Debug: copy out and clear the forward phase timers (zeros in a normal build).
+int gsr_debug_fwd_timing(unsigned long long* out16) {
+#ifdef GSR_TILE_TIMING
+  GSR_HIP_CHECK(hipDeviceSynchronize());
+  GSR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fwd_timing), sizeof(unsigned long long) * 16));
+  unsigned long long z[16] = {0};
+  GSR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_timing), z, sizeof z));
+  return 0;
+#else
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  return 1;
+#endif
+}
 
 static bool env_flag(const char* name) {
   const char* v = getenv(name);
@@ -442,7 +506,7 @@ int gsr_launch_render_fwd(const GsrCam& cam, const GeomState& g, const BinningSt
                          bs.point_list, g.rec, cam.bg, im.final_T, im.n_contrib, out_color, out_depth);
     } else {
       const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue + 0, cam.W,
+      hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue, cam.W,
                          cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
                          im.n_contrib, out_color, out_depth);
     }
@@ -464,7 +528,7 @@ int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, con
                          g.offsets, partials);
     } else {
       const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue + 1, cam.W,
+      hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue, cam.W,
                          cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
                          im.n_contrib, dL_dcolor, g.rect, g.offsets, partials);
     }

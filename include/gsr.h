@@ -131,6 +131,10 @@ int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t image_height, 
                         const void* geom_state, const void* binning_state, const void* image_state,
                         gsr_debug_views* out);
 
+/* Debug builds only (make TIMING=1): accumulated s_memtime cycles per phase of the forward tile loop
+ * (16 words; returns 1 and zeros in a normal build). */
+int gsr_debug_phase_timing(uint64_t* out16);
+
 /* Device self-test of the wave-64 building blocks (DPP reduction, ballot match, scan, sorts).
  * Returns 0 when all pass, else a bitmask of failed checks. */
 int gsr_selftest(void* stream);
