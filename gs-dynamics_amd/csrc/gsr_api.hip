@@ -239,30 +239,43 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
 }
 
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
-                       const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                       const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
-                       void* const* scratch, float* const* dL_dmeans3D, float* const* dL_dmeans2D,
-                       float* const* dL_dcolors, float* const* dL_dopacity, float* const* dL_dscales,
-                       float* const* dL_drotations, float* const* dL_dcov3D, float* const* dL_dsh, void* stream) {
+                       void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D, float* dL_dcolors,
+                       float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream) {
   if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
   if (!s || !num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
-      !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) {
+      !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !means3D) {
     gsr_set_error("gsr_backward_batch: NULL argument");
     return -2;
   }
+  if (P <= 0) return 0;
   StreamPool* pool = nullptr;
   if (int rc = get_pool(V, &pool)) return rc;
   if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  GsrBwdViews vw;
+  vw.V = V;
   for (int v = 0; v < V; ++v) {
-    if (int rc = gsr_backward(&s[v], P, num_rendered[v], means3D, scales, rotations, colors_precomp, shs, cov3D_precomp,
-                              radii[v], geom_states[v], binning_states[v], image_states[v], dL_dcolor[v], scratch[v],
-                              dL_dmeans3D[v], dL_dmeans2D[v], dL_dcolors ? dL_dcolors[v] : nullptr, dL_dopacity[v],
-                              dL_dscales ? dL_dscales[v] : nullptr, dL_drotations ? dL_drotations[v] : nullptr,
-                              dL_dcov3D ? dL_dcov3D[v] : nullptr, dL_dsh ? dL_dsh[v] : nullptr, pool->streams[v]))
+    GsrCam cam;
+    if (int rc = make_cam(&s[v], &cam)) return rc;
+    GeomState g; ImageState im; BinningState bs;
+    gsr_carve_geom(geom_states[v], P, &g);
+    gsr_carve_image(image_states[v], cam.H, cam.W, &im);
+    gsr_carve_binning(binning_states[v], num_rendered[v], &bs);
+    if (num_rendered[v] > 0 && (!binning_states[v] || !scratch[v])) { gsr_set_error("gsr_backward_batch: NULL binning/scratch"); return -2; }
+    if (int rc = gsr_launch_render_bwd(cam, num_rendered[v], g, bs, im, dL_dcolor[v], (float4*)scratch[v], pool->streams[v]))
       return rc;
+    GsrBwdView& w = vw.v[v];
+    w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
+    w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
+    w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
-  return join_streams(*pool, V, (hipStream_t)stream);
+  if (int rc = join_streams(*pool, V, (hipStream_t)stream)) return rc;
+  (void)colors_precomp;
+  return gsr_launch_preprocess_bwd_views(vw, P, s[0].scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D,
+                                         dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D,
+                                         (hipStream_t)stream);
 }
 
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {

@@ -149,6 +149,24 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
                               const float4* partials, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                               float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                               float* dL_dsh, hipStream_t st);
+// Per-view pointers of the multi-view preprocess backward (passed by value as a kernel argument).
+struct GsrBwdView {
+  const float *view, *proj;
+  const int32_t* radii;
+  const uint32_t* offsets;
+  const float4* partials;
+  float* dL_dmeans2D;
+  int W, H;
+  float tanfovx, tanfovy;
+};
+struct GsrBwdViews {
+  int V;
+  GsrBwdView v[GSR_MAX_BATCH];
+};
+int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_modifier, const float* means3D,
+                                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                                    float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
+                                    float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
 int gsr_debug_fwd_timing(unsigned long long* out16);

@@ -91,6 +91,147 @@ __device__ void sh_backward(int deg, int M, const float* __restrict__ sh, float3
   dmean[2] = (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 }
 
+// ---- shared pieces ---------------------------------------------------------------------------------
+struct PartialSum { float gmx, gmy, gA, gB, gC, gop, dr, dg, db; };
+
+// Sum of a Gaussian's entry records (one per touched tile, contiguous, ascending tile order).
+__device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__ partials, uint32_t e0, uint32_t e1) {
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2x = 0.f;
+  for (uint32_t e = e0; e < e1; ++e) {
+    const float4 q0 = partials[(size_t)e * GSR_PARTIAL_F4 + 0];
+    const float4 q1 = partials[(size_t)e * GSR_PARTIAL_F4 + 1];
+    const float4 q2 = partials[(size_t)e * GSR_PARTIAL_F4 + 2];
+    r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
+    r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
+    r2x += q2.x;
+  }
+  PartialSum ps;
+  ps.gmx = r0.x; ps.gmy = r0.y; ps.gA = r0.z; ps.gB = r0.w; ps.gC = r1.x; ps.gop = r1.y;
+  ps.dr = r1.z; ps.dg = r1.w; ps.db = r2x;
+  return ps;
+}
+
+// Rotation matrix, scaled axes and 3D covariance of one Gaussian (view independent).
+struct Cov3 { float R[3][3]; float s[3]; float q[4]; float c[6]; };
+__device__ __forceinline__ void build_cov3(int i, float mod, const float* __restrict__ scales,
+                                           const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                                           Cov3& o) {
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.c[k] = cov3D_precomp[6 * i + k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o.s[a] = 0.f; for (int b = 0; b < 3; ++b) o.R[a][b] = 0.f; }
+    o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f;
+    return;
+  }
+  const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+  o.q[0] = r; o.q[1] = x; o.q[2] = y; o.q[3] = z;
+  o.R[0][0] = 1.f - 2.f * (y * y + z * z); o.R[0][1] = 2.f * (x * y - r * z); o.R[0][2] = 2.f * (x * z + r * y);
+  o.R[1][0] = 2.f * (x * y + r * z); o.R[1][1] = 1.f - 2.f * (x * x + z * z); o.R[1][2] = 2.f * (y * z - r * x);
+  o.R[2][0] = 2.f * (x * z - r * y); o.R[2][1] = 2.f * (y * z + r * x); o.R[2][2] = 1.f - 2.f * (x * x + y * y);
+  o.s[0] = mod * scales[3 * i]; o.s[1] = mod * scales[3 * i + 1]; o.s[2] = mod * scales[3 * i + 2];
+  float Mm[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Mm[a][b] = o.R[a][b] * o.s[b];
+  o.c[0] = Mm[0][0] * Mm[0][0] + Mm[0][1] * Mm[0][1] + Mm[0][2] * Mm[0][2];
+  o.c[1] = Mm[0][0] * Mm[1][0] + Mm[0][1] * Mm[1][1] + Mm[0][2] * Mm[1][2];
+  o.c[2] = Mm[0][0] * Mm[2][0] + Mm[0][1] * Mm[2][1] + Mm[0][2] * Mm[2][2];
+  o.c[3] = Mm[1][0] * Mm[1][0] + Mm[1][1] * Mm[1][1] + Mm[1][2] * Mm[1][2];
+  o.c[4] = Mm[1][0] * Mm[2][0] + Mm[1][1] * Mm[2][1] + Mm[1][2] * Mm[2][2];
+  o.c[5] = Mm[2][0] * Mm[2][0] + Mm[2][1] * Mm[2][1] + Mm[2][2] * Mm[2][2];
+}
+
+// One view's chain: conic -> cov2D -> (cov3D, view-space mean) and 2D mean -> 3D mean.  ACCUMULATES into
+// gcov[6] and gm3[3]; returns this view's dL/d(NDC mean) in gm2.
+__device__ __forceinline__ void view_chain(const float* __restrict__ view, const float* __restrict__ proj, int W, int H,
+                                           float tanfovx, float tanfovy, float3 p, const float c[6],
+                                           const PartialSum& ps, float gcov[6], float gm3[3], float gm2[2]) {
+  const float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
+  const float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
+  const float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
+  const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+  const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  const float tz = pvz;
+  const float txtz = pvx / tz, tytz = pvy / tz;
+  const float xm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  const float ym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float tx = clampf(txtz, -limx, limx) * tz, ty = clampf(tytz, -limy, limy) * tz;
+  const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+  const float T0[3] = {J00 * view[0] + J02 * view[2], J00 * view[4] + J02 * view[6], J00 * view[8] + J02 * view[10]};
+  const float T1[3] = {J11 * view[1] + J12 * view[2], J11 * view[5] + J12 * view[6], J11 * view[9] + J12 * view[10]};
+  const float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+  float U0[3], U1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    U0[k] = S[k][0] * T0[0] + S[k][1] * T0[1] + S[k][2] * T0[2];
+    U1[k] = S[k][0] * T1[0] + S[k][1] * T1[1] + S[k][2] * T1[2];
+  }
+  const float a = U0[0] * T0[0] + U0[1] * T0[1] + U0[2] * T0[2] + 0.3f;
+  const float b = U0[0] * T1[0] + U0[1] * T1[1] + U0[2] * T1[2];
+  const float cc = U1[0] * T1[0] + U1[1] * T1[1] + U1[2] * T1[2] + 0.3f;
+  const float det = a * cc - b * b;
+  const float d2inv = 1.0f / (det * det + 0.0000001f);
+  const float gA = ps.gA, gB = ps.gB, gC = ps.gC;
+  const float dL_da = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
+  const float dL_dc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
+  const float dL_db = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+  gcov[0] += T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+  gcov[3] += T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+  gcov[5] += T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+  gcov[1] += 2.0f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.0f * T1[0] * T1[1] * dL_dc;
+  gcov[2] += 2.0f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.0f * T1[0] * T1[2] * dL_dc;
+  gcov[4] += 2.0f * T0[1] * T0[2] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.0f * T1[1] * T1[2] * dL_dc;
+  float dT0[3], dT1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    dT0[j] = 2.0f * U0[j] * dL_da + U1[j] * dL_db;
+    dT1[j] = 2.0f * U1[j] * dL_dc + U0[j] * dL_db;
+  }
+  const float dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
+  const float dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
+  const float dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
+  const float dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
+  const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  const float dtx = xm * -fx * itz2 * dJ02;
+  const float dty = ym * -fy * itz2 * dJ12;
+  const float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
+  gm2[0] = ps.gmx * 0.5f * (float)W;
+  gm2[1] = ps.gmy * 0.5f * (float)H;
+  const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
+  const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
+  const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
+  const float mw = 1.0f / (hw + 0.0000001f);
+  const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+  gm3[0] += view[0] * dtx + view[1] * dty + view[2] * dtz + (proj[0] * mw - proj[3] * mul1) * gm2[0] + (proj[1] * mw - proj[3] * mul2) * gm2[1];
+  gm3[1] += view[4] * dtx + view[5] * dty + view[6] * dtz + (proj[4] * mw - proj[7] * mul1) * gm2[0] + (proj[5] * mw - proj[7] * mul2) * gm2[1];
+  gm3[2] += view[8] * dtx + view[9] * dty + view[10] * dtz + (proj[8] * mw - proj[11] * mul1) * gm2[0] + (proj[9] * mw - proj[11] * mul2) * gm2[1];
+}
+
+// dL/dcov3D -> dL/dscale, dL/drotation (linear in gcov: in the multi-view kernel it runs once on the sum).
+__device__ __forceinline__ void cov3_to_scale_rot(const Cov3& cv, float mod, const float gcov[6], float gs[3], float gq[4]) {
+  const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                          {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                          {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+  float G[3][3];
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const float dM0 = 2.0f * (dS[0][0] * cv.R[0][jj] + dS[0][1] * cv.R[1][jj] + dS[0][2] * cv.R[2][jj]) * cv.s[jj];
+    const float dM1 = 2.0f * (dS[1][0] * cv.R[0][jj] + dS[1][1] * cv.R[1][jj] + dS[1][2] * cv.R[2][jj]) * cv.s[jj];
+    const float dM2 = 2.0f * (dS[2][0] * cv.R[0][jj] + dS[2][1] * cv.R[1][jj] + dS[2][2] * cv.R[2][jj]) * cv.s[jj];
+    gs[jj] = mod * (cv.R[0][jj] * dM0 + cv.R[1][jj] * dM1 + cv.R[2][jj] * dM2);
+    G[0][jj] = dM0 * cv.s[jj]; G[1][jj] = dM1 * cv.s[jj]; G[2][jj] = dM2 * cv.s[jj];
+  }
+  const float r = cv.q[0], x = cv.q[1], y = cv.q[2], z = cv.q[3];
+  gq[0] = 2.0f * (-z * G[0][1] + y * G[0][2] + z * G[1][0] - x * G[1][2] - y * G[2][0] + x * G[2][1]);
+  gq[1] = 2.0f * (y * G[0][1] + z * G[0][2] + y * G[1][0] - 2.0f * x * G[1][1] - r * G[1][2] + z * G[2][0] + r * G[2][1] - 2.0f * x * G[2][2]);
+  gq[2] = 2.0f * (-2.0f * y * G[0][0] + x * G[0][1] + r * G[0][2] + x * G[1][0] + z * G[1][2] - r * G[2][0] + z * G[2][1] - 2.0f * y * G[2][2]);
+  gq[3] = 2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]);
+}
+
+// ---- single view ------------------------------------------------------------------------------------
 template <bool USE_SH>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     int P, int W, int H, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
@@ -110,139 +251,65 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     for (int k = 0; k < M * 3; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
   }
   if (alive) {
-    // 1. reduce entry records
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    float r2x = 0.f;
-    const uint32_t e0 = offsets[i], e1 = offsets[i + 1];
-    for (uint32_t e = e0; e < e1; ++e) {
-      const float4 q0 = partials[(size_t)e * GSR_PARTIAL_F4 + 0];
-      const float4 q1 = partials[(size_t)e * GSR_PARTIAL_F4 + 1];
-      const float4 q2 = partials[(size_t)e * GSR_PARTIAL_F4 + 2];
-      r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
-      r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
-      r2x += q2.x;
-    }
-    const float gmx = r0.x, gmy = r0.y, gA = r0.z, gB = r0.w, gC = r1.x;
-    gop = r1.y;
-    float drgb[3] = {r1.z, r1.w, r2x};
+    const PartialSum ps = reduce_partials(partials, offsets[i], offsets[i + 1]);
+    gop = ps.gop;
     const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
-    float dmean_sh[3] = {0.f, 0.f, 0.f};
     if (USE_SH) {
-      sh_backward(sh_degree, M, shs + (size_t)i * M * 3, p, campos, clamped[i], drgb[0], drgb[1], drgb[2],
+      float dmean_sh[3] = {0.f, 0.f, 0.f};
+      sh_backward(sh_degree, M, shs + (size_t)i * M * 3, p, campos, clamped[i], ps.dr, ps.dg, ps.db,
                   dL_dsh + (size_t)i * M * 3, dmean_sh);
+      gm3[0] = dmean_sh[0]; gm3[1] = dmean_sh[1]; gm3[2] = dmean_sh[2];
     } else {
-      gcol[0] = drgb[0]; gcol[1] = drgb[1]; gcol[2] = drgb[2];
+      gcol[0] = ps.dr; gcol[1] = ps.dg; gcol[2] = ps.db;
     }
-    // 2. geometry chain
-    const float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
-    const float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
-    const float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
-    float R[3][3] = {{0}}, s[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-    float c0, c1, c2, c3, c4, c5;
-    if (cov3D_precomp) {
-      c0 = cov3D_precomp[6 * i]; c1 = cov3D_precomp[6 * i + 1]; c2 = cov3D_precomp[6 * i + 2];
-      c3 = cov3D_precomp[6 * i + 3]; c4 = cov3D_precomp[6 * i + 4]; c5 = cov3D_precomp[6 * i + 5];
-    } else {
-      const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
-      q4[0] = r; q4[1] = x; q4[2] = y; q4[3] = z;
-      R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
-      R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
-      R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
-      s[0] = mod * scales[3 * i]; s[1] = mod * scales[3 * i + 1]; s[2] = mod * scales[3 * i + 2];
-      float Mm[3][3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) Mm[a][b] = R[a][b] * s[b];
-      c0 = Mm[0][0] * Mm[0][0] + Mm[0][1] * Mm[0][1] + Mm[0][2] * Mm[0][2];
-      c1 = Mm[0][0] * Mm[1][0] + Mm[0][1] * Mm[1][1] + Mm[0][2] * Mm[1][2];
-      c2 = Mm[0][0] * Mm[2][0] + Mm[0][1] * Mm[2][1] + Mm[0][2] * Mm[2][2];
-      c3 = Mm[1][0] * Mm[1][0] + Mm[1][1] * Mm[1][1] + Mm[1][2] * Mm[1][2];
-      c4 = Mm[1][0] * Mm[2][0] + Mm[1][1] * Mm[2][1] + Mm[1][2] * Mm[2][2];
-      c5 = Mm[2][0] * Mm[2][0] + Mm[2][1] * Mm[2][1] + Mm[2][2] * Mm[2][2];
-    }
-    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-    const float tz = pvz;
-    const float txtz = pvx / tz, tytz = pvy / tz;
-    const float xm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-    const float ym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-    const float tx = clampf(txtz, -limx, limx) * tz, ty = clampf(tytz, -limy, limy) * tz;
-    const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
-    const float T0[3] = {J00 * view[0] + J02 * view[2], J00 * view[4] + J02 * view[6], J00 * view[8] + J02 * view[10]};
-    const float T1[3] = {J11 * view[1] + J12 * view[2], J11 * view[5] + J12 * view[6], J11 * view[9] + J12 * view[10]};
-    const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
-    float U0[3], U1[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      U0[k] = S[k][0] * T0[0] + S[k][1] * T0[1] + S[k][2] * T0[2];
-      U1[k] = S[k][0] * T1[0] + S[k][1] * T1[1] + S[k][2] * T1[2];
-    }
-    const float a = U0[0] * T0[0] + U0[1] * T0[1] + U0[2] * T0[2] + 0.3f;
-    const float b = U0[0] * T1[0] + U0[1] * T1[1] + U0[2] * T1[2];
-    const float cc = U1[0] * T1[0] + U1[1] * T1[1] + U1[2] * T1[2] + 0.3f;
-    const float det = a * cc - b * b;
-    const float d2inv = 1.0f / (det * det + 0.0000001f);
-    const float dL_da = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
-    const float dL_dc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
-    const float dL_db = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
-    gcov[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
-    gcov[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
-    gcov[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
-    gcov[1] = 2.0f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.0f * T1[0] * T1[1] * dL_dc;
-    gcov[2] = 2.0f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.0f * T1[0] * T1[2] * dL_dc;
-    gcov[4] = 2.0f * T0[1] * T0[2] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.0f * T1[1] * T1[2] * dL_dc;
-    float dT0[3], dT1[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      dT0[j] = 2.0f * U0[j] * dL_da + U1[j] * dL_db;
-      dT1[j] = 2.0f * U1[j] * dL_dc + U0[j] * dL_db;
-    }
-    const float dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
-    const float dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
-    const float dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
-    const float dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
-    const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
-    const float dtx = xm * -fx * itz2 * dJ02;
-    const float dty = ym * -fy * itz2 * dJ12;
-    const float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
-    gm3[0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
-    gm3[1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
-    gm3[2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
-    // 3. 2D mean -> 3D mean
-    gm2[0] = gmx * 0.5f * (float)W;
-    gm2[1] = gmy * 0.5f * (float)H;
-    const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
-    const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
-    const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
-    const float mw = 1.0f / (hw + 0.0000001f);
-    const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-    gm3[0] += (proj[0] * mw - proj[3] * mul1) * gm2[0] + (proj[1] * mw - proj[3] * mul2) * gm2[1] + dmean_sh[0];
-    gm3[1] += (proj[4] * mw - proj[7] * mul1) * gm2[0] + (proj[5] * mw - proj[7] * mul2) * gm2[1] + dmean_sh[1];
-    gm3[2] += (proj[8] * mw - proj[11] * mul1) * gm2[0] + (proj[9] * mw - proj[11] * mul2) * gm2[1] + dmean_sh[2];
-    // 4. cov3D -> scale, rotation
-    if (!cov3D_precomp) {
-      const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                              {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                              {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-      float G[3][3];
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) {
-        float dM0 = 2.0f * (dS[0][0] * R[0][jj] + dS[0][1] * R[1][jj] + dS[0][2] * R[2][jj]) * s[jj];
-        float dM1 = 2.0f * (dS[1][0] * R[0][jj] + dS[1][1] * R[1][jj] + dS[1][2] * R[2][jj]) * s[jj];
-        float dM2 = 2.0f * (dS[2][0] * R[0][jj] + dS[2][1] * R[1][jj] + dS[2][2] * R[2][jj]) * s[jj];
-        gs[jj] = mod * (R[0][jj] * dM0 + R[1][jj] * dM1 + R[2][jj] * dM2);
-        G[0][jj] = dM0 * s[jj]; G[1][jj] = dM1 * s[jj]; G[2][jj] = dM2 * s[jj];
-      }
-      const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
-      gq[0] = 2.0f * (-z * G[0][1] + y * G[0][2] + z * G[1][0] - x * G[1][2] - y * G[2][0] + x * G[2][1]);
-      gq[1] = 2.0f * (y * G[0][1] + z * G[0][2] + y * G[1][0] - 2.0f * x * G[1][1] - r * G[1][2] + z * G[2][0] + r * G[2][1] - 2.0f * x * G[2][2]);
-      gq[2] = 2.0f * (-2.0f * y * G[0][0] + x * G[0][1] + r * G[0][2] + x * G[1][0] + z * G[1][2] - r * G[2][0] + z * G[2][1] - 2.0f * y * G[2][2]);
-      gq[3] = 2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]);
-    }
+    Cov3 cv;
+    build_cov3(i, mod, scales, rotations, cov3D_precomp, cv);
+    view_chain(view, proj, W, H, tanfovx, tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+    if (!cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
   }
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   dL_dmeans2D[3 * i] = gm2[0]; dL_dmeans2D[3 * i + 1] = gm2[1]; dL_dmeans2D[3 * i + 2] = 0.f;
+  if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
+  dL_dopacity[i] = gop;
+  if (dL_dscales) { dL_dscales[3 * i] = gs[0]; dL_dscales[3 * i + 1] = gs[1]; dL_dscales[3 * i + 2] = gs[2]; }
+  if (dL_drot) { dL_drot[4 * i] = gq[0]; dL_drot[4 * i + 1] = gq[1]; dL_drot[4 * i + 2] = gq[2]; dL_drot[4 * i + 3] = gq[3]; }
+  if (dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = gcov[k];
+  }
+}
+
+// ---- all views of a step at once (precomputed colours) ----------------------------------------------
+// One lane per Gaussian loops over the V views: per view it reduces that view's entry records and runs the
+// view-dependent chain; colour / opacity / mean / cov3D gradients are summed in registers and the
+// scale/rotation chain (linear in dL/dcov3D) runs once.  Replaces V kernels + the host-side sums over views.
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
+    GsrBwdViews vw, int P, float mod, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D) {
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  float gm3[3] = {0.f, 0.f, 0.f}, gcol[3] = {0.f, 0.f, 0.f}, gop = 0.f;
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+  Cov3 cv;
+  build_cov3(i, mod, scales, rotations, cov3D_precomp, cv);
+  bool any = false;
+  for (int v = 0; v < vw.V; ++v) {
+    const GsrBwdView& w = vw.v[v];
+    float gm2[2] = {0.f, 0.f};
+    if (w.radii[i] > 0) {
+      any = true;
+      const PartialSum ps = reduce_partials(w.partials, w.offsets[i], w.offsets[i + 1]);
+      gop += ps.gop;
+      gcol[0] += ps.dr; gcol[1] += ps.dg; gcol[2] += ps.db;
+      view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+    }
+    w.dL_dmeans2D[3 * i] = gm2[0]; w.dL_dmeans2D[3 * i + 1] = gm2[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+  }
+  if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
+  dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
   dL_dopacity[i] = gop;
   if (dL_dscales) { dL_dscales[3 * i] = gs[0]; dL_dscales[3 * i + 1] = gs[1]; dL_dscales[3 * i + 2] = gs[2]; }
@@ -276,6 +343,19 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
   hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, st, GSR_PBWD_ARGS); }
   }
 #undef GSR_PBWD_ARGS
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_modifier, const float* means3D,
+                                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                                    float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
+                                    float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
+  if (P <= 0) return 0;
+  { GSR_PROF("preprocess_bwd_views", st);
+    hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, vw, P,
+                       scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity,
+                       dL_dscales, dL_drotations, dL_dcov3D); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -219,7 +219,7 @@ struct BwdLds {
   float4 sB[4][BWD_BATCH + 1];                 // C, opacity, r, g
   float2 sC[4][BWD_BATCH + 1];                 // b, bits(batch index j)
   float4 sRed[4][BWD_BATCH][GSR_PARTIAL_F4];   // per-wave totals, indexed by batch index
-  uint64_t sActive[4][BWD_BATCH / 64];         // which (wave, entry) totals are valid
+  uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
   uint32_t sG[BWD_BATCH];                      // gaussian id by batch index
   uint32_t cnt[4][4];                          // [staging wave][strip]
   int sMaxLast;

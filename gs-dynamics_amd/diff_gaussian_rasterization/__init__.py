@@ -127,10 +127,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         d3, d2, dc, do, ds, dr, dcov, dsh = _hip.rasterize_backward_batch(
             ctx.states, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
             sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
-        ctx.states = None
-        sm = lambda t: None if t is None else t.sum(0)  # noqa: E731
-        return (sm(d3), d2, sm(dsh) if has_sh else None, sm(dc) if has_col else None, sm(do), sm(ds) if has_sc else None,
-                sm(dr) if has_sc else None, sm(dcov) if has_cov else None, None)
+        ctx.states = None  # gradients arrive already summed over views (means2D stays per view)
+        return (d3, d2, dsh if has_sh else None, dc if has_col else None, do, ds if has_sc else None,
+                dr if has_sc else None, dcov if has_cov else None, None)
 
 
 def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,

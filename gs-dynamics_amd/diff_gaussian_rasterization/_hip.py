@@ -75,7 +75,7 @@ def load_library():
     lib.gsr_forward_render_batch.restype = C.c_int
     lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, PV, PV, vp]
     lib.gsr_backward_batch.restype = C.c_int
-    lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 6 + [PV] * 14 + [vp]
+    lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 6 + [vp, PV, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [vp, i32, vp, vp, vp]
     lib.gsr_debug_get_views.restype = C.c_int
@@ -248,14 +248,18 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
 
 
 def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
-    """Backward of all views; returns per-view gradient stacks [V, P, ...] (the caller sums over views) and
-    the per-view means2D gradients [V, P, 3]."""
+    """Backward of all views.  Returns gradients already SUMMED over views (dmeans3D[P,3], dcolors, dopacity[P,1],
+    dscales, drotations, dcov3D, dsh) plus the per-view means2D gradients [V,P,3]."""
     lib = load_library()
     dev = means3D.device
     V = len(states)
     P = states[0].P
-    M = 0 if shs is None else int(shs.shape[1])
     f32 = dict(dtype=torch.float32, device=dev)
+    if shs is not None:  # SH colours: per-view backward + sum (the fused multi-view kernel covers precomputed colours)
+        outs = [rasterize_backward(states[v], grad_color[v], means3D, radii[v], None, shs, scales, rotations, cov3D_precomp)
+                for v in range(V)]
+        sm = lambda k: None if outs[0][k] is None else torch.stack([o[k] for o in outs]).sum(0)  # noqa: E731
+        return sm(0), torch.stack([o[1] for o in outs]), None, sm(3), sm(4), sm(5), sm(6), sm(7)
     with torch.cuda.device(dev):
         g = grad_color.to(**f32).contiguous()
         sarr = (GsrSettings * V)()
@@ -263,27 +267,25 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
         for v, stt in enumerate(states):
             sarr[v] = stt.settings
             Ds[v] = stt.num_rendered
-        d_means3D = torch.empty((V, P, 3), **f32)
+        d_means3D = torch.empty((P, 3), **f32)
         d_means2D = torch.empty((V, P, 3), **f32)
-        d_colors = torch.empty((V, P, 3), **f32) if shs is None else None
-        d_opacity = torch.empty((V, P, 1), **f32)
-        d_scales = torch.empty((V, P, 3), **f32) if cov3D_precomp is None else None
-        d_rot = torch.empty((V, P, 4), **f32) if cov3D_precomp is None else None
-        d_cov = torch.empty((V, P, 6), **f32)
-        d_sh = torch.empty((V, P, M, 3), **f32) if shs is not None else None
+        d_colors = torch.empty((P, 3), **f32)
+        d_opacity = torch.empty((P, 1), **f32)
+        d_scales = torch.empty((P, 3), **f32) if cov3D_precomp is None else None
+        d_rot = torch.empty((P, 4), **f32) if cov3D_precomp is None else None
+        d_cov = torch.empty((P, 6), **f32)
         scratch = [torch.empty((lib.gsr_backward_scratch_bytes(P, stt.num_rendered),), dtype=torch.uint8, device=dev)
                    for stt in states]
 
         def per_view(t):
-            return None if t is None else _ptr_array([t[v] for v in range(V)])
+            return _ptr_array([t[v] for v in range(V)])
         _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(colors_precomp),
-                                      _ptr(shs), _ptr(cov3D_precomp), per_view(radii),
-                                      _ptr_array([stt.geom for stt in states]), _ptr_array([stt.binning for stt in states]),
-                                      _ptr_array([stt.image for stt in states]), per_view(g), _ptr_array(scratch),
-                                      per_view(d_means3D), per_view(d_means2D), per_view(d_colors), per_view(d_opacity),
-                                      per_view(d_scales), per_view(d_rot), per_view(d_cov), per_view(d_sh), _stream(dev)),
+                                      _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
+                                      _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
+                                      per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D), _ptr(d_colors),
+                                      _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
-    return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
+    return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None
 
 
 def mark_visible(positions, viewmatrix) -> torch.Tensor:

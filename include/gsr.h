@@ -94,8 +94,7 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
  * optimiser step, /root/reference/src/tracking/train_gs.py:25-39).  The V views of a sharded step share the
  * Gaussian inputs; view v's kernel chain runs on internal stream v, forked from / joined to `stream` with
  * events, so the chains overlap on the GPU, and stage 1 synchronises ONCE for all V duplicate counts.
- * Array arguments have V entries (host arrays of device pointers).  Per-view gradient outputs are NOT summed
- * here: the caller reduces over views.  The library keeps a small per-device pool of streams/events and one
+ * Array arguments have V entries (host arrays of device pointers).  The library keeps a small per-device pool of streams/events and one
  * pinned host word per view for this (the only persistent state in the library). */
 #define GSR_MAX_BATCH 16
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -105,13 +104,15 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
                              float* const* out_color, float* const* out_depth, void* stream);
+/* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): per-view blend
+ * backward on the internal streams, then ONE per-Gaussian kernel that loops over the views and writes the
+ * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
-                       const float* scales, const float* rotations, const float* colors_precomp, const float* shs,
+                       const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
-                       void* const* scratch, float* const* dL_dmeans3D, float* const* dL_dmeans2D,
-                       float* const* dL_dcolors, float* const* dL_dopacity, float* const* dL_dscales,
-                       float* const* dL_drotations, float* const* dL_dcov3D, float* const* dL_dsh, void* stream);
+                       void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D, float* dL_dcolors,
+                       float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 
 /* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);
