@@ -14,10 +14,11 @@
 //                       wave come from wave-64 __ballot peer masks, histograms live in LDS, and no global
 //                       atomics are used anywhere, so the result is deterministic;
 //   3. tile_ranges      run boundaries of the tile id -> ranges[tile];
-//   4. tile_sort        one workgroup per tile sorts its segment by the 64-bit unique key
-//                       (depth_bits << 32 | gaussian_id) with a compare-exchange network in LDS
-//                       (global-memory network for segments above the LDS capacity).  Because the key is
-//                       unique and includes the Gaussian id, the result is exactly the stable-sort order.
+//   4. tile_sort        one workgroup per tile sorts its segment by depth: a stable LSD radix sort on the 32
+//                       depth bits inside LDS (segments arrive in Gaussian-id order, so stability gives the
+//                       reference tie rule); segments of 2049..4096 entries use a compare-exchange network
+//                       on the unique 64-bit key (depth_bits << 32 | gaussian_id) in LDS, larger ones the
+//                       same network in global memory.
 // HBM traffic: emit 12 B/entry written; each radix pass 4 B read (hist) + 12 B read + 12 B written
 // (scatter) per entry; tile_sort 8 B read + 4 B written per entry.
 // Launches per view: emit, 2 x (hist, scatter), ranges, tile_sort = 7 (no scan kernels in the sort).
@@ -344,22 +345,111 @@ __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
   }
 }
 
+// Stable LSD radix sort of one tile's entries inside LDS (n <= TS_RADIX_CAP).  The segment arrives in
+// ascending Gaussian-id order (the global tile-digit passes are stable and emission was id-major), so a
+// STABLE sort on the 32-bit depth key alone yields exactly the reference order (depth, ties by id).
+// 8-bit digits; a pass whose digit is identical for every key of the tile is skipped (the top exponent
+// byte almost always).  Per pass: per-wave histograms (LDS atomics) -> 256-bin scan -> ordered walk with
+// ranks from wave-64 __ballot peer masks.  ~5 barriers per pass instead of one per compare-exchange stage.
+#define TS_RADIX_CAP 2048
+struct TileSortLds {
+  union {
+    struct { uint32_t key[2][TS_RADIX_CAP]; uint32_t val[2][TS_RADIX_CAP]; } r;   // 32 KiB
+    uint64_t net[TILE_SORT_LDS_CAP];                                              // 32 KiB (network path)
+  };
+  uint32_t whist[4][256];
+  uint32_t wtot[4];
+  uint32_t diff;
+};
+
+__device__ __forceinline__ int tile_radix_sort(TileSortLds& L, uint32_t n, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const uint32_t q = ((n + 255u) >> 8) << 6;            // per-wave share, a multiple of 64
+  const uint32_t wstart = min(n, (uint32_t)wv * q), wstop = min(n, wstart + q);
+  const uint32_t diff = L.diff;
+  int cur = 0;
+  for (int shift = 0; shift < 32; shift += 8) {
+    if (((diff >> shift) & 0xffu) == 0u) continue;      // uniform: this digit is the same for all keys
+    const uint32_t* __restrict__ kin = L.r.key[cur];
+    const uint32_t* __restrict__ vin = L.r.val[cur];
+    uint32_t* __restrict__ kout = L.r.key[cur ^ 1];
+    uint32_t* __restrict__ vout = L.r.val[cur ^ 1];
+    for (int i = tid; i < 4 * 256; i += GSR_BLOCK) (&L.whist[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = wstart + lane; i < wstop; i += 64) atomicAdd(&L.whist[wv][(kin[i] >> shift) & 0xffu], 1u);
+    __syncthreads();
+    {  // bin tid: total over waves, exclusive scan over the 256 bins, then per-wave bases
+      const uint32_t c0 = L.whist[0][tid], c1 = L.whist[1][tid], c2 = L.whist[2][tid], c3 = L.whist[3][tid];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      uint32_t inc = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) L.wtot[wv] = inc;
+      __syncthreads();
+      uint32_t base = inc - tot;
+      for (int w = 0; w < wv; ++w) base += L.wtot[w];
+      L.whist[0][tid] = base; L.whist[1][tid] = base + c0; L.whist[2][tid] = base + c0 + c1;
+      L.whist[3][tid] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    volatile uint32_t* wbase = L.whist[wv];
+    for (uint32_t i0 = wstart; i0 < wstop; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool valid = i < wstop;
+      uint32_t key = 0, val = 0;
+      if (valid) { key = kin[i]; val = vin[i]; }
+      const uint32_t digit = (key >> shift) & 0xffu;
+      const uint64_t peers = match_peers(digit, valid, 8);
+      const uint32_t rank = (uint32_t)__popcll(peers & gsr_lanemask_lt());
+      uint32_t pos = 0;
+      if (valid) pos = wbase[digit] + rank;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && rank == 0) wbase[digit] = pos + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      if (valid) { kout[pos] = key; vout[pos] = val; }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  return cur;
+}
+
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                               const uint4* __restrict__ tile_order,
                                                               uint64_t* __restrict__ dg,
                                                               uint32_t* __restrict__ point_list) {
-  __shared__ uint64_t skeys[TILE_SORT_LDS_CAP];
+  __shared__ TileSortLds L;
   const int tid = threadIdx.x;
   const uint4 ord = tile_order[blockIdx.x];  // longest lists are dispatched first
   const uint2 rg = make_uint2(ord.y, ord.z);
   const uint32_t n = rg.y - rg.x;
   if (n == 0) return;
   uint64_t* seg = dg + rg.x;
-  if (n <= TILE_SORT_LDS_CAP) {
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) skeys[i] = seg[i];
+  if (n == 1) {
+    if (tid == 0) point_list[rg.x] = (uint32_t)seg[0];
+  } else if (n <= TS_RADIX_CAP) {
+    if (tid == 0) L.diff = 0;
     __syncthreads();
-    if (n > 1) tile_sort_network(skeys, n, tid);
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)skeys[i];
+    const uint32_t k0 = (uint32_t)(seg[0] >> 32);
+    uint32_t d = 0;
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) {
+      const uint64_t e = seg[i];
+      const uint32_t k = (uint32_t)(e >> 32);
+      L.r.key[0][i] = k; L.r.val[0][i] = (uint32_t)e;
+      d |= k ^ k0;
+    }
+    if (d) atomicOr(&L.diff, d);
+    __syncthreads();
+    const int cur = tile_radix_sort(L, n, tid);
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = L.r.val[cur][i];
+  } else if (n <= TILE_SORT_LDS_CAP) {
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) L.net[i] = seg[i];
+    __syncthreads();
+    tile_sort_network(L.net, n, tid);
+    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)L.net[i];
   } else {
     __syncthreads();
     tile_sort_network((volatile uint64_t*)seg, n, tid);

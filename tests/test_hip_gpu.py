@@ -160,6 +160,17 @@ def test_huge_tile_lists_take_the_global_sort_path(dev):
     assert (o2.ranges[:, 1] - o2.ranges[:, 0]).max() > 4096
 
 
+@pytest.mark.parametrize("P", [1500, 3000])
+def test_tile_sort_paths(dev, P):
+    """Per-tile list lengths that select each tile_sort path: <= 2048 LDS radix sort, 2049..4096 LDS network
+    (the > 4096 global-memory network is covered by test_huge_tile_lists...)."""
+    g = random_gaussians(P, seed=40 + P, scale_lo=0.5, scale_hi=0.9, spread=0.5)
+    g["opacities"][:] = 0.03
+    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=8, min_ok=0.9)
+    n = int((o2.ranges[:, 1] - o2.ranges[:, 0]).max())
+    assert (n <= 2048) if P == 1500 else (2048 < n <= 4096)
+
+
 def test_early_termination_dense_scene(dev):
     g = random_gaussians(3000, seed=34, scale_lo=0.1, scale_hi=0.5, spread=0.6)
     g["opacities"][:] = 0.95
