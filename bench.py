@@ -277,15 +277,20 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)  # assets/datasets.md weights
         views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
 
-        def getloss_step():
-            for p in params.values():
-                p.grad = None
-            for d in views:
-                loss, _ = get_loss(params, d, variables, False, w)
-                loss.backward()
-        ms = _time_ms(getloss_step, 5, 2)
-        out["getloss_step"] = {"ms_per_step": ms, "ms_per_view": ms / len(views), "views": len(views),
-                               "what": "train_gs.py get_loss (colour+seg renders, 0.8 L1 + 0.2 (1-SSIM), rigid/rot/iso/floor/bg) + backward, t>0"}
+        def make_step(initial):
+            def getloss_step():
+                for p in params.values():
+                    p.grad = None
+                for d in views:
+                    loss, _ = get_loss(params, d, variables, initial, w)
+                    loss.backward()
+            return getloss_step
+        for name, initial in (("getloss_step_t0", True), ("getloss_step", False)):
+            ms = _time_ms(make_step(initial), 5, 2)
+            out[name] = {"ms_per_step": ms, "ms_per_view": ms / len(views), "views": len(views),
+                         "what": "train_gs.py get_loss (colour+seg renders, fused 0.8 L1 + 0.2 (1-SSIM)"
+                                 + ("" if initial else ", rigid/rot/iso/floor/bg terms") + ") + backward, "
+                                 + ("t = 0" if initial else "t > 0")}
     except Exception as e:  # noqa: BLE001
         out["getloss_step"] = {"error": repr(e)}
     try:

@@ -278,6 +278,28 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                                          (hipStream_t)stream);
 }
 
+int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * ((H + 15) / 16) * ((W + 15) / 16); }
+
+int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,
+                           float* fA, float* fC, float* fE, float* block_l1, float* block_ssim, void* stream) {
+  if (!window11_host || !pred || !target || !fA || !fC || !fE || !block_l1 || !block_ssim || C <= 0 || H <= 0 || W <= 0) {
+    gsr_set_error("gsr_image_loss_forward: bad argument");
+    return -2;
+  }
+  return gsr_launch_image_loss_fwd(window11_host, C, H, W, pred, target, fA, fC, fE, block_l1, block_ssim, (hipStream_t)stream);
+}
+
+int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
+                            const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
+                            float w_l1, float w_ssim, float* d_pred, void* stream) {
+  if (!window11_host || !pred || !target || !fA || !fC || !fE || !grad_loss || !d_pred || C <= 0 || H <= 0 || W <= 0) {
+    gsr_set_error("gsr_image_loss_backward: bad argument");
+    return -2;
+  }
+  return gsr_launch_image_loss_bwd(window11_host, C, H, W, pred, target, fA, fC, fE, grad_loss, w_l1, w_ssim, d_pred,
+                                   (hipStream_t)stream);
+}
+
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {
   if (P <= 0) return 0;
   if (!viewmatrix || !means3D || !present) { gsr_set_error("gsr_mark_visible: NULL argument"); return -2; }

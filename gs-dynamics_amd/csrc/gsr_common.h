@@ -167,6 +167,11 @@ int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_mo
                                     const float* scales, const float* rotations, const float* cov3D_precomp,
                                     float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
                                     float* dL_drotations, float* dL_dcov3D, hipStream_t st);
+int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, float* fA,
+                              float* fC, float* fE, float* block_l1, float* block_ssim, hipStream_t st);
+int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
+                              const float* fC, const float* fE, const float* grad_loss, float w_l1, float w_ssim, float* dx,
+                              hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
 int gsr_debug_fwd_timing(unsigned long long* out16);

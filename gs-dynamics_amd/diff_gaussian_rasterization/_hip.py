@@ -41,7 +41,8 @@ class GsrKernelTime(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
-           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_backward_batch", "gsr_debug_phase_timing")
+           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_backward_batch", "gsr_debug_phase_timing",
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward")
 
 
 def load_library():
@@ -76,6 +77,12 @@ def load_library():
     lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, PV, PV, vp]
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 6 + [vp, PV, vp, vp, vp, vp, vp, vp]
+    lib.gsr_image_loss_blocks.restype = i32
+    lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
+    lib.gsr_image_loss_forward.restype = C.c_int
+    lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
+    lib.gsr_image_loss_backward.restype = C.c_int
+    lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [C.c_float, C.c_float, vp, vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [vp, i32, vp, vp, vp]
     lib.gsr_debug_get_views.restype = C.c_int
@@ -348,3 +355,33 @@ def profile_end():
     n = C.c_int32(0)
     _check(lib.gsr_profile_end(arr, 64, C.byref(n)), "gsr_profile_end")
     return {arr[i].name.decode(): (float(arr[i].total_ms), int(arr[i].launches)) for i in range(n.value)}
+
+
+def image_loss_forward(window11, pred, target):
+    """Fused 0.8 L1 + 0.2 (1 - SSIM) building blocks: returns (l1_sum, ssim_sum, fA, fC, fE) device tensors."""
+    lib = load_library()
+    _require_device(pred)
+    dev = pred.device
+    Cc, H, W = (int(d) for d in pred.shape)
+    win = (C.c_float * 11)(*[float(v) for v in window11])
+    with torch.cuda.device(dev):
+        nb = int(lib.gsr_image_loss_blocks(Cc, H, W))
+        f32 = dict(dtype=torch.float32, device=dev)
+        fA, fC, fE = (torch.empty((Cc, H, W), **f32) for _ in range(3))
+        bl1, bss = torch.empty((nb,), **f32), torch.empty((nb,), **f32)
+        _check(lib.gsr_image_loss_forward(win, Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(bl1),
+                                          _ptr(bss), _stream(dev)), "gsr_image_loss_forward")
+    return bl1.sum(), bss.sum(), fA, fC, fE
+
+
+def image_loss_backward(window11, pred, target, fA, fC, fE, grad_loss, w_l1, w_ssim):
+    lib = load_library()
+    dev = pred.device
+    Cc, H, W = (int(d) for d in pred.shape)
+    win = (C.c_float * 11)(*[float(v) for v in window11])
+    with torch.cuda.device(dev):
+        g = grad_loss.to(dtype=torch.float32, device=dev).reshape(1).contiguous()
+        d_pred = torch.empty_like(pred)
+        _check(lib.gsr_image_loss_backward(win, Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(g),
+                                           float(w_l1), float(w_ssim), _ptr(d_pred), _stream(dev)), "gsr_image_loss_backward")
+    return d_pred

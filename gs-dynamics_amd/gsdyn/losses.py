@@ -92,3 +92,41 @@ def calc_ssim(img1, img2, window_size: int = 11, size_average: bool = True):
     if img1.dim() != 4:
         m = m.squeeze(0)
     return m.mean() if size_average else m.mean(-1).mean(-1).mean(-1)
+
+
+# ---------------------------------------------------------------------------------------------------- fused image term
+def _window_1d(size: int = 11, sigma: float = 1.5):
+    """The reference's normalised 1-D Gaussian (float32), /root/reference/src/tracking/external.py:54-69."""
+    g = torch.tensor([math.exp(-(i - size // 2) ** 2 / (2 * sigma ** 2)) for i in range(size)])
+    return (g / g.sum()).tolist()
+
+
+class _FusedImageLoss(torch.autograd.Function):
+    """0.8 * L1 + 0.2 * (1 - SSIM) as ONE forward and ONE backward HIP kernel (gsr_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w_l1, w_ssim):
+        from diff_gaussian_rasterization import _hip
+        p = pred.contiguous().float()
+        t = target.contiguous().float()
+        win = _window_1d()
+        l1_sum, ssim_sum, fA, fC, fE = _hip.image_loss_forward(win, p, t)
+        n = float(p.numel())
+        ctx.save_for_backward(p, t, fA, fC, fE)
+        ctx.win, ctx.w = win, (float(w_l1), float(w_ssim))
+        return w_l1 * (l1_sum / n) + w_ssim * (1.0 - ssim_sum / n)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        from diff_gaussian_rasterization import _hip
+        p, t, fA, fC, fE = ctx.saved_tensors
+        d_pred = _hip.image_loss_backward(ctx.win, p, t, fA, fC, fE, grad_loss, ctx.w[0], ctx.w[1])
+        return d_pred, None, None, None
+
+
+def image_loss(pred, target, w_l1: float = 0.8, w_ssim: float = 0.2):
+    """The image term of the tracking loss (/root/reference/src/tracking/train_utils.py:185,195).
+    HIP tensors take the fused kernels; CPU tensors (host-logic tests) evaluate the reference's own torch formula."""
+    if pred.is_cuda:
+        return _FusedImageLoss.apply(pred, target, w_l1, w_ssim)
+    return w_l1 * l1_loss_v1(pred, target) + w_ssim * (1.0 - calc_ssim(pred, target))

@@ -114,6 +114,20 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D, float* dL_dcolors,
                        float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 
+/* ---- fused image loss of the tracking step (caller side of the path):
+ *   loss = w_l1 * mean|pred - target| + w_ssim * (1 - mean SSIM(pred, target)),  SSIM with the reference's 11x11
+ *   Gaussian window (sigma 1.5, zero padding): /root/reference/src/tracking/external.py:101-135, used at
+ *   /root/reference/src/tracking/train_utils.py:185,195 with w_l1 = 0.8, w_ssim = 0.2.
+ * forward: writes one partial sum of |.| and of the SSIM map per block (gsr_image_loss_blocks of them; the caller
+ * adds them up) and the three per-pixel partials fA/fC/fE ([C,H,W] each) the backward needs.
+ * backward: d_pred[C,H,W] = grad_loss[0] * d loss / d pred.  `window11_host` = the 11 normalised 1-D weights (host). */
+int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W);
+int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,
+                           float* fA, float* fC, float* fE, float* block_l1, float* block_ssim, void* stream);
+int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
+                            const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
+                            float w_l1, float w_ssim, float* d_pred, void* stream);
+
 /* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);
 

@@ -359,3 +359,34 @@ def test_batched_views_equal_per_view_calls(dev):
         ga, gb = a[k].grad, b[k].grad
         scale = ga.abs().max().item()
         assert (ga - gb).abs().max().item() <= 2e-6 * scale, k   # same per-view values, different summation order
+
+
+# ------------------------------------------------------------------ fused image loss (row N2)
+@pytest.mark.parametrize("H,W", [(64, 48), (37, 53), (800, 800)])
+def test_fused_image_loss_matches_torch_formula(dev, H, W):
+    """Fused 0.8 L1 + 0.2 (1 - SSIM) kernels vs the torch restatement of the reference formula (value and gradient)."""
+    from gsdyn import losses as L
+    rng = np.random.default_rng(H * 1000 + W)
+    x = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=dev, requires_grad=True)
+    y = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=dev)
+    ref = 0.8 * L.l1_loss_v1(x, y) + 0.2 * (1.0 - L.calc_ssim(x, y))
+    (gref,) = torch.autograd.grad(ref * 3.0, x)
+    x2 = x.detach().clone().requires_grad_(True)
+    got = L.image_loss(x2, y)
+    (ggot,) = torch.autograd.grad(got * 3.0, x2)
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert (ggot - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
+
+
+def test_fused_image_loss_matches_reference_golden(dev, golden_dir):
+    """Against vectors captured from the imported reference (calc_ssim value and input gradient)."""
+    from gsdyn import losses as L
+    ref = np.load(os.path.join(golden_dir, "reference_host.npz"))
+    x = torch.tensor(ref["ssim_im1"], device=dev, requires_grad=True)
+    y = torch.tensor(ref["ssim_im2"], device=dev)
+    got = L.image_loss(x, y, 0.0, 1.0)           # = 1 - SSIM
+    np.testing.assert_allclose(1.0 - got.item(), float(ref["ssim"]), rtol=2e-5)
+    got.backward()
+    np.testing.assert_allclose(-x.grad.cpu().numpy(), ref["ssim_grad"], rtol=2e-4, atol=2e-8)
+    comb = L.image_loss(x.detach(), y)
+    np.testing.assert_allclose(comb.item(), float(ref["im_term"]), rtol=2e-5)
