@@ -35,6 +35,8 @@
 // workgroup accumulates s_memtime deltas per phase and adds them to g_fwd_timing at kernel end.
 #ifdef GSR_TILE_TIMING
 __device__ unsigned long long g_fwd_timing[16];
+__device__ unsigned long long g_bwd_timing[16];
+#define GSR_TFLUSH_B() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_bwd_timing[_i], _t_acc[_i]); atomicAdd(&g_bwd_timing[15], 1ull); } } while (0)
 #define GSR_T0() unsigned long long _t_prev = __builtin_readcyclecounter(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define GSR_TP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); _t_acc[i] += _t - _t_prev; _t_prev = _t; } while (0)
 #define GSR_TFLUSH() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_fwd_timing[_i], _t_acc[_i]); atomicAdd(&g_fwd_timing[15], 1ull); } } while (0)
@@ -42,6 +44,7 @@ __device__ unsigned long long g_fwd_timing[16];
 #define GSR_T0() do {} while (0)
 #define GSR_TP(i) do {} while (0)
 #define GSR_TFLUSH() do {} while (0)
+#define GSR_TFLUSH_B() do {} while (0)
 #endif
 
 namespace {
@@ -249,6 +252,7 @@ __device__ __forceinline__ void bwd_tile(
   float T = T_final;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
+  GSR_T0();
   if (tid == 0) L.sMaxLast = 0;
   __syncthreads();
   atomicMax(&L.sMaxLast, last);
@@ -277,6 +281,7 @@ __device__ __forceinline__ void bwd_tile(
     { const float4 t2 = rec[3 * ng + 2]; na = rec[3 * ng]; nb = rec[3 * ng + 1]; nblue = t2.x;
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
   }
+  GSR_TP(0);
   for (int base = 0; base < max_last; base += BWD_BATCH) {
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
     const int m_all = min(BWD_BATCH, max_last - base);
@@ -302,7 +307,9 @@ __device__ __forceinline__ void bwd_tile(
 #pragma unroll
       for (int w = 0; w < 4; ++w) L.cnt[wv][w] = (uint32_t)__popcll(bal[w]);
     }
+    GSR_TP(1);
     __syncthreads();
+    GSR_TP(2);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if ((mask >> w) & 1u) {
@@ -313,6 +320,7 @@ __device__ __forceinline__ void bwd_tile(
     }
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
     __syncthreads();
+    GSR_TP(3);
     uint64_t active_lo = 0ull, active_hi = 0ull;
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
@@ -362,7 +370,9 @@ __device__ __forceinline__ void bwd_tile(
       if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
     }
     if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
+    GSR_TP(4);
     __syncthreads();
+    GSR_TP(5);
     if (tid < m_all) {
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 #pragma unroll
@@ -382,8 +392,11 @@ __device__ __forceinline__ void bwd_tile(
       partials[(size_t)e * GSR_PARTIAL_F4 + 1] = r1;
       partials[(size_t)e * GSR_PARTIAL_F4 + 2] = r2;
     }
+    GSR_TP(6);
     __syncthreads();
+    GSR_TP(7);
   }
+  GSR_TFLUSH_B();
 }
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -476,9 +489,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(const uint4* 
 int gsr_debug_fwd_timing(unsigned long long* out16) {
 #ifdef GSR_TILE_TIMING
   GSR_HIP_CHECK(hipDeviceSynchronize());
-  GSR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fwd_timing), sizeof(unsigned long long) * 16));
+  const char* which = getenv("GSR_TIMING_KERNEL");
   unsigned long long z[16] = {0};
-  GSR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_timing), z, sizeof z));
+  if (which && which[0] == 'b') {
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bwd_timing), sizeof(unsigned long long) * 16));
+    GSR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_timing), z, sizeof z));
+  } else {
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fwd_timing), sizeof(unsigned long long) * 16));
+    GSR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_timing), z, sizeof z));
+  }
   return 0;
 #else
   for (int i = 0; i < 16; ++i) out16[i] = 0;

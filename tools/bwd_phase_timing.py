@@ -1,0 +1,34 @@
+"""GPU box, debug build (TIMING=1, GSR_TIMING_KERNEL=b): phase breakdown of render_bwd (wave 0 view)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gs-dynamics_amd")):
+    sys.path.insert(0, p)
+os.environ["GSR_TIMING_KERNEL"] = "b"
+from diff_gaussian_rasterization import GaussianRasterizer, _hip
+from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+dev = torch.device("cuda:0")
+params = synth_scene_params(100_000, device=dev)
+cam = synth_ring_cameras(4, 800, 800, device=dev)[0]
+with torch.no_grad():
+    rv0 = params2rendervar(params)
+rv = {k: v.detach().clone().requires_grad_(True) for k, v in rv0.items()}
+dL = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (3, 800, 800)).astype(np.float32), device=dev)
+lib = _hip.load_library()
+buf = (C.c_uint64 * 16)()
+def run():
+    im, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+    im.backward(gradient=dL)
+for _ in range(3):
+    run()
+lib.gsr_debug_phase_timing(buf)
+N = 10
+for _ in range(N):
+    run()
+lib.gsr_debug_phase_timing(buf)
+names = ["setup (loads, max_last, zero tail, first gather)", "classify + issue prefetch", "barrier after counts",
+         "compaction writes + barrier", "replay + reduce loop", "barrier before combine", "combine + record stores", "end-of-batch barrier"]
+tot = sum(buf[i] for i in range(8))
+print("tiles per launch", buf[15] / N)
+for i, n in enumerate(names):
+    print(f"{n:50s} {buf[i] / N / 1e6:10.2f} Mcycles  {100.0 * buf[i] / max(tot, 1):5.1f} %")
