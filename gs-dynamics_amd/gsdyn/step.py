@@ -94,8 +94,11 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
     weights = {"im": w.im, "seg": w.seg, "rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg,
                "soft_col_cons": w.soft_col_cons}
     loss = sum(weights[k] * v for k, v in losses.items())
+    # Same values as the reference's `max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen])`
+    # (train_utils.py:243-245) without boolean-mask indexing, which costs a device->host sync per call.
     seen = radius > 0
-    variables["max_2D_radius"][seen] = torch.max(radius[seen], variables["max_2D_radius"][seen])
+    m2r = variables["max_2D_radius"]
+    variables["max_2D_radius"] = torch.where(seen, torch.maximum(radius.to(m2r.dtype), m2r), m2r)
     variables["seen"] = seen
     return loss, variables
 
