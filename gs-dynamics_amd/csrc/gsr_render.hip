@@ -2,7 +2,8 @@
 // (replaces the reference extension's two renderCUDA kernels).
 //
 // Tile work: a 256-thread workgroup (4 waves of 64) renders one 16x16 tile, one lane per pixel; a wave
-// owns a 16x4 strip, so its colour/depth stores are 64-byte runs.
+// owns an 8x8 pixel quad ("strip" below = that wave's pixel region; 8x8 regions intersect 11 % fewer list
+// entries than 16x4 rows on the benchmark scene: measured -4 % forward, -2 % backward kernel time).
 //
 // Staging + strip culling: the tile's depth-sorted list is staged through LDS 128 entries at a time (one
 // entry gathered per lane: 16 + 16 + 8 + 8 B from the record arrays).  Each staged entry carries the
@@ -49,6 +50,8 @@ __device__ unsigned long long g_bwd_timing[16];
 
 namespace {
 
+#define GSR_QW 8   // pixel region of one wave inside the 16x16 tile: 8x8 quad (2 x 2 quads per tile)
+#define GSR_QH 8
 #define FWD_BATCH 128
 #define BWD_BATCH 128
 
@@ -65,26 +68,25 @@ __device__ __forceinline__ float qmin_on_horizontal_edge(float A, float B, float
   return C * dy * dy + (2.0f * B * dy + A * dx) * dx;
 }
 
-// Which of the tile's four 16x4 strips can this Gaussian reach with alpha >= 1/255?  (bit w = strip w)
+// Which of the tile's four per-wave pixel regions (8x8 quads) can this Gaussian reach with alpha >= 1/255?  (bit w = wave w)
 // Level 1: the integer pixel box from preprocess.  Level 2, for strips that pass: the exact minimum of the
 // quadratic form over the strip rectangle (0 when the mean is inside, else the least edge minimum -- the
 // form is convex) against 2 ln(255 o) + 0.04.  Both are conservative: a pair they drop fails the alpha
 // test at every pixel of the strip, so results are unchanged.
 __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC, float opacity, int tx0, int ty0) {
   const int xmin = sext16(box.x), xmax = sext16(box.x >> 16), ymin = sext16(box.y), ymax = sext16(box.y >> 16);
-  if (xmax < tx0 || xmin > tx0 + 15 || xmin > xmax) return 0u;
+  if (xmax < tx0 || xmin > tx0 + 15 || xmin > xmax || ymax < ty0 || ymin > ty0 + 15) return 0u;
   const float mx = a.x, my = a.y, A = a.z, B = a.w, C = conicC;
   const float tau2 = 2.0f * (__logf(255.0f * opacity) + 0.02f);
   const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(C);
-  const float dxlo = (float)tx0 - mx, dxhi = (float)(tx0 + 15) - mx;
-  const bool x_inside = dxlo <= 0.0f && dxhi >= 0.0f;
   uint32_t m = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int y0 = ty0 + 4 * w;
-    if (ymax < y0 || ymin > y0 + 3) continue;
-    const float dylo = (float)y0 - my, dyhi = (float)(y0 + 3) - my;
-    bool keep = x_inside && dylo <= 0.0f && dyhi >= 0.0f;
+  for (int w = 0; w < 4; ++w) {   // wave w owns the 8x8 pixel quad (w & 1, w >> 1) of the tile
+    const int x0 = tx0 + GSR_QW * (w & 1), y0 = ty0 + GSR_QH * (w >> 1);
+    if (xmax < x0 || xmin > x0 + GSR_QW - 1 || ymax < y0 || ymin > y0 + GSR_QH - 1) continue;
+    const float dxlo = (float)x0 - mx, dxhi = (float)(x0 + GSR_QW - 1) - mx;
+    const float dylo = (float)y0 - my, dyhi = (float)(y0 + GSR_QH - 1) - my;
+    bool keep = dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f;
     if (!keep) {
       float q = qmin_on_vertical_edge(A, B, C, invC, dxlo, dylo, dyhi);
       q = fminf(q, qmin_on_vertical_edge(A, B, C, invC, dxhi, dylo, dyhi));
@@ -112,7 +114,7 @@ __device__ __forceinline__ void fwd_tile(
     float* __restrict__ out_depth) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
-  const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
+  const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const int n = (int)(rg.y - rg.x);
@@ -236,7 +238,7 @@ __device__ __forceinline__ void bwd_tile(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx = tile % gx, ty = tile / gx;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
-  const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
+  const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const int n = (int)(rg.y - rg.x);
