@@ -56,6 +56,8 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float* __restric
   (void)M;
 }
 
+__device__ __forceinline__ int sext16_(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     int P, int W, int H, int gx, int gy, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ rec,
     uint2* __restrict__ rect,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii,
-    uint32_t* __restrict__ block_sums) {
+    uint32_t* __restrict__ block_sums, int tight_lists) {
   __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   const bool in_range = i < P;
@@ -166,6 +168,21 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
           box = make_uint2(((uint32_t)xmin & 0xffffu) | ((uint32_t)xmax << 16),
                            ((uint32_t)ymin & 0xffffu) | ((uint32_t)ymax << 16));
         }
+        if (tight_lists) {
+          // Tile lists from the alpha box instead of the 3-sigma rect: a (Gaussian, tile) pair outside the
+          // box fails the alpha test at every pixel of the tile, so dropping it from the lists changes no
+          // pixel and no gradient -- it only shortens the sort and the per-tile walks.  radii keep the
+          // reference's 3-sigma value.  (GSR_REFERENCE_LISTS=1 restores the reference's duplicates.)
+          const int bx0 = sext16_(box.x) >> 4, bx1 = (sext16_(box.x >> 16) >> 4) + 1;
+          const int by0 = sext16_(box.y) >> 4, by1 = (sext16_(box.y >> 16) >> 4) + 1;
+          const int tx0 = max(minx, bx0), tx1 = min(maxx, bx1), ty0 = max(miny, by0), ty1 = min(maxy, by1);
+          if (tau2 > 0.0f && tx0 < tx1 && ty0 < ty1) {
+            tiles = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
+            rc = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+          } else {
+            tiles = 0; rc = make_uint2(0u, 0u);
+          }
+        }
         a4 = make_float4(px, py, cA, cB);
         b4 = make_float4(cC, opacities[i], rgb[0], rgb[1]);
         c2 = make_float2(rgb[2], pvz);
@@ -207,11 +224,13 @@ int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const 
                           hipStream_t st) {
   if (P <= 0) return 0;
   int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+  const char* ref_lists = getenv("GSR_REFERENCE_LISTS");
+  const int tight = (ref_lists && ref_lists[0] == '1') ? 0 : 1;
   { GSR_PROF("preprocess_fwd", st);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
                      cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
                      cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.rec,
-                     g.rect, g.tiles_touched, g.clamped, radii, g.block_sums); }
+                     g.rect, g.tiles_touched, g.clamped, radii, g.block_sums, tight); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
