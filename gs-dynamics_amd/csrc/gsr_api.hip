@@ -89,10 +89,23 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
                                      g, radii, st))
     return rc;
   const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
-  if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
   uint32_t D = 0;
-  GSR_HIP_CHECK(hipMemcpyAsync(&D, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  GSR_HIP_CHECK(hipStreamSynchronize(st));
+  if (gsr_host_block_scan(P)) {
+    // the per-block entry counts come back in one small pinned copy and are added up here; emit blocks add up
+    // their own base from the same array, so no scan kernel runs
+    static thread_local uint32_t* t_sums = nullptr;  // pinned, per host thread, lives for the process
+    if (!t_sums) GSR_HIP_CHECK(hipHostMalloc((void**)&t_sums, sizeof(uint32_t) * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault));
+    GSR_HIP_CHECK(hipMemcpyAsync(t_sums, g.block_sums, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+    uint64_t tot = 0;
+    for (uint32_t b = 0; b < nblk; ++b) tot += t_sums[b];
+    if (tot > 0xffffffffull) { gsr_set_error("gsr_forward_preprocess: %llu tile entries overflow 32 bits", (unsigned long long)tot); return -3; }
+    D = (uint32_t)tot;
+  } else {
+    if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
+    GSR_HIP_CHECK(hipMemcpyAsync(&D, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+  }
   if (num_rendered_host) *num_rendered_host = D;
   return 0;
 }
@@ -162,7 +175,8 @@ int get_pool(int V, StreamPool** out) {
   StreamPool& p = g_pools[dev];
   p.device = dev;
   if (!p.fork) GSR_HIP_CHECK(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
-  if (!p.host_counts) GSR_HIP_CHECK(hipHostMalloc((void**)&p.host_counts, sizeof(uint32_t) * GSR_MAX_BATCH, hipHostMallocDefault));
+  if (!p.host_counts)
+    GSR_HIP_CHECK(hipHostMalloc((void**)&p.host_counts, sizeof(uint32_t) * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault));
   while ((int)p.streams.size() < V) {
     hipStream_t st; hipEvent_t ev;
     GSR_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -211,11 +225,23 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                        g, radii[v], st))
       return rc;
     const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
-    if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
-    GSR_HIP_CHECK(hipMemcpyAsync(&pool->host_counts[v], g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    uint32_t* slot = pool->host_counts + (size_t)v * GSR_HOST_SCAN_MAX_BLOCKS;
+    if (gsr_host_block_scan(P)) {
+      GSR_HIP_CHECK(hipMemcpyAsync(slot, g.block_sums, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, st));
+    } else {
+      if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
+      GSR_HIP_CHECK(hipMemcpyAsync(slot, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
   }
-  for (int v = 0; v < V; ++v) GSR_HIP_CHECK(hipStreamSynchronize(pool->streams[v]));
-  for (int v = 0; v < V; ++v) num_rendered_host[v] = pool->host_counts[v];
+  const uint32_t nsum = gsr_host_block_scan(P) ? (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK) : 1u;
+  for (int v = 0; v < V; ++v) {
+    GSR_HIP_CHECK(hipStreamSynchronize(pool->streams[v]));
+    const uint32_t* slot = pool->host_counts + (size_t)v * GSR_HOST_SCAN_MAX_BLOCKS;
+    uint64_t tot = 0;
+    for (uint32_t b = 0; b < nsum; ++b) tot += slot[b];
+    if (tot > 0xffffffffull) { gsr_set_error("gsr_forward_preprocess_batch: tile entries overflow 32 bits"); return -3; }
+    num_rendered_host[v] = (uint32_t)tot;
+  }
   return 0;
 }
 

@@ -87,14 +87,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
 __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float4* __restrict__ rec,
                                                                  const uint2* __restrict__ rect,
                                                                  const uint32_t* __restrict__ tiles_touched,
+                                                                 const uint32_t* __restrict__ block_sums,
                                                                  const uint32_t* __restrict__ block_offsets,
                                                                  uint32_t* __restrict__ offsets,
                                                                  uint32_t* __restrict__ tkey,
-                                                                 uint64_t* __restrict__ dg) {
+                                                                 uint64_t* __restrict__ dg,
+                                                                 uint2* __restrict__ ranges, int T) {
   __shared__ uint32_t soff[GSR_BLOCK + 1];
   __shared__ uint32_t swave[GSR_BLOCK / GSR_WAVE];
+  __shared__ uint32_t spre[GSR_BLOCK / GSR_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = blockIdx.x * GSR_BLOCK;
+  // housekeeping for tile_ranges_kernel further down the stream (saves a memset launch): empty tiles keep (0,0)
+  for (int t = g0 + tid; t < T; t += (int)gridDim.x * GSR_BLOCK) ranges[t] = make_uint2(0u, 0u);
+  uint32_t pre = 0;  // entries of all earlier blocks, when no scanned block_offsets were prepared (P <= 512 Ki)
+  if (!block_offsets) {
+    for (uint32_t j = tid; j < blockIdx.x; j += GSR_BLOCK) pre += block_sums[j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m, 64);
+    if (lane == 0) spre[wv] = pre;
+  }
   const uint32_t mine = (g0 + tid < P) ? tiles_touched[g0 + tid] : 0u;
   uint32_t inc = mine;
 #pragma unroll
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, 
   }
   if (lane == 63) swave[wv] = inc;
   __syncthreads();
-  uint32_t base = block_offsets[blockIdx.x];
+  uint32_t base = block_offsets ? block_offsets[blockIdx.x] : spre[0] + spre[1] + spre[2] + spre[3];
   for (int w = 0; w < wv; ++w) base += swave[w];
   const uint32_t excl = base + inc - mine;
   soff[tid] = excl;
@@ -153,7 +165,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* _
   const uint32_t mask = (1u << bits) - 1u;
   const uint32_t start = blockIdx.x * GSR_RADIX_EPB;
   const uint32_t stop = min(D, start + GSR_RADIX_EPB);
-  for (uint32_t i = start + tid; i < stop; i += GSR_BLOCK) atomicAdd(&hist[(tkey[i] >> shift) & mask], 1u);
+  uint32_t k[GSR_RADIX_ITEMS];
+#pragma unroll
+  for (int u = 0; u < GSR_RADIX_ITEMS; ++u) { const uint32_t i = start + (uint32_t)u * GSR_BLOCK + tid; k[u] = i < stop ? tkey[i] : 0u; }
+#pragma unroll
+  for (int u = 0; u < GSR_RADIX_ITEMS; ++u)
+    if (start + (uint32_t)u * GSR_BLOCK + tid < stop) atomicAdd(&hist[(k[u] >> shift) & mask], 1u);
   __syncthreads();
   if (tid < (1 << bits)) block_hist[blockIdx.x * (uint32_t)(1 << bits) + tid] = hist[tid];
 }
@@ -175,6 +192,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
   const uint32_t mask = (1u << bits) - 1u;
   const int nb = 1 << bits;
   for (int i = tid; i < 4 * 256; i += GSR_BLOCK) (&wcount[0][0])[i] = 0;
+  // this wave's keys and payloads: all loads are issued here, ahead of the histogram-matrix sums that hide them
+  const uint32_t chunk0 = blockIdx.x * GSR_RADIX_EPB;
+  constexpr uint32_t per_wave = GSR_RADIX_EPB / 4;
+  constexpr int STEPS = per_wave / 64;
+  const uint32_t wstart = chunk0 + wv * per_wave;
+  const uint32_t wstop = min(D, wstart + per_wave);
+  uint32_t key[STEPS];
+  uint64_t pay[STEPS];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const uint32_t i = wstart + (uint32_t)k * 64u + lane;
+    key[k] = 0; pay[k] = 0;
+    if (i < wstop) { key[k] = tkey_in[i]; pay[k] = dg_in[i]; }
+  }
   // column sums of the histogram matrix: wave w takes blocks w, w+4, ...; lane l takes bins l, l+64, ...
   for (int bin = lane; bin < nb; bin += 64) {
     uint32_t tot = 0, pre = 0;
@@ -217,12 +248,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
       run += t4[q];
     }
   }
-  const uint32_t chunk0 = blockIdx.x * GSR_RADIX_EPB;
-  const uint32_t per_wave = GSR_RADIX_EPB / 4;
-  const uint32_t wstart = chunk0 + wv * per_wave;
-  const uint32_t wstop = min(D, wstart + per_wave);
   // A: per-wave digit histogram
-  for (uint32_t i = wstart + lane; i < wstop; i += 64) atomicAdd(&wcount[wv][(tkey_in[i] >> shift) & mask], 1u);
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k)
+    if (wstart + (uint32_t)k * 64u + lane < wstop) atomicAdd(&wcount[wv][(key[k] >> shift) & mask], 1u);
   __syncthreads();
   // B: wave bases = global base of (bin, block) + counts of earlier waves
   if (tid < nb) {
@@ -236,13 +265,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
   }
   __syncthreads();
   // C: ordered walk
-  for (uint32_t i0 = wstart; i0 < wstop; i0 += 64) {
-    const uint32_t i = i0 + lane;
-    const bool valid = i < wstop;
-    uint32_t key = 0;
-    uint64_t pay = 0;
-    if (valid) { key = tkey_in[i]; pay = dg_in[i]; }
-    const uint32_t digit = (key >> shift) & mask;
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const bool valid = wstart + (uint32_t)k * 64u + lane < wstop;
+    const uint32_t digit = (key[k] >> shift) & mask;
     const uint64_t peers = match_peers(digit, valid, bits);
     const uint32_t rank = (uint32_t)__popcll(peers & gsr_lanemask_lt());
     uint32_t pos = 0;
@@ -250,34 +276,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     __builtin_amdgcn_wave_barrier();
     if (valid && rank == 0) wbase[wv][digit] = pos + (uint32_t)__popcll(peers);  // group leader advances
     __builtin_amdgcn_wave_barrier();
-    if (valid) { tkey_out[pos] = key; dg_out[pos] = pay; }
+    if (valid) { tkey_out[pos] = key[k]; dg_out[pos] = pay[k]; }
   }
 }
 
 // ------------------------------------------------------------------ tile ranges
-__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
-                                                                uint2* __restrict__ ranges) {
-  uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  if (i >= D) return;
-  uint32_t t = tkey[i];
-  if (i == 0) ranges[t].x = 0;
-  else {
-    uint32_t pt = tkey[i - 1];
-    if (pt != t) { ranges[pt].y = i; ranges[t].x = i; }
-  }
-  if (i == D - 1) ranges[t].y = D;
-}
+// (tile_ranges_kernel: after the LPT-order builder below.  Merging the two into one launch -- last finished
+// workgroup builds the order -- was measured slower: the agent-scope release each workgroup needs writes back its
+// XCD's L2, 15 us against 6.4 + 6.3 us for two launches.)
 
 // ------------------------------------------------------------------ LPT work queue
 // Tiles bucketed by list length (8 entries per bucket, 256 buckets), longest first.  The blend kernels'
 // persistent workgroups pop tickets from this order, so heavy tiles start first and the tail of the
 // kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
 // is arbitrary: per-tile results do not depend on it.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int T,
-                                                          uint4* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ queue) {
-  __shared__ uint32_t cnt[256];
-  __shared__ uint32_t start[256];
+__device__ __forceinline__ void build_tile_order(const uint2* __restrict__ ranges, int T,
+                                                 uint4* __restrict__ tile_order, uint32_t* __restrict__ queue,
+                                                 uint32_t* cnt, uint32_t* start) {   // cnt, start: 256 LDS words each
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < 256) cnt[tid] = 0;
   if (tid < 8) queue[tid] = 0;
@@ -309,6 +324,28 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     tile_order[atomicAdd(&start[bucket], 1u)] = make_uint4((uint32_t)t, r.x, r.y, 0u);
   }
   if (tid == 0) queue[4] = (uint32_t)T - cnt[255];  // bucket 255 = empty tiles (sorted last)
+}
+
+// Standalone launch (D == 0: every tile is empty).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int T,
+                                                          uint4* __restrict__ tile_order,
+                                                          uint32_t* __restrict__ queue) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t start[256];
+  build_tile_order(ranges, T, tile_order, queue, cnt, start);
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
+                                                                uint2* __restrict__ ranges) {
+  uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= D) return;
+  uint32_t t = tkey[i];
+  if (i == 0) ranges[t].x = 0;
+  else {
+    uint32_t pt = tkey[i - 1];
+    if (pt != t) { ranges[pt].y = i; ranges[t].x = i; }
+  }
+  if (i == D - 1) ranges[t].y = D;
 }
 
 // ------------------------------------------------------------------ per-tile depth sort
@@ -474,8 +511,8 @@ static int ceil_log2_u32(uint32_t n) {
 
 int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
                        const ImageState& im, hipStream_t st) {
-  GSR_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.T, st));
   if (D == 0 || P <= 0) {
+    GSR_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.T, st));
     { GSR_PROF("tile_order", st);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
     GSR_HIP_CHECK(hipGetLastError());
@@ -483,7 +520,9 @@ int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g,
   }
   { GSR_PROF("emit_entries", st);
   hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
-                     g.rec, g.rect, g.tiles_touched, g.block_offsets, g.offsets, bs.tkey[0], bs.dg[0]); }
+                     g.rec, g.rect, g.tiles_touched, g.block_sums,
+                     gsr_host_block_scan(P) ? (const uint32_t*)nullptr : (const uint32_t*)g.block_offsets, g.offsets,
+                     bs.tkey[0], bs.dg[0], im.ranges, cam.T); }
   GSR_HIP_CHECK(hipGetLastError());
   const int tbits = ceil_log2_u32((uint32_t)cam.T);
   const int npass = (tbits + 7) / 8;

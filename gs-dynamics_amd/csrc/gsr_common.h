@@ -98,6 +98,11 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
 // k = row-major rank of the tile inside the Gaussian's rect):
 //   float4 {d mean2D.x, d mean2D.y, dA, dB}, float4 {dC, d opacity, dr, dg}, float4 {db, 0, 0, 0}
 #define GSR_PARTIAL_F4 3
+// Up to this many preprocess blocks (P <= 512 Ki Gaussians) the per-block entry counts are summed on the host
+// (one small pinned copy that replaces the count read-back) and emit blocks add up their own base; above it a
+// scan kernel prepares block_offsets as before.
+#define GSR_HOST_SCAN_MAX_BLOCKS 2048
+static inline bool gsr_host_block_scan(int P) { return (P + GSR_BLOCK - 1) / GSR_BLOCK <= GSR_HOST_SCAN_MAX_BLOCKS; }
 
 // ---------------------------------------------------------------- error plumbing (gsr_api.hip)
 void gsr_set_error(const char* fmt, ...);

@@ -255,6 +255,13 @@ def test_tile_sort_paths(dev, P):
     assert (n <= 2048) if P == 1500 else (2048 < n <= 4096)
 
 
+def test_many_gaussians_take_the_scan_kernel_path(dev):
+    """More than 512 Ki Gaussians: per-block entry counts are scanned on the device (below that the host adds
+    them up and emit blocks derive their own base)."""
+    g = random_gaussians(540_000, seed=91, scale_lo=0.004, scale_hi=0.02, spread=1.2)
+    _check_against_oracle(ring_camera(96, 64, v=1), g, dev, seed=9, nthreads=min(64, os.cpu_count() or 8))
+
+
 def test_early_termination_dense_scene(dev):
     g = random_gaussians(3000, seed=34, scale_lo=0.1, scale_hi=0.5, spread=0.6)
     g["opacities"][:] = 0.95

@@ -17,7 +17,7 @@ def find(d, pat):
 
 def short(name):
     for tag in ("render_fwd", "render_bwd", "preprocess_fwd", "preprocess_bwd", "emit_entries", "radix_hist", "radix_scatter",
-                "tile_ranges", "tile_sort", "scan_exclusive", "mark_visible"):
+                "tile_ranges_order", "tile_order", "tile_sort", "scan_exclusive", "mark_visible"):
         if tag in name:
             return tag
     name = name.replace("void ", "").replace("at::native::", "")
