@@ -200,21 +200,12 @@ int join_streams(StreamPool& p, int V, hipStream_t caller) {
 }
 }  // namespace
 
-int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                                 const float* rotations, const float* opacities, const float* colors_precomp,
-                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
-                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s || !geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
-  for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
-  if (P <= 0) return 0;
-  if ((colors_precomp == nullptr) == (shs == nullptr) || ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
-    gsr_set_error("gsr_forward_preprocess_batch: provide exactly one of colors_precomp/shs and of scales+rotations/cov3D_precomp");
-    return -2;
-  }
-  StreamPool* pool = nullptr;
-  if (int rc = get_pool(V, &pool)) return rc;
-  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+namespace {
+// Stage 1 of all views on the pool's streams (already forked from the caller's stream), one sync per stream.
+int preprocess_views(StreamPool* pool, int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                     const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
+                     const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
+                     uint32_t* num_rendered_host) {
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
     if (int rc = make_cam(&s[v], &cam)) return rc;
@@ -239,10 +230,68 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
     const uint32_t* slot = pool->host_counts + (size_t)v * GSR_HOST_SCAN_MAX_BLOCKS;
     uint64_t tot = 0;
     for (uint32_t b = 0; b < nsum; ++b) tot += slot[b];
-    if (tot > 0xffffffffull) { gsr_set_error("gsr_forward_preprocess_batch: tile entries overflow 32 bits"); return -3; }
+    if (tot > 0xffffffffull) { gsr_set_error("gsr forward: tile entries overflow 32 bits"); return -3; }
     num_rendered_host[v] = (uint32_t)tot;
   }
   return 0;
+}
+int check_batch_inputs(const char* who, int32_t V, const gsr_settings* s, const float* colors_precomp, const float* shs,
+                       const float* scales, const float* rotations, const float* cov3D_precomp) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s) { gsr_set_error("%s: NULL settings", who); return -2; }
+  if ((colors_precomp == nullptr) == (shs == nullptr) || ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    gsr_set_error("%s: provide exactly one of colors_precomp/shs and of scales+rotations/cov3D_precomp", who);
+    return -2;
+  }
+  return 0;
+}
+}  // namespace
+
+int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                 const float* rotations, const float* opacities, const float* colors_precomp,
+                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
+                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s || !geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
+  for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
+  if (P <= 0) return 0;
+  if (int rc = check_batch_inputs("gsr_forward_preprocess_batch", V, s, colors_precomp, shs, scales, rotations, cov3D_precomp)) return rc;
+  StreamPool* pool = nullptr;
+  if (int rc = get_pool(V, &pool)) return rc;
+  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  return preprocess_views(pool, V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
+                          geom_states, radii, num_rendered_host);
+}
+
+int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                      const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
+                      const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
+                      void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
+                      float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host, void* stream) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
+  if (!s || !geom_states || !radii || !num_rendered_host || !image_states || !out_color || !out_depth) {
+    gsr_set_error("gsr_forward_batch: NULL argument");
+    return -2;
+  }
+  for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
+  if (P <= 0) return 1;  // nothing to preprocess: the caller takes the render-stage call (it paints the background)
+  if (int rc = check_batch_inputs("gsr_forward_batch", V, s, colors_precomp, shs, scales, rotations, cov3D_precomp)) return rc;
+  StreamPool* pool = nullptr;
+  if (int rc = get_pool(V, &pool)) return rc;
+  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  if (int rc = preprocess_views(pool, V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
+                                geom_states, radii, num_rendered_host))
+    return rc;
+  bool fits = binning_states != nullptr && binning_bytes != nullptr;
+  for (int v = 0; fits && v < V; ++v)
+    fits = num_rendered_host[v] == 0 || (binning_states[v] && binning_bytes[v] >= gsr_binning_bytes(num_rendered_host[v], 0, 0));
+  if (!fits) return 1;
+  for (int v = 0; v < V; ++v) {
+    if (int rc = gsr_forward_render(&s[v], P, num_rendered_host[v], geom_states[v], binning_states[v], image_states[v],
+                                    out_color[v], out_depth[v], pool->streams[v]))
+      return rc;
+  }
+  return join_streams(*pool, V, (hipStream_t)stream);
 }
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,

@@ -483,6 +483,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(const uint4* 
     ticket = s_ticket;
     __syncthreads();
   }
+  // The last workgroup to leave re-arms the queue for a possible second backward over the same state
+  // (retain_graph): no workgroup can still be popping once all of them have checked out.  Saves a memset launch.
+  if (threadIdx.x == 0 && atomicAdd(&queue[5], 1u) == gridDim.x - 1u) {
+    atomicExch(&queue[1], 0u);
+    atomicExch(&queue[5], 0u);
+  }
 }
 
 }  // namespace
@@ -541,7 +547,6 @@ int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, con
   if (cam.T <= 0 || D == 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 3);
-  if (!use_static) GSR_HIP_CHECK(hipMemsetAsync(im.queue + 1, 0, sizeof(uint32_t), st));  // backward may run more than once
   { GSR_PROF("render_bwd", st);
     if (use_static) {
       hipLaunchKernelGGL(render_bwd_static, dim3(cam.T), dim3(GSR_BLOCK), 0, st, cam.W, cam.H, cam.gx, cam.T, im.ranges,

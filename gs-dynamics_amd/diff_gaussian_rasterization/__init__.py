@@ -53,6 +53,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
+        ctx.set_materialize_grads(False)  # grad_depth is ignored: do not let autograd fill a zero image for it
         m3 = _prep(means3D)
         if m3 is None:
             if means3D is not None and means3D.dim() == 2 and means3D.shape[1] == 3:
@@ -89,7 +90,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh = _hip.rasterize_backward(
             ctx.state, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
             sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
-        ctx.state = None
         return (d_means3D, d_means2D, d_sh if has_sh else None, d_colors if has_col else None, d_opacity,
                 d_scales if has_sc else None, d_rot if has_sc else None, d_cov if has_cov else None, None)
 
@@ -102,6 +102,7 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+        ctx.set_materialize_grads(False)
         m3 = _prep(means3D)
         if m3 is None or m3.dim() != 2 or m3.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -127,7 +128,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
         d3, d2, dc, do, ds, dr, dcov, dsh = _hip.rasterize_backward_batch(
             ctx.states, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
             sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
-        ctx.states = None  # gradients arrive already summed over views (means2D stays per view)
+        # gradients arrive already summed over views (means2D stays per view); the state stays on ctx so that a
+        # second backward (retain_graph=True) works, and is released with the graph
         return (d3, d2, dsh if has_sh else None, dc if has_col else None, do, ds if has_sc else None,
                 dr if has_sc else None, dcov if has_cov else None, None)
 

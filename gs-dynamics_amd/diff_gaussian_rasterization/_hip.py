@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -41,7 +42,7 @@ class GsrKernelTime(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
-           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_backward_batch", "gsr_debug_phase_timing",
+           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch", "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward")
 
 
@@ -75,6 +76,8 @@ def load_library():
     lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
     lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, PV, PV, vp]
+    lib.gsr_forward_batch.restype = C.c_int
+    lib.gsr_forward_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, PV, C.POINTER(sz), PV, PV, PV, C.POINTER(u32), vp]
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 6 + [vp, PV, vp, vp, vp, vp, vp, vp]
     lib.gsr_image_loss_blocks.restype = i32
@@ -110,11 +113,25 @@ def _stream(dev: torch.device):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+_settings_cache = {}   # id(tensor) -> (weakref, version, contiguous fp32 copy on the render device)
+
+
 def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Tensor:
     """Settings tensors: n contiguous fp32 values on the render device (viewmatrix may be [1,4,4])."""
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t, dtype=torch.float32)
-    t = t.to(device=dev, dtype=torch.float32).contiguous()
+    if not (t.is_contiguous() and t.dtype == torch.float32 and t.device == dev):
+        # The reference's setup_camera hands over transposed / strided views (helpers.py:14,18): convert once per
+        # tensor object and version instead of launching a copy kernel per camera per call.
+        hit = _settings_cache.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version:
+            t = hit[2]
+        else:
+            conv = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if len(_settings_cache) > 1024:
+                _settings_cache.clear()
+            _settings_cache[id(t)] = (weakref.ref(t), t._version, conv)
+            t = conv
     if t.numel() < n:
         raise ValueError(f"raster_settings.{name} must hold {n} floats, got shape {tuple(t.shape)}")
     return t
@@ -202,6 +219,10 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
 
 
+_binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
+_BINNING_SLACK = 1.25
+
+
 def _ptr_array(tensors):
     """Host array of device pointers (void* const*) for the *_batch entry points."""
     arr = (C.c_void_p * len(tensors))()
@@ -237,14 +258,27 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         images = [torch.empty((lib.gsr_image_bytes(H, W),), **u8) for _ in range(V)]
         Ds = (C.c_uint32 * V)()
         st = _stream(dev)
-        _check(lib.gsr_forward_preprocess_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                                _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
-                                                _ptr_array([radii[v] for v in range(V)]), Ds, st),
-               "gsr_forward_preprocess_batch")
-        binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) for v in range(V)]
-        _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                            _ptr_array([color[v] for v in range(V)]),
-                                            _ptr_array([depth[v] for v in range(V)]), st), "gsr_forward_render_batch")
+        # Binning buffers sized from the previous call with the same shape (+25 %): the library then goes from stage 1
+        # to stage 2 without returning here in between.  First call / grown scene: it returns 1 and stage 2 is
+        # launched from here with exact sizes.
+        key = (dev.index, P, H, W)
+        cap = _binning_capacity.get(key, 0)
+        binnings = [torch.empty((cap,), **u8) for _ in range(V)] if cap else [None] * V
+        caps = (C.c_size_t * V)(*([cap] * V))
+        color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
+        rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                   _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
+                                   _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
+                                   _ptr_array(images), _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
+        if rc not in (0, 1):
+            _check(rc, "gsr_forward_batch")
+        need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
+        if rc == 1:
+            binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) for v in range(V)]
+            _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
+                                                _ptr_array(color_v), _ptr_array(depth_v), st), "gsr_forward_render_batch")
+        if rc == 1 or need * 2 < cap:
+            _binning_capacity[key] = int(need * _BINNING_SLACK)
     states = []
     for v in range(V):
         state = RasterState()

@@ -35,10 +35,10 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100, bg=(0, 0, 0), device=None) ->
         tanfovy=h / (2 * fy),
         bg=torch.tensor(list(bg), dtype=torch.float32, device=device),
         scale_modifier=1.0,
-        viewmatrix=w2c,
+        viewmatrix=w2c.contiguous(),   # same values as the reference's transposed view; no per-call copy
         projmatrix=full_proj,
         sh_degree=0,
-        campos=cam_center,
+        campos=cam_center.contiguous(),
         prefiltered=False,
     )
 

@@ -104,6 +104,17 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
                              float* const* out_color, float* const* out_depth, void* stream);
+/* Both forward stages in ONE call: preprocess all views, synchronise once for the duplicate counts, and -- when
+ * every view's binning state fits the buffer the caller provided (binning_bytes[v] >= gsr_binning_bytes(D_v)) --
+ * launch the render stage straight away, with no host round trip through the caller in between (that round trip
+ * is ~60 us of GPU idle time per step from Python).  Callers size the buffers from the previous step's counts.
+ * Returns 0: rendered; 1: some buffer was too small (or NULL) -- nothing was rendered, num_rendered_host is
+ * filled, allocate exact sizes and call gsr_forward_render_batch; < 0: error. */
+int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                      const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
+                      const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
+                      void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
+                      float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host, void* stream);
 /* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): per-view blend
  * backward on the internal streams, then ONE per-Gaussian kernel that loops over the views and writes the
  * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */

@@ -452,6 +452,93 @@ def test_batched_views_equal_per_view_calls(dev):
         assert (ga - gb).abs().max().item() <= 2e-6 * scale, k   # same per-view values, different summation order
 
 
+def test_one_call_forward_paths_and_repeated_backward(dev):
+    """gsr_forward_batch: first call has no pre-sized binning buffers (falls back to the two-stage calls), the second
+    one runs both stages inside the library, a shrunken capacity falls back again -- all three bit-identical.
+    Backward twice over the same state (retain_graph) re-arms the blend kernel's work queue by itself."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H, V = 15000, 256, 192, 3
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.06)
+    cams = synth_ring_cameras(V, W, H, device=dev)
+    dL = torch.tensor(np.random.default_rng(4).uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    key = (dev.index, P, H, W)
+
+    def run():
+        leaves = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+        m2v = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        im, radii, depth = rasterize_gaussians_views(cams, leaves["means3D"], m2v, leaves["opacities"],
+                                                     colors_precomp=leaves["colors_precomp"], scales=leaves["scales"],
+                                                     rotations=leaves["rotations"])
+        im.backward(gradient=dL, retain_graph=True)
+        g1 = {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}
+        assert len(g1) >= 5
+        for v in leaves.values():
+            v.grad = None
+        im.backward(gradient=dL)
+        g2 = {k: v.grad.clone() for k, v in leaves.items() if v.grad is not None}
+        torch.cuda.synchronize()
+        for k in g1:
+            assert torch.equal(g1[k], g2[k]), f"second backward differs: {k}"
+        return im.detach(), radii, depth.detach(), g1
+
+    _hip._binning_capacity.pop(key, None)
+    first = run()                                   # no capacity yet: two-stage fallback
+    assert _hip._binning_capacity.get(key, 0) > 0
+    second = run()                                  # both stages inside gsr_forward_batch
+    _hip._binning_capacity[key] = 4096              # far too small: fallback again, capacity re-learnt
+    third = run()
+    assert _hip._binning_capacity[key] > 4096
+    for other in (second, third):
+        assert torch.equal(first[0], other[0]) and torch.equal(first[1], other[1]) and torch.equal(first[2], other[2])
+        for k in first[3]:
+            assert torch.equal(first[3][k], other[3][k]), k
+    # single-view path: backward twice as well
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    im, _, _ = GaussianRasterizer(raster_settings=cams[0])(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                           colors_precomp=leaves["colors_precomp"], scales=leaves["scales"],
+                                                           rotations=leaves["rotations"])
+    im.backward(gradient=dL[0], retain_graph=True)
+    ga = leaves["means3D"].grad.clone()
+    leaves["means3D"].grad = None
+    im.backward(gradient=dL[0])
+    assert torch.equal(ga, leaves["means3D"].grad)
+
+
+def test_strided_camera_tensors_are_converted_once_and_tracked(dev):
+    """The reference's setup_camera passes transposed / column views; the wrapper caches their contiguous copies per
+    tensor object + version, so an in-place camera update must still be picked up."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    g = random_gaussians(500, seed=5, scale_lo=0.03, scale_hi=0.2)
+    cam = ring_camera(64, 48, v=0)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)  # noqa: E731
+    vm_store = t(cam.viewmatrix).reshape(4, 4).t().contiguous()      # holds the transpose; .t() view = the matrix
+    pm_store = t(cam.projmatrix).reshape(4, 4).t().contiguous()
+    def settings():
+        return GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, t(cam.bg), 1.0,
+                                             vm_store.t().unsqueeze(0), pm_store.t().unsqueeze(0), 0, t(cam.campos), False)
+    rs = settings()
+    assert not rs.viewmatrix.is_contiguous()
+    x = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    def render(rs_):
+        return GaussianRasterizer(raster_settings=rs_)(means3D=x["means3D"], means2D=torch.zeros_like(x["means3D"]),
+                                                       opacities=x["opacities"], colors_precomp=x["colors_precomp"],
+                                                       scales=x["scales"], rotations=x["rotations"])[0]
+    a = render(rs)
+    ref = _run_hip(cam, g, dev)[0]
+    assert np.array_equal(a.cpu().numpy(), ref)
+    assert torch.equal(render(rs), a)                                  # cached conversion
+    cam2 = ring_camera(64, 48, v=1)
+    vm_store.copy_(t(cam2.viewmatrix).reshape(4, 4).t()); pm_store.copy_(t(cam2.projmatrix).reshape(4, 4).t())
+    rs2 = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, rs.bg, 1.0,
+                                        rs.viewmatrix, rs.projmatrix, 0, t(cam2.campos), False)   # same view objects, new content
+    b = render(rs2)
+    assert np.array_equal(b.cpu().numpy(), _run_hip(cam2, g, dev)[0])
+
+
 # ------------------------------------------------------------------ fused image loss (row N2)
 @pytest.mark.parametrize("H,W", [(64, 48), (37, 53), (800, 800)])
 def test_fused_image_loss_matches_torch_formula(dev, H, W):
