@@ -61,68 +61,170 @@ size_t gsr_image_bytes(int32_t H, int32_t W) { ImageState im; return gsr_carve_i
 size_t gsr_binning_bytes(uint32_t D, int32_t, int32_t) { BinningState b; return gsr_carve_binning(nullptr, D, &b); }
 size_t gsr_backward_scratch_bytes(int32_t, uint32_t D) { return gsr_align((size_t)(D ? D : 1) * GSR_PARTIAL_F4 * 16); }
 
+// ---------------------------------------------------------------------------------------- table builders
+}  // extern "C"
+namespace {
+void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t* radii, uint32_t* block_sums) {
+  o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
+  o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
+  o.block_sums = block_sums;
+}
+void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
+                   const uint32_t* block_sums) {
+  o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
+  o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
+  o.offsets = g.offsets;
+  o.tkey[0] = bs.tkey[0]; o.tkey[1] = bs.tkey[1]; o.dg[0] = bs.dg[0]; o.dg[1] = bs.dg[1];
+  o.point_list = bs.point_list; o.block_hist = bs.block_hist; o.ranges = im.ranges;
+  o.D = D; o.nblocks = D ? gsr_radix_blocks(D) : 0u;
+}
+void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, const BinningState& bs, const ImageState& im,
+                      float* out_color, float* out_depth, const float* dL_dcolor, float4* partials) {
+  o.point_list = bs.point_list; o.rec = g.rec; o.bg = cam.bg; o.final_T = im.final_T; o.n_contrib = im.n_contrib;
+  o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
+  o.partials = partials; o.ranges = im.ranges;
+}
+void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue;
+}
+
+// Pinned host staging for the per-block entry counts (per host thread; lives for the process).
+uint32_t* pinned_sums() {
+  static thread_local uint32_t* p = nullptr;
+  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
+    p = nullptr;
+  return p;
+}
+
+int check_inputs(const char* who, const float* means3D, const float* opacities, const float* colors_precomp, const float* shs,
+                 const float* scales, const float* rotations, const float* cov3D_precomp, const GsrCam& cam) {
+  if (!means3D || !opacities) { gsr_set_error("%s: NULL argument", who); return -2; }
+  if ((colors_precomp == nullptr) == (shs == nullptr)) {
+    gsr_set_error("%s: provide exactly one of colors_precomp / shs", who);
+    return -2;
+  }
+  if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    gsr_set_error("%s: provide exactly one of scales+rotations / cov3D_precomp", who);
+    return -2;
+  }
+  if (shs && (cam.M < (cam.sh_degree + 1) * (cam.sh_degree + 1) || cam.sh_degree > 3 || cam.sh_degree < 0 || cam.M > 16)) {
+    gsr_set_error("%s: sh_degree %d needs (deg+1)^2 <= sh_coeffs (%d) <= 16", who, cam.sh_degree, cam.M);
+    return -2;
+  }
+  return 0;
+}
+
+// Stage 1 of V views: ONE preprocess launch, the entry counts of all views back in one pinned copy (P <= 512 Ki;
+// above that a scan launch + a 4-byte copy per view), ONE stream synchronisation.
+// `sums`: device array [V][nblk] (the views' block_sums; for V = 1 the view's own GeomState::block_sums).
+int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
+           const float* opacities, const float* colors_precomp, const float* shs, const float* cov3D_precomp,
+           void* const* geom_states, int32_t* const* radii, uint32_t* sums, uint32_t* num_rendered_host, hipStream_t st) {
+  GsrPreViews tab;
+  tab.V = V;
+  GsrCam cam0;
+  const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
+  for (int v = 0; v < V; ++v) {
+    GsrCam cam;
+    if (int rc = make_cam(&s[v], &cam)) return rc;
+    if (v == 0) {
+      cam0 = cam;
+      if (int rc = check_inputs("gsr forward", means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp, cam)) return rc;
+    } else if (cam.W != cam0.W || cam.H != cam0.H || cam.sh_degree != cam0.sh_degree || cam.M != cam0.M ||
+               cam.scale_modifier != cam0.scale_modifier) {
+      gsr_set_error("gsr batch: all views must share image size, sh_degree and scale_modifier");
+      return -2;
+    }
+    if (!geom_states[v] || !radii[v]) { gsr_set_error("gsr forward: NULL geom_state / radii"); return -2; }
+    GeomState g;
+    gsr_carve_geom(geom_states[v], P, &g);
+    fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk);
+  }
+  if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
+    return rc;
+  uint32_t* host = pinned_sums();
+  if (!host) { gsr_set_error("gsr forward: pinned host allocation failed"); return -1; }
+  if (gsr_host_block_scan(P)) {
+    GSR_HIP_CHECK(hipMemcpyAsync(host, sums, sizeof(uint32_t) * nblk * V, hipMemcpyDeviceToHost, st));
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+    for (int v = 0; v < V; ++v) {
+      uint64_t tot = 0;
+      for (uint32_t b = 0; b < nblk; ++b) tot += host[(size_t)v * nblk + b];
+      if (tot > 0xffffffffull) { gsr_set_error("gsr forward: %llu tile entries overflow 32 bits", (unsigned long long)tot); return -3; }
+      num_rendered_host[v] = (uint32_t)tot;
+    }
+  } else {
+    for (int v = 0; v < V; ++v) {
+      GeomState g;
+      gsr_carve_geom(geom_states[v], P, &g);
+      if (int rc = gsr_launch_scan_exclusive(sums + (size_t)v * nblk, g.block_offsets, nblk, g.counters, st)) return rc;
+      GSR_HIP_CHECK(hipMemcpyAsync(host + v, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    GSR_HIP_CHECK(hipStreamSynchronize(st));
+    for (int v = 0; v < V; ++v) num_rendered_host[v] = host[v];
+  }
+  return 0;
+}
+
+// Stage 2 of V views: binning chain + blend, one launch per kernel for all views.
+int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
+           void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
+           const uint32_t* sums, uint4* order, uint32_t* queue, hipStream_t st) {
+  GsrBinViews bt;
+  GsrRenderViews rt;
+  const uint32_t nblk = (uint32_t)(((P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK);
+  for (int v = 0; v < V; ++v) {
+    GsrCam cam;
+    if (int rc = make_cam(&s[v], &cam)) return rc;
+    if (!image_states[v] || !out_color[v] || !out_depth[v]) { gsr_set_error("gsr forward render: NULL argument"); return -2; }
+    if (num_rendered[v] > 0 && (!geom_states[v] || !binning_states[v])) { gsr_set_error("gsr forward render: NULL state"); return -2; }
+    GeomState g; ImageState im; BinningState bs;
+    gsr_carve_geom(geom_states[v], P, &g);
+    gsr_carve_image(image_states[v], cam.H, cam.W, &im);
+    gsr_carve_binning(binning_states[v], num_rendered[v], &bs);
+    if (v == 0) {
+      bt.V = V; bt.T = cam.T; bt.gx = cam.gx;
+      bt.order = order ? order : im.tile_order;
+      bt.queue = queue ? queue : im.queue;
+      render_header(rt, V, cam, bt.order, bt.queue);
+    } else if (cam.W != rt.W || cam.H != rt.H) {
+      gsr_set_error("gsr batch: all views must share the image size");
+      return -2;
+    }
+    fill_bin_view(bt.v[v], P, num_rendered[v], g, bs, im, sums ? sums + (size_t)v * nblk : g.block_sums);
+    fill_render_view(rt.v[v], cam, g, bs, im, out_color[v], out_depth[v], nullptr, nullptr);
+  }
+  if (int rc = gsr_launch_binning(bt, P, st)) return rc;
+  return gsr_launch_render_fwd(rt, st);
+}
+}  // namespace
+extern "C" {
+
 int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                            const float* rotations, const float* opacities, const float* colors_precomp,
                            const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
                            uint32_t* num_rendered_host, void* stream) {
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
-  hipStream_t st = (hipStream_t)stream;
   if (num_rendered_host) *num_rendered_host = 0;
   if (P <= 0) return 0;
-  if (!means3D || !opacities || !geom_state || !radii) { gsr_set_error("gsr_forward_preprocess: NULL argument"); return -2; }
-  if ((colors_precomp == nullptr) == (shs == nullptr)) {
-    gsr_set_error("gsr_forward_preprocess: provide exactly one of colors_precomp / shs");
-    return -2;
-  }
-  if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
-    gsr_set_error("gsr_forward_preprocess: provide exactly one of scales+rotations / cov3D_precomp");
-    return -2;
-  }
-  if (shs && (cam.M < (cam.sh_degree + 1) * (cam.sh_degree + 1) || cam.sh_degree > 3 || cam.sh_degree < 0 || cam.M > 16)) {
-    gsr_set_error("gsr_forward_preprocess: sh_degree %d needs (deg+1)^2 <= sh_coeffs (%d) <= 16", cam.sh_degree, cam.M);
-    return -2;
-  }
+  if (!geom_state || !radii) { gsr_set_error("gsr_forward_preprocess: NULL argument"); return -2; }
   GeomState g;
   gsr_carve_geom(geom_state, P, &g);
-  if (int rc = gsr_launch_preprocess(cam, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
-                                     g, radii, st))
-    return rc;
-  const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
   uint32_t D = 0;
-  if (gsr_host_block_scan(P)) {
-    // the per-block entry counts come back in one small pinned copy and are added up here; emit blocks add up
-    // their own base from the same array, so no scan kernel runs
-    static thread_local uint32_t* t_sums = nullptr;  // pinned, per host thread, lives for the process
-    if (!t_sums) GSR_HIP_CHECK(hipHostMalloc((void**)&t_sums, sizeof(uint32_t) * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault));
-    GSR_HIP_CHECK(hipMemcpyAsync(t_sums, g.block_sums, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, st));
-    GSR_HIP_CHECK(hipStreamSynchronize(st));
-    uint64_t tot = 0;
-    for (uint32_t b = 0; b < nblk; ++b) tot += t_sums[b];
-    if (tot > 0xffffffffull) { gsr_set_error("gsr_forward_preprocess: %llu tile entries overflow 32 bits", (unsigned long long)tot); return -3; }
-    D = (uint32_t)tot;
-  } else {
-    if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
-    GSR_HIP_CHECK(hipMemcpyAsync(&D, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GSR_HIP_CHECK(hipStreamSynchronize(st));
-  }
+  if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, &geom_state,
+                      &radii, g.block_sums, &D, (hipStream_t)stream))
+    return rc;
   if (num_rendered_host) *num_rendered_host = D;
   return 0;
 }
 
 int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state,
                        void* binning_state, void* image_state, float* out_color, float* out_depth, void* stream) {
-  GsrCam cam;
-  if (int rc = make_cam(s, &cam)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  if (!image_state || !out_color || !out_depth) { gsr_set_error("gsr_forward_render: NULL argument"); return -2; }
-  GeomState g; ImageState im; BinningState bs;
-  gsr_carve_geom(const_cast<void*>(geom_state), P, &g);
-  gsr_carve_image(image_state, cam.H, cam.W, &im);
-  gsr_carve_binning(binning_state, num_rendered, &bs);
-  if (num_rendered > 0 && (!geom_state || !binning_state)) { gsr_set_error("gsr_forward_render: NULL state"); return -2; }
-  if (int rc = gsr_launch_binning(cam, P, num_rendered, g, bs, im, st)) return rc;
-  return gsr_launch_render_fwd(cam, g, bs, im, out_color, out_depth, st);
+  if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
+  void* geom = const_cast<void*>(geom_state);
+  return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
+                nullptr, (hipStream_t)stream);
 }
 
 int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,
@@ -145,192 +247,106 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
   gsr_carve_image(const_cast<void*>(image_state), cam.H, cam.W, &im);
   gsr_carve_binning(const_cast<void*>(binning_state), num_rendered, &bs);
   float4* partials = (float4*)scratch;
-  if (int rc = gsr_launch_render_bwd(cam, num_rendered, g, bs, im, dL_dcolor, partials, st)) return rc;
+  if (num_rendered > 0) {
+    GsrRenderViews rt;
+    render_header(rt, 1, cam, im.tile_order, im.queue);
+    fill_render_view(rt.v[0], cam, g, bs, im, nullptr, nullptr, dL_dcolor, partials);
+    if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
+  }
   return gsr_launch_preprocess_bwd(cam, P, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g,
                                    partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales,
                                    dL_drotations, dL_dcov3D, dL_dsh, st);
 }
 
-
 // ------------------------------------------------------------------------------------------ multi-view batch
-// The views of one optimisation step share the Gaussians and are independent until the gradients are
-// summed, and a single 800x800 view cannot fill 256 CUs (most binning kernels are launch/latency bound).
-// The *_batch entry points run view v's kernel chain on internal stream v (forked from / joined to the
-// caller's stream with events), so the chains of different views overlap on the GPU, and stage 1 does
-// ONE host synchronisation for all views' duplicate counts instead of one per view.
-namespace {
-struct StreamPool {
-  std::vector<hipStream_t> streams;
-  std::vector<hipEvent_t> done;
-  hipEvent_t fork = nullptr;
-  uint32_t* host_counts = nullptr;  // pinned
-  int device = -1;
-};
-StreamPool g_pools[16];
+// The views of one optimisation step share the Gaussians and are independent until the gradients are summed.
+// Every stage of a batch call is ONE launch covering all views (tables above) on the caller's stream: no internal
+// streams, no events, ~13 HIP calls per 4-view step.  `batch_state` (gsr_batch_state_bytes) holds what the views
+// share: the per-block entry counts of all views (one D2H copy), the combined LPT tile order and its queue heads;
+// the caller keeps it from the forward to the backward like the other state buffers.
+size_t gsr_batch_state_bytes(int32_t V, int32_t P, int32_t H, int32_t W) { BatchState b; return gsr_carve_batch(nullptr, V, P, H, W, &b); }
 
-int get_pool(int V, StreamPool** out) {
-  int dev = 0;
-  GSR_HIP_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) { gsr_set_error("gsr batch: device index %d out of range", dev); return -2; }
-  StreamPool& p = g_pools[dev];
-  p.device = dev;
-  if (!p.fork) GSR_HIP_CHECK(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
-  if (!p.host_counts)
-    GSR_HIP_CHECK(hipHostMalloc((void**)&p.host_counts, sizeof(uint32_t) * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault));
-  while ((int)p.streams.size() < V) {
-    hipStream_t st; hipEvent_t ev;
-    GSR_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    GSR_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    p.streams.push_back(st); p.done.push_back(ev);
-  }
-  *out = &p;
+static int check_batch(const char* who, int32_t V, const gsr_settings* s, const void* batch_state) {
+  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("%s: V must be in 1..%d", who, GSR_MAX_BATCH); return -2; }
+  if (!s || !batch_state) { gsr_set_error("%s: NULL settings / batch_state", who); return -2; }
   return 0;
 }
-int fork_streams(StreamPool& p, int V, hipStream_t caller) {
-  GSR_HIP_CHECK(hipEventRecord(p.fork, caller));
-  for (int v = 0; v < V; ++v) GSR_HIP_CHECK(hipStreamWaitEvent(p.streams[v], p.fork, 0));
-  return 0;
-}
-int join_streams(StreamPool& p, int V, hipStream_t caller) {
-  for (int v = 0; v < V; ++v) {
-    GSR_HIP_CHECK(hipEventRecord(p.done[v], p.streams[v]));
-    GSR_HIP_CHECK(hipStreamWaitEvent(caller, p.done[v], 0));
-  }
-  return 0;
-}
-}  // namespace
-
-namespace {
-// Stage 1 of all views on the pool's streams (already forked from the caller's stream), one sync per stream.
-int preprocess_views(StreamPool* pool, int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                     const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
-                     const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
-                     uint32_t* num_rendered_host) {
-  for (int v = 0; v < V; ++v) {
-    GsrCam cam;
-    if (int rc = make_cam(&s[v], &cam)) return rc;
-    hipStream_t st = pool->streams[v];
-    GeomState g;
-    gsr_carve_geom(geom_states[v], P, &g);
-    if (int rc = gsr_launch_preprocess(cam, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
-                                       g, radii[v], st))
-      return rc;
-    const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
-    uint32_t* slot = pool->host_counts + (size_t)v * GSR_HOST_SCAN_MAX_BLOCKS;
-    if (gsr_host_block_scan(P)) {
-      GSR_HIP_CHECK(hipMemcpyAsync(slot, g.block_sums, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, st));
-    } else {
-      if (int rc = gsr_launch_scan_exclusive(g.block_sums, g.block_offsets, nblk, g.counters, st)) return rc;
-      GSR_HIP_CHECK(hipMemcpyAsync(slot, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    }
-  }
-  const uint32_t nsum = gsr_host_block_scan(P) ? (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK) : 1u;
-  for (int v = 0; v < V; ++v) {
-    GSR_HIP_CHECK(hipStreamSynchronize(pool->streams[v]));
-    const uint32_t* slot = pool->host_counts + (size_t)v * GSR_HOST_SCAN_MAX_BLOCKS;
-    uint64_t tot = 0;
-    for (uint32_t b = 0; b < nsum; ++b) tot += slot[b];
-    if (tot > 0xffffffffull) { gsr_set_error("gsr forward: tile entries overflow 32 bits"); return -3; }
-    num_rendered_host[v] = (uint32_t)tot;
-  }
-  return 0;
-}
-int check_batch_inputs(const char* who, int32_t V, const gsr_settings* s, const float* colors_precomp, const float* shs,
-                       const float* scales, const float* rotations, const float* cov3D_precomp) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s) { gsr_set_error("%s: NULL settings", who); return -2; }
-  if ((colors_precomp == nullptr) == (shs == nullptr) || ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
-    gsr_set_error("%s: provide exactly one of colors_precomp/shs and of scales+rotations/cov3D_precomp", who);
-    return -2;
-  }
-  return 0;
-}
-}  // namespace
 
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                  const float* rotations, const float* opacities, const float* colors_precomp,
                                  const float* shs, const float* cov3D_precomp, void* const* geom_states,
-                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s || !geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
+                                 int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream) {
+  if (int rc = check_batch("gsr_forward_preprocess_batch", V, s, batch_state)) return rc;
+  if (!geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
   for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
   if (P <= 0) return 0;
-  if (int rc = check_batch_inputs("gsr_forward_preprocess_batch", V, s, colors_precomp, shs, scales, rotations, cov3D_precomp)) return rc;
-  StreamPool* pool = nullptr;
-  if (int rc = get_pool(V, &pool)) return rc;
-  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
-  return preprocess_views(pool, V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
-                          geom_states, radii, num_rendered_host);
+  BatchState b;
+  gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  return stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_states, radii, b.sums,
+                num_rendered_host, (hipStream_t)stream);
+}
+
+int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
+                             void* const* geom_states, void* const* binning_states, void* const* image_states,
+                             void* batch_state, float* const* out_color, float* const* out_depth, void* stream) {
+  if (int rc = check_batch("gsr_forward_render_batch", V, s, batch_state)) return rc;
+  if (!num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
+    gsr_set_error("gsr_forward_render_batch: NULL argument");
+    return -2;
+  }
+  BatchState b;
+  gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  return stage2(V, s, P, num_rendered, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
+                b.queue, (hipStream_t)stream);
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                       const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
                       const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
-                      float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host, void* stream) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s || !geom_states || !radii || !num_rendered_host || !image_states || !out_color || !out_depth) {
+                      void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
+                      void* stream) {
+  if (int rc = check_batch("gsr_forward_batch", V, s, batch_state)) return rc;
+  if (!geom_states || !radii || !num_rendered_host || !image_states || !out_color || !out_depth) {
     gsr_set_error("gsr_forward_batch: NULL argument");
     return -2;
   }
   for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
   if (P <= 0) return 1;  // nothing to preprocess: the caller takes the render-stage call (it paints the background)
-  if (int rc = check_batch_inputs("gsr_forward_batch", V, s, colors_precomp, shs, scales, rotations, cov3D_precomp)) return rc;
-  StreamPool* pool = nullptr;
-  if (int rc = get_pool(V, &pool)) return rc;
-  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
-  if (int rc = preprocess_views(pool, V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp,
-                                geom_states, radii, num_rendered_host))
+  BatchState b;
+  gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_states, radii,
+                      b.sums, num_rendered_host, (hipStream_t)stream))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
   for (int v = 0; fits && v < V; ++v)
     fits = num_rendered_host[v] == 0 || (binning_states[v] && binning_bytes[v] >= gsr_binning_bytes(num_rendered_host[v], 0, 0));
   if (!fits) return 1;
-  for (int v = 0; v < V; ++v) {
-    if (int rc = gsr_forward_render(&s[v], P, num_rendered_host[v], geom_states[v], binning_states[v], image_states[v],
-                                    out_color[v], out_depth[v], pool->streams[v]))
-      return rc;
-  }
-  return join_streams(*pool, V, (hipStream_t)stream);
-}
-
-int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
-                             void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             float* const* out_color, float* const* out_depth, void* stream) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s || !num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
-    gsr_set_error("gsr_forward_render_batch: NULL argument");
-    return -2;
-  }
-  StreamPool* pool = nullptr;
-  if (int rc = get_pool(V, &pool)) return rc;
-  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
-  for (int v = 0; v < V; ++v) {
-    if (int rc = gsr_forward_render(&s[v], P, num_rendered[v], geom_states[v], binning_states[v], image_states[v],
-                                    out_color[v], out_depth[v], pool->streams[v]))
-      return rc;
-  }
-  return join_streams(*pool, V, (hipStream_t)stream);
+  return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
+                b.queue, (hipStream_t)stream);
 }
 
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
-                       void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
-                       void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D, float* dL_dcolors,
-                       float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream) {
-  if (V <= 0 || V > GSR_MAX_BATCH) { gsr_set_error("gsr batch: V must be in 1..%d", GSR_MAX_BATCH); return -2; }
-  if (!s || !num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
+                       void* const* binning_states, void* const* image_states, void* batch_state,
+                       const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D,
+                       float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                       void* stream) {
+  if (int rc = check_batch("gsr_backward_batch", V, s, batch_state)) return rc;
+  if (!num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
       !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !means3D) {
     gsr_set_error("gsr_backward_batch: NULL argument");
     return -2;
   }
   if (P <= 0) return 0;
-  StreamPool* pool = nullptr;
-  if (int rc = get_pool(V, &pool)) return rc;
-  if (int rc = fork_streams(*pool, V, (hipStream_t)stream)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  BatchState b;
+  gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   GsrBwdViews vw;
   vw.V = V;
+  GsrRenderViews rt;
+  bool any = false;
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
     if (int rc = make_cam(&s[v], &cam)) return rc;
@@ -339,18 +355,20 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     gsr_carve_image(image_states[v], cam.H, cam.W, &im);
     gsr_carve_binning(binning_states[v], num_rendered[v], &bs);
     if (num_rendered[v] > 0 && (!binning_states[v] || !scratch[v])) { gsr_set_error("gsr_backward_batch: NULL binning/scratch"); return -2; }
-    if (int rc = gsr_launch_render_bwd(cam, num_rendered[v], g, bs, im, dL_dcolor[v], (float4*)scratch[v], pool->streams[v]))
-      return rc;
+    if (v == 0) render_header(rt, V, cam, b.order, b.queue);
+    fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
+    any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
     w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
-  if (int rc = join_streams(*pool, V, (hipStream_t)stream)) return rc;
+  if (any) {
+    if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
+  }
   (void)colors_precomp;
   return gsr_launch_preprocess_bwd_views(vw, P, s[0].scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D,
-                                         dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D,
-                                         (hipStream_t)stream);
+                                         dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, st);
 }
 
 int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * ((H + 15) / 16) * ((W + 15) / 16); }

@@ -84,15 +84,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
 // Block b owns Gaussians [256b, 256b+256).  Its first entry offset comes from the scan of the preprocess
 // block sums; the per-Gaussian offsets inside the block are scanned here in LDS and written out once
 // (offsets[] is what render_bwd / preprocess_bwd use to address the Gaussian-major partial records).
-__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, int gx, const float4* __restrict__ rec,
-                                                                 const uint2* __restrict__ rect,
-                                                                 const uint32_t* __restrict__ tiles_touched,
-                                                                 const uint32_t* __restrict__ block_sums,
-                                                                 const uint32_t* __restrict__ block_offsets,
-                                                                 uint32_t* __restrict__ offsets,
-                                                                 uint32_t* __restrict__ tkey,
-                                                                 uint64_t* __restrict__ dg,
-                                                                 uint2* __restrict__ ranges, int T) {
+__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinViews tab) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  const int gx = tab.gx, T = tab.T;
+  const float4* __restrict__ rec = vw.rec;
+  const uint2* __restrict__ rect = vw.rect;
+  const uint32_t* __restrict__ tiles_touched = vw.tiles_touched;
+  const uint32_t* __restrict__ block_sums = vw.block_sums;
+  const uint32_t* __restrict__ block_offsets = vw.block_offsets;
+  uint32_t* __restrict__ offsets = vw.offsets;
+  uint32_t* __restrict__ tkey = vw.tkey[0];
+  uint64_t* __restrict__ dg = vw.dg[0];
+  uint2* __restrict__ ranges = vw.ranges;
   __shared__ uint32_t soff[GSR_BLOCK + 1];
   __shared__ uint32_t swave[GSR_BLOCK / GSR_WAVE];
   __shared__ uint32_t spre[GSR_BLOCK / GSR_WAVE];
@@ -155,9 +158,12 @@ __device__ __forceinline__ uint64_t match_peers(uint32_t digit, bool valid, int 
 }
 
 // Per-block digit histogram, block-major: block_hist[block * nbins + bin] (a coalesced row per block).
-__global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
-                                                               int shift, int bits, uint32_t nblocks,
-                                                               uint32_t* __restrict__ block_hist) {
+__global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(GsrBinViews tab, int cur, int shift, int bits) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (blockIdx.x >= vw.nblocks || vw.D == 0) return;   // grid.x is the maximum over the views
+  const uint32_t* __restrict__ tkey = vw.tkey[cur];
+  const uint32_t D = vw.D;
+  uint32_t* __restrict__ block_hist = vw.block_hist;
   __shared__ uint32_t hist[256];
   const int tid = threadIdx.x;
   hist[tid] = 0;
@@ -179,10 +185,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t* _
 // (nblocks x nbins, L2-resident): base(bin) = sum of all counts of lower bins + counts of this bin in
 // earlier blocks.  Then wave w of the block owns the w-th quarter of the block's chunk and walks it in
 // order, 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
-__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
-    const uint32_t* __restrict__ tkey_in, const uint64_t* __restrict__ dg_in, uint32_t* __restrict__ tkey_out,
-    uint64_t* __restrict__ dg_out, uint32_t D, int shift, int bits, uint32_t nblocks,
-    const uint32_t* __restrict__ block_hist) {
+__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (blockIdx.x >= vw.nblocks || vw.D == 0) return;
+  const uint32_t* __restrict__ tkey_in = vw.tkey[cur];
+  const uint64_t* __restrict__ dg_in = vw.dg[cur];
+  uint32_t* __restrict__ tkey_out = vw.tkey[cur ^ 1];
+  uint64_t* __restrict__ dg_out = vw.dg[cur ^ 1];
+  const uint32_t D = vw.D, nblocks = vw.nblocks;
+  const uint32_t* __restrict__ block_hist = vw.block_hist;
   __shared__ uint32_t wcount[4][256];
   __shared__ uint32_t s_tot[4][256];   // per-wave partial: total count of each bin over all blocks
   __shared__ uint32_t s_pre[4][256];   // per-wave partial: count of each bin in blocks before this one
@@ -286,19 +297,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
 // XCD's L2, 15 us against 6.4 + 6.3 us for two launches.)
 
 // ------------------------------------------------------------------ LPT work queue
+// Entries {tile, list start, list end, view} for ALL tiles of ALL views of the call.
 // Tiles bucketed by list length (8 entries per bucket, 256 buckets), longest first.  The blend kernels'
 // persistent workgroups pop tickets from this order, so heavy tiles start first and the tail of the
 // kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
 // is arbitrary: per-tile results do not depend on it.
-__device__ __forceinline__ void build_tile_order(const uint2* __restrict__ ranges, int T,
-                                                 uint4* __restrict__ tile_order, uint32_t* __restrict__ queue,
-                                                 uint32_t* cnt, uint32_t* start) {   // cnt, start: 256 LDS words each
+__global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t start[256];
   const int tid = threadIdx.x, lane = tid & 63;
+  const int T = tab.T, N = tab.V * T;   // all tiles of all views, one order
+  uint4* __restrict__ tile_order = tab.order;
+  uint32_t* __restrict__ queue = tab.queue;
   if (tid < 256) cnt[tid] = 0;
   if (tid < 8) queue[tid] = 0;
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) {
-    const uint2 r = ranges[t];
+  for (int i = tid; i < N; i += 1024) {
+    const uint2 r = tab.v[i / T].ranges[i % T];
     const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
     atomicAdd(&cnt[bucket], 1u);
   }
@@ -318,25 +333,20 @@ __device__ __forceinline__ void build_tile_order(const uint2* __restrict__ range
     for (int q = 0; q < 4; ++q) { start[lane * 4 + q] = run; run += c4[q]; }
   }
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) {
-    const uint2 r = ranges[t];
+  for (int i = tid; i < N; i += 1024) {
+    const int v = i / T, t = i % T;
+    const uint2 r = tab.v[v].ranges[t];
     const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
-    tile_order[atomicAdd(&start[bucket], 1u)] = make_uint4((uint32_t)t, r.x, r.y, 0u);
+    tile_order[atomicAdd(&start[bucket], 1u)] = make_uint4((uint32_t)t, r.x, r.y, (uint32_t)v);
   }
-  if (tid == 0) queue[4] = (uint32_t)T - cnt[255];  // bucket 255 = empty tiles (sorted last)
+  if (tid == 0) queue[4] = (uint32_t)N - cnt[255];  // bucket 255 = empty tiles (sorted last)
 }
 
-// Standalone launch (D == 0: every tile is empty).
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int T,
-                                                          uint4* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ queue) {
-  __shared__ uint32_t cnt[256];
-  __shared__ uint32_t start[256];
-  build_tile_order(ranges, T, tile_order, queue, cnt, start);
-}
-
-__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t* __restrict__ tkey, uint32_t D,
-                                                                uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  const uint32_t* __restrict__ tkey = vw.tkey[cur];
+  uint2* __restrict__ ranges = vw.ranges;
+  const uint32_t D = vw.D;
   uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   if (i >= D) return;
   uint32_t t = tkey[i];
@@ -454,13 +464,14 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds& L, uint32_t n, int t
   return cur;
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                              const uint4* __restrict__ tile_order,
-                                                              uint64_t* __restrict__ dg,
-                                                              uint32_t* __restrict__ point_list) {
+__global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, int cur) {
   __shared__ TileSortLds L;
   const int tid = threadIdx.x;
-  const uint4 ord = tile_order[blockIdx.x];  // longest lists are dispatched first
+  if (blockIdx.x >= tab.queue[4]) return;      // only the non-empty tiles (they lead the order)
+  const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
+  const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
+  uint64_t* __restrict__ dg = vw.dg[cur];
+  uint32_t* __restrict__ point_list = vw.point_list;
   const uint2 rg = make_uint2(ord.y, ord.z);
   const uint32_t n = rg.y - rg.x;
   if (n == 0) return;
@@ -509,49 +520,42 @@ static int ceil_log2_u32(uint32_t n) {
   return b;
 }
 
-int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
-                       const ImageState& im, hipStream_t st) {
-  if (D == 0 || P <= 0) {
-    GSR_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.T, st));
-    { GSR_PROF("tile_order", st);
-      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
-    GSR_HIP_CHECK(hipGetLastError());
-    return 0;
-  }
-  { GSR_PROF("emit_entries", st);
-  hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, cam.gx,
-                     g.rec, g.rect, g.tiles_touched, g.block_sums,
-                     gsr_host_block_scan(P) ? (const uint32_t*)nullptr : (const uint32_t*)g.block_offsets, g.offsets,
-                     bs.tkey[0], bs.dg[0], im.ranges, cam.T); }
-  GSR_HIP_CHECK(hipGetLastError());
-  const int tbits = ceil_log2_u32((uint32_t)cam.T);
-  const int npass = (tbits + 7) / 8;
-  const int bpp = npass ? (tbits + npass - 1) / npass : 0;
-  const uint32_t nblocks = gsr_radix_blocks(D);
+int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
+  if (tab.V <= 0 || tab.T <= 0) return 0;
+  uint32_t maxD = 0, maxblk = 0;
+  for (int v = 0; v < tab.V; ++v) { maxD = tab.v[v].D > maxD ? tab.v[v].D : maxD; maxblk = tab.v[v].nblocks > maxblk ? tab.v[v].nblocks : maxblk; }
   int cur = 0;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int shift = pass * bpp;
-    const int bits = (tbits - shift) < bpp ? (tbits - shift) : bpp;
-    { GSR_PROF("radix_hist", st);
-  hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D, shift, bits, nblocks,
-                       bs.block_hist); }
+  if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
+    for (int v = 0; v < tab.V; ++v) GSR_HIP_CHECK(hipMemsetAsync(tab.v[v].ranges, 0, sizeof(uint2) * (size_t)tab.T, st));
+  } else {
+    { GSR_PROF("emit_entries", st);
+    hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, P, tab); }
     GSR_HIP_CHECK(hipGetLastError());
-    { GSR_PROF("radix_scatter", st);
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], bs.dg[cur],
-                       bs.tkey[cur ^ 1], bs.dg[cur ^ 1], D, shift, bits, nblocks, bs.block_hist); }
+    const int tbits = ceil_log2_u32((uint32_t)tab.T);
+    const int npass = (tbits + 7) / 8;
+    const int bpp = npass ? (tbits + npass - 1) / npass : 0;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int shift = pass * bpp;
+      const int bits = (tbits - shift) < bpp ? (tbits - shift) : bpp;
+      { GSR_PROF("radix_hist", st);
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits); }
+      GSR_HIP_CHECK(hipGetLastError());
+      { GSR_PROF("radix_scatter", st);
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits); }
+      GSR_HIP_CHECK(hipGetLastError());
+      cur ^= 1;
+    }
+    { GSR_PROF("tile_ranges", st);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((maxD + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur); }
     GSR_HIP_CHECK(hipGetLastError());
-    cur ^= 1;
   }
-  { GSR_PROF("tile_ranges", st);
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((D + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, bs.tkey[cur], D,
-                     im.ranges); }
-  GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("tile_order", st);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, im.ranges, cam.T, im.tile_order, im.queue); }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
   GSR_HIP_CHECK(hipGetLastError());
-  { GSR_PROF("tile_sort", st);
-  hipLaunchKernelGGL(tile_sort_kernel, dim3(cam.T), dim3(GSR_BLOCK), 0, st, im.ranges, im.tile_order, bs.dg[cur],
-                     bs.point_list); }
-  GSR_HIP_CHECK(hipGetLastError());
+  if (maxD > 0 && P > 0) {
+    { GSR_PROF("tile_sort", st);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur); }
+    GSR_HIP_CHECK(hipGetLastError());
+  }
   return 0;
 }

@@ -137,17 +137,59 @@ struct GsrCam {  // host copy of the scalar settings; matrices stay on the devic
   const float *bg, *view, *proj, *campos;
 };
 
-int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const float* scales,
+// Every stage is ONE launch for all V views of a call (V = 1 for the single-view entry points): a kernel finds
+// its view in blockIdx.y -- or, for the per-tile kernels, in the 4th word of the work-queue ticket -- and takes
+// that view's pointers from a table passed by value as a kernel argument (kernarg segment: scalar loads, no
+// extra copy).  One launch per stage instead of one per view keeps the host off the critical path (a HIP launch
+// costs ~3 us of host time; a 4-view step used to issue ~75 of them) and lets all views share one LPT tile queue.
+struct GsrPreView {            // preprocess
+  const float *view, *proj, *campos;
+  float tanfovx, tanfovy;
+  float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
+};
+struct GsrPreViews { int V; GsrPreView v[GSR_MAX_BATCH]; };
+struct GsrBinView {            // emit .. tile_sort
+  const float4* rec; const uint2* rect; const uint32_t* tiles_touched;
+  const uint32_t* block_sums; const uint32_t* block_offsets;   // block_offsets == nullptr: emit adds up block_sums itself
+  uint32_t* offsets;
+  uint32_t* tkey[2]; uint64_t* dg[2]; uint32_t* point_list; uint32_t* block_hist;
+  uint2* ranges;
+  uint32_t D, nblocks;
+};
+struct GsrBinViews { int V, T, gx; uint4* order; uint32_t* queue; GsrBinView v[GSR_MAX_BATCH]; };
+struct GsrRenderView {         // blend forward / backward
+  const uint32_t* point_list; const float4* rec; const float* bg;
+  float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
+  const float* dL_dcolor; const uint2* rect; const uint32_t* offsets; float4* partials;
+  const uint2* ranges;
+};
+struct GsrRenderViews { int V, W, H, gx, T; const uint4* order; uint32_t* queue; GsrRenderView v[GSR_MAX_BATCH]; };
+
+// Batch state (V > 1): the structures shared by the views of one call.
+struct BatchState {
+  uint32_t* sums;    // [V][ceil(P/256)] per-preprocess-block entry counts of every view (one D2H copy)
+  uint4* order;      // [V*T] {tile, list start, list end, view}: all tiles of the call, longest list first
+  uint32_t* queue;   // [16] work-queue heads, see ImageState::queue
+};
+static inline size_t gsr_carve_batch(void* base, int V, int32_t P, int32_t H, int32_t W, BatchState* b) {
+  size_t off = 0;
+  const size_t nblk = ((size_t)(P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK;
+  const size_t T = (size_t)((H + GSR_TILE - 1) / GSR_TILE) * ((W + GSR_TILE - 1) / GSR_TILE);
+  char* p0 = (char*)base;
+  auto take = [&](size_t bytes) { char* p = p0 ? p0 + off : nullptr; off += gsr_align(bytes); return p; };
+  b->sums = (uint32_t*)take((size_t)V * nblk * 4);
+  b->order = (uint4*)take((size_t)V * (T ? T : 1) * 16);
+  b->queue = (uint32_t*)take(64);
+  return off;
+}
+
+int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, const GeomState& g, int32_t* radii,
-                          hipStream_t st);
+                          const float* shs, const float* cov3D_precomp, hipStream_t st);
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
-int gsr_launch_binning(const GsrCam& cam, int P, uint32_t D, const GeomState& g, const BinningState& bs,
-                       const ImageState& im, hipStream_t st);
-int gsr_launch_render_fwd(const GsrCam& cam, const GeomState& g, const BinningState& bs, const ImageState& im,
-                          float* out_color, float* out_depth, hipStream_t st);
-int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, const BinningState& bs,
-                          const ImageState& im, const float* dL_dcolor, float4* partials, hipStream_t st);
+int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
+int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st);
+int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
                               const float* rotations, const float* colors_precomp, const float* shs,
                               const float* cov3D_precomp, const int32_t* radii, const GeomState& g,

@@ -59,14 +59,22 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float* __restric
 __device__ __forceinline__ int sext16_(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
-    int P, int W, int H, int gx, int gy, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
-    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    GsrPreViews tab, int P, int W, int H, int gx, int gy, float mod, int sh_degree, int M,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
-    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, float4* __restrict__ rec,
-    uint2* __restrict__ rect,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii,
-    uint32_t* __restrict__ block_sums, int tight_lists) {
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
+  // this block's view (blockIdx.y): its pointers come out of the kernarg table with scalar loads
+  const GsrPreView& vw = tab.v[blockIdx.y];
+  const float* __restrict__ view = vw.view;
+  const float* __restrict__ proj = vw.proj;
+  const float* __restrict__ campos = vw.campos;
+  const float tanfovx = vw.tanfovx, tanfovy = vw.tanfovy;
+  float4* __restrict__ rec = vw.rec;
+  uint2* __restrict__ rect = vw.rect;
+  uint32_t* __restrict__ tiles_touched = vw.tiles_touched;
+  uint32_t* __restrict__ clamped_out = vw.clamped;
+  int32_t* __restrict__ radii = vw.radii;
+  uint32_t* __restrict__ block_sums = vw.block_sums;
   __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   const bool in_range = i < P;
@@ -218,19 +226,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 
 }  // namespace
 
-int gsr_launch_preprocess(const GsrCam& cam, int P, const float* means3D, const float* scales,
+int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, const GeomState& g, int32_t* radii,
-                          hipStream_t st) {
-  if (P <= 0) return 0;
+                          const float* shs, const float* cov3D_precomp, hipStream_t st) {
+  if (P <= 0 || tab.V <= 0) return 0;
   int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
   const char* ref_lists = getenv("GSR_REFERENCE_LISTS");
   const int tight = (ref_lists && ref_lists[0] == '1') ? 0 : 1;
   { GSR_PROF("preprocess_fwd", st);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, st, P, cam.W, cam.H, cam.gx, cam.gy,
-                     cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,
-                     cam.campos, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, g.rec,
-                     g.rect, g.tiles_touched, g.clamped, radii, g.block_sums, tight); }
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks, tab.V), dim3(GSR_BLOCK), 0, st, tab, P, cam.W, cam.H, cam.gx,
+                     cam.gy, cam.scale_modifier, cam.sh_degree, cam.M, means3D, scales, rotations, opacities,
+                     colors_precomp, shs, cov3D_precomp, tight); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

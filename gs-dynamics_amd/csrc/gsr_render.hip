@@ -402,45 +402,50 @@ __device__ __forceinline__ void bwd_tile(
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-#define GSR_FWD_ARGS                                                                                          \
-  int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-      const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,              \
-      uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth
-#define GSR_FWD_PASS W, H, gx, point_list, rec, bg, final_T, n_contrib, out_color, out_depth
+// One launch serves every view of the call: a ticket of the combined LPT order is {tile, list start, list end,
+// view}; the view's pointers come from the kernarg table (uniform index: scalar loads).
+#define GSR_FWD_PASS(vw) tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).out_color, (vw).out_depth
+#define GSR_BWD_PASS(vw) \
+  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).rect, (vw).offsets, (vw).partials
 
-__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GSR_FWD_ARGS) {
+__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
   __shared__ FwdLds L;
-  fwd_tile((int)blockIdx.x, ranges[blockIdx.x], L, GSR_FWD_PASS);
+  const GsrRenderView& vw = tab.v[blockIdx.y];
+  fwd_tile((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_FWD_PASS(vw));
 }
 
 // Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
 // (grid-stride over the tail of the order array), then pop busy tiles longest-first.
-__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint4* __restrict__ tile_order,
-                                                                  uint32_t* __restrict__ queue, GSR_FWD_ARGS) {
+__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(GsrRenderViews tab) {
   __shared__ FwdLds L;
   __shared__ uint32_t s_ticket;
+  const uint4* __restrict__ tile_order = tab.order;
+  uint32_t* __restrict__ queue = tab.queue;
   const uint32_t n_busy = queue[4];
   // Tickets: the first one is implicit (blockIdx.x, no atomic: no thundering herd at kernel start); later ones
   // are gridDim.x + atomicAdd(head), popped after the tile.  (Popping the next ticket early was measured
   // slower: the in-flight returning atomic sits in front of the wave's gather waits -- vmcnt retires in order.)
   {  // background of the empty tiles
-    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    const int W = tab.W, H = tab.H, gx = tab.gx;
     const size_t N = (size_t)H * W;
-    for (uint32_t i = n_busy + blockIdx.x; i < (uint32_t)T_tiles; i += gridDim.x) {
-      const int tile = (int)tile_order[i].x;
+    for (uint32_t i = n_busy + blockIdx.x; i < (uint32_t)(tab.V * tab.T); i += gridDim.x) {
+      const uint4 ord = tile_order[i];
+      const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
+      const int tile = (int)ord.x;
       const int px = (tile % gx) * GSR_TILE + (threadIdx.x & 15), py = (tile / gx) * GSR_TILE + (threadIdx.x >> 4);
       if (px < W && py < H) {
         const int pix = py * W + px;
-        final_T[pix] = 1.0f; n_contrib[pix] = 0u;
-        out_color[pix] = b0; out_color[N + pix] = b1; out_color[2 * N + pix] = b2;
-        out_depth[pix] = 0.0f;
+        vw.final_T[pix] = 1.0f; vw.n_contrib[pix] = 0u;
+        vw.out_color[pix] = vw.bg[0]; vw.out_color[N + pix] = vw.bg[1]; vw.out_color[2 * N + pix] = vw.bg[2];
+        vw.out_depth[pix] = 0.0f;
       }
     }
   }
   uint32_t ticket = blockIdx.x;
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
-    fwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS);
+    const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
+    fwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw));
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
@@ -454,30 +459,25 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(const uint4* 
   }
 }
 
-#define GSR_BWD_ARGS                                                                                          \
-  int W, int H, int gx, int T_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,        \
-      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const uint2* __restrict__ rect, \
-      const uint32_t* __restrict__ offsets, float4* __restrict__ partials
-#define GSR_BWD_PASS \
-  W, H, gx, point_list, rec, bg, final_T, n_contrib, dL_dcolor, rect, offsets, partials
-
-__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GSR_BWD_ARGS) {
+__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews tab) {   // grid (T, V)
   __shared__ BwdLds L;
-  bwd_tile((int)blockIdx.x, ranges[blockIdx.x], L, GSR_BWD_PASS);
+  const GsrRenderView& vw = tab.v[blockIdx.y];
+  bwd_tile((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_BWD_PASS(vw));
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(const uint4* __restrict__ tile_order,
-                                                                  uint32_t* __restrict__ queue, GSR_BWD_ARGS) {
+__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLds L;
   __shared__ uint32_t s_ticket;
+  const uint4* __restrict__ tile_order = tab.order;
+  uint32_t* __restrict__ queue = tab.queue;
   const uint32_t n_busy = queue[4];  // empty tiles have nothing to differentiate: they never enter the queue
   // First ticket implicit (blockIdx.x); later ones popped after the tile.  (No ticket prefetch here: every wave
   // of bwd_tile issues global loads right at tile start, and they would queue behind the in-flight atomic.)
   uint32_t ticket = blockIdx.x;
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
-    bwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS);
+    const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
+    bwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS(vw));
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
     __syncthreads();  // also: the tile's LDS (incl. sMaxLast) is dead before the next tile reuses it
     ticket = s_ticket;
@@ -522,41 +522,34 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-int gsr_launch_render_fwd(const GsrCam& cam, const GeomState& g, const BinningState& bs, const ImageState& im,
-                          float* out_color, float* out_depth, hipStream_t st) {
-  if (cam.T <= 0) return 0;
+int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
+  if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 4);
   { GSR_PROF("render_fwd", st);
     if (use_static) {
-      hipLaunchKernelGGL(render_fwd_static, dim3(cam.T), dim3(GSR_BLOCK), 0, st, cam.W, cam.H, cam.gx, cam.T, im.ranges,
-                         bs.point_list, g.rec, cam.bg, im.final_T, im.n_contrib, out_color, out_depth);
+      hipLaunchKernelGGL(render_fwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
-      const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue, cam.W,
-                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
-                         im.n_contrib, out_color, out_depth);
+      const int tiles = tab.T * tab.V;
+      const int grid = tiles < 256 * wg_per_cu ? tiles : 256 * wg_per_cu;
+      hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-int gsr_launch_render_bwd(const GsrCam& cam, uint32_t D, const GeomState& g, const BinningState& bs,
-                          const ImageState& im, const float* dL_dcolor, float4* partials, hipStream_t st) {
-  if (cam.T <= 0 || D == 0) return 0;
+int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
+  if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 3);
   { GSR_PROF("render_bwd", st);
     if (use_static) {
-      hipLaunchKernelGGL(render_bwd_static, dim3(cam.T), dim3(GSR_BLOCK), 0, st, cam.W, cam.H, cam.gx, cam.T, im.ranges,
-                         bs.point_list, g.rec, cam.bg, im.final_T, im.n_contrib, dL_dcolor, g.rect,
-                         g.offsets, partials);
+      hipLaunchKernelGGL(render_bwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
-      const int grid = cam.T < 256 * wg_per_cu ? cam.T : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, im.tile_order, im.queue, cam.W,
-                         cam.H, cam.gx, cam.T, im.ranges, bs.point_list, g.rec, cam.bg, im.final_T,
-                         im.n_contrib, dL_dcolor, g.rect, g.offsets, partials);
+      const int tiles = tab.T * tab.V;
+      const int grid = tiles < 256 * wg_per_cu ? tiles : 256 * wg_per_cu;
+      hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());

@@ -42,7 +42,8 @@ class GsrKernelTime(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
-           "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch", "gsr_backward_batch", "gsr_debug_phase_timing",
+           "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
+           "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward")
 
 
@@ -72,14 +73,17 @@ def load_library():
     lib.gsr_backward.argtypes = [C.POINTER(GsrSettings), i32, u32] + [vp] * 20 + [vp]
     PS = C.POINTER(GsrSettings)
     PV = C.POINTER(C.c_void_p)
+    lib.gsr_batch_state_bytes.restype = sz; lib.gsr_batch_state_bytes.argtypes = [i32, i32, i32, i32]
     lib.gsr_forward_preprocess_batch.restype = C.c_int
-    lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, C.POINTER(u32), vp]
+    lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, vp, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
-    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, PV, PV, vp]
+    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, PV, PV, vp]
     lib.gsr_forward_batch.restype = C.c_int
-    lib.gsr_forward_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, PV, C.POINTER(sz), PV, PV, PV, C.POINTER(u32), vp]
+    lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 7 + [PV, PV, PV, C.POINTER(sz), PV, vp, PV, PV,
+                                      C.POINTER(u32), vp])
     lib.gsr_backward_batch.restype = C.c_int
-    lib.gsr_backward_batch.argtypes = [i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 6 + [vp, PV, vp, vp, vp, vp, vp, vp]
+    lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, PV, PV]
+                                       + [vp, PV, vp, vp, vp, vp, vp, vp])
     lib.gsr_image_loss_blocks.restype = i32
     lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
     lib.gsr_image_loss_forward.restype = C.c_int
@@ -139,7 +143,7 @@ def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Ten
 
 class RasterState:
     """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
-    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W")
+    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch")
 
 
 def _make_settings(rs, dev, sh_coeffs: int):
@@ -189,6 +193,7 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
     state = RasterState()
     state.settings, state.keep, state.P, state.num_rendered = s, keep, P, int(D.value)
     state.geom, state.binning, state.image, state.H, state.W = geom, binning, image, H, W
+    state.pre = state.batch = None
     return color, radii, depth, state
 
 
@@ -220,6 +225,7 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
 
 
 _binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
+_scratch_capacity = {}   # same key -> bytes per view of backward scratch
 _BINNING_SLACK = 1.25
 
 
@@ -231,9 +237,20 @@ def _ptr_array(tensors):
     return arr
 
 
-def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp):
-    """All views of a step in one call: per-view kernel chains on the library's internal streams, one host
-    sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V])."""
+def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot):
+    """Output + scratch tensors of the batched backward.  The forward allocates them ahead of its stage-1 wait, where
+    the host has slack; between that wait and the backward launch the host is the critical path of a step."""
+    f32 = dict(dtype=torch.float32, device=dev)
+    return dict(
+        d_means3D=torch.empty((P, 3), **f32), d_means2D=torch.empty((V, P, 3), **f32), d_colors=torch.empty((P, 3), **f32),
+        d_opacity=torch.empty((P, 1), **f32), d_scales=torch.empty((P, 3), **f32) if with_scale_rot else None,
+        d_rot=torch.empty((P, 4), **f32) if with_scale_rot else None, d_cov=torch.empty((P, 6), **f32),
+        scratch=[torch.empty((b,), dtype=torch.uint8, device=dev) for b in scratch_bytes])
+
+
+def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
+                            prepare_backward: bool = False):
+    """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V])."""
     lib = load_library()
     _require_device(means3D)
     dev = means3D.device
@@ -256,6 +273,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         radii = torch.zeros((V, P), dtype=torch.int32, device=dev)
         geoms = [torch.empty((lib.gsr_geom_bytes(P),), **u8) for _ in range(V)]
         images = [torch.empty((lib.gsr_image_bytes(H, W),), **u8) for _ in range(V)]
+        batch = torch.empty((lib.gsr_batch_state_bytes(V, P, H, W),), **u8)
         Ds = (C.c_uint32 * V)()
         st = _stream(dev)
         # Binning buffers sized from the previous call with the same shape (+25 %): the library then goes from stage 1
@@ -265,25 +283,34 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         cap = _binning_capacity.get(key, 0)
         binnings = [torch.empty((cap,), **u8) for _ in range(V)] if cap else [None] * V
         caps = (C.c_size_t * V)(*([cap] * V))
+        pre = None
+        if prepare_backward and cap and shs is None:   # scratch sized like the binning buffers: from the last call
+            pre = _alloc_backward(dev, V, P, [_scratch_capacity.get(key, 0)] * V, cov3D_precomp is None)
         color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
         rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
                                    _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
                                    _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
-                                   _ptr_array(images), _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
+                                   _ptr_array(images), _ptr(batch), _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
         if rc not in (0, 1):
             _check(rc, "gsr_forward_batch")
         need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
         if rc == 1:
             binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) for v in range(V)]
             _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                                _ptr_array(color_v), _ptr_array(depth_v), st), "gsr_forward_render_batch")
+                                                _ptr(batch), _ptr_array(color_v), _ptr_array(depth_v), st),
+                   "gsr_forward_render_batch")
         if rc == 1 or need * 2 < cap:
             _binning_capacity[key] = int(need * _BINNING_SLACK)
+            _scratch_capacity[key] = int(max(lib.gsr_backward_scratch_bytes(P, Ds[v]) for v in range(V)) * _BINNING_SLACK)
+        if pre is not None and any(lib.gsr_backward_scratch_bytes(P, Ds[v]) > pre["scratch"][v].numel() for v in range(V)):
+            pre = None
     states = []
     for v in range(V):
         state = RasterState()
         state.settings, state.keep, state.P, state.num_rendered = sarr[v], keeps[v], P, int(Ds[v])
         state.geom, state.binning, state.image, state.H, state.W = geoms[v], binnings[v], images[v], H, W
+        state.pre = pre if v == 0 else None
+        state.batch = batch if v == 0 else None
         states.append(state)
     return color, radii, depth, states
 
@@ -308,22 +335,19 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
         for v, stt in enumerate(states):
             sarr[v] = stt.settings
             Ds[v] = stt.num_rendered
-        d_means3D = torch.empty((P, 3), **f32)
-        d_means2D = torch.empty((V, P, 3), **f32)
-        d_colors = torch.empty((P, 3), **f32)
-        d_opacity = torch.empty((P, 1), **f32)
-        d_scales = torch.empty((P, 3), **f32) if cov3D_precomp is None else None
-        d_rot = torch.empty((P, 4), **f32) if cov3D_precomp is None else None
-        d_cov = torch.empty((P, 6), **f32)
-        scratch = [torch.empty((lib.gsr_backward_scratch_bytes(P, stt.num_rendered),), dtype=torch.uint8, device=dev)
-                   for stt in states]
+        pre, states[0].pre = states[0].pre, None   # one use only: autograd may keep the returned tensors as .grad
+        if pre is None:
+            pre = _alloc_backward(dev, V, P, [lib.gsr_backward_scratch_bytes(P, stt.num_rendered) for stt in states],
+                                  cov3D_precomp is None)
+        d_means3D, d_means2D, d_colors, d_opacity = pre["d_means3D"], pre["d_means2D"], pre["d_colors"], pre["d_opacity"]
+        d_scales, d_rot, d_cov, scratch = pre["d_scales"], pre["d_rot"], pre["d_cov"], pre["scratch"]
 
         def per_view(t):
             return _ptr_array([t[v] for v in range(V)])
         _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(colors_precomp),
                                       _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
                                       _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
-                                      per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D), _ptr(d_colors),
+                                      _ptr(states[0].batch), per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D), _ptr(d_colors),
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None

@@ -92,18 +92,21 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
 
 /* ---- multi-view batch (new design, no counterpart in the reference: its training loop renders one view per
  * optimiser step, /root/reference/src/tracking/train_gs.py:25-39).  The V views of a sharded step share the
- * Gaussian inputs; view v's kernel chain runs on internal stream v, forked from / joined to `stream` with
- * events, so the chains overlap on the GPU, and stage 1 synchronises ONCE for all V duplicate counts.
- * Array arguments have V entries (host arrays of device pointers).  The library keeps a small per-device pool of streams/events and one
- * pinned host word per view for this (the only persistent state in the library). */
+ * Gaussian inputs and the image size.  Every stage of a batch call is ONE kernel launch covering all views (the
+ * kernels take per-view pointer tables as arguments; all tiles of all views share one longest-first work queue),
+ * enqueued on `stream`; stage 1 synchronises ONCE for all V duplicate counts.
+ * Array arguments have V entries (host arrays of device pointers).  `batch_state` is one more caller-allocated
+ * device buffer of gsr_batch_state_bytes(V, P, H, W) bytes holding what the views share (per-block entry counts,
+ * the combined tile order, queue heads); keep it from the forward to the backward like the other states. */
 #define GSR_MAX_BATCH 16
+size_t gsr_batch_state_bytes(int32_t V, int32_t P, int32_t image_height, int32_t image_width);
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                  const float* rotations, const float* opacities, const float* colors_precomp,
                                  const float* shs, const float* cov3D_precomp, void* const* geom_states,
-                                 int32_t* const* radii, uint32_t* num_rendered_host, void* stream);
+                                 int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             float* const* out_color, float* const* out_depth, void* stream);
+                             void* batch_state, float* const* out_color, float* const* out_depth, void* stream);
 /* Both forward stages in ONE call: preprocess all views, synchronise once for the duplicate counts, and -- when
  * every view's binning state fits the buffer the caller provided (binning_bytes[v] >= gsr_binning_bytes(D_v)) --
  * launch the render stage straight away, with no host round trip through the caller in between (that round trip
@@ -114,16 +117,18 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
                       const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
-                      float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host, void* stream);
-/* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): per-view blend
- * backward on the internal streams, then ONE per-Gaussian kernel that loops over the views and writes the
+                      void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
+                      void* stream);
+/* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): ONE blend-backward launch
+ * over the combined tile queue, then ONE per-Gaussian kernel that loops over the views and writes the
  * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
-                       void* const* binning_states, void* const* image_states, const float* const* dL_dcolor,
-                       void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D, float* dL_dcolors,
-                       float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
+                       void* const* binning_states, void* const* image_states, void* batch_state,
+                       const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
+                       float* const* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D, void* stream);
 
 /* ---- fused image loss of the tracking step (caller side of the path):
  *   loss = w_l1 * mean|pred - target| + w_ssim * (1 - mean SSIM(pred, target)),  SSIM with the reference's 11x11

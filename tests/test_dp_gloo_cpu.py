@@ -108,7 +108,7 @@ def test_view_sharded_step_world2(tmp_path):
     stepper = ViewShardedStep(params, opt, LossWeights())
     variables = _variables(rig)
     total, variables = stepper(views, variables, is_initial_timestep=False)
-    flat = stepper.bucket.flat.numpy()
+    flat = stepper.bucket.pack().numpy()    # a single rank never packs by itself
     scale = np.abs(flat).max()
     assert np.abs(flat - r0["flat"]).max() <= 1e-5 * scale      # sum order differs: 1e-5 rel (section 8e)
     np.testing.assert_allclose(float(total), float(r0["loss"]) + float(r1["loss"]), rtol=1e-5)
@@ -130,8 +130,12 @@ def test_grad_bucket_layout():
     b = GradBucket(params)
     assert "rgb_colors" not in b.names                      # frozen in the reference (train_utils.py:133)
     assert b.flat.numel() == 10 * (3 + 3 + 4 + 1 + 3) + 2 * 50 * 3
-    params["means3D"].grad.add_(1.0)
-    s, e = b.slices["means3D"]
-    assert torch.all(b.flat[s:e] == 1.0)                    # gradients ARE the bucket storage
     b.zero()
-    assert torch.all(params["means3D"].grad == 0)
+    assert all(p.grad is None for p in b.params)            # set-to-none: the next backward hands its tensors over
+    params["means3D"].grad = torch.ones_like(params["means3D"])
+    flat = b.pack()
+    s, e = b.slices["means3D"]
+    assert torch.all(flat[s:e] == 1.0) and float(flat.sum()) == 30.0   # missing gradients packed as zeros
+    assert params["means3D"].grad.data_ptr() == flat[s:e].data_ptr()  # after packing, .grad IS the bucket slice
+    params["means3D"].grad.add_(1.0)
+    assert torch.all(b.flat[s:e] == 2.0)
