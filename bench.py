@@ -172,10 +172,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_step = float(t.item())
 
-    # ---- per-kernel HIP-event pass (outside the timed region).  Kernel durations are only meaningful when
-    # the kernels of different views do not overlap, so this pass always uses one call per view on one stream.
+    # ---- per-kernel HIP-event pass (outside the timed region), same call pattern as the timed region: in the
+    # batched pattern every stage is one launch for all views of the step on one stream, so nothing overlaps.
     saved = (args.per_view_calls, streams)
-    args.per_view_calls, streams = True, None
+    streams = None
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -188,6 +188,8 @@ def main():
     args.per_view_calls, streams = saved
     per_launch_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}
     per_view_us = {k: 1e3 * ms / (prof_steps * VIEWS_PER_RANK) for k, (ms, n) in prof.items()}
+    views_per_launch = 1 if args.per_view_calls else VIEWS_PER_RANK
+    busy_us = sum(1e3 * ms for ms, n in prof.values()) / prof_steps
 
     D = float(np.mean(num_rendered)) if num_rendered else 0.0
     Npx = H * W
@@ -197,19 +199,22 @@ def main():
     dom = "render_fwd" if args.forward_only else max(
         (k for k in per_view_us if k in ("render_fwd", "render_bwd")), key=lambda k: per_view_us[k], default="render_bwd")
     dom_us = per_launch_us.get(dom, float("nan"))
-    dom_achieved = ab[dom] / (dom_us * 1e-6) / 1e9 if dom_us == dom_us and dom_us > 0 else None
+    dom_bytes = ab[dom] * views_per_launch      # one launch blends `views_per_launch` views
+    dom_achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us == dom_us and dom_us > 0 else None
     pairs = 256.0 * D
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": dom_achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": (dom_achieved / (HBM_PEAK / 1e9)) if dom_achieved else None, "traffic": None,
-        "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": dom_us,
+        "algorithmic_bytes_per_launch": dom_bytes, "views_per_launch": views_per_launch, "avg_launch_us": dom_us,
         "path": {"algorithmic_bytes_per_step_per_gpu": path_bytes, "achieved_GBps": path_bytes / t_step / 1e9,
                  "frac_of_hbm_peak": path_bytes / t_step / HBM_PEAK},
         "valu": {"pixel_gaussian_pairs_per_view": pairs,
-                 "render_fwd_lane_instr_per_s": (pairs * 25 / (per_launch_us["render_fwd"] * 1e-6)) if "render_fwd" in per_launch_us else None,
+                 "render_fwd_lane_instr_per_s": (pairs * views_per_launch * 25 / (per_launch_us["render_fwd"] * 1e-6)) if "render_fwd" in per_launch_us else None,
                  "peak_lane_instr_per_s": VALU_PEAK},
         "per_kernel_us_per_view": {k: round(v, 2) for k, v in sorted(per_view_us.items())},
-        "per_kernel_timing": "HIP events around every launch, per-view sequential pass after the timed region",
+        "per_kernel_us_per_launch": {k: round(v, 2) for k, v in sorted(per_launch_us.items())},
+        "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
+        "per_kernel_timing": "HIP events around every launch of the library, separate pass after the timed region, same call pattern",
     }
 
     # measured HBM traffic of the dominant kernel, if a PMC summary of this round is committed (tools/prof_traffic.sh)
@@ -218,7 +223,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             if dom in tj:
-                roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
+                roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"] * (views_per_launch / max(1, tj.get("views_per_launch", 1)))
                 roofline["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
         except Exception:  # noqa: BLE001
             pass
@@ -243,7 +248,7 @@ def main():
                        "gaussians": P_GAUSS, "views_per_gpu": VIEWS_PER_RANK, "image": [H, W],
                        "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}",
                        "call_pattern": "per-view GaussianRasterizer calls" if args.per_view_calls else
-                                       "one rasterize_gaussians_views call per step (per-view chains on internal streams)"},
+                                       "one rasterize_gaussians_views call per step (one launch per stage for all views)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line))

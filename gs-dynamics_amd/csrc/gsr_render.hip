@@ -223,7 +223,8 @@ struct BwdLds {
   float4 sA[4][BWD_BATCH + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
   float4 sB[4][BWD_BATCH + 1];                 // C, opacity, r, g
   float2 sC[4][BWD_BATCH + 1];                 // b, bits(batch index j)
-  float4 sRed[4][BWD_BATCH][GSR_PARTIAL_F4];   // per-wave totals, indexed by batch index
+  float sRed[4][BWD_BATCH][9];                 // per-wave totals of the 9 partials, by batch index (36 B stride: odd
+                                               // word count, so both the 9-lane write and the per-entry read are conflict-free)
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
   uint32_t sG[BWD_BATCH];                      // gaussian id by batch index
   uint32_t cnt[4][4];                          // [staging wave][strip]
@@ -368,7 +369,7 @@ __device__ __forceinline__ void bwd_tile(
         v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;
       }
       const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-      if (lane >= 48 && lane <= 56) reinterpret_cast<float*>(&L.sRed[wv][j][0])[lane - 48] = z;  // one ds_write_b32
+      if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z;  // one ds_write_b32
       if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
     }
     if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
@@ -380,10 +381,10 @@ __device__ __forceinline__ void bwd_tile(
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         if ((L.sActive[w][tid >> 6] >> (tid & 63)) & 1ull) {
-          const float4 q0 = L.sRed[w][tid][0], q1 = L.sRed[w][tid][1], q2 = L.sRed[w][tid][2];
-          r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
-          r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
-          r2.x += q2.x;
+          const float* q = L.sRed[w][tid];
+          r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
+          r1.x += q[4]; r1.y += q[5]; r1.z += q[6]; r1.w += q[7];
+          r2.x += q[8];
         }
       }
       const uint32_t g = L.sG[tid];
@@ -525,7 +526,7 @@ static int env_int(const char* name, int dflt) {
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
-  static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 4);
+  static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 6);
   { GSR_PROF("render_fwd", st);
     if (use_static) {
       hipLaunchKernelGGL(render_fwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
@@ -542,7 +543,7 @@ int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
 int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
-  static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 3);
+  static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
   { GSR_PROF("render_bwd", st);
     if (use_static) {
       hipLaunchKernelGGL(render_bwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);

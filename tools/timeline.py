@@ -19,7 +19,9 @@ for s, e, n in rows:
 want = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # preprocess_fwd launches per step (views per call)
 cands = []
 for a, b in zip(starts[:-1], starts[1:]):
-    if sum(1 for s, e, n in rows if a <= s < b and n == "preprocess_fwd") == want:
+    pre = [r for r in rows if a <= r[0] < b and r[2] == "preprocess_fwd"]
+    # one multi-view launch per step (batched call) or `want` single-view launches
+    if (want > 1 and len(pre) == 1 and (pre[0][1] - pre[0][0]) > 15_000) or len(pre) == want:
         cands.append((a, b))
 t0, t1 = cands[len(cands) // 2]
 print(f"{len(cands)} steps with {want} views found; showing the middle one")
