@@ -198,6 +198,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
   __shared__ uint32_t s_tot[4][256];   // per-wave partial: total count of each bin over all blocks
   __shared__ uint32_t s_pre[4][256];   // per-wave partial: count of each bin in blocks before this one
   __shared__ uint32_t s_binbase[256];
+  __shared__ uint32_t s_local[256];
+  __shared__ uint32_t s_delta[256];
+  __shared__ uint32_t s_key[GSR_RADIX_EPB];
+  __shared__ uint64_t s_pay[GSR_RADIX_EPB];
   volatile uint32_t(*wbase)[256] = wcount;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t mask = (1u << bits) - 1u;
@@ -264,18 +268,46 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
   for (int k = 0; k < STEPS; ++k)
     if (wstart + (uint32_t)k * 64u + lane < wstop) atomicAdd(&wcount[wv][(key[k] >> shift) & mask], 1u);
   __syncthreads();
-  // B: wave bases = global base of (bin, block) + counts of earlier waves
-  if (tid < nb) {
-    uint32_t base = s_binbase[tid] + s_pre[0][tid] + s_pre[1][tid] + s_pre[2][tid] + s_pre[3][tid];
+  // B: block-local layout.  The chunk is first reordered by digit inside LDS (slot = local exclusive prefix of the
+  // digit + keys of that digit in earlier waves + rank inside the step), then written out: consecutive LDS slots of
+  // one digit go to consecutive global addresses, so the stores are runs (~32 keys at 64 bins) instead of one
+  // scattered element per lane.  (Pays once the pass is bandwidth-bound, i.e. with all views in one launch.)
+  if (wv == 0) {  // exclusive scan of this block's bin counts: lane l owns bins 4l .. 4l+3
+    uint32_t t4[4], sum = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = wcount[w][tid];
-      wcount[w][tid] = base;
-      base += c;
+    for (int q = 0; q < 4; ++q) {
+      const int bin = lane * 4 + q;
+      t4[q] = bin < nb ? (wcount[0][bin] + wcount[1][bin] + wcount[2][bin] + wcount[3][bin]) : 0u;
+      sum += t4[q];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bin = lane * 4 + q;
+      if (bin < nb) s_local[bin] = run;
+      run += t4[q];
     }
   }
   __syncthreads();
-  // C: ordered walk
+  if (tid < nb) {
+    const uint32_t gbase = s_binbase[tid] + s_pre[0][tid] + s_pre[1][tid] + s_pre[2][tid] + s_pre[3][tid];
+    uint32_t lbase = s_local[tid];
+    s_delta[tid] = gbase - lbase;   // global position = local slot + delta(digit)   (mod 2^32)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = wcount[w][tid];
+      wcount[w][tid] = lbase;
+      lbase += c;
+    }
+  }
+  __syncthreads();
+  // C: ordered walk into LDS
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) {
     const bool valid = wstart + (uint32_t)k * 64u + lane < wstop;
@@ -287,7 +319,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
     __builtin_amdgcn_wave_barrier();
     if (valid && rank == 0) wbase[wv][digit] = pos + (uint32_t)__popcll(peers);  // group leader advances
     __builtin_amdgcn_wave_barrier();
-    if (valid) { tkey_out[pos] = key[k]; dg_out[pos] = pay[k]; }
+    if (valid) { s_key[pos] = key[k]; s_pay[pos] = pay[k]; }
+  }
+  __syncthreads();
+  // D: write-out in runs
+  const uint32_t nvalid = min(D, chunk0 + GSR_RADIX_EPB) - chunk0;
+#pragma unroll
+  for (int j = 0; j < GSR_RADIX_ITEMS; ++j) {
+    const uint32_t l = (uint32_t)j * GSR_BLOCK + tid;
+    if (l < nvalid) {
+      const uint32_t kk = s_key[l];
+      const uint32_t pos = l + s_delta[(kk >> shift) & mask];
+      tkey_out[pos] = kk;
+      dg_out[pos] = s_pay[l];
+    }
   }
 }
 
@@ -302,20 +347,35 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 // persistent workgroups pop tickets from this order, so heavy tiles start first and the tail of the
 // kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
 // is arbitrary: per-tile results do not depend on it.
+#define ORD_CHUNK 12
 __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t start[256];
+  __shared__ uint32_t n_busy_s;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int T = tab.T, N = tab.V * T;   // all tiles of all views, one order
+  const int T = tab.T;   // all tiles of all views, one order
   uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
   if (tid < 256) cnt[tid] = 0;
   if (tid < 8) queue[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
-    const uint2 r = tab.v[i / T].ranges[i % T];
-    const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
-    atomicAdd(&cnt[bucket], 1u);
+  // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before
+  // any is used (one memory latency per chunk instead of one per item); the view index is uniform, so the table
+  // lookup stays a scalar load.
+  const int n_it = (T + 1023) / 1024, n_items = tab.V * n_it;
+  for (int k0 = 0; k0 < n_items; k0 += ORD_CHUNK) {
+    uint2 r[ORD_CHUNK];
+#pragma unroll
+    for (int u = 0; u < ORD_CHUNK; ++u) {
+      const int k = k0 + u, t = (k % n_it) * 1024 + tid;
+      r[u] = make_uint2(0u, 0u);
+      if (k < n_items && t < T) r[u] = tab.v[k / n_it].ranges[t];
+    }
+#pragma unroll
+    for (int u = 0; u < ORD_CHUNK; ++u) {
+      const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
+      if (bucket != 255u) atomicAdd(&cnt[bucket], 1u);   // empty tiles (and padding): not counted, no hot LDS word
+    }
   }
   __syncthreads();
   if (tid < 64) {  // exclusive scan of the 256 bucket counts: lane l owns buckets 4l .. 4l+3
@@ -331,15 +391,40 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
     uint32_t run = inc - sum;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { start[lane * 4 + q] = run; run += c4[q]; }
+    if (lane == 63) n_busy_s = run;   // buckets 0..254 only: cnt[255] was never incremented
   }
   __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
-    const int v = i / T, t = i % T;
-    const uint2 r = tab.v[v].ranges[t];
-    const uint32_t bucket = 255u - min((r.y - r.x + 7u) >> 3, 255u);
-    tile_order[atomicAdd(&start[bucket], 1u)] = make_uint4((uint32_t)t, r.x, r.y, (uint32_t)v);
+  const uint32_t n_busy = n_busy_s;
+  for (int k0 = 0; k0 < n_items; k0 += ORD_CHUNK) {
+    uint2 r[ORD_CHUNK];
+#pragma unroll
+    for (int u = 0; u < ORD_CHUNK; ++u) {
+      const int k = k0 + u, t = (k % n_it) * 1024 + tid;
+      r[u] = make_uint2(0u, 0u);
+      if (k < n_items && t < T) r[u] = tab.v[k / n_it].ranges[t];
+    }
+#pragma unroll
+    for (int u = 0; u < ORD_CHUNK; ++u) {
+      const int k = k0 + u, t = (k % n_it) * 1024 + tid;
+      if (k < n_items && t < T) {
+        const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
+        // empty tiles go behind the busy ones in any order: a wave-aggregated slot (one LDS atomic per wave).
+        // (Aggregating the busy buckets too -- 8 ballots per item -- was measured slower than the plain atomics.)
+        uint32_t slot;
+        if (bucket != 255u) slot = atomicAdd(&start[bucket], 1u);
+        else {
+          const uint64_t m = __ballot(1);
+          const int leader = __ffsll((long long)m) - 1;
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(&start[255], (uint32_t)__popcll(m));
+          base = __shfl(base, leader, 64);
+          slot = base + (uint32_t)__popcll(m & gsr_lanemask_lt());
+        }
+        tile_order[slot] = make_uint4((uint32_t)t, r[u].x, r[u].y, (uint32_t)(k / n_it));
+      }
+    }
   }
-  if (tid == 0) queue[4] = (uint32_t)N - cnt[255];  // bucket 255 = empty tiles (sorted last)
+  if (tid == 0) queue[4] = n_busy;  // the empty tiles (bucket 255) are sorted last and never enter the queues
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {

@@ -52,8 +52,18 @@ namespace {
 
 #define GSR_QW 8   // pixel region of one wave inside the 16x16 tile: 8x8 quad (2 x 2 quads per tile)
 #define GSR_QH 8
+#ifndef FWD_BATCH
 #define FWD_BATCH 128
+#endif
+#ifndef BWD_BATCH
 #define BWD_BATCH 128
+#endif
+#ifndef FWD_WAVES_PER_EU
+#define FWD_WAVES_PER_EU 1
+#endif
+#ifndef BWD_WAVES_PER_EU
+#define BWD_WAVES_PER_EU 1
+#endif
 
 __device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(v & 0xffffu); }
 
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews ta
 
 // Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
 // (grid-stride over the tail of the order array), then pop busy tiles longest-first.
-__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_persistent(GsrRenderViews tab) {
+__global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persistent(GsrRenderViews tab) {
   __shared__ FwdLds L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews ta
   bwd_tile((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_BWD_PASS(vw));
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_persistent(GsrRenderViews tab) {
+__global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLds L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
