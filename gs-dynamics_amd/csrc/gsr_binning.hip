@@ -351,7 +351,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t start[256];
-  __shared__ uint32_t n_busy_s;
+  __shared__ uint32_t n_busy_s, n_long_s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int T = tab.T;   // all tiles of all views, one order
   uint4* __restrict__ tile_order = tab.order;
@@ -392,6 +392,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { start[lane * 4 + q] = run; run += c4[q]; }
     if (lane == 63) n_busy_s = run;   // buckets 0..254 only: cnt[255] was never incremented
+    // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
+    if (lane == 47) n_long_s = start[188] + c4[0] + c4[1] + c4[2];
   }
   __syncthreads();
   const uint32_t n_busy = n_busy_s;
@@ -424,7 +426,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
       }
     }
   }
-  if (tid == 0) queue[4] = n_busy;  // the empty tiles (bucket 255) are sorted last and never enter the queues
+  // the empty tiles (bucket 255) are sorted last and never enter the queues
+  if (tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; }
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
@@ -476,6 +479,68 @@ __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
     }
   }
 }
+
+// ---- wave-level sort for short lists (n <= 512: the typical tile).  One WAVE sorts one tile: the entries sit in
+// registers, NR per lane (element e = r * 64 + lane), and run through the same normalised bitonic network on the
+// unique 64-bit key (depth bits << 32 | gaussian id) as tile_sort_network -- but the partner of a compare-exchange
+// is fetched through the DPP / swizzle / bpermute crossbar, so there are no LDS arrays and no workgroup barriers,
+// and the four waves of a workgroup work on four different tiles.
+template <int M>
+__device__ __forceinline__ uint32_t gsr_lane_xor(uint32_t v) {   // value of lane (lane ^ M), M in 1..63
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xf, 0xf, true);   // quad_perm [3,2,1,0]
+  else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); // row_mirror
+  else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);          // bit mode: xor M
+  else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
+// One compare-exchange step of the network: partner of element e is e ^ MASK; the lower index keeps the minimum.
+template <int MASK, int NR>
+__device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
+  constexpr int L = MASK & 63, R = MASK >> 6;
+  constexpr int HB = MASK >= 256 ? 256 : MASK >= 128 ? 128 : MASK >= 64 ? 64 : MASK >= 32 ? 32 : MASK >= 16 ? 16 : MASK >= 8 ? 8 : MASK >= 4 ? 4 : MASK >= 2 ? 2 : 1;
+  uint64_t y[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint64_t src = x[r ^ R];
+    if constexpr (L == 0) y[r] = src;
+    else y[r] = ((uint64_t)gsr_lane_xor<L>((uint32_t)(src >> 32)) << 32) | gsr_lane_xor<L>((uint32_t)src);
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const bool lower = HB < 64 ? ((lane & HB) == 0) : (((r * 64) & HB) == 0);
+    const bool take = lower ? (y[r] < x[r]) : (y[r] > x[r]);
+    x[r] = take ? y[r] : x[r];
+  }
+}
+template <int LK, int NR>
+__device__ __forceinline__ void wave_sort_stage(uint64_t (&x)[NR], int lane) {   // merge size k = 2^LK
+  wave_sort_step<(1 << LK) - 1, NR>(x, lane);
+  if constexpr (LK >= 9) wave_sort_step<128, NR>(x, lane);
+  if constexpr (LK >= 8) wave_sort_step<64, NR>(x, lane);
+  if constexpr (LK >= 7) wave_sort_step<32, NR>(x, lane);
+  if constexpr (LK >= 6) wave_sort_step<16, NR>(x, lane);
+  if constexpr (LK >= 5) wave_sort_step<8, NR>(x, lane);
+  if constexpr (LK >= 4) wave_sort_step<4, NR>(x, lane);
+  if constexpr (LK >= 3) wave_sort_step<2, NR>(x, lane);
+  if constexpr (LK >= 2) wave_sort_step<1, NR>(x, lane);
+}
+template <int NR>
+__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ seg, uint32_t* __restrict__ out, uint32_t n, int lane) {
+  uint64_t x[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { const uint32_t e = (uint32_t)(r * 64 + lane); x[r] = e < n ? seg[e] : ~0ull; }
+  wave_sort_stage<1, NR>(x, lane); wave_sort_stage<2, NR>(x, lane); wave_sort_stage<3, NR>(x, lane);
+  wave_sort_stage<4, NR>(x, lane); wave_sort_stage<5, NR>(x, lane); wave_sort_stage<6, NR>(x, lane);
+  if constexpr (NR >= 2) wave_sort_stage<7, NR>(x, lane);
+  if constexpr (NR >= 4) wave_sort_stage<8, NR>(x, lane);
+  if constexpr (NR >= 8) wave_sort_stage<9, NR>(x, lane);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { const uint32_t e = (uint32_t)(r * 64 + lane); if (e < n) out[e] = (uint32_t)x[r]; }
+}
+#define TS_WAVE_CAP 512
 
 // Stable LSD radix sort of one tile's entries inside LDS (n <= TS_RADIX_CAP).  The segment arrives in
 // ascending Gaussian-id order (the global tile-digit passes are stable and emission was id-major), so a
@@ -552,7 +617,23 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds& L, uint32_t n, int t
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, int cur) {
   __shared__ TileSortLds L;
   const int tid = threadIdx.x;
-  if (blockIdx.x >= tab.queue[4]) return;      // only the non-empty tiles (they lead the order)
+  // The order array leads with the longest lists.  Its first n_long tickets (n > TS_WAVE_CAP) take a whole workgroup
+  // each; behind them every WAVE takes one ticket (register-resident wave sort, no barriers).
+  const uint32_t n_busy = tab.queue[4], n_long = tab.queue[6];
+  if (blockIdx.x >= n_long) {
+    const uint32_t ticket = n_long + (blockIdx.x - n_long) * 4u + (uint32_t)(tid >> 6);
+    if (ticket >= n_busy) return;
+    const uint4 ord = tab.order[ticket];
+    const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
+    const uint32_t n = __builtin_amdgcn_readfirstlane(ord.z - ord.y);
+    const uint64_t* seg = vw.dg[cur] + ord.y;
+    uint32_t* out = vw.point_list + ord.y;
+    if (n <= 64) wave_sort_tile<1>(seg, out, n, tid & 63);
+    else if (n <= 128) wave_sort_tile<2>(seg, out, n, tid & 63);
+    else if (n <= 256) wave_sort_tile<4>(seg, out, n, tid & 63);
+    else wave_sort_tile<8>(seg, out, n, tid & 63);
+    return;
+  }
   const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
   const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
   uint64_t* __restrict__ dg = vw.dg[cur];
