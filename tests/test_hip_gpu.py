@@ -244,15 +244,17 @@ def test_huge_tile_lists_take_the_global_sort_path(dev):
     assert o2.hip_max_list > 4096
 
 
-@pytest.mark.parametrize("P", [1500, 3000])
+@pytest.mark.parametrize("P", [50, 100, 200, 400, 1500, 3000])
 def test_tile_sort_paths(dev, P):
-    """Per-tile list lengths that select each tile_sort path: <= 2048 LDS radix sort, 2049..4096 LDS network
-    (the > 4096 global-memory network is covered by test_huge_tile_lists...)."""
+    """Per-tile list lengths that select each tile_sort path: <= 64 / 128 / 256 / 512 one wave in registers (1, 2, 4, 8
+    keys per lane), <= 2048 LDS radix sort, 2049..4096 LDS network (the > 4096 global-memory network is covered by
+    test_huge_tile_lists...)."""
     g = random_gaussians(P, seed=40 + P, scale_lo=0.5, scale_hi=0.9, spread=0.5)
     g["opacities"][:] = 0.03
     o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=8, min_ok=0.9)
     n = o2.hip_max_list
-    assert (n <= 2048) if P == 1500 else (2048 < n <= 4096)
+    lo, hi = {50: (1, 64), 100: (65, 128), 200: (129, 256), 400: (257, 512), 1500: (513, 2048), 3000: (2049, 4096)}[P]
+    assert lo <= n <= hi, n
 
 
 def test_many_gaussians_take_the_scan_kernel_path(dev):
