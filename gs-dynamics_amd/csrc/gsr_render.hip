@@ -434,8 +434,9 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
   uint32_t* __restrict__ queue = tab.queue;
   const uint32_t n_busy = queue[4];
   // Tickets: the first one is implicit (blockIdx.x, no atomic: no thundering herd at kernel start); later ones
-  // are gridDim.x + atomicAdd(head), popped after the tile.  (Popping the next ticket early was measured
-  // slower: the in-flight returning atomic sits in front of the wave's gather waits -- vmcnt retires in order.)
+  // are gridDim.x + atomicAdd(head), popped after the tile.  (Popping the next ticket one tile ahead -- even from
+  // wave 3, which stages nothing, so the returning atomic blocks no gather wait -- was measured 30 % slower: a
+  // workgroup then commits to its next tile while it is still busy, and the tail of the launch loses its balance.)
   {  // background of the empty tiles
     const int W = tab.W, H = tab.H, gx = tab.gx;
     const size_t N = (size_t)H * W;
