@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
 __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinViews tab) {
   const GsrBinView& vw = tab.v[blockIdx.y];
   const int gx = tab.gx, T = tab.T;
-  const float4* __restrict__ rec = vw.rec;
+  float4* __restrict__ rec = const_cast<float4*>(vw.rec);
   const uint2* __restrict__ rect = vw.rect;
   const uint32_t* __restrict__ tiles_touched = vw.tiles_touched;
   const uint32_t* __restrict__ block_sums = vw.block_sums;
@@ -124,7 +124,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
   const uint32_t excl = base + inc - mine;
   soff[tid] = excl;
   if (tid == GSR_BLOCK - 1) soff[GSR_BLOCK] = excl + mine;
-  if (g0 + tid < P) offsets[g0 + tid] = excl;
+  if (g0 + tid < P) {
+    offsets[g0 + tid] = excl;
+    reinterpret_cast<uint32_t*>(rec + GSR_REC_F4 * (size_t)(g0 + tid) + 3)[2] = excl;   // the blend backward reads it from the record
+  }
   if (g0 + tid == P - 1) offsets[P] = excl + mine;
   __syncthreads();
   const uint32_t begin = soff[0], end = soff[GSR_BLOCK];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
     const uint32_t w = maxx - minx;
     const uint32_t ty = miny + k / w, tx = minx + k % w;
     tkey[e] = ty * (uint32_t)gx + tx;
-    dg[e] = ((uint64_t)__float_as_uint(rec[3 * g + 2].y) << 32) | (uint32_t)g;
+    dg[e] = ((uint64_t)__float_as_uint(rec[GSR_REC_F4 * g + 2].y) << 32) | (uint32_t)g;
   }
 }
 

@@ -15,14 +15,17 @@
 
 // ---------------------------------------------------------------- state layouts (HBM)
 // Geometry state: per-Gaussian records written by preprocess, read (gathered) by the blend kernels.
-// ONE 48-byte AoS record per Gaussian (3 x float4), so that a blend-kernel gather touches one or two
-// cache lines instead of four separate arrays:
-//   rec[3g+0] {mean2D.x, mean2D.y, conicA, conicB}
-//   rec[3g+1] {conicC, opacity, r, g}
-//   rec[3g+2] {b, depth, bits(alpha-box x: xmin | xmax<<16), bits(alpha-box y: ymin | ymax<<16)}
+// ONE 64-byte, 64-byte-aligned AoS record per Gaussian (4 x float4): a blend-kernel gather touches exactly one
+// cache line (a 48-byte record straddled two lines half of the time), and the backward finds everything it needs
+// to address the Gaussian's partial-gradient slots in the same line (no separate rect / offsets gathers):
+//   rec[4g+0] {mean2D.x, mean2D.y, conicA, conicB}
+//   rec[4g+1] {conicC, opacity, r, g}
+//   rec[4g+2] {b, depth, bits(alpha-box x: xmin | xmax<<16), bits(alpha-box y: ymin | ymax<<16)}
+//   rec[4g+3] {bits(rect.x: minx | miny<<16), bits(rect.y: maxx | maxy<<16), bits(offsets[g]) (written by emit), 0}
 // The alpha-box is the int16 pixel box outside which alpha < 1/255.
+#define GSR_REC_F4 4
 struct GeomState {
-  float4* rec;            // [3P]
+  float4* rec;            // [4P]
   uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
   uint32_t* tiles_touched;
   uint32_t* offsets;      // [P+1] exclusive prefix of tiles_touched (written by emit_entries)
@@ -57,7 +60,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   size_t off = 0, Pn = (size_t)(P > 0 ? P : 1);
   char* b = (char*)base;
   auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
-  g->rec = (float4*)take(Pn * 48);
+  g->rec = (float4*)take(Pn * 16 * GSR_REC_F4);
   g->rect = (uint2*)take(Pn * 8);
   g->tiles_touched = (uint32_t*)take(Pn * 4);
   g->offsets = (uint32_t*)take((Pn + 1) * 4);

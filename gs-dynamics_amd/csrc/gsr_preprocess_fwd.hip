@@ -198,9 +198,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     }
   }
   if (in_range) {
-    rec[3 * i + 0] = a4;
-    rec[3 * i + 1] = b4;
-    rec[3 * i + 2] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
+    rec[GSR_REC_F4 * i + 0] = a4;
+    rec[GSR_REC_F4 * i + 1] = b4;
+    rec[GSR_REC_F4 * i + 2] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
+    rec[GSR_REC_F4 * i + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, 0.f);  // .z = offset (emit)
     rect[i] = rc;
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;

@@ -141,7 +141,7 @@ __device__ __forceinline__ void fwd_tile(
   uint2 nbox = make_uint2(1u, 1u);
   if (tid < FWD_BATCH && tid < n) {
     const uint32_t g = point_list[rg.x + tid];
-    { const float4 t2 = rec[3 * g + 2]; na = rec[3 * g]; nb = rec[3 * g + 1]; nc = make_float2(t2.x, t2.y);
+    { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
   }
   GSR_TP(0);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void fwd_tile(
       const int nidx = idx + FWD_BATCH;
       if (tid < FWD_BATCH && nidx < n) {
         const uint32_t g = point_list[rg.x + nidx];
-        { const float4 t2 = rec[3 * g + 2]; na = rec[3 * g]; nb = rec[3 * g + 1]; nc = make_float2(t2.x, t2.y);
+        { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
       }
     }
@@ -236,7 +236,7 @@ struct BwdLds {
   float sRed[4][BWD_BATCH][9];                 // per-wave totals of the 9 partials, by batch index (36 B stride: odd
                                                // word count, so both the 9-lane write and the per-entry read are conflict-free)
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
-  uint32_t sG[BWD_BATCH];                      // gaussian id by batch index
+  uint32_t sSlot[BWD_BATCH];                   // by batch index: the entry's record slot in the Gaussian-major scratch
   uint32_t cnt[4][4];                          // [staging wave][strip]
   int sMaxLast;
 };
@@ -287,11 +287,13 @@ __device__ __forceinline__ void bwd_tile(
   // Software-pipelined staging (see fwd_tile): batch b+1 is fetched while batch b is processed.
   float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
   float nblue = 0.f;
+  float4 nslot = na;   // record word 3: rect bits, offsets[g]
   uint2 nbox = make_uint2(1u, 1u);
   uint32_t ng = 0;
   if (tid < BWD_BATCH && tid < max_last) {
     ng = point_list[rg.x + (max_last - 1 - tid)];
-    { const float4 t2 = rec[3 * ng + 2]; na = rec[3 * ng]; nb = rec[3 * ng + 1]; nblue = t2.x;
+    { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
+      nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
   }
   GSR_TP(0);
@@ -302,14 +304,19 @@ __device__ __forceinline__ void bwd_tile(
     const float2 c = make_float2(nblue, __uint_as_float((uint32_t)tid));
     uint32_t mask = 0;
     if (tid < m_all) {
-      L.sG[tid] = ng;
+      {  // slot of this (Gaussian, tile) pair: offsets[g] + row-major rank of the tile inside the Gaussian's rect
+        const uint32_t rx = __float_as_uint(nslot.x), ry = __float_as_uint(nslot.y);
+        const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu;
+        L.sSlot[tid] = __float_as_uint(nslot.z) + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
+      }
       mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
     }
     {
       const int nj = base + BWD_BATCH + tid;
       if (tid < BWD_BATCH && nj < max_last) {
         ng = point_list[rg.x + (max_last - 1 - nj)];
-        { const float4 t2 = rec[3 * ng + 2]; na = rec[3 * ng]; nb = rec[3 * ng + 1]; nblue = t2.x;
+        { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
+      nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
       }
     }
@@ -397,10 +404,7 @@ __device__ __forceinline__ void bwd_tile(
           r2.x += q[8];
         }
       }
-      const uint32_t g = L.sG[tid];
-      const uint2 r = rect[g];
-      const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu;
-      const uint32_t e = offsets[g] + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
+      const uint32_t e = L.sSlot[tid];
       partials[(size_t)e * GSR_PARTIAL_F4 + 0] = r0;
       partials[(size_t)e * GSR_PARTIAL_F4 + 1] = r1;
       partials[(size_t)e * GSR_PARTIAL_F4 + 2] = r2;

@@ -387,7 +387,7 @@ def debug_views(state: RasterState):
 
     i32 = torch.int32  # torch has no uint32 arithmetic; values here are < 2^31
     return dict(
-        rec=view(state.geom, v.rec, torch.float32, (P, 12)), rect=view(state.geom, v.rect, i32, (P, 2)),
+        rec=view(state.geom, v.rec, torch.float32, (P, 16)), rect=view(state.geom, v.rect, i32, (P, 2)),
         tiles_touched=view(state.geom, v.tiles_touched, i32, (P,)), offsets=view(state.geom, v.offsets, i32, (P + 1,)),
         point_list=view(state.binning, v.point_list, i32, (D,)), ranges=view(state.image, v.ranges, i32, (T, 2)),
         final_T=view(state.image, v.final_T, torch.float32, (H, W)),

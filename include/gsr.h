@@ -149,7 +149,8 @@ int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, u
 
 /* ---- introspection for tests / benches (copies of internal state, device -> caller's DEVICE buffers) */
 typedef struct gsr_debug_views {
-  const float* rec;           /* [P,12] mean2D.xy, conic A,B | conic C, opacity, r, g | b, depth, alpha-box bits x2 */
+  const float* rec;           /* [P,16] mean2D.xy, conic A,B | conic C, opacity, r, g | b, depth, alpha-box bits x2 |
+                                 tile-rect bits x2, offsets[g] bits, 0   (one 64-byte line per Gaussian) */
   const uint32_t* rect;       /* [P,2] minx|miny<<16, maxx|maxy<<16 */
   const uint32_t* tiles_touched; /* [P] */
   const uint32_t* offsets;    /* [P+1] exclusive prefix of tiles_touched */

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c --kernel-include-regex "render_" -d $O/prof_$c -o run -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --per-view-calls > $O/prof_$c.log 2>&1
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_$c.log 2>&1
 done
 cd $R
 python - <<'PY'
@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = "render_fwd" if "render_fwd" in r["Kernel_Name"] else "render_bwd" if "render_bwd" in r["Kernel_Name"] else None
             if k and r["Counter_Name"] == c:
                 a = acc.setdefault(k, {}).setdefault(c, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/prof_traffic.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md"}
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/prof_traffic.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md",
+       "views_per_launch": 4, "call_pattern": "bench.py default: one launch per stage for the 4 views of a step"}
 for k, v in acc.items():
     f = v.get("FETCH_SIZE", [1, 0.0]); w = v.get("WRITE_SIZE", [1, 0.0])
     fetch_kib, write_kib = f[1] / max(f[0], 1), w[1] / max(w[0], 1)
