@@ -184,11 +184,44 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(GsrBinViews tab, 
   if (tid < (1 << bits)) block_hist[blockIdx.x * (uint32_t)(1 << bits) + tid] = hist[tid];
 }
 
-// Stable scatter.  No separate scan launch: every block derives its own bases from the histogram matrix
+// Large sorts (many radix blocks): exclusive prefix of every histogram column over the blocks, in place, plus the
+// bin totals behind the matrix.  One workgroup per (bin, view).
+__global__ __launch_bounds__(1024) void radix_colscan_kernel(GsrBinViews tab, int bits) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (vw.D == 0) return;
+  const uint32_t nb = 1u << bits, bin = blockIdx.x, nblocks = vw.nblocks;
+  uint32_t* __restrict__ hist = vw.block_hist;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblocks; base += 1024) {
+    const uint32_t i = base + (uint32_t)tid;
+    const uint32_t v = i < nblocks ? hist[(size_t)i * nb + bin] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wv; ++w) off += wave_tot[w];
+    if (i < nblocks) hist[(size_t)i * nb + bin] = off + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = off + inc;
+    __syncthreads();
+  }
+  if (tid == 0) hist[(size_t)nblocks * nb + bin] = carry_s;
+}
+
+// Stable scatter.  No separate scan launch (below GSR_COLSCAN_MIN_BLOCKS radix blocks): every block derives its own bases from the histogram matrix
 // (nblocks x nbins, L2-resident): base(bin) = sum of all counts of lower bins + counts of this bin in
 // earlier blocks.  Then wave w of the block owns the w-th quarter of the block's chunk and walks it in
 // order, 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
-__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits) {
+__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits, int prescanned) {
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (blockIdx.x >= vw.nblocks || vw.D == 0) return;
   const uint32_t* __restrict__ tkey_in = vw.tkey[cur];
@@ -225,9 +258,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
     if (i < wstop) { key[k] = tkey_in[i]; pay[k] = dg_in[i]; }
   }
   // column sums of the histogram matrix: wave w takes blocks w, w+4, ...; lane l takes bins l, l+64, ...
+  // (prescanned: radix_colscan_kernel already turned the columns into exclusive prefixes + bin totals -- the
+  // per-block summing is O(nblocks^2) overall and only pays while the matrix is small)
   for (int bin = lane; bin < nb; bin += 64) {
     uint32_t tot = 0, pre = 0;
     uint32_t b = wv;
+    if (prescanned) {
+      if (wv == 0) { tot = block_hist[(size_t)nblocks * nb + bin]; pre = block_hist[(size_t)blockIdx.x * nb + bin]; }
+      b = nblocks;
+    }
     for (; b + 28 < nblocks; b += 32) {  // 8 independent loads in flight per lane
       uint32_t v[8];
 #pragma unroll
@@ -350,6 +389,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 // persistent workgroups pop tickets from this order, so heavy tiles start first and the tail of the
 // kernel is made of the cheapest tiles (greedy longest-processing-time scheduling).  Order inside a bucket
 // is arbitrary: per-tile results do not depend on it.
+#define GSR_COLSCAN_MIN_BLOCKS 768u
 #define ORD_CHUNK 12
 __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
   __shared__ uint32_t cnt[256];
@@ -452,7 +492,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab,
 // ------------------------------------------------------------------ per-tile depth sort
 // Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
 // +inf padding above n never moves and pairs touching it are skipped.
-#define TILE_SORT_LDS_CAP 4096
 template <typename PTR>
 __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
   uint32_t lg = 1;  // log2 of the padded size
@@ -545,24 +584,27 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ seg,
 }
 #define TS_WAVE_CAP 512
 
-// Stable LSD radix sort of one tile's entries inside LDS (n <= TS_RADIX_CAP).  The segment arrives in
+// Stable LSD radix sort of one tile's entries inside LDS (n <= RCAP).  The segment arrives in
 // ascending Gaussian-id order (the global tile-digit passes are stable and emission was id-major), so a
 // STABLE sort on the 32-bit depth key alone yields exactly the reference order (depth, ties by id).
 // 8-bit digits; a pass whose digit is identical for every key of the tile is skipped (the top exponent
 // byte almost always).  Per pass: per-wave histograms (LDS atomics) -> 256-bin scan -> ordered walk with
 // ranks from wave-64 __ballot peer masks.  ~5 barriers per pass instead of one per compare-exchange stage.
-#define TS_RADIX_CAP 2048
+// Two builds of the kernel: RCAP = 2048 (36 KiB of LDS, 4 workgroups per CU) for ordinary scenes, RCAP = 4096
+// (68 KiB, 2 per CU) when the average list is long (dense scenes: the network path above RCAP is n log^2 n).
+template <int RCAP>
 struct TileSortLds {
   union {
-    struct { uint32_t key[2][TS_RADIX_CAP]; uint32_t val[2][TS_RADIX_CAP]; } r;   // 32 KiB
-    uint64_t net[TILE_SORT_LDS_CAP];                                              // 32 KiB (network path)
+    struct { uint32_t key[2][RCAP]; uint32_t val[2][RCAP]; } r;   // radix path, n <= RCAP
+    uint64_t net[2 * RCAP];                                       // network path, n <= 2 RCAP
   };
   uint32_t whist[4][256];
   uint32_t wtot[4];
   uint32_t diff;
 };
 
-__device__ __forceinline__ int tile_radix_sort(TileSortLds& L, uint32_t n, int tid) {
+template <int RCAP>
+__device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP>& L, uint32_t n, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
   const uint32_t q = ((n + 255u) >> 8) << 6;            // per-wave share, a multiple of 64
   const uint32_t wstart = min(n, (uint32_t)wv * q), wstop = min(n, wstart + q);
@@ -617,8 +659,9 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds& L, uint32_t n, int t
   return cur;
 }
 
+template <int RCAP>
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, int cur) {
-  __shared__ TileSortLds L;
+  __shared__ TileSortLds<RCAP> L;
   const int tid = threadIdx.x;
   // The order array leads with the longest lists.  Its first n_long tickets (n > TS_WAVE_CAP) take a whole workgroup
   // each; behind them every WAVE takes one ticket (register-resident wave sort, no barriers).
@@ -647,7 +690,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
   uint64_t* seg = dg + rg.x;
   if (n == 1) {
     if (tid == 0) point_list[rg.x] = (uint32_t)seg[0];
-  } else if (n <= TS_RADIX_CAP) {
+  } else if (n <= (uint32_t)RCAP) {
     if (tid == 0) L.diff = 0;
     __syncthreads();
     const uint32_t k0 = (uint32_t)(seg[0] >> 32);
@@ -662,7 +705,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     __syncthreads();
     const int cur = tile_radix_sort(L, n, tid);
     for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = L.r.val[cur][i];
-  } else if (n <= TILE_SORT_LDS_CAP) {
+  } else if (n <= 2u * (uint32_t)RCAP) {
     for (uint32_t i = tid; i < n; i += GSR_BLOCK) L.net[i] = seg[i];
     __syncthreads();
     tile_sort_network(L.net, n, tid);
@@ -709,8 +752,14 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
       { GSR_PROF("radix_hist", st);
       hipLaunchKernelGGL(radix_hist_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits); }
       GSR_HIP_CHECK(hipGetLastError());
+      const int prescanned = maxblk >= GSR_COLSCAN_MIN_BLOCKS ? 1 : 0;
+      if (prescanned) {
+        GSR_PROF("radix_colscan", st);
+        hipLaunchKernelGGL(radix_colscan_kernel, dim3(1u << bits, tab.V), dim3(1024), 0, st, tab, bits);
+      }
+      GSR_HIP_CHECK(hipGetLastError());
       { GSR_PROF("radix_scatter", st);
-      hipLaunchKernelGGL(radix_scatter_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits); }
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits, prescanned); }
       GSR_HIP_CHECK(hipGetLastError());
       cur ^= 1;
     }
@@ -723,7 +772,12 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
   GSR_HIP_CHECK(hipGetLastError());
   if (maxD > 0 && P > 0) {
     { GSR_PROF("tile_sort", st);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur); }
+    const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
+    const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);
+    if (big)   // long lists on average: the big-LDS build
+      hipLaunchKernelGGL(tile_sort_kernel<4096>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
+    else
+      hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur); }
     GSR_HIP_CHECK(hipGetLastError());
   }
   return 0;

@@ -93,7 +93,7 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
   bs->dg[0] = (uint64_t*)take(Dn * 8);
   bs->dg[1] = (uint64_t*)take(Dn * 8);
   bs->point_list = (uint32_t*)take(Dn * 4);
-  bs->block_hist = (uint32_t*)take(256 * nb * 4);
+  bs->block_hist = (uint32_t*)take(256 * (nb + 1) * 4);   // + one row: bin totals of the column-scanned form
   return off;
 }
 
