@@ -66,11 +66,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    single_dev = os.environ.get("GSR_BENCH_SINGLE_DEVICE") == "1"   # smoke test of the N > 1 code path on a 1-GPU box
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if single_dev:   # all ranks share cuda:0; the collective goes through gloo on a host copy (NOT a perf number)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _ar = dist.all_reduce
+
+            def _host_all_reduce(t, *a, **k):
+                h = t.cpu()
+                _ar(h, *a, **k)
+                t.copy_(h)
+            dist.all_reduce = _host_all_reduce
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
