@@ -59,7 +59,7 @@ const char* gsr_last_error(void) { return g_err; }
 size_t gsr_geom_bytes(int32_t P) { GeomState g; return gsr_carve_geom(nullptr, P, &g); }
 size_t gsr_image_bytes(int32_t H, int32_t W) { ImageState im; return gsr_carve_image(nullptr, H, W, &im); }
 size_t gsr_binning_bytes(uint32_t D, int32_t, int32_t) { BinningState b; return gsr_carve_binning(nullptr, D, &b); }
-size_t gsr_backward_scratch_bytes(int32_t, uint32_t D) { return gsr_align((size_t)(D ? D : 1) * GSR_PARTIAL_F4 * 16); }
+size_t gsr_backward_scratch_bytes(int32_t, uint32_t D) { return gsr_align((size_t)(D ? D : 1) * GSR_PARTIAL_FLOATS * 4); }
 
 // ---------------------------------------------------------------------------------------- table builders
 }  // extern "C"

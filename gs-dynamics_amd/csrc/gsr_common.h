@@ -97,10 +97,10 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
   return off;
 }
 
-// Backward scratch: one 48-byte record per duplicate, Gaussian-major (entry e = offsets[g] + k,
-// k = row-major rank of the tile inside the Gaussian's rect):
-//   float4 {d mean2D.x, d mean2D.y, dA, dB}, float4 {dC, d opacity, dr, dg}, float4 {db, 0, 0, 0}
-#define GSR_PARTIAL_F4 3
+// Backward scratch: one 36-byte record per list entry, Gaussian-major (entry e = offsets[g] + k,
+// k = row-major rank of the tile inside the Gaussian's rect): nine floats
+//   {d mean2D.x, d mean2D.y, dA, dB, dC, d opacity, dr, dg, db}, moved as three 12-byte (dwordx3) accesses.
+#define GSR_PARTIAL_FLOATS 9
 // Up to this many preprocess blocks (P <= 512 Ki Gaussians) the per-block entry counts are summed on the host
 // (one small pinned copy that replaces the count read-back) and emit blocks add up their own base; above it a
 // scan kernel prepares block_offsets as before.
@@ -329,6 +329,16 @@ __device__ __forceinline__ float gsr_exp(float x) {
   tl = __builtin_fmaf(x, L2E_LO, tl);
   const float e = __builtin_amdgcn_exp2f(th);
   return __builtin_fmaf(e, tl * 0.693147182464599609375f, e);  // e * 2^tl, |tl| <= 1e-5
+}
+struct GsrF3 { float x, y, z; };   // 12 bytes, 4-byte aligned: one global_load/store_dwordx3
+__device__ __forceinline__ void gsr_store_partial(float4* base, size_t e, float4 r0, float4 r1, float r2x) {
+  GsrF3* p = reinterpret_cast<GsrF3*>(reinterpret_cast<float*>(base) + e * GSR_PARTIAL_FLOATS);
+  p[0] = GsrF3{r0.x, r0.y, r0.z}; p[1] = GsrF3{r0.w, r1.x, r1.y}; p[2] = GsrF3{r1.z, r1.w, r2x};
+}
+__device__ __forceinline__ void gsr_load_partial(const float4* base, size_t e, float4& r0, float4& r1, float& r2x) {
+  const GsrF3* p = reinterpret_cast<const GsrF3*>(reinterpret_cast<const float*>(base) + e * GSR_PARTIAL_FLOATS);
+  const GsrF3 a = p[0], b = p[1], c = p[2];
+  r0 = make_float4(a.x, a.y, a.z, b.x); r1 = make_float4(b.y, b.z, c.x, c.y); r2x = c.z;
 }
 // Reference (slow, LDS-crossbar) version used by the self-test.
 __device__ __forceinline__ float gsr_wave_sum_shfl(float v) {

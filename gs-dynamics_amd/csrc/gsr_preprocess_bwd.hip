@@ -99,12 +99,12 @@ __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2x = 0.f;
   for (uint32_t e = e0; e < e1; ++e) {
-    const float4 q0 = partials[(size_t)e * GSR_PARTIAL_F4 + 0];
-    const float4 q1 = partials[(size_t)e * GSR_PARTIAL_F4 + 1];
-    const float4 q2 = partials[(size_t)e * GSR_PARTIAL_F4 + 2];
+    float4 q0, q1;
+    float q2x;
+    gsr_load_partial(partials, e, q0, q1, q2x);
     r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
     r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
-    r2x += q2.x;
+    r2x += q2x;
   }
   PartialSum ps;
   ps.gmx = r0.x; ps.gmy = r0.y; ps.gA = r0.z; ps.gB = r0.w; ps.gC = r1.x; ps.gop = r1.y;

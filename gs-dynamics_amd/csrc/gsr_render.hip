@@ -275,13 +275,12 @@ __device__ __forceinline__ void bwd_tile(
   // entries nobody reached still own a slot in the Gaussian-major partial buffer: zero them
   for (int k = max_last + tid; k < n; k += GSR_BLOCK) {
     const uint32_t g = point_list[rg.x + k];
-    const uint2 r = rect[g];
-    const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu;
-    const uint32_t e = offsets[g] + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
+    const float4 sl = rec[GSR_REC_F4 * g + 3];   // rect bits, offsets[g]
+    const uint32_t rx = __float_as_uint(sl.x), ry = __float_as_uint(sl.y);
+    const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu;
+    const uint32_t e = __float_as_uint(sl.z) + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    partials[(size_t)e * GSR_PARTIAL_F4 + 0] = z;
-    partials[(size_t)e * GSR_PARTIAL_F4 + 1] = z;
-    partials[(size_t)e * GSR_PARTIAL_F4 + 2] = z;
+    gsr_store_partial(partials, e, z, z, 0.f);
   }
 
   // Software-pipelined staging (see fwd_tile): batch b+1 is fetched while batch b is processed.
@@ -405,9 +404,7 @@ __device__ __forceinline__ void bwd_tile(
         }
       }
       const uint32_t e = L.sSlot[tid];
-      partials[(size_t)e * GSR_PARTIAL_F4 + 0] = r0;
-      partials[(size_t)e * GSR_PARTIAL_F4 + 1] = r1;
-      partials[(size_t)e * GSR_PARTIAL_F4 + 2] = r2;
+      gsr_store_partial(partials, e, r0, r1, r2.x);
     }
     GSR_TP(6);
     __syncthreads();
