@@ -107,7 +107,9 @@ def main():
     # the activations and their autograd backward back inside the step (what train_gs.py executes).
     with torch.no_grad():
         rv_leaf = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
-    for k in ("means3D", "rotations", "opacities", "scales", "means2D"):
+    # differentiated inputs of the rasterizer = what the all-reduce bucket carries for N > 1: 14 floats per Gaussian
+    # (means2D is a per-view gradient holder for the densification statistics, not a parameter: it stays out)
+    for k in ("means3D", "rotations", "opacities", "scales", "colors_precomp"):
         rv_leaf[k].requires_grad_(True)
     leaf_bucket = GradBucket({k: v for k, v in rv_leaf.items() if v.requires_grad})
 
@@ -287,7 +289,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
     """Reported beside the headline: the full get_loss-shaped step of train_gs.py
     (2 renders + SSIM/L1 + rigidity terms + backward, per view) and BASELINE configs[1] (forward only)."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    from gsdyn import LossWeights, get_loss, params2rendervar, synth_targets
+    from gsdyn import LossWeights, get_loss, get_loss_views, params2rendervar, synth_targets
     from gsdyn.dp import init_variables
     from gsdyn.step import make_rigidity_variables
     out = {}
@@ -298,20 +300,30 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)  # assets/datasets.md weights
         views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
 
-        def make_step(initial):
+        def make_step(initial, mode):
             def getloss_step():
                 for p in params.values():
                     p.grad = None
+                if mode == "all":            # all cameras, colour + seg renders: ONE rasterizer call (8 views)
+                    loss, _, _ = get_loss_views(params, views, variables, initial, w)
+                    loss.backward()
+                    return
                 for d in views:
-                    loss, _ = get_loss(params, d, variables, initial, w)
+                    if mode == "pair":       # the reference's pattern, one camera per iteration: colour + seg as a 2-view call
+                        loss, _, _ = get_loss_views(params, [d], variables, initial, w)
+                    else:                    # two separate GaussianRasterizer calls per camera, as train_utils.py writes it
+                        loss, _ = get_loss(params, d, variables, initial, w)
                     loss.backward()
             return getloss_step
         for name, initial in (("getloss_step_t0", True), ("getloss_step", False)):
-            ms = _time_ms(make_step(initial), 5, 2)
-            out[name] = {"ms_per_step": ms, "ms_per_view": ms / len(views), "views": len(views),
+            res = {}
+            for mode in ("separate", "pair", "all"):
+                ms = _time_ms(make_step(initial, mode), 5, 2)
+                res[mode] = {"ms_per_step": ms, "ms_per_view": ms / len(views)}
+            out[name] = {"views": len(views), **res["all"], "per_camera_2view_call": res["pair"], "separate_calls": res["separate"],
                          "what": "train_gs.py get_loss (colour+seg renders, fused 0.8 L1 + 0.2 (1-SSIM)"
                                  + ("" if initial else ", rigid/rot/iso/floor/bg terms") + ") + backward, "
-                                 + ("t = 0" if initial else "t > 0")}
+                                 + ("t = 0" if initial else "t > 0") + "; headline = all cameras in one rasterizer call"}
     except Exception as e:  # noqa: BLE001
         out["getloss_step"] = {"error": repr(e)}
     try:

@@ -64,7 +64,9 @@ size_t gsr_backward_scratch_bytes(int32_t, uint32_t D) { return gsr_align((size_
 // ---------------------------------------------------------------------------------------- table builders
 }  // extern "C"
 namespace {
-void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t* radii, uint32_t* block_sums) {
+void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t* radii, uint32_t* block_sums,
+                   const float* colors) {
+  o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
   o.block_sums = block_sums;
@@ -118,8 +120,14 @@ int check_inputs(const char* who, const float* means3D, const float* opacities, 
 // above that a scan launch + a 4-byte copy per view), ONE stream synchronisation.
 // `sums`: device array [V][nblk] (the views' block_sums; for V = 1 the view's own GeomState::block_sums).
 int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
-           const float* opacities, const float* colors_precomp, const float* shs, const float* cov3D_precomp,
-           void* const* geom_states, int32_t* const* radii, uint32_t* sums, uint32_t* num_rendered_host, hipStream_t st) {
+           const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
+           const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
+           uint32_t* num_rendered_host, hipStream_t st) {
+  if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
+    if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
+    for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
+    colors_precomp = colors_views[0];
+  }
   GsrPreViews tab;
   tab.V = V;
   GsrCam cam0;
@@ -138,7 +146,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     if (!geom_states[v] || !radii[v]) { gsr_set_error("gsr forward: NULL geom_state / radii"); return -2; }
     GeomState g;
     gsr_carve_geom(geom_states[v], P, &g);
-    fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk);
+    fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
   }
   if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
     return rc;
@@ -212,7 +220,7 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
   GeomState g;
   gsr_carve_geom(geom_state, P, &g);
   uint32_t D = 0;
-  if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, &geom_state,
+  if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, nullptr, shs, cov3D_precomp, &geom_state,
                       &radii, g.block_sums, &D, (hipStream_t)stream))
     return rc;
   if (num_rendered_host) *num_rendered_host = D;
@@ -274,7 +282,8 @@ static int check_batch(const char* who, int32_t V, const gsr_settings* s, const 
 
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                  const float* rotations, const float* opacities, const float* colors_precomp,
-                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
+                                 const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                                 void* const* geom_states,
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream) {
   if (int rc = check_batch("gsr_forward_preprocess_batch", V, s, batch_state)) return rc;
   if (!geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
@@ -282,8 +291,8 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
   if (P <= 0) return 0;
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
-  return stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_states, radii, b.sums,
-                num_rendered_host, (hipStream_t)stream);
+  return stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp, geom_states,
+                radii, b.sums, num_rendered_host, (hipStream_t)stream);
 }
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
@@ -301,8 +310,9 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                      const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
-                      const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
+                      const float* rotations, const float* opacities, const float* colors_precomp,
+                      const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                      void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
                       void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
                       void* stream) {
@@ -315,8 +325,8 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   if (P <= 0) return 1;  // nothing to preprocess: the caller takes the render-stage call (it paints the background)
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
-  if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_states, radii,
-                      b.sums, num_rendered_host, (hipStream_t)stream))
+  if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
+                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
   for (int v = 0; fits && v < V; ++v)
@@ -331,8 +341,8 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, void* batch_state,
                        const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D,
-                       float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                       void* stream) {
+                       float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D, void* stream) {
   if (int rc = check_batch("gsr_backward_batch", V, s, batch_state)) return rc;
   if (!num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
       !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !means3D) {
@@ -361,6 +371,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
     w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
+    w.dL_dcolors = dL_dcolors_views ? dL_dcolors_views[v] : nullptr;
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
   if (any) {

@@ -147,6 +147,7 @@ struct GsrCam {  // host copy of the scalar settings; matrices stay on the devic
 // costs ~3 us of host time; a 4-view step used to issue ~75 of them) and lets all views share one LPT tile queue.
 struct GsrPreView {            // preprocess
   const float *view, *proj, *campos;
+  const float* colors;   // this view's precomputed colours [P,3] (nullptr: the colours shared by all views, or SH)
   float tanfovx, tanfovy;
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
 };
@@ -206,6 +207,7 @@ struct GsrBwdView {
   const uint32_t* offsets;
   const float4* partials;
   float* dL_dmeans2D;
+  float* dL_dcolors;      // per-view colour gradient [P,3] (views with their own colours), else nullptr: summed
   int W, H;
   float tanfovx, tanfovy;
 };

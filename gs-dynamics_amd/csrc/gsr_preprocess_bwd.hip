@@ -303,8 +303,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
       any = true;
       const PartialSum ps = reduce_partials(w.partials, w.offsets[i], w.offsets[i + 1]);
       gop += ps.gop;
-      gcol[0] += ps.dr; gcol[1] += ps.dg; gcol[2] += ps.db;
+      if (w.dL_dcolors) { w.dL_dcolors[3 * i] = ps.dr; w.dL_dcolors[3 * i + 1] = ps.dg; w.dL_dcolors[3 * i + 2] = ps.db; }
+      else { gcol[0] += ps.dr; gcol[1] += ps.dg; gcol[2] += ps.db; }
       view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+    } else if (w.dL_dcolors) {
+      w.dL_dcolors[3 * i] = 0.f; w.dL_dcolors[3 * i + 1] = 0.f; w.dL_dcolors[3 * i + 2] = 0.f;
     }
     w.dL_dmeans2D[3 * i] = gm2[0]; w.dL_dmeans2D[3 * i + 1] = gm2[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
   }

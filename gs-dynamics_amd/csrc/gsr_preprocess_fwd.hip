@@ -68,6 +68,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   const float* __restrict__ view = vw.view;
   const float* __restrict__ proj = vw.proj;
   const float* __restrict__ campos = vw.campos;
+  if (vw.colors) colors_precomp = vw.colors;
   const float tanfovx = vw.tanfovx, tanfovy = vw.tanfovy;
   float4* __restrict__ rec = vw.rec;
   uint2* __restrict__ rect = vw.rect;

@@ -75,15 +75,15 @@ def load_library():
     PV = C.POINTER(C.c_void_p)
     lib.gsr_batch_state_bytes.restype = sz; lib.gsr_batch_state_bytes.argtypes = [i32, i32, i32, i32]
     lib.gsr_forward_preprocess_batch.restype = C.c_int
-    lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 7 + [PV, PV, vp, C.POINTER(u32), vp]
+    lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, vp, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
     lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, PV, PV, vp]
     lib.gsr_forward_batch.restype = C.c_int
-    lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 7 + [PV, PV, PV, C.POINTER(sz), PV, vp, PV, PV,
+    lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(sz), PV, vp, PV, PV,
                                       C.POINTER(u32), vp])
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, PV, PV]
-                                       + [vp, PV, vp, vp, vp, vp, vp, vp])
+                                       + [vp, PV, vp, PV, vp, vp, vp, vp, vp])
     lib.gsr_image_loss_blocks.restype = i32
     lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
     lib.gsr_image_loss_forward.restype = C.c_int
@@ -237,12 +237,13 @@ def _ptr_array(tensors):
     return arr
 
 
-def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot):
+def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False):
     """Output + scratch tensors of the batched backward.  The forward allocates them ahead of its stage-1 wait, where
     the host has slack; between that wait and the backward launch the host is the critical path of a step."""
     f32 = dict(dtype=torch.float32, device=dev)
     return dict(
-        d_means3D=torch.empty((P, 3), **f32), d_means2D=torch.empty((V, P, 3), **f32), d_colors=torch.empty((P, 3), **f32),
+        d_means3D=torch.empty((P, 3), **f32), d_means2D=torch.empty((V, P, 3), **f32),
+        d_colors=torch.empty((V, P, 3) if per_view_col else (P, 3), **f32),
         d_opacity=torch.empty((P, 1), **f32), d_scales=torch.empty((P, 3), **f32) if with_scale_rot else None,
         d_rot=torch.empty((P, 4), **f32) if with_scale_rot else None, d_cov=torch.empty((P, 6), **f32),
         scratch=[torch.empty((b,), dtype=torch.uint8, device=dev) for b in scratch_bytes])
@@ -285,10 +286,16 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         caps = (C.c_size_t * V)(*([cap] * V))
         pre = None
         if prepare_backward and cap and shs is None:   # scratch sized like the binning buffers: from the last call
-            pre = _alloc_backward(dev, V, P, [_scratch_capacity.get(key, 0)] * V, cov3D_precomp is None)
+            pre = _alloc_backward(dev, V, P, [_scratch_capacity.get(key, 0)] * V, cov3D_precomp is None,
+                                  colors_precomp is not None and colors_precomp.dim() == 3)
         color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
+        per_view_col = colors_precomp is not None and colors_precomp.dim() == 3   # [V,P,3]: every view its own colours
+        if per_view_col and colors_precomp.shape[0] != V:
+            raise ValueError("rasterize_forward_batch: per-view colours must be [V,P,3]")
+        col_shared = None if per_view_col else colors_precomp
+        col_views = _ptr_array([colors_precomp[v] for v in range(V)]) if per_view_col else None
         rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                   _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
+                                   _ptr(col_shared), col_views, _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
                                    _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
                                    _ptr_array(images), _ptr(batch), _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
         if rc not in (0, 1):
@@ -335,19 +342,22 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
         for v, stt in enumerate(states):
             sarr[v] = stt.settings
             Ds[v] = stt.num_rendered
+        per_view_col = colors_precomp is not None and colors_precomp.dim() == 3
         pre, states[0].pre = states[0].pre, None   # one use only: autograd may keep the returned tensors as .grad
         if pre is None:
             pre = _alloc_backward(dev, V, P, [lib.gsr_backward_scratch_bytes(P, stt.num_rendered) for stt in states],
-                                  cov3D_precomp is None)
+                                  cov3D_precomp is None, per_view_col)
         d_means3D, d_means2D, d_colors, d_opacity = pre["d_means3D"], pre["d_means2D"], pre["d_colors"], pre["d_opacity"]
         d_scales, d_rot, d_cov, scratch = pre["d_scales"], pre["d_rot"], pre["d_cov"], pre["scratch"]
 
         def per_view(t):
             return _ptr_array([t[v] for v in range(V)])
-        _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(colors_precomp),
+        _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                      _ptr(None if per_view_col else colors_precomp),
                                       _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
                                       _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
-                                      _ptr(states[0].batch), per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D), _ptr(d_colors),
+                                      _ptr(states[0].batch), per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D),
+                                      _ptr(None if per_view_col else d_colors), per_view(d_colors) if per_view_col else None,
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None

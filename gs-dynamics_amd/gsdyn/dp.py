@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .step import LossWeights, get_loss
+from .step import LossWeights, get_loss, get_loss_views
 
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:
@@ -72,8 +72,12 @@ class ViewShardedStep:
     """One optimiser step over a set of views, sharded over the ranks of ``group``."""
 
     def __init__(self, params, optimizer: Optional[torch.optim.Optimizer], weights: LossWeights = LossWeights(),
-                 group=None):
+                 group=None, batched: Optional[bool] = None):
         self.params, self.optimizer, self.weights, self.group = params, optimizer, weights, group
+        if batched is None:   # the multi-view entry point exists in the HIP package (not in the CPU test double)
+            import diff_gaussian_rasterization as dgr
+            batched = hasattr(dgr, "rasterize_gaussians_views")
+        self.batched = batched
         self.bucket = GradBucket(params)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -89,6 +93,19 @@ class ViewShardedStep:
         stat = torch.zeros((2, P), dtype=torch.float32, device=dev)   # [grad-norm * seen, seen]
         rad = torch.zeros((P,), dtype=torch.float32, device=dev)
         total = torch.zeros((), dtype=torch.float32, device=dev)
+        if self.batched and mine:
+            # all cameras of the shard, colour + segmentation renders, in ONE rasterizer call
+            loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights)
+            loss.backward()
+            total += loss.detach()
+            with torch.no_grad():
+                seen_v = aux["radii"] > 0                                    # [V,P]
+                g2 = aux["means2D"].grad
+                if g2 is not None:
+                    stat[0] += (torch.norm(g2[0::2, :, :2], dim=-1) * seen_v).sum(0)
+                stat[1] += seen_v.sum(0)
+                rad = torch.maximum(rad, variables["max_2D_radius"])
+            mine = []
         for data in mine:
             loss, variables = get_loss(self.params, data, variables, is_initial_timestep, self.weights)
             loss.backward()

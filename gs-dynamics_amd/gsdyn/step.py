@@ -103,6 +103,63 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
     return loss, variables
 
 
+def _shared_terms(params, rendervar, variables, losses):
+    """View-independent terms of the t > 0 loss (/root/reference/src/tracking/train_utils.py:198-232)."""
+    is_fg = (params["seg_colors"][:, 0] > 0.5).detach()
+    fg_pts = rendervar["means3D"][is_fg]
+    fg_rot = rendervar["rotations"][is_fg]
+    rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
+    rot = build_rotation(rel_rot)
+    nbr = variables["neighbor_indices"]
+    curr_offset = fg_pts[nbr] - fg_pts[:, None]
+    offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)   # see get_loss
+    nw = variables["neighbor_weight"]
+    losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
+    losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
+    offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
+    losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
+    losses["floor"] = torch.clamp(fg_pts[:, 1], min=0).mean()
+    bg_pts = rendervar["means3D"][~is_fg]
+    bg_rot = rendervar["rotations"][~is_fg]
+    losses["bg"] = l1_loss_v2(bg_pts, variables["init_bg_pts"]) + l1_loss_v2(bg_rot, variables["init_bg_rot"])
+    losses["soft_col_cons"] = 0.0
+
+
+def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights):
+    """``get_loss`` for several cameras at once, equal to the SUM of the per-camera ``get_loss`` values, with ONE
+    rasterizer call: the colour and the segmentation render of every camera (2 V renders) share the Gaussians'
+    geometry and differ only in their colour array, so they go through ``rasterize_gaussians_views`` as 2 V views
+    with per-view colours -- one kernel launch per stage for all of them.  Even the
+    reference's own pattern (one camera per iteration, /root/reference/src/tracking/train_gs.py:25-39) becomes a 2-view batch.
+    Returns (loss, variables, aux) with aux = dict(means2D=[2V,P,3] gradient holder (rows 0, 2, ... = colour renders),
+    radii=[V,P] of the colour renders)."""
+    from diff_gaussian_rasterization import rasterize_gaussians_views
+    V = len(datas)
+    rendervar = params2rendervar(params)
+    P = rendervar["means3D"].shape[0]
+    cams = [d["cam"] for d in datas for _ in (0, 1)]
+    colours = torch.stack([params["rgb_colors"], params["seg_colors"]]).repeat(V, 1, 1)        # [2V,P,3]
+    m2 = torch.zeros((2 * V, P, 3), device=rendervar["means3D"].device, requires_grad=True)
+    ims, radii, _ = rasterize_gaussians_views(cams, rendervar["means3D"], m2, rendervar["opacities"], colors_precomp=colours,
+                                              scales=rendervar["scales"], rotations=rendervar["rotations"])
+    total = 0.0
+    for v, d in enumerate(datas):
+        cid = d["id"]
+        im = torch.exp(params["cam_m"][cid])[:, None, None] * ims[2 * v] + params["cam_c"][cid][:, None, None]
+        total = total + w.im * _image_term(im, d["im"]) + w.seg * _image_term(ims[2 * v + 1], d["seg"])
+    if not is_initial_timestep:
+        losses = {}
+        _shared_terms(params, rendervar, variables, losses)
+        weights = {"rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg, "soft_col_cons": w.soft_col_cons}
+        total = total + V * sum(weights[k] * val for k, val in losses.items())   # every per-camera get_loss adds them once
+    rad = radii[0::2]                                                             # colour renders
+    m2r = variables["max_2D_radius"]
+    variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))
+    variables["seen"] = (rad > 0).any(0)
+    variables["means2D"] = m2
+    return total, variables, dict(means2D=m2, radii=rad)
+
+
 @torch.no_grad()
 def report_psnr(params, data):
     """The extra forward render of /root/reference/src/tracking/train_utils.py:377-384."""

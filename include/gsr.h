@@ -97,12 +97,17 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
  * enqueued on `stream`; stage 1 synchronises ONCE for all V duplicate counts.
  * Array arguments have V entries (host arrays of device pointers).  `batch_state` is one more caller-allocated
  * device buffer of gsr_batch_state_bytes(V, P, H, W) bytes holding what the views share (per-block entry counts,
- * the combined tile order, queue heads); keep it from the forward to the backward like the other states. */
+ * the combined tile order, queue heads); keep it from the forward to the backward like the other states.
+ * Per-view colours (row N1 of SURVEY.md section 8f: the colour and the segmentation render of get_loss share the
+ * geometry, /root/reference/src/tracking/train_utils.py:174-192): pass `colors_views` ([V] device pointers to [P,3],
+ * with colors_precomp = shs = NULL) and every "view" blends its own colour array; the backward then writes one colour
+ * gradient per view into `dL_dcolors_views` instead of the sum into `dL_dcolors`. */
 #define GSR_MAX_BATCH 16
 size_t gsr_batch_state_bytes(int32_t V, int32_t P, int32_t image_height, int32_t image_width);
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                  const float* rotations, const float* opacities, const float* colors_precomp,
-                                 const float* shs, const float* cov3D_precomp, void* const* geom_states,
+                                 const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                                 void* const* geom_states,
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
@@ -114,8 +119,9 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
  * Returns 0: rendered; 1: some buffer was too small (or NULL) -- nothing was rendered, num_rendered_host is
  * filled, allocate exact sizes and call gsr_forward_render_batch; < 0: error. */
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                      const float* rotations, const float* opacities, const float* colors_precomp, const float* shs,
-                      const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii,
+                      const float* rotations, const float* opacities, const float* colors_precomp,
+                      const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                      void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
                       void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
                       void* stream);
@@ -127,8 +133,8 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, void* batch_state,
                        const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
-                       float* const* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
-                       float* dL_drotations, float* dL_dcov3D, void* stream);
+                       float* const* dL_dmeans2D, float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity,
+                       float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 
 /* ---- fused image loss of the tracking step (caller side of the path):
  *   loss = w_l1 * mean|pred - target| + w_ssim * (1 - mean SSIM(pred, target)),  SSIM with the reference's 11x11

@@ -35,7 +35,28 @@ def rasterize_backward(state, grad_color, means3D, radii, colors_precomp, shs, s
             t(g["rotations"]), t(g["cov3D_precomp"]), t(g["shs"]))
 
 
+def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
+                            prepare_backward=False):
+    """V views, optionally with per-view colours ([V,P,3]) -- one oracle run per view."""
+    per_view = colors_precomp is not None and colors_precomp.dim() == 3
+    outs = [rasterize_forward(rs, means3D, opacities, colors_precomp[v] if per_view else colors_precomp, shs, scales, rotations,
+                              cov3D_precomp) for v, rs in enumerate(settings_list)]
+    return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.stack([o[2] for o in outs]),
+            [o[3] for o in outs])
+
+
+def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
+    per_view = colors_precomp is not None and colors_precomp.dim() == 3
+    outs = [rasterize_backward(st, grad_color[v], means3D, radii[v], colors_precomp[v] if per_view else colors_precomp, shs,
+                               scales, rotations, cov3D_precomp) for v, st in enumerate(states)]
+    sm = lambda k: None if outs[0][k] is None else torch.stack([o[k] for o in outs]).sum(0)  # noqa: E731
+    d_col = None if outs[0][2] is None else (torch.stack([o[2] for o in outs]) if per_view else sm(2))
+    return sm(0), torch.stack([o[1] for o in outs]), d_col, sm(3), sm(4), sm(5), sm(6), sm(7)
+
+
 def install(monkeypatch):
     from diff_gaussian_rasterization import _hip
     monkeypatch.setattr(_hip, "rasterize_forward", rasterize_forward)
     monkeypatch.setattr(_hip, "rasterize_backward", rasterize_backward)
+    monkeypatch.setattr(_hip, "rasterize_forward_batch", rasterize_forward_batch)
+    monkeypatch.setattr(_hip, "rasterize_backward_batch", rasterize_backward_batch)

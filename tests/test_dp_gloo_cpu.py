@@ -38,6 +38,8 @@ def _install_double():
     from diff_gaussian_rasterization import _hip
     _hip.rasterize_forward = oracle_double.rasterize_forward
     _hip.rasterize_backward = oracle_double.rasterize_backward
+    _hip.rasterize_forward_batch = oracle_double.rasterize_forward_batch
+    _hip.rasterize_backward_batch = oracle_double.rasterize_backward_batch
 
 
 def _make_problem():

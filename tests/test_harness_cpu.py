@@ -101,6 +101,50 @@ def test_rigidity_block_matches_reference(ref, monkeypatch):
     np.testing.assert_allclose(params["unnorm_rotations"].grad.numpy()[:n], ref["rig_grad_rot"], rtol=1e-4, atol=1e-5)
 
 
+def test_batched_get_loss_equals_sum_of_per_camera_get_loss(monkeypatch):
+    """get_loss_views (one rasterizer call: colour + segmentation renders of all cameras as 2 V views with per-view
+    colours) == sum of get_loss over the cameras: value, parameter gradients, densification bookkeeping."""
+    import oracle_double
+    oracle_double.install(monkeypatch)
+    from gsdyn import LossWeights, get_loss, get_loss_views, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.step import make_rigidity_variables
+    P, W, H, V = 60, 48, 32, 3
+    cams = synth_ring_cameras(V, W, H, device="cpu")
+    datas = []
+    for i, cam in enumerate(cams):
+        im, seg = synth_targets(W, H, seed=3 + i, device="cpu")
+        datas.append(dict(cam=cam, im=im, seg=seg, id=i))
+    w = LossWeights()
+
+    def fresh():
+        params = synth_scene_params(P, device="cpu", scale_lo=0.05, scale_hi=0.25)
+        params["seg_colors"].requires_grad_(True)
+        variables = dict(make_rigidity_variables(params, num_knn=5), max_2D_radius=torch.zeros(P))
+        with torch.no_grad():
+            params["means3D"].add_(0.01 * torch.randn(P, 3, generator=torch.Generator().manual_seed(1)))
+        return params, variables
+
+    pa, va = fresh()
+    total_a, g2_a, seen_a = 0.0, [], []
+    for d in datas:
+        loss, va = get_loss(pa, d, va, False, w)
+        loss.backward()
+        total_a += loss.item()
+        g2_a.append(va["means2D"].grad.clone()); seen_a.append(va["seen"].clone())
+    pb, vb = fresh()
+    loss_b, vb, aux = get_loss_views(pb, datas, vb, False, w)
+    loss_b.backward()
+    np.testing.assert_allclose(loss_b.item(), total_a, rtol=1e-5)
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "seg_colors", "cam_m", "cam_c"):
+        ga, gb = pa[k].grad, pb[k].grad
+        assert gb is not None, k
+        np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=2e-4, atol=1e-6 * float(ga.abs().max()) + 1e-12, err_msg=k)
+    for v in range(V):
+        np.testing.assert_allclose(aux["means2D"].grad[2 * v].numpy(), g2_a[v].numpy(), rtol=1e-4, atol=1e-9)
+        assert torch.equal(aux["radii"][v] > 0, seen_a[v])
+    np.testing.assert_allclose(vb["max_2D_radius"].numpy(), va["max_2D_radius"].numpy())
+
+
 def test_synth_scene_is_deterministic_and_shaped():
     from gsdyn import synth_ring_cameras, synth_scene_params, synth_targets
     a, b = synth_scene_params(100, device="cpu"), synth_scene_params(100, device="cpu")

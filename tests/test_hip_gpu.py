@@ -545,6 +545,45 @@ def test_strided_camera_tensors_are_converted_once_and_tracked(dev):
     assert np.array_equal(b.cpu().numpy(), _run_hip(cam2, g, dev)[0])
 
 
+def test_per_view_colours_share_geometry(dev):
+    """Row N1: the colour and the segmentation render of a camera as ONE 2-view call with per-view colours ==
+    two separate GaussianRasterizer calls: identical images, colour gradients per view, geometry gradients summed."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H = 12000, 240, 176
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.06)
+    cams = synth_ring_cameras(2, W, H, device=dev)
+    dL = torch.tensor(np.random.default_rng(9).uniform(-1, 1, (4, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    cols = torch.stack([rv["colors_precomp"], params["seg_colors"].detach()])             # [2,P,3]
+
+    a = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    ca = cols.clone().requires_grad_(True)
+    ims = []
+    for v in range(4):          # views 0,1: camera 0 colour / seg; views 2,3: camera 1
+        im, _, _ = GaussianRasterizer(raster_settings=cams[v // 2])(
+            means3D=a["means3D"], means2D=torch.zeros((P, 3), device=dev, requires_grad=True), opacities=a["opacities"],
+            colors_precomp=ca[v % 2], scales=a["scales"], rotations=a["rotations"])
+        im.backward(gradient=dL[v])
+        ims.append(im.detach())
+    b = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    cb = cols.repeat(2, 1, 1).clone().requires_grad_(True)                                # [4,P,3]
+    m2 = torch.zeros((4, P, 3), device=dev, requires_grad=True)
+    imb, radb, _ = rasterize_gaussians_views([cams[0], cams[0], cams[1], cams[1]], b["means3D"], m2, b["opacities"],
+                                             colors_precomp=cb, scales=b["scales"], rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    torch.cuda.synchronize()
+    assert torch.equal(imb.detach(), torch.stack(ims))
+    assert torch.equal(radb[0], radb[1]) and torch.equal(radb[2], radb[3])
+    gcb = cb.grad
+    assert torch.equal(gcb[0] + gcb[2], ca.grad[0]) or (gcb[0] + gcb[2] - ca.grad[0]).abs().max() <= 2e-6 * ca.grad[0].abs().max()
+    assert (gcb[1] + gcb[3] - ca.grad[1]).abs().max() <= 2e-6 * ca.grad[1].abs().max()
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        ga, gb = a[k].grad, b[k].grad
+        assert (ga - gb).abs().max().item() <= 2e-6 * ga.abs().max().item(), k
+
+
 # ------------------------------------------------------------------ fused image loss (row N2)
 @pytest.mark.parametrize("H,W", [(64, 48), (37, 53), (800, 800)])
 def test_fused_image_loss_matches_torch_formula(dev, H, W):
