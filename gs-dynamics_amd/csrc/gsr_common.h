@@ -313,7 +313,10 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
   // xor 8 (row_ror:8): 2 -> 1   (lanes with bit 3 clear: v_(lane&7); bit 3 set: v8)
   float z = (b3 ? p8 : p07) + gsr_dpp_get<0x128>(b3 ? p07 : p8);
   // rows: the packed layout differs per lane, so the row levels must be lane-wise exchanges (row_bcast would
-  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  Every lane ends up
+  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  (An LDS-free variant -- xor 4 as
+  // two bank-masked DPP row shifts, xor 16 / 32 as v_permlane16/32_swap on two copies -- passes the self-test but
+  // costs 4 more VALU issues per reduction and measured 3 % SLOWER: SQ counters put the blend backward at 99 % VALU
+  // issue occupancy, so the crossbar round trips are already hidden by the other waves and VALU slots are what count.)  Every lane ends up
   // with the total of "its" value: lane & 15 in 0..7 -> v_(lane & 7), lane & 8 set -> v8.
   z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
   z += __shfl_xor(z, 32, 64);
