@@ -191,28 +191,40 @@ __device__ __forceinline__ void fwd_tile(
       const float4* __restrict__ wA = L.sA[wv];
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
-      float4 ea = wA[0], eb = wB[0], ec = wC[0];
-      for (int j = 0; j < m; ++j) {
-        const float4 xa = wA[j + 1], xb = wB[j + 1], xc = wC[j + 1];
-        const float dx = ea.x - pxf, dy = ea.y - pyf;
-        const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-        // (the plain 2-instruction exp would save 5 of ~30 VALU slots per pair here -- measured 35.3 -> 33.2 us per view, all
-        // parity tests still green -- but the backward re-evaluates alpha with gsr_exp, and the two must take the same
-        // alpha >= 1/255 decisions)
-        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * gsr_exp(power));
-        const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;
-        const float test_T = T * (1.0f - alpha);
-        const bool stop = hit && test_T < GSR_T_EPS;
-        const bool blend = hit && !stop;
-        done = done || stop;
-        const float w = blend ? alpha * T : 0.0f;
-        C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);
-        C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);
-        T = blend ? test_T : T;
-        last = blend ? __float_as_uint(ec.z) : last;
-        ea = xa; eb = xb; ec = xc;
-        if ((j & 7) == 7 && __ballot(!done) == 0ull) break;
+      // One list entry: evaluate, then blend predicated.
+      // (the plain 2-instruction exp would save 5 of ~30 VALU slots per pair here -- measured 35.3 -> 33.2 us per view, all
+      // parity tests still green -- but the backward re-evaluates alpha with gsr_exp, and the two must take the same
+      // alpha >= 1/255 decisions)
+#define GSR_FWD_ENTRY(ea, eb, ec)                                                                   \
+      {                                                                                             \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
+        const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;             \
+        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * gsr_exp(power));                            \
+        const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                          \
+        const float test_T = T * (1.0f - alpha);                                                    \
+        const bool stop = hit && test_T < GSR_T_EPS;                                                \
+        const bool blend = hit && !stop;                                                            \
+        done = done || stop;                                                                        \
+        const float w = blend ? alpha * T : 0.0f;                                                   \
+        C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                         \
+        C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                         \
+        T = blend ? test_T : T;                                                                     \
+        last = blend ? __float_as_uint(ec.z) : last;                                                \
       }
+      // Two entries per trip on ping-pong registers: the record of entry j+1 (j+2) is fetched from LDS while entry j
+      // (j+1) is evaluated, and no register copies are needed to rotate the prefetch (they were 6 of ~40 VALU
+      // slots per entry, and the blend kernels run at the VALU issue limit).
+      float4 ea = wA[0], eb = wB[0], ec = wC[0];
+      int j = 0;
+      for (; j + 1 < m; j += 2) {
+        const float4 xa = wA[j + 1], xb = wB[j + 1], xc = wC[j + 1];
+        GSR_FWD_ENTRY(ea, eb, ec)
+        ea = wA[j + 2]; eb = wB[j + 2]; ec = wC[j + 2];
+        GSR_FWD_ENTRY(xa, xb, xc)
+        if ((j & 6) == 6 && __ballot(!done) == 0ull) { j = m; break; }
+      }
+      if (j < m) GSR_FWD_ENTRY(ea, eb, ec)
+#undef GSR_FWD_ENTRY
     }
     GSR_TP(5);
   }
