@@ -359,50 +359,62 @@ __device__ __forceinline__ void bwd_tile(
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
-    float4 xa = wA[0], xb = wB[0];
-    float2 xc = wC[0];
-    for (int jj = 0; jj < m; ++jj) {
-      const float4 ea = xa, eb = xb;
-      const float2 ec = xc;
-      xa = wA[jj + 1]; xb = wB[jj + 1]; xc = wC[jj + 1];  // next entry, in flight during this one
-      const int j = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ec.y));  // batch index (wave-uniform)
-      const int pos = max_last - 1 - (base + j);
-      const float blue = ec.x;
-      const float dx = ea.x - pxf, dy = ea.y - pyf;
-      const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-      const float G = gsr_exp(power);
-      const float alpha = fminf(GSR_ALPHA_MAX, eb.y * G);
-      const bool hit = (pos < last) && power <= 0.0f && alpha >= GSR_ALPHA_MIN;
-      if (__ballot(hit) == 0ull) continue;  // wave-uniform: nothing to add for this entry
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-      if (hit) {
-        const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
-        T = T * rcp;
-        const float w = alpha * T;
-        acc0 = __builtin_fmaf(last_alpha, lc0 - acc0, acc0);
-        acc1 = __builtin_fmaf(last_alpha, lc1 - acc1, acc1);
-        acc2 = __builtin_fmaf(last_alpha, lc2 - acc2, acc2);
-        lc0 = eb.z; lc1 = eb.w; lc2 = blue;
-        last_alpha = alpha;
-        float dL_dalpha = (eb.z - acc0) * dL0;
-        dL_dalpha = __builtin_fmaf(eb.w - acc1, dL1, dL_dalpha);
-        dL_dalpha = __builtin_fmaf(blue - acc2, dL2, dL_dalpha);
-        dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);
-        const float dL_dG = eb.y * dL_dalpha;  // min(0.99, .) is straight-through
-        const float gdx = G * dx, gdy = G * dy;
-        const float hG = -0.5f * dL_dG;
-        v0 = dL_dG * (-(gdx * ea.z) - gdy * ea.w);
-        v1 = dL_dG * (-(gdy * eb.x) - gdx * ea.w);
-        v2 = hG * (gdx * dx);
-        v3 = -dL_dG * (gdx * dy);
-        v4 = hG * (gdy * dy);
-        v5 = G * dL_dalpha;
-        v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;
-      }
-      const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-      if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z;  // one ds_write_b32
-      if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
+    // One list entry: re-evaluate alpha; when some pixel of the quad used the entry, back out T, form the nine partials,
+    // reduce them over the wave and park the totals.
+#define GSR_BWD_ENTRY(ea, eb, ec)                                                                             \
+    {                                                                                                         \
+      const int j = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ec.y)); /* batch index, wave-uniform */ \
+      const int pos = max_last - 1 - (base + j);                                                              \
+      const float blue = ec.x;                                                                                \
+      const float dx = ea.x - pxf, dy = ea.y - pyf;                                                           \
+      const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;                         \
+      const float G = gsr_exp(power);                                                                         \
+      const float alpha = fminf(GSR_ALPHA_MAX, eb.y * G);                                                     \
+      const bool hit = (pos < last) && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                               \
+      if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;       \
+        if (hit) {                                                                                            \
+          const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);                                              \
+          T = T * rcp;                                                                                        \
+          const float w = alpha * T;                                                                          \
+          acc0 = __builtin_fmaf(last_alpha, lc0 - acc0, acc0);                                                \
+          acc1 = __builtin_fmaf(last_alpha, lc1 - acc1, acc1);                                                \
+          acc2 = __builtin_fmaf(last_alpha, lc2 - acc2, acc2);                                                \
+          lc0 = eb.z; lc1 = eb.w; lc2 = blue;                                                                 \
+          last_alpha = alpha;                                                                                 \
+          float dL_dalpha = (eb.z - acc0) * dL0;                                                              \
+          dL_dalpha = __builtin_fmaf(eb.w - acc1, dL1, dL_dalpha);                                            \
+          dL_dalpha = __builtin_fmaf(blue - acc2, dL2, dL_dalpha);                                            \
+          dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                              \
+          const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                        \
+          const float gdx = G * dx, gdy = G * dy;                                                             \
+          const float hG = -0.5f * dL_dG;                                                                     \
+          v0 = dL_dG * (-(gdx * ea.z) - gdy * ea.w);                                                          \
+          v1 = dL_dG * (-(gdy * eb.x) - gdx * ea.w);                                                          \
+          v2 = hG * (gdx * dx);                                                                               \
+          v3 = -dL_dG * (gdx * dy);                                                                           \
+          v4 = hG * (gdy * dy);                                                                               \
+          v5 = G * dL_dalpha;                                                                                 \
+          v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;                                                           \
+        }                                                                                                     \
+        const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \
+        if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
+        if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));                           \
+      }                                                                                                       \
     }
+    // two entries per trip on ping-pong registers (see fwd_tile): no copies to rotate the LDS prefetch
+    float4 ea = wA[0], eb = wB[0];
+    float2 ec = wC[0];
+    int jj = 0;
+    for (; jj + 1 < m; jj += 2) {
+      const float4 xa = wA[jj + 1], xb = wB[jj + 1];
+      const float2 xc = wC[jj + 1];
+      GSR_BWD_ENTRY(ea, eb, ec)
+      ea = wA[jj + 2]; eb = wB[jj + 2]; ec = wC[jj + 2];
+      GSR_BWD_ENTRY(xa, xb, xc)
+    }
+    if (jj < m) GSR_BWD_ENTRY(ea, eb, ec)
+#undef GSR_BWD_ENTRY
     if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
     GSR_TP(4);
     __syncthreads();
