@@ -481,7 +481,10 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   const float z = gsr_wave_sum9_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v, 9.f * v);
   const int l = threadIdx.x & 63;
   const float zexp = ((l & 8) == 0) ? (float)((l & 7) + 1) * b : 9.f * b;
-  const bool okz = __ballot(z != zexp) == 0ull;
+  bool okz = __ballot(z != zexp) == 0ull;
+  // the blend backward runs unused lanes with alpha = 0 and relies on 1 / (1 - 0) being exactly 1 (v_rcp_f32)
+  const float alpha0 = fminf(0.99f, 0.7f * (v * 0.0f));
+  okz = okz && __ballot(__builtin_amdgcn_rcpf(1.0f - alpha0) != 1.0f) == 0ull;
   if ((threadIdx.x & 63) == 63) {
     const bool ok9 = okz && q0 == b && q1 == 2.f * b && q2 == 3.f * b && q3 == 4.f * b && q4 == 5.f * b && q5 == 6.f * b &&
                      q6 == 7.f * b && q7 == 8.f * b && q8 == 9.f * b;

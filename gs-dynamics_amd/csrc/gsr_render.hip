@@ -368,35 +368,38 @@ __device__ __forceinline__ void bwd_tile(
       const float blue = ec.x;                                                                                \
       const float dx = ea.x - pxf, dy = ea.y - pyf;                                                           \
       const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;                         \
-      const float G = gsr_exp(power);                                                                         \
-      const float alpha = fminf(GSR_ALPHA_MAX, eb.y * G);                                                     \
-      const bool hit = (pos < last) && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                               \
+      const float G0 = gsr_exp(power);                                                                        \
+      const bool hit = (pos < last) && power <= 0.0f && fminf(GSR_ALPHA_MAX, eb.y * G0) >= GSR_ALPHA_MIN;     \
       if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;       \
-        if (hit) {                                                                                            \
-          const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);                                              \
-          T = T * rcp;                                                                                        \
-          const float w = alpha * T;                                                                          \
-          acc0 = __builtin_fmaf(last_alpha, lc0 - acc0, acc0);                                                \
-          acc1 = __builtin_fmaf(last_alpha, lc1 - acc1, acc1);                                                \
-          acc2 = __builtin_fmaf(last_alpha, lc2 - acc2, acc2);                                                \
-          lc0 = eb.z; lc1 = eb.w; lc2 = blue;                                                                 \
-          last_alpha = alpha;                                                                                 \
-          float dL_dalpha = (eb.z - acc0) * dL0;                                                              \
-          dL_dalpha = __builtin_fmaf(eb.w - acc1, dL1, dL_dalpha);                                            \
-          dL_dalpha = __builtin_fmaf(blue - acc2, dL2, dL_dalpha);                                            \
-          dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                              \
-          const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                        \
-          const float gdx = G * dx, gdy = G * dy;                                                             \
-          const float hG = -0.5f * dL_dG;                                                                     \
-          v0 = dL_dG * (-(gdx * ea.z) - gdy * ea.w);                                                          \
-          v1 = dL_dG * (-(gdy * eb.x) - gdx * ea.w);                                                          \
-          v2 = hG * (gdx * dx);                                                                               \
-          v3 = -dL_dG * (gdx * dy);                                                                           \
-          v4 = hG * (gdy * dy);                                                                               \
-          v5 = G * dL_dalpha;                                                                                 \
-          v6 = w * dL0; v7 = w * dL1; v8 = w * dL2;                                                           \
-        }                                                                                                     \
+        /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
+           alpha = 0, 1/(1-alpha) = 1, T and the accumulated colour are unchanged (an alpha = 0 entry only flushes \
+           the pending (last_alpha, last colour) pair, which the next real entry would have done with the same    \
+           operands), and all nine partials come out as exact zeros because each carries a factor G or alpha.    \
+           Saves the 9 zero-moves, the state copies and the exec save/restore of the masked form (VALU-bound). */ \
+        const float G = hit ? G0 : 0.0f;                                                                      \
+        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * G);                                                   \
+        const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);                                                \
+        T = T * rcp;                                                                                          \
+        const float w = alpha * T;                                                                            \
+        acc0 = __builtin_fmaf(last_alpha, lc0 - acc0, acc0);                                                  \
+        acc1 = __builtin_fmaf(last_alpha, lc1 - acc1, acc1);                                                  \
+        acc2 = __builtin_fmaf(last_alpha, lc2 - acc2, acc2);                                                  \
+        lc0 = eb.z; lc1 = eb.w; lc2 = blue;                                                                   \
+        last_alpha = alpha;                                                                                   \
+        float dL_dalpha = (eb.z - acc0) * dL0;                                                                \
+        dL_dalpha = __builtin_fmaf(eb.w - acc1, dL1, dL_dalpha);                                              \
+        dL_dalpha = __builtin_fmaf(blue - acc2, dL2, dL_dalpha);                                              \
+        dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                                \
+        const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                          \
+        const float gdx = G * dx, gdy = G * dy;                                                               \
+        const float hG = -0.5f * dL_dG;                                                                       \
+        const float v0 = dL_dG * (-(gdx * ea.z) - gdy * ea.w);                                                \
+        const float v1 = dL_dG * (-(gdy * eb.x) - gdx * ea.w);                                                \
+        const float v2 = hG * (gdx * dx);                                                                     \
+        const float v3 = -dL_dG * (gdx * dy);                                                                 \
+        const float v4 = hG * (gdy * dy);                                                                     \
+        const float v5 = G * dL_dalpha;                                                                       \
+        const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \
         if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
         if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));                           \
