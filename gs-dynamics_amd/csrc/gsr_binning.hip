@@ -141,9 +141,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
     const int g = g0 + lo;
     const uint32_t k = e - soff[lo];
     const uint2 r = rect[g];
-    const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu;
+    const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu, maxy = r.y >> 16;
     const uint32_t w = maxx - minx;
-    const uint32_t ty = miny + k / w, tx = minx + k % w;
+    uint32_t b = k;                                    // index of the entry's tile inside the rect (row-major)
+    if (w * (maxy - miny) <= 32u) {                    // small rect: the k-th set bit of the Gaussian's tile mask
+      uint32_t m = __float_as_uint(rec[GSR_REC_F4 * g + 3].w);
+      for (uint32_t t = 0; t < k; ++t) m &= m - 1u;
+      b = (uint32_t)__ffs((int)m) - 1u;
+    }
+    const uint32_t ty = miny + b / w, tx = minx + b % w;
     tkey[e] = ty * (uint32_t)gx + tx;
     dg[e] = ((uint64_t)__float_as_uint(rec[GSR_REC_F4 * g + 2].y) << 32) | (uint32_t)g;
   }

@@ -21,7 +21,8 @@
 //   rec[4g+0] {mean2D.x, mean2D.y, conicA, conicB}
 //   rec[4g+1] {conicC, opacity, r, g}
 //   rec[4g+2] {b, depth, bits(alpha-box x: xmin | xmax<<16), bits(alpha-box y: ymin | ymax<<16)}
-//   rec[4g+3] {bits(rect.x: minx | miny<<16), bits(rect.y: maxx | maxy<<16), bits(offsets[g]) (written by emit), 0}
+//   rec[4g+3] {bits(rect.x: minx | miny<<16), bits(rect.y: maxx | maxy<<16), bits(offsets[g]) (written by emit),
+//              bits(tile mask: which tiles of a rect of <= 32 tiles are in the Gaussian's lists)}
 // The alpha-box is the int16 pixel box outside which alpha < 1/255.
 #define GSR_REC_F4 4
 struct GeomState {
@@ -344,6 +345,33 @@ __device__ __forceinline__ void gsr_load_partial(const float4* base, size_t e, f
   const GsrF3* p = reinterpret_cast<const GsrF3*>(reinterpret_cast<const float*>(base) + e * GSR_PARTIAL_FLOATS);
   const GsrF3 a = p[0], b = p[1], c = p[2];
   r0 = make_float4(a.x, a.y, a.z, b.x); r1 = make_float4(b.y, b.z, c.x, c.y); r2x = c.z;
+}
+// q(d) = A dx^2 + 2 B dx dy + C dy^2 restricted to a vertical (dx fixed) or horizontal (dy fixed) edge,
+// minimised over the edge's extent (used for the exact Gaussian-vs-rectangle culling tests).
+__device__ __forceinline__ float qmin_on_vertical_edge(float A, float B, float C, float invC, float dx, float dylo, float dyhi) {
+  const float dy = fminf(fmaxf(-B * dx * invC, dylo), dyhi);
+  return A * dx * dx + (2.0f * B * dx + C * dy) * dy;
+}
+__device__ __forceinline__ float qmin_on_horizontal_edge(float A, float B, float C, float invA, float dy, float dxlo, float dxhi) {
+  const float dx = fminf(fmaxf(-B * dy * invA, dxlo), dxhi);
+  return C * dy * dy + (2.0f * B * dy + A * dx) * dx;
+}
+// Can alpha reach 1/255 anywhere on the pixel rectangle [x0, x1] x [y0, y1]?  Exact minimum of the (convex) quadratic form
+// over the rectangle -- 0 when the mean is inside, else the least edge minimum -- against tau2 = 2 ln(255 o) + 0.04: conservative.
+__device__ __forceinline__ bool gsr_rect_reachable(float mx, float my, float A, float B, float C, float invA, float invC, float tau2,
+                                                   int x0, int y0, int x1, int y1) {
+  const float dxlo = (float)x0 - mx, dxhi = (float)x1 - mx, dylo = (float)y0 - my, dyhi = (float)y1 - my;
+  if (dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f) return true;
+  float q = qmin_on_vertical_edge(A, B, C, invC, dxlo, dylo, dyhi);
+  q = fminf(q, qmin_on_vertical_edge(A, B, C, invC, dxhi, dylo, dyhi));
+  q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dylo, dxlo, dxhi));
+  q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dyhi, dxlo, dxhi));
+  return q <= tau2;
+}
+// Tile set of a Gaussian: its (tight) tile rect, and -- for rects of at most 32 tiles -- a bit per tile of the rect
+// (row-major) telling whether the tile is in the set.  Larger rects are taken whole.
+__device__ __forceinline__ uint32_t gsr_tile_rank(uint32_t mask, uint32_t area, uint32_t r) {   // rank of rect tile r in the set
+  return area <= 32u ? (uint32_t)__popc(mask & ((1u << r) - 1u)) : r;
 }
 // Reference (slow, LDS-crossbar) version used by the self-test.
 __device__ __forceinline__ float gsr_wave_sum_shfl(float v) {

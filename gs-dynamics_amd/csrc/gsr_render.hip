@@ -67,17 +67,6 @@ namespace {
 
 __device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(v & 0xffffu); }
 
-// q(d) = A dx^2 + 2 B dx dy + C dy^2 restricted to a vertical (dx fixed) or horizontal (dy fixed) edge,
-// minimised over the edge's extent.
-__device__ __forceinline__ float qmin_on_vertical_edge(float A, float B, float C, float invC, float dx, float dylo, float dyhi) {
-  const float dy = fminf(fmaxf(-B * dx * invC, dylo), dyhi);
-  return A * dx * dx + (2.0f * B * dx + C * dy) * dy;
-}
-__device__ __forceinline__ float qmin_on_horizontal_edge(float A, float B, float C, float invA, float dy, float dxlo, float dxhi) {
-  const float dx = fminf(fmaxf(-B * dy * invA, dxlo), dxhi);
-  return C * dy * dy + (2.0f * B * dy + A * dx) * dx;
-}
-
 // Which of the tile's four per-wave pixel regions (8x8 quads) can this Gaussian reach with alpha >= 1/255?  (bit w = wave w)
 // Level 1: the integer pixel box from preprocess.  Level 2, for strips that pass: the exact minimum of the
 // quadratic form over the strip rectangle (0 when the mean is inside, else the least edge minimum -- the
@@ -292,8 +281,9 @@ __device__ __forceinline__ void bwd_tile(
     const uint32_t g = point_list[rg.x + k];
     const float4 sl = rec[GSR_REC_F4 * g + 3];   // rect bits, offsets[g]
     const uint32_t rx = __float_as_uint(sl.x), ry = __float_as_uint(sl.y);
-    const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu;
-    const uint32_t e = __float_as_uint(sl.z) + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
+    const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu, maxy = ry >> 16;
+    const uint32_t e = __float_as_uint(sl.z) + gsr_tile_rank(__float_as_uint(sl.w), (maxx - minx) * (maxy - miny),
+                                                            ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     gsr_store_partial(partials, e, z, z, 0.f);
   }
@@ -320,8 +310,9 @@ __device__ __forceinline__ void bwd_tile(
     if (tid < m_all) {
       {  // slot of this (Gaussian, tile) pair: offsets[g] + row-major rank of the tile inside the Gaussian's rect
         const uint32_t rx = __float_as_uint(nslot.x), ry = __float_as_uint(nslot.y);
-        const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu;
-        L.sSlot[tid] = __float_as_uint(nslot.z) + ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx);
+        const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu, maxy = ry >> 16;
+        L.sSlot[tid] = __float_as_uint(nslot.z) + gsr_tile_rank(__float_as_uint(nslot.w), (maxx - minx) * (maxy - miny),
+                                                                ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
       }
       mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
     }

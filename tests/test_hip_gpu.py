@@ -101,6 +101,12 @@ def _check_lists(views, H, W, o_point_list, o_ranges, o_n_contrib, ok, o_means2D
     x0, y0 = (rect[:, 0] & 0xffff).astype(np.int64), (rect[:, 0] >> 16).astype(np.int64)
     x1, y1 = (rect[:, 1] & 0xffff).astype(np.int64), (rect[:, 1] >> 16).astype(np.int64)
     keep = (tx >= x0[g_of]) & (tx < x1[g_of]) & (ty >= y0[g_of]) & (ty < y1[g_of])
+    # rects of at most 32 tiles carry a bit per tile (row-major) in the record's last word: exact per-tile culling
+    tmask = views["rec"][:, 15].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    wt, area = (x1 - x0), (x1 - x0) * (y1 - y0)
+    r_in = np.where(keep, (ty - y0[g_of]) * wt[g_of] + (tx - x0[g_of]), 0)
+    small = area[g_of] <= 32
+    keep &= ~small | (((tmask[g_of] >> np.minimum(r_in, 31)) & 1) == 1)
     if o_means2D is not None:                                  # soundness of every dropped pair
         dropped = np.flatnonzero(~keep)
         for c0 in range(0, dropped.size, 1 << 15):
