@@ -144,10 +144,23 @@ def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=No
             ((scales is not None or rotations is not None) and cov3D_precomp is not None):
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     empty = torch.Tensor([])
-    return _RasterizeGaussiansViews.apply(
-        means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, opacities,
-        empty if scales is None else scales, empty if rotations is None else rotations,
-        empty if cov3D_precomp is None else cov3D_precomp, tuple(settings_list))
+    settings_list = tuple(settings_list)
+    V = len(settings_list)
+    if V == 0:
+        raise ValueError("rasterize_gaussians_views: no views")
+    per_view_col = colors_precomp is not None and colors_precomp.dim() == 3
+
+    def call(lo, hi):
+        return _RasterizeGaussiansViews.apply(
+            means3D, means2D[lo:hi], empty if shs is None else shs,
+            empty if colors_precomp is None else (colors_precomp[lo:hi] if per_view_col else colors_precomp), opacities,
+            empty if scales is None else scales, empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp, settings_list[lo:hi])
+    if V <= _hip.MAX_BATCH:
+        return call(0, V)
+    # more views than one library call takes: several calls, outputs concatenated (autograd sums the shared inputs)
+    parts = [call(lo, min(V, lo + _hip.MAX_BATCH)) for lo in range(0, V, _hip.MAX_BATCH)]
+    return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -224,6 +224,7 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh
 
 
+MAX_BATCH = 16           # GSR_MAX_BATCH of include/gsr.h: views per library call
 _binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
 _scratch_capacity = {}   # same key -> bytes per view of backward scratch
 _BINNING_SLACK = 1.25

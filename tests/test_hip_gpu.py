@@ -590,6 +590,35 @@ def test_per_view_colours_share_geometry(dev):
         assert (ga - gb).abs().max().item() <= 2e-6 * ga.abs().max().item(), k
 
 
+def test_more_views_than_one_library_call(dev):
+    """18 views (> GSR_MAX_BATCH = 16): the Python entry point splits the call; results equal per-view calls."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H, V = 3000, 96, 64, 18
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.1)
+    cams = synth_ring_cameras(V, W, H, device=dev)
+    dL = torch.tensor(np.random.default_rng(2).uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items() if k != "means2D"}
+    a = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    ims = []
+    for v in range(V):
+        im, _, _ = GaussianRasterizer(raster_settings=cams[v])(means2D=torch.zeros((P, 3), device=dev), **a)
+        im.backward(gradient=dL[v])
+        ims.append(im.detach())
+    b = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    m2 = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+    imb, radb, depb = rasterize_gaussians_views(cams, b["means3D"], m2, b["opacities"], colors_precomp=b["colors_precomp"],
+                                                scales=b["scales"], rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    assert imb.shape == (V, 3, H, W) and radb.shape == (V, P) and depb.shape == (V, 1, H, W)
+    assert torch.equal(imb.detach(), torch.stack(ims))
+    assert m2.grad is not None and m2.grad.shape == (V, P, 3)
+    for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
+        ga, gb = a[k].grad, b[k].grad
+        assert (ga - gb).abs().max().item() <= 4e-6 * ga.abs().max().item(), k
+
+
 # ------------------------------------------------------------------ fused image loss (row N2)
 @pytest.mark.parametrize("H,W", [(64, 48), (37, 53), (800, 800)])
 def test_fused_image_loss_matches_torch_formula(dev, H, W):
