@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_VERSION 110 /* 0.1.10: multi-view tables, batch_state, per-view colours */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
