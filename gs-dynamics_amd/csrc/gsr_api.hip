@@ -73,6 +73,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
+  o.shares_lists = 0;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
   o.offsets = g.offsets;
@@ -175,9 +176,21 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
 }
 
 // Stage 2 of V views: binning chain + blend, one launch per kernel for all views.
+// `geometry_of` (may be NULL): geometry_of[v] = u <= v means view v has the same camera as view u and differs only in its
+// colours (the colour and the segmentation render of get_loss): v then uses u's tile lists --
+// no entries emitted, no global sort passes, no tile sort for v.
+int check_geometry_of(int V, const int32_t* geometry_of) {
+  if (!geometry_of) return 0;
+  for (int v = 0; v < V; ++v) {
+    const int u = geometry_of[v];
+    if (u < 0 || u > v || geometry_of[u] != u) { gsr_set_error("gsr batch: geometry_of[%d] = %d is not an earlier primary view", v, u); return -2; }
+  }
+  return 0;
+}
 int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
            void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
-           const uint32_t* sums, uint4* order, uint32_t* queue, hipStream_t st) {
+           const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st) {
+  if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
   const uint32_t nblk = (uint32_t)(((P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK);
@@ -185,11 +198,14 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     GsrCam cam;
     if (int rc = make_cam(&s[v], &cam)) return rc;
     if (!image_states[v] || !out_color[v] || !out_depth[v]) { gsr_set_error("gsr forward render: NULL argument"); return -2; }
-    if (num_rendered[v] > 0 && (!geom_states[v] || !binning_states[v])) { gsr_set_error("gsr forward render: NULL state"); return -2; }
-    GeomState g; ImageState im; BinningState bs;
+    const int owner = geometry_of ? geometry_of[v] : v;   // the view whose tile lists this one uses
+    if (num_rendered[v] > 0 && (!geom_states[v] || !binning_states[owner])) { gsr_set_error("gsr forward render: NULL state"); return -2; }
+    if (owner != v && num_rendered[owner] != num_rendered[v]) { gsr_set_error("gsr batch: view %d shares view %d's camera but not its entry count", v, owner); return -2; }
+    GeomState g; ImageState im, im_owner; BinningState bs;
     gsr_carve_geom(geom_states[v], P, &g);
     gsr_carve_image(image_states[v], cam.H, cam.W, &im);
-    gsr_carve_binning(binning_states[v], num_rendered[v], &bs);
+    gsr_carve_image(image_states[owner], cam.H, cam.W, &im_owner);
+    gsr_carve_binning(binning_states[owner], num_rendered[owner], &bs);
     if (v == 0) {
       bt.V = V; bt.T = cam.T; bt.gx = cam.gx;
       bt.order = order ? order : im.tile_order;
@@ -201,6 +217,10 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     }
     fill_bin_view(bt.v[v], P, num_rendered[v], g, bs, im, sums ? sums + (size_t)v * nblk : g.block_sums);
     fill_render_view(rt.v[v], cam, g, bs, im, out_color[v], out_depth[v], nullptr, nullptr);
+    if (owner != v) {   // lists, ranges and sort belong to the owner; this view only gets its offsets from emit
+      bt.v[v].shares_lists = 1; bt.v[v].D = 0; bt.v[v].nblocks = 0; bt.v[v].ranges = im_owner.ranges;
+      rt.v[v].ranges = im_owner.ranges;
+    }
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
   return gsr_launch_render_fwd(rt, st);
@@ -232,7 +252,7 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
   if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
   void* geom = const_cast<void*>(geom_state);
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
-                nullptr, (hipStream_t)stream);
+                nullptr, nullptr, (hipStream_t)stream);
 }
 
 int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,
@@ -297,7 +317,8 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             void* batch_state, float* const* out_color, float* const* out_depth, void* stream) {
+                             void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                             void* stream) {
   if (int rc = check_batch("gsr_forward_render_batch", V, s, batch_state)) return rc;
   if (!num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
     gsr_set_error("gsr_forward_render_batch: NULL argument");
@@ -306,7 +327,7 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   return stage2(V, s, P, num_rendered, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, (hipStream_t)stream);
+                b.queue, geometry_of, (hipStream_t)stream);
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -314,9 +335,10 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       const float* const* colors_views, const float* shs, const float* cov3D_precomp,
                       void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
-                      void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
-                      void* stream) {
+                      void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                      uint32_t* num_rendered_host, void* stream) {
   if (int rc = check_batch("gsr_forward_batch", V, s, batch_state)) return rc;
+  if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!geom_states || !radii || !num_rendered_host || !image_states || !out_color || !out_depth) {
     gsr_set_error("gsr_forward_batch: NULL argument");
     return -2;
@@ -329,21 +351,25 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
-  for (int v = 0; fits && v < V; ++v)
+  for (int v = 0; fits && v < V; ++v) {
+    if (geometry_of && geometry_of[v] != v) continue;   // uses its owner's binning state
     fits = num_rendered_host[v] == 0 || (binning_states[v] && binning_bytes[v] >= gsr_binning_bytes(num_rendered_host[v], 0, 0));
+  }
   if (!fits) return 1;
   return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, (hipStream_t)stream);
+                b.queue, geometry_of, (hipStream_t)stream);
 }
 
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, void* batch_state,
-                       const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D, float* const* dL_dmeans2D,
+                       const int32_t* geometry_of, const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
+                       float* const* dL_dmeans2D,
                        float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* stream) {
   if (int rc = check_batch("gsr_backward_batch", V, s, batch_state)) return rc;
+  if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
       !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !means3D) {
     gsr_set_error("gsr_backward_batch: NULL argument");
@@ -360,13 +386,16 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
     if (int rc = make_cam(&s[v], &cam)) return rc;
-    GeomState g; ImageState im; BinningState bs;
+    const int owner = geometry_of ? geometry_of[v] : v;
+    GeomState g; ImageState im, im_owner; BinningState bs;
     gsr_carve_geom(geom_states[v], P, &g);
     gsr_carve_image(image_states[v], cam.H, cam.W, &im);
-    gsr_carve_binning(binning_states[v], num_rendered[v], &bs);
-    if (num_rendered[v] > 0 && (!binning_states[v] || !scratch[v])) { gsr_set_error("gsr_backward_batch: NULL binning/scratch"); return -2; }
+    gsr_carve_image(image_states[owner], cam.H, cam.W, &im_owner);
+    gsr_carve_binning(binning_states[owner], num_rendered[owner], &bs);
+    if (num_rendered[v] > 0 && (!binning_states[owner] || !scratch[v])) { gsr_set_error("gsr_backward_batch: NULL binning/scratch"); return -2; }
     if (v == 0) render_header(rt, V, cam, b.order, b.queue);
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
+    rt.v[v].ranges = im_owner.ranges;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;

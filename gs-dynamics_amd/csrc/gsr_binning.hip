@@ -130,6 +130,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
   }
   if (g0 + tid == P - 1) offsets[P] = excl + mine;
   __syncthreads();
+  if (vw.shares_lists) return;   // the lists come from the view with the same camera: only offsets were needed here
   const uint32_t begin = soff[0], end = soff[GSR_BLOCK];
   for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
     int lo = 0, hi = GSR_BLOCK;  // invariant: soff[lo] <= e < soff[hi]
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     if (ticket >= n_busy) return;
     const uint4 ord = tab.order[ticket];
     const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
+    if (vw.shares_lists) return;   // sorted as part of the view that owns the lists
     const uint32_t n = __builtin_amdgcn_readfirstlane(ord.z - ord.y);
     const uint64_t* seg = vw.dg[cur] + ord.y;
     uint32_t* out = vw.point_list + ord.y;
@@ -688,6 +690,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
   }
   const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
   const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
+  if (vw.shares_lists) return;
   uint64_t* __restrict__ dg = vw.dg[cur];
   uint32_t* __restrict__ point_list = vw.point_list;
   const uint2 rg = make_uint2(ord.y, ord.z);

@@ -160,6 +160,7 @@ struct GsrBinView {            // emit .. tile_sort
   uint32_t* tkey[2]; uint64_t* dg[2]; uint32_t* point_list; uint32_t* block_hist;
   uint2* ranges;
   uint32_t D, nblocks;
+  uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
 };
 struct GsrBinViews { int V, T, gx; uint4* order; uint32_t* queue; GsrBinView v[GSR_MAX_BATCH]; };
 struct GsrRenderView {         // blend forward / backward

@@ -77,12 +77,12 @@ def load_library():
     lib.gsr_forward_preprocess_batch.restype = C.c_int
     lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, vp, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
-    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, PV, PV, vp]
+    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, C.POINTER(i32), PV, PV, vp]
     lib.gsr_forward_batch.restype = C.c_int
-    lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(sz), PV, vp, PV, PV,
-                                      C.POINTER(u32), vp])
+    lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(sz), PV, vp,
+                                      C.POINTER(i32), PV, PV, C.POINTER(u32), vp])
     lib.gsr_backward_batch.restype = C.c_int
-    lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, PV, PV]
+    lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, C.POINTER(i32), PV, PV]
                                        + [vp, PV, vp, PV, vp, vp, vp, vp, vp])
     lib.gsr_image_loss_blocks.restype = i32
     lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
@@ -143,7 +143,7 @@ def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Ten
 
 class RasterState:
     """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
-    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch")
+    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch", "geometry_of")
 
 
 def _make_settings(rs, dev, sh_coeffs: int):
@@ -193,7 +193,7 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
     state = RasterState()
     state.settings, state.keep, state.P, state.num_rendered = s, keep, P, int(D.value)
     state.geom, state.binning, state.image, state.H, state.W = geom, binning, image, H, W
-    state.pre = state.batch = None
+    state.pre = state.batch = state.geometry_of = None
     return color, radii, depth, state
 
 
@@ -283,7 +283,15 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         # launched from here with exact sizes.
         key = (dev.index, P, H, W)
         cap = _binning_capacity.get(key, 0)
-        binnings = [torch.empty((cap,), **u8) for _ in range(V)] if cap else [None] * V
+        # views with the same camera (the colour and the segmentation render of get_loss) share one set of tile lists
+        first, geo = {}, []
+        for v, rs in enumerate(settings_list):
+            k = (id(rs.viewmatrix), id(rs.projmatrix), id(rs.campos), float(rs.tanfovx), float(rs.tanfovy),
+                 float(rs.scale_modifier), bool(rs.prefiltered))
+            geo.append(first.setdefault(k, v))
+        geometry_of = (C.c_int32 * V)(*geo) if any(g != v for v, g in enumerate(geo)) else None
+        owner = [geometry_of is None or geo[v] == v for v in range(V)]
+        binnings = [torch.empty((cap,), **u8) if (cap and owner[v]) else None for v in range(V)]
         caps = (C.c_size_t * V)(*([cap] * V))
         pre = None
         if prepare_backward and cap and shs is None:   # scratch sized like the binning buffers: from the last call
@@ -298,14 +306,14 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
                                    _ptr(col_shared), col_views, _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
                                    _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
-                                   _ptr_array(images), _ptr(batch), _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
+                                   _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
         if rc not in (0, 1):
             _check(rc, "gsr_forward_batch")
         need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
         if rc == 1:
-            binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) for v in range(V)]
+            binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) if owner[v] else None for v in range(V)]
             _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                                _ptr(batch), _ptr_array(color_v), _ptr_array(depth_v), st),
+                                                _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), st),
                    "gsr_forward_render_batch")
         if rc == 1 or need * 2 < cap:
             _binning_capacity[key] = int(need * _BINNING_SLACK)
@@ -319,6 +327,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         state.geom, state.binning, state.image, state.H, state.W = geoms[v], binnings[v], images[v], H, W
         state.pre = pre if v == 0 else None
         state.batch = batch if v == 0 else None
+        state.geometry_of = geometry_of if v == 0 else None
         states.append(state)
     return color, radii, depth, states
 
@@ -357,7 +366,8 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
                                       _ptr(None if per_view_col else colors_precomp),
                                       _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
                                       _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
-                                      _ptr(states[0].batch), per_view(g), _ptr_array(scratch), _ptr(d_means3D), per_view(d_means2D),
+                                      _ptr(states[0].batch), states[0].geometry_of, per_view(g), _ptr_array(scratch), _ptr(d_means3D),
+                                      per_view(d_means2D),
                                       _ptr(None if per_view_col else d_colors), per_view(d_colors) if per_view_col else None,
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")

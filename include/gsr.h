@@ -101,7 +101,10 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
  * Per-view colours (row N1 of SURVEY.md section 8f: the colour and the segmentation render of get_loss share the
  * geometry, /root/reference/src/tracking/train_utils.py:174-192): pass `colors_views` ([V] device pointers to [P,3],
  * with colors_precomp = shs = NULL) and every "view" blends its own colour array; the backward then writes one colour
- * gradient per view into `dL_dcolors_views` instead of the sum into `dL_dcolors`. */
+ * gradient per view into `dL_dcolors_views` instead of the sum into `dL_dcolors`.
+ * `geometry_of` ([V] or NULL): geometry_of[v] = u <= v declares that view v has the SAME camera as the earlier view u
+ * (geometry_of[u] = u) and differs only in its colours.  View v then uses u's tile lists: nothing is emitted, sorted or
+ * ranged for it (binning_states[v] may be NULL), and its entry count equals u's. */
 #define GSR_MAX_BATCH 16
 size_t gsr_batch_state_bytes(int32_t V, int32_t P, int32_t image_height, int32_t image_width);
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -111,7 +114,8 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             void* batch_state, float* const* out_color, float* const* out_depth, void* stream);
+                             void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                             void* stream);
 /* Both forward stages in ONE call: preprocess all views, synchronise once for the duplicate counts, and -- when
  * every view's binning state fits the buffer the caller provided (binning_bytes[v] >= gsr_binning_bytes(D_v)) --
  * launch the render stage straight away, with no host round trip through the caller in between (that round trip
@@ -123,8 +127,8 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       const float* const* colors_views, const float* shs, const float* cov3D_precomp,
                       void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
-                      void* batch_state, float* const* out_color, float* const* out_depth, uint32_t* num_rendered_host,
-                      void* stream);
+                      void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                      uint32_t* num_rendered_host, void* stream);
 /* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): ONE blend-backward launch
  * over the combined tile queue, then ONE per-Gaussian kernel that loops over the views and writes the
  * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */
@@ -132,7 +136,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
                        void* const* binning_states, void* const* image_states, void* batch_state,
-                       const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
+                       const int32_t* geometry_of, const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
                        float* const* dL_dmeans2D, float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity,
                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 

@@ -576,8 +576,23 @@ def test_per_view_colours_share_geometry(dev):
     b = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
     cb = cols.repeat(2, 1, 1).clone().requires_grad_(True)                                # [4,P,3]
     m2 = torch.zeros((4, P, 3), device=dev, requires_grad=True)
-    imb, radb, _ = rasterize_gaussians_views([cams[0], cams[0], cams[1], cams[1]], b["means3D"], m2, b["opacities"],
-                                             colors_precomp=cb, scales=b["scales"], rotations=b["rotations"])
+    from diff_gaussian_rasterization import _hip
+    seen_states = {}
+    orig = _hip.rasterize_forward_batch
+
+    def spy(*a_, **k_):
+        out = orig(*a_, **k_)
+        seen_states["s"] = out[3]
+        return out
+    _hip.rasterize_forward_batch = spy
+    try:
+        imb, radb, _ = rasterize_gaussians_views([cams[0], cams[0], cams[1], cams[1]], b["means3D"], m2, b["opacities"],
+                                                 colors_precomp=cb, scales=b["scales"], rotations=b["rotations"])
+    finally:
+        _hip.rasterize_forward_batch = orig
+    st = seen_states["s"]   # views 1 and 3 have the cameras of views 0 and 2: they own no binning state (shared tile lists)
+    assert list(st[0].geometry_of) == [0, 0, 2, 2] and st[1].binning is None and st[3].binning is None
+    assert st[0].binning is not None and st[1].num_rendered == st[0].num_rendered
     imb.backward(gradient=dL)
     torch.cuda.synchronize()
     assert torch.equal(imb.detach(), torch.stack(ims))
