@@ -411,6 +411,21 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                                          dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, st);
 }
 
+int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
+  if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }
+  if (npoints > N || (N > 0 && (start_idx < 0 || start_idx >= N))) { gsr_set_error("gsr_fps: npoints / start_idx out of range"); return -2; }
+  return gsr_launch_fps(N, pos, npoints, start_idx, scratch, (long long*)out_idx, (hipStream_t)stream);
+}
+
+int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
+            const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream) {
+  if (P < 0 || n_bones <= 0 || !bones || !rotations || !translations || !bone_quats || (P > 0 && (!xyz || !out_xyz))) {
+    gsr_set_error("gsr_lbs: bad argument");
+    return -2;
+  }
+  return gsr_launch_lbs(P, n_bones, bones, rotations, translations, bone_quats, xyz, quat, out_xyz, out_quat, (hipStream_t)stream);
+}
+
 int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * ((H + 15) / 16) * ((W + 15) / 16); }
 
 int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,

@@ -226,6 +226,9 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
                               const float* fC, const float* fE, const float* grad_loss, float w_l1, float w_ssim, float* dx,
                               hipStream_t st);
+int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st);
+int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
+                   const float* quat, float* out_xyz, float* out_quat, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
 int gsr_debug_fwd_timing(unsigned long long* out16);

@@ -44,7 +44,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_backward_batch", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward")
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs")
 
 
 def load_library():
@@ -90,6 +90,10 @@ def load_library():
     lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
     lib.gsr_image_loss_backward.restype = C.c_int
     lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [C.c_float, C.c_float, vp, vp]
+    lib.gsr_fps.restype = C.c_int
+    lib.gsr_fps.argtypes = [i32, vp, i32, i32, vp, vp, vp]
+    lib.gsr_lbs.restype = C.c_int
+    lib.gsr_lbs.argtypes = [i32, i32] + [vp] * 8 + [vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [vp, i32, vp, vp, vp]
     lib.gsr_debug_get_views.restype = C.c_int
@@ -372,6 +376,35 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None
+
+
+def farthest_point_sampling(pos: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
+    """pos [N,3] fp32 on a HIP device -> int64 indices [npoints] (gsr_fps)."""
+    lib = load_library()
+    _require_device(pos)
+    N = int(pos.shape[0])
+    with torch.cuda.device(pos.device):
+        scratch = torch.empty((max(N, 1),), dtype=torch.float32, device=pos.device)
+        out = torch.empty((npoints,), dtype=torch.int64, device=pos.device)
+        _check(lib.gsr_fps(N, _ptr(pos), int(npoints), int(start_idx), _ptr(scratch), _ptr(out), _stream(pos.device)), "gsr_fps")
+    return out
+
+
+def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat):
+    """gsr_lbs: returns (xyz_new [P,3], quat_new [P,4] or None, None) -- the [P, n_bones] weight matrix of the reference is
+    never materialised."""
+    lib = load_library()
+    _require_device(xyz)
+    dev = xyz.device
+    P, nb = int(xyz.shape[0]), int(bones.shape[0])
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    bones, rotations, translations, bone_quats = f(bones), f(rotations).reshape(nb, 9), f(translations), f(bone_quats)
+    with torch.cuda.device(dev):
+        out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None
+        _check(lib.gsr_lbs(P, nb, _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
+                           _ptr(out_xyz), _ptr(out_q), _stream(dev)), "gsr_lbs")
+    return out_xyz, out_q, None
 
 
 def mark_visible(positions, viewmatrix) -> torch.Tensor:

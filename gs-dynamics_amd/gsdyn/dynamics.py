@@ -1,0 +1,354 @@
+"""Graph building, one GNN rollout step and motion interpolation -- SURVEY.md section 8f row N4: the plumbing between
+a tracked Gaussian scene and the rasterizer in the reference's ``predict.py`` path
+(/root/reference/src/render/dynamics_module.py:44-170).
+
+Re-designed rather than transcribed:
+  * relations are INDEX lists (receiver[e], sender[e]) -- the reference builds dense one-hot ``Rr/Rs`` matrices and moves
+    information with ``bmm`` (/root/reference/src/gnn/model.py:175-229); here message passing is gather + ``index_add_``.
+    ``edges_to_dense`` gives the reference's matrices back (same row order) and ``DynamicsPredictor`` accepts either form;
+  * ``DynamicsPredictor`` keeps the reference's parameter names, so its checkpoints load with ``load_state_dict``;
+  * ``interpolate_motions`` fits all bone rotations at once (batched 3x3 covariances via ``index_add_``, one batched SVD on
+    the host -- the matrices are tiny and the rank-1 branch of the reference depends on the SVD's sign convention, which
+    only a fixed backend pins) and skins the Gaussians with one fused HIP kernel (``gsr_lbs``) instead of a Python loop over
+    bones that materialises [n_particles, n_bones, 3];
+  * farthest point sampling is a HIP kernel (``gsr_fps``); DGL, which the reference uses for it, is a third-party
+    dependency that is absent here, so its tie rule (first maximum) is our choice, not a pinned behaviour.
+Every function also runs on CPU tensors in plain torch (that is how the golden vectors captured from the imported reference
+are checked without a GPU); on a HIP device the two kernels take over.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+
+# ------------------------------------------------------------------------------------------ sampling
+def farthest_point_sampler(pos: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:
+    """pos [B,N,3] -> indices [B,npoints] (int64).  First pick = ``start_idx``; every further pick maximises the squared
+    distance to the picked set, first maximum on ties (role of ``dgl.geometry.farthest_point_sampler``,
+    /root/reference/src/render/dynamics_module.py:46,65)."""
+    B, N, _ = pos.shape
+    npoints = min(int(npoints), N)
+    if pos.is_cuda:
+        from diff_gaussian_rasterization import _hip
+        return torch.stack([_hip.farthest_point_sampling(pos[b].float().contiguous(), npoints, start_idx) for b in range(B)])
+    out = torch.zeros((B, npoints), dtype=torch.long)
+    for b in range(B):
+        p = pos[b].float()
+        mind = torch.full((N,), float("inf"))
+        cur = int(start_idx)
+        for k in range(npoints):
+            out[b, k] = cur
+            d = ((p - p[cur]) ** 2).sum(-1)
+            mind = torch.minimum(mind, d)
+            cur = int(torch.argmax(mind))          # torch.argmax returns the first maximum
+    return out
+
+
+def fps_radius(pcd: torch.Tensor, radius: float, start_idx: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Keep adding the farthest point until every point lies within ``radius`` of the picked set
+    (/root/reference/src/data/utils.py:50-65; the reference draws the first index at random, here it is an argument).
+    Returns (points [M,3], indices [M])."""
+    idx = [int(start_idx)]
+    dist = torch.norm(pcd - pcd[idx[0]], dim=1)
+    while float(dist.max()) > radius:
+        nxt = int(dist.argmax())
+        idx.append(nxt)
+        dist = torch.minimum(dist, torch.norm(pcd - pcd[nxt], dim=1))
+    ii = torch.tensor(idx, device=pcd.device)
+    return pcd[ii], ii
+
+
+# ------------------------------------------------------------------------------------------ relations
+def construct_edges(states: torch.Tensor, adj_thresh: float, mask: torch.Tensor, tool_mask: torch.Tensor, topk: int = 10,
+                    connect_all: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Relations between particles as index lists (receiver, sender), ordered like the rows of the reference's ``Rr/Rs``
+    (/root/reference/src/data/dataset.py:88-147): a pair is related when both particles are valid, not both tools, closer
+    than ``adj_thresh`` and -- among object particles -- the sender is one of the receiver's ``topk`` nearest (itself
+    included); ``connect_all`` relates every valid particle with every tool in both directions.  Tool particles are the
+    last rows, as in the reference."""
+    N = states.shape[0]
+    dis = ((states[:, None, :] - states[None, :, :]) ** 2).sum(-1)
+    valid = mask[:, None] & mask[None, :]
+    tools = tool_mask[:, None] & tool_mask[None, :]
+    dis = torch.where(valid & ~tools, dis, torch.full_like(dis, 1e10))
+    adj = dis < adj_thresh * adj_thresh
+    n_tool = int(tool_mask.sum())
+    n_obj = N - n_tool
+    k = min(N, int(topk))
+    near = torch.topk(dis[:n_obj, :n_obj], k=min(k, n_obj), dim=-1, largest=False)[1]
+    keep = torch.zeros((n_obj, n_obj), dtype=torch.bool, device=states.device)
+    keep.scatter_(1, near, True)
+    adj[:n_obj, :n_obj] &= keep
+    if connect_all:
+        adj = adj | (tool_mask[:, None] & mask[None, :]) | (mask[:, None] & tool_mask[None, :])
+        adj = adj & ~tools
+    rel = adj.nonzero()
+    return rel[:, 0].contiguous(), rel[:, 1].contiguous()
+
+
+def edges_to_dense(receivers: torch.Tensor, senders: torch.Tensor, N: int, dtype=torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The reference's one-hot matrices Rr, Rs [n_rel, N]."""
+    n = receivers.shape[0]
+    Rr = torch.zeros((n, N), dtype=dtype, device=receivers.device)
+    Rs = torch.zeros((n, N), dtype=dtype, device=receivers.device)
+    ar = torch.arange(n, device=receivers.device)
+    Rr[ar, receivers] = 1
+    Rs[ar, senders] = 1
+    return Rr, Rs
+
+
+def relations_to_matrix(receivers: torch.Tensor, senders: torch.Tensor, N: int) -> torch.Tensor:
+    """[N,N] 0/1 matrix of the relations (/root/reference/src/render/utils.py:129-136)."""
+    m = torch.zeros((N, N), dtype=torch.long, device=receivers.device)
+    m[receivers, senders] = 1
+    return m
+
+
+# ------------------------------------------------------------------------------------------ GNN
+class _MLP3(nn.Module):      # Linear-ReLU x3, parameters under ``model.{0,2,4}`` like the reference's Encoder
+    def __init__(self, i, h, o):
+        super().__init__()
+        self.model = nn.Sequential(nn.Linear(i, h), nn.ReLU(), nn.Linear(h, h), nn.ReLU(), nn.Linear(h, o), nn.ReLU())
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _Prop(nn.Module):      # relu(linear(x) [+ res]), parameter under ``linear``
+    def __init__(self, i, o):
+        super().__init__()
+        self.linear = nn.Linear(i, o)
+
+    def forward(self, x, res=None):
+        y = self.linear(x)
+        return torch.relu(y if res is None else y + res)
+
+
+class _Head(nn.Module):      # parameters ``linear_0/1/2``
+    def __init__(self, i, h, o):
+        super().__init__()
+        self.linear_0, self.linear_1, self.linear_2 = nn.Linear(i, h), nn.Linear(h, h), nn.Linear(h, o)
+
+    def forward(self, x):
+        return self.linear_2(torch.relu(self.linear_1(torch.relu(self.linear_0(x)))))
+
+
+class DynamicsPredictor(nn.Module):
+    """Propagation-network particle dynamics (/root/reference/src/gnn/model.py:70-246) on index-form relations.
+    ``model_config`` keys as in /root/reference/src/config/rope.yaml (+ ``n_his``)."""
+
+    def __init__(self, model_config: Dict, device=None):
+        super().__init__()
+        c = self.model_config = dict(model_config)
+        self.motion_dim = int(c.get("motion_dim", 0))
+        self.motion_clamp = 100.0
+        nf_p, nf_r, nf_e = c["nf_particle"], c["nf_relation"], c["nf_effect"]
+        in_dim = c["n_his"] * c["state_dim"] + (c["n_his"] - 1) * self.motion_dim + c["attr_dim"] + c["action_dim"]
+        rel_dim = 2 * c["rel_attr_dim"] + c["rel_group_dim"] + c["rel_distance_dim"] * c["n_his"]
+        self.particle_encoder = _MLP3(in_dim, nf_p, nf_e)
+        self.relation_encoder = _MLP3(rel_dim, nf_r, nf_e)
+        self.particle_propagator = _Prop(2 * nf_e, nf_e)
+        self.relation_propagator = _Prop(3 * nf_e, nf_e)
+        self.non_rigid_predictor = _Head(nf_e, nf_e, 3)
+        if device is not None:
+            self.to(device)
+
+    @staticmethod
+    def _indices(Rr, Rs):
+        """Dense one-hot [B,n_rel,N] -> index form [B,n_rel] (rows that are all zero -- padding -- get weight 0)."""
+        return Rr.argmax(-1), Rs.argmax(-1), (Rr.sum(-1) > 0).to(Rr.dtype)
+
+    def forward(self, state, attrs, p_instance, action=None, Rr=None, Rs=None, receivers=None, senders=None, **_):
+        c = self.model_config
+        B, N = attrs.shape[0], attrs.shape[1]
+        n_p = p_instance.shape[1]
+        n_his = c["n_his"]
+        if receivers is None:
+            receivers, senders, w = self._indices(Rr, Rs)
+        else:
+            if receivers.dim() == 1:
+                receivers, senders = receivers[None].expand(B, -1), senders[None].expand(B, -1)
+            w = torch.ones(receivers.shape, dtype=attrs.dtype, device=attrs.device)
+        bidx = torch.arange(B, device=attrs.device)[:, None]
+        take = lambda x, idx: x[bidx, idx]                           # noqa: E731  [B,N,F] , [B,E] -> [B,E,F]
+        state_t = state.transpose(1, 2).reshape(B, N, n_his * state.shape[3])
+        parts = [attrs]
+        if c["state_dim"] == 3:
+            parts.append(state_t)
+        elif c["state_dim"] == 1:
+            parts.append(state_t.view(B, N, n_his, 3)[..., 2])
+        if self.motion_dim > 0:
+            s4 = state_t.view(B, N, n_his, 3)
+            parts.append((s4[:, :, 1:] - s4[:, :, :-1]).reshape(B, N, (n_his - 1) * 3))
+        if c["action_dim"] > 0:
+            parts.append(action)
+        p_inputs = torch.cat(parts, 2)
+        rel_parts = []
+        if c["rel_attr_dim"] > 0:
+            rel_parts += [take(attrs, receivers), take(attrs, senders)]
+        if c["rel_group_dim"] > 0:
+            g = torch.cat([p_instance, torch.zeros(B, N - n_p, p_instance.shape[2], dtype=attrs.dtype, device=attrs.device)], 1)
+            rel_parts.append((take(g, receivers) - take(g, senders)).abs().sum(2, keepdim=True))
+        if c["rel_distance_dim"] > 0:
+            rel_parts.append(take(state_t, receivers) - take(state_t, senders))
+        rel_inputs = torch.cat(rel_parts, 2) * w[..., None]
+        particle_encode = self.particle_encoder(p_inputs)
+        relation_encode = self.relation_encoder(rel_inputs)
+        effect = particle_encode
+        for _ in range(c["pstep"]):
+            e_rel = self.relation_propagator(torch.cat([relation_encode, take(effect, receivers) * w[..., None],
+                                                        take(effect, senders) * w[..., None]], 2))
+            agg = torch.zeros_like(effect)
+            agg.scatter_add_(1, receivers[..., None].expand(-1, -1, effect.shape[2]), e_rel * w[..., None])
+            effect = self.particle_propagator(torch.cat([particle_encode, agg], 2), res=effect)
+        pred_motion = self.non_rigid_predictor(effect[:, :n_p])
+        pred_pos = state[:, -1, :n_p] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
+        return pred_pos, pred_motion
+
+
+# ------------------------------------------------------------------------------------------ rotations
+def quat2mat(q: torch.Tensor) -> torch.Tensor:
+    """(w,x,y,z) -> rotation matrices, normalising first (/root/reference/src/render/utils.py:50-68)."""
+    q = q / q.norm(dim=-1, keepdim=True)
+    r, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
+
+
+def mat2quat(R: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices -> (w,x,y,z), branch on the trace / the largest diagonal element with the reference's
+    comparisons (/root/reference/src/render/utils.py:71-111): not normalised, w >= 0 on the trace branch."""
+    m = lambda i, j: R[..., i, j]  # noqa: E731
+    t = torch.clamp(m(0, 0) + m(1, 1) + m(2, 2), min=-1)
+    b0 = t > -1
+    b1 = ~b0 & (m(0, 0) >= m(1, 1)) & (m(0, 0) >= m(2, 2))
+    b2 = ~b0 & (m(1, 1) >= m(2, 2)) & (m(1, 1) > m(0, 0))
+    s0 = torch.sqrt(torch.where(b0, t + 1, torch.ones_like(t)))
+    s1 = torch.sqrt(torch.clamp(1 + m(0, 0) - m(1, 1) - m(2, 2), min=1e-30))
+    s2 = torch.sqrt(torch.clamp(1 + m(1, 1) - m(0, 0) - m(2, 2), min=1e-30))
+    s3 = torch.sqrt(torch.clamp(1 + m(2, 2) - m(0, 0) - m(1, 1), min=1e-30))
+    q0 = torch.stack([0.5 * s0, (m(2, 1) - m(1, 2)) * (0.5 / s0), (m(0, 2) - m(2, 0)) * (0.5 / s0), (m(1, 0) - m(0, 1)) * (0.5 / s0)], -1)
+    h1, h2, h3 = 0.5 / s1, 0.5 / s2, 0.5 / s3
+    q1 = torch.stack([(m(2, 1) - m(1, 2)) * h1, 0.5 * h1, (m(1, 0) + m(0, 1)) * h1, (m(2, 0) + m(0, 2)) * h1], -1)
+    q2 = torch.stack([(m(0, 2) - m(2, 0)) * h2, (m(2, 1) + m(1, 2)) * h2, 0.5 * h2, (m(0, 1) + m(1, 0)) * h2], -1)
+    q3 = torch.stack([(m(1, 0) - m(0, 1)) * h3, (m(0, 2) + m(2, 0)) * h3, (m(1, 2) + m(2, 1)) * h3, 0.5 * h3], -1)
+    return torch.where(b0[..., None], q0, torch.where(b1[..., None], q1, torch.where(b2[..., None], q2, q3)))
+
+
+def quat_multiply(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
+    w1, x1, y1, z1 = q1.unbind(-1)
+    w2, x2, y2, z2 = q2.unbind(-1)
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+
+
+# ------------------------------------------------------------------------------------------ motion interpolation
+def fit_bone_rotations(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor) -> torch.Tensor:
+    """One rotation per bone from how its related bones move around it (/root/reference/src/render/utils.py:147-205):
+    F_i = sum_j (new_j - new_i)(old_j - old_i)^T over the bones j related to i, then by the rank of F_i
+      0 neighbours -> identity;  rank 1 -> the rotation taking the x axis onto the dominant left singular vector;
+      otherwise the Kabsch rotation U S V^T, with the reference's quirks kept: for a full-rank F with negative determinant
+      its index error falls back to the identity, and a result with det = -1 is repaired by flipping S[rank, rank].
+    The 3x3 problems are solved on the host in one batched SVD (see the module docstring)."""
+    nb = bones.shape[0]
+    dev = bones.device
+    rel = relations.to(torch.bool)
+    i_idx, j_idx = rel.nonzero(as_tuple=True)
+    old = (bones[j_idx] - bones[i_idx]).float()
+    new = ((bones[j_idx] + motions[j_idx]) - (bones[i_idx] + motions[i_idx])).float()
+    F = torch.zeros((nb, 3, 3), dtype=torch.float32, device=dev)
+    F.index_add_(0, i_idx, new[:, :, None] * old[:, None, :])
+    n_adj = rel.sum(1).cpu()
+    F = F.cpu()
+    U, S, Vh = torch.linalg.svd(F)
+    V = Vh.transpose(1, 2)
+    eps = torch.finfo(torch.float32).eps
+    rank = (S > S.max(dim=1, keepdim=True).values * 3 * eps).sum(1)
+    detF = torch.linalg.det(F)
+    eye = torch.eye(3)
+    R = torch.empty((nb, 3, 3))
+    for i in range(nb):                               # decision tree per bone; the linear algebra above is batched
+        if int(n_adj[i]) == 0:
+            R[i] = eye
+            continue
+        r = int(rank[i])
+        if r == 1:
+            axis, x = U[i][:, 0], torch.tensor([1.0, 0.0, 0.0])
+            perp = torch.linalg.cross(axis, x)
+            if float(perp.norm()) < 1e-6:
+                R[i] = eye
+            else:
+                perp = perp / perp.norm()
+                X = torch.stack([x, perp, torch.linalg.cross(x, perp)], 1)
+                Y = torch.stack([axis, perp, torch.linalg.cross(axis, perp)], 1)
+                R[i] = Y @ X.T
+            continue
+        Sg = torch.eye(3)
+        if float(detF[i]) < 0:
+            if r > 2:                                  # S[3,3] does not exist: the reference's try/except yields the identity
+                R[i] = eye
+                continue
+            Sg[r, r] = -1
+        Ri = U[i] @ Sg @ V[i].T
+        if abs(float(torch.linalg.det(Ri)) - 1) > 1e-3 and abs(float(torch.linalg.det(Ri)) + 1) < 1e-3 and r <= 2:
+            Sg[r, r] *= -1
+            Ri = U[i] @ Sg @ V[i].T
+        R[i] = Ri
+    return R.to(dev)
+
+
+def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None):
+    """Move every Gaussian with the bones (/root/reference/src/render/utils.py:138-243): per-bone rigid transform
+    (rotation from ``fit_bone_rotations``, translation = the bone's motion), blended with inverse-distance weights
+    (distance clamped at 1e-4); orientations: weighted sum of the bones' unit quaternions, normalised, times the Gaussian's
+    quaternion.  Returns (xyz_new [P,3], quat_new [P,4] or None, weights [P,n_bones])."""
+    R = fit_bone_rotations(bones, motions, relations)
+    base_q = torch.nn.functional.normalize(mat2quat(R), dim=-1)
+    if xyz.is_cuda and weights is None:
+        from diff_gaussian_rasterization import _hip
+        return _hip.linear_blend_skinning(bones.float().contiguous(), R.contiguous(), motions.float().contiguous(), base_q.contiguous(),
+                                          xyz.float().contiguous(), None if quat is None else quat.float().contiguous())
+    if weights is None:
+        d = torch.clamp(torch.cdist(xyz[None].float(), bones[None].float())[0], min=1e-4)
+        weights = 1.0 / d
+        weights = weights / weights.sum(1, keepdim=True)
+    moved = torch.einsum("pbk,bjk->pbj", xyz[:, None, :] - bones[None], R) + motions[None] + bones[None]
+    xyz_new = (moved * weights[:, :, None]).sum(1)
+    rot = None
+    if quat is not None:
+        q = torch.nn.functional.normalize((base_q[None] * weights[:, :, None]).sum(1), dim=-1)
+        rot = quat_multiply(q, quat)
+    return xyz_new, rot, weights
+
+
+# ------------------------------------------------------------------------------------------ one rollout step
+@torch.no_grad()
+def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_history: torch.Tensor, eef_next: torch.Tensor,
+                 all_xyz: torch.Tensor, all_quat: torch.Tensor, adj_thresh: float, topk: int, connect_all: bool = False):
+    """One step of /root/reference/src/render/dynamics_module.py:99-170: graph on the last positions, GNN prediction of the
+    object particles, interpolation of all Gaussians.  particle_history [n_his,nobj,3], eef_history [n_his,1,3],
+    eef_next [1,3].  Returns (pred_particles [nobj,3], xyz_new, quat_new, (receivers, senders))."""
+    dev = particle_history.device
+    n_his, nobj = particle_history.shape[0], particle_history.shape[1]
+    states = torch.zeros((1, n_his, nobj + 1, 3), device=dev)
+    states[0, :, :nobj] = particle_history
+    states[0, :, nobj:] = eef_history
+    action = torch.zeros((1, nobj + 1, 3), device=dev)
+    action[0, nobj:] = eef_next - eef_history[-1]
+    attrs = torch.zeros((1, nobj + 1, 2), device=dev)
+    attrs[0, :nobj, 0] = 1.0
+    attrs[0, nobj:, 1] = 1.0
+    mask = torch.ones(nobj + 1, dtype=torch.bool, device=dev)
+    tool = torch.zeros(nobj + 1, dtype=torch.bool, device=dev)
+    tool[nobj] = True
+    recv, send = construct_edges(states[0, -1], adj_thresh, mask, tool, topk=topk, connect_all=connect_all)
+    pred, _ = model(state=states, attrs=attrs, p_instance=torch.ones((1, nobj, 1), device=dev), action=action,
+                    receivers=recv, senders=send)
+    bones = particle_history[-1]
+    rel = relations_to_matrix(recv, send, nobj + 1)[:nobj, :nobj]
+    xyz_new, quat_new, _ = interpolate_motions(bones, pred[0] - bones, rel, all_xyz, quat=all_quat)
+    return pred[0], xyz_new, quat_new, (recv, send)

@@ -140,6 +140,17 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        float* const* dL_dmeans2D, float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity,
                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 
+/* ---- rollout plumbing (callers: gsdyn/dynamics.py)
+ * gsr_fps: farthest point sampling of pos[N,3] -> out_idx[npoints] (int64), first pick start_idx, every further pick the
+ *   point with the largest squared distance to the picked set (first maximum on ties).  Stands in for
+ *   dgl.geometry.farthest_point_sampler (/root/reference/src/render/dynamics_module.py:46,65).  scratch: N floats.
+ * gsr_lbs: moves P Gaussians with n_bones bones (/root/reference/src/render/utils.py:207-239): weights 1/max(|x - bone|, 1e-4)
+ *   normalised over the bones; out_xyz = sum_b w_b (R_b (x - bone_b) + t_b + bone_b); out_quat = normalise(sum_b w_b q_b) * quat
+ *   (quaternions w,x,y,z; rotations row-major 3x3; quat / out_quat may be NULL). */
+int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream);
+int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
+            const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);
+
 /* ---- fused image loss of the tracking step (caller side of the path):
  *   loss = w_l1 * mean|pred - target| + w_ssim * (1 - mean SSIM(pred, target)),  SSIM with the reference's 11x11
  *   Gaussian window (sigma 1.5, zero padding): /root/reference/src/tracking/external.py:101-135, used at

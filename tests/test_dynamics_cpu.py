@@ -1,0 +1,116 @@
+"""CPU tests of the rollout plumbing against golden vectors captured from the imported
+reference (tests/golden/gen_dynamics_goldens.py -> dynamics_host.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+
+
+def _edge_inputs(gold):
+    states = torch.tensor(gold["edge_states"])
+    N = states.shape[0]
+    mask = torch.ones(N, dtype=torch.bool)
+    tool = torch.zeros(N, dtype=torch.bool)
+    tool[N - 1] = True
+    return states, mask, tool
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_relations_match_reference(gold, case):
+    from gsdyn.dynamics import construct_edges, edges_to_dense, relations_to_matrix
+    states, mask, tool = _edge_inputs(gold)
+    thr, topk, call = gold[f"edge_{case}_cfg"]
+    recv, send = construct_edges(states, float(thr), mask, tool, topk=int(topk), connect_all=bool(call))
+    Rr, Rs = edges_to_dense(recv, send, states.shape[0])
+    assert np.array_equal(Rr.numpy(), gold[f"edge_{case}_Rr"]) and np.array_equal(Rs.numpy(), gold[f"edge_{case}_Rs"])
+    assert np.array_equal(relations_to_matrix(recv, send, states.shape[0]).numpy(), gold[f"edge_{case}_rel"])
+
+
+def _model(gold):
+    from gsdyn.dynamics import DynamicsPredictor
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = DynamicsPredictor(cfg)
+    sd = {k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")}
+    model.load_state_dict(sd, strict=True)      # the reference's parameter names load unchanged
+    return model.eval()
+
+
+def test_dynamics_predictor_matches_reference_dense_and_index_form(gold):
+    from gsdyn.dynamics import construct_edges
+    model = _model(gold)
+    state, action, attrs = (torch.tensor(gold[k]) for k in ("gnn_state", "gnn_action", "gnn_attrs"))
+    N = attrs.shape[1]
+    p_instance = torch.ones(1, N - 1, 1)
+    Rr, Rs = torch.tensor(gold["edge_a_Rr"])[None], torch.tensor(gold["edge_a_Rs"])[None]
+    with torch.no_grad():
+        pos_d, mot_d = model(state=state, attrs=attrs, p_instance=p_instance, action=action, Rr=Rr, Rs=Rs)
+        states, mask, tool = _edge_inputs(gold)
+        recv, send = construct_edges(states, 0.08, mask, tool, topk=5, connect_all=False)
+        pos_i, mot_i = model(state=state, attrs=attrs, p_instance=p_instance, action=action, receivers=recv, senders=send)
+    np.testing.assert_allclose(pos_d.numpy(), gold["gnn_pred_pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mot_d.numpy(), gold["gnn_pred_motion"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pos_i.numpy(), gold["gnn_pred_pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mot_i.numpy(), gold["gnn_pred_motion"], rtol=1e-4, atol=1e-6)
+
+
+def test_quaternion_helpers_match_reference(gold):
+    from gsdyn.dynamics import mat2quat, quat2mat
+    q = torch.tensor(gold["q_in"])
+    R = quat2mat(q)
+    np.testing.assert_allclose(R.numpy(), gold["q_mat"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(mat2quat(torch.tensor(gold["q_mat"])).numpy(), gold["q_back"], rtol=1e-5, atol=1e-6)
+    # all four branches of mat2quat: rotations by pi about x, y, z have trace -1
+    for axis in range(3):
+        Rm = -torch.eye(3)
+        Rm[axis, axis] = 1.0
+        qq = mat2quat(Rm[None])[0]              # un-normalised like the reference's (its callers normalise)
+        expect = torch.zeros(4)
+        expect[axis + 1] = 1.0
+        np.testing.assert_allclose(torch.nn.functional.normalize(qq, dim=0).abs().numpy(), expect.numpy(), atol=1e-6)
+
+
+def test_interpolate_motions_matches_reference(gold):
+    from gsdyn.dynamics import interpolate_motions
+    t = lambda k: torch.tensor(gold[k])  # noqa: E731
+    xyz_new, rot_new, weights = interpolate_motions(t("im_bones"), t("im_motions"), t("im_rel"), t("im_xyz"), quat=t("im_quat"))
+    np.testing.assert_allclose(weights.numpy(), gold["im_weights"], rtol=2e-4, atol=1e-7)   # the reference's cdist uses the mm form
+    np.testing.assert_allclose(xyz_new.numpy(), gold["im_xyz_new"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rot_new.numpy(), gold["im_rot_new"], rtol=1e-4, atol=2e-6)
+
+
+def test_radius_fps_matches_reference_and_fps_properties(gold):
+    from gsdyn.dynamics import farthest_point_sampler, fps_radius
+    pts = torch.tensor(gold["fpsr_pts"])
+    sel, idx = fps_radius(pts, 0.03, start_idx=3)
+    assert np.array_equal(idx.numpy(), gold["fpsr_idx"])
+    np.testing.assert_allclose(sel.numpy(), gold["fpsr_sel"])
+    # farthest point sampling (DGL's routine is not pinned): start index first, no repeats, greedy max-min property
+    pick = farthest_point_sampler(pts[None], 20, start_idx=5)[0]
+    assert int(pick[0]) == 5 and len(set(pick.tolist())) == 20
+    d = torch.cdist(pts, pts) ** 2
+    mind = torch.full((pts.shape[0],), float("inf"))
+    for k in range(19):
+        mind = torch.minimum(mind, d[pick[k]])
+        assert float(mind[pick[k + 1]]) == float(mind.max())
+
+
+def test_rollout_step_runs_and_is_consistent(gold):
+    from gsdyn.dynamics import rollout_step
+    model = _model(gold)
+    states, _, _ = _edge_inputs(gold)
+    nobj = states.shape[0] - 1
+    hist = torch.stack([states[:nobj] + 0.002 * i for i in range(3)])
+    eef_hist = states[nobj:][None].repeat(3, 1, 1)
+    g = torch.Generator().manual_seed(1)
+    xyz = states[:nobj][torch.randint(0, nobj, (500,), generator=g)] + 0.01 * torch.randn(500, 3, generator=g)
+    quat = torch.nn.functional.normalize(torch.randn(500, 4, generator=g), dim=-1)
+    pred, xyz_new, quat_new, (recv, send) = rollout_step(model, hist, eef_hist, states[nobj:] + 0.01, xyz, quat, 0.08, 5)
+    assert pred.shape == (nobj, 3) and xyz_new.shape == xyz.shape and quat_new.shape == quat.shape
+    assert torch.isfinite(xyz_new).all() and torch.allclose(quat_new.norm(dim=-1), torch.ones(500), atol=1e-5)
+    assert recv.shape == send.shape and recv.numel() > nobj          # at least the self relations

@@ -1,0 +1,99 @@
+"""GPU tests of the rollout plumbing kernels (gsr_fps, gsr_lbs) through the C-ABI, against the plain-torch restatements
+in gsdyn/dynamics.py (which the CPU tests pin on the reference's golden vectors)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("N,npoints,start", [(37, 37, 0), (3491, 1000, 0), (100_000, 1000, 17)])
+def test_fps_kernel_matches_host_restatement(dev, N, npoints, start):
+    from gsdyn.dynamics import farthest_point_sampler
+    g = torch.Generator().manual_seed(N)
+    pts = torch.rand(N, 3, generator=g) * torch.tensor([0.4, 0.2, 0.1])
+    got = farthest_point_sampler(pts[None].to(dev), npoints, start_idx=start)[0].cpu()
+    # host restatement with the kernel's operation order: (dx*dx + dy*dy) + dz*dz in fp32, first maximum
+    p = pts.numpy()
+    mind = np.full(N, np.inf, np.float32)
+    cur, want = start, []
+    for _ in range(npoints):
+        want.append(cur)
+        d = p - p[cur]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        mind = np.minimum(mind, d2.astype(np.float32))
+        cur = int(np.argmax(mind))
+    assert got.tolist() == want
+
+
+def test_lbs_kernel_matches_torch_path_and_goldens(dev, golden_dir):
+    from gsdyn.dynamics import interpolate_motions
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    t = lambda k: torch.tensor(gold[k])  # noqa: E731
+    xyz_new, rot_new, _ = interpolate_motions(t("im_bones").to(dev), t("im_motions").to(dev), t("im_rel").to(dev), t("im_xyz").to(dev),
+                                              quat=t("im_quat").to(dev))
+    np.testing.assert_allclose(xyz_new.cpu().numpy(), gold["im_xyz_new"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rot_new.cpu().numpy(), gold["im_rot_new"], rtol=1e-4, atol=2e-6)
+    # a Gaussian-scale cloud (100k particles, 300 bones: more than one LDS round) against the torch path on the host
+    g = torch.Generator().manual_seed(3)
+    nb, P = 300, 100_000
+    bones = torch.rand(nb, 3, generator=g)
+    motions = 0.02 * torch.randn(nb, 3, generator=g)
+    rel = (torch.cdist(bones, bones) < 0.15).long()
+    xyz = torch.rand(P, 3, generator=g)
+    quat = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)
+    a = interpolate_motions(bones.to(dev), motions.to(dev), rel.to(dev), xyz.to(dev), quat=quat.to(dev))
+    # fp64 evaluation of the same definition with direct distances (torch.cdist's matmul form, which the fp32 host path
+    # shares with the reference, loses digits for particles that sit almost on a bone)
+    from gsdyn.dynamics import fit_bone_rotations, mat2quat, quat_multiply
+    R = fit_bone_rotations(bones, motions, rel).double()
+    bq = torch.nn.functional.normalize(mat2quat(R.float()), dim=-1).double()
+    X, B, M = xyz.double(), bones.double(), motions.double()
+    want_xyz = torch.zeros(P, 3, dtype=torch.float64)
+    want_q = torch.zeros(P, 4, dtype=torch.float64)
+    for s0 in range(0, P, 10000):
+        x = X[s0:s0 + 10000]
+        d = torch.clamp((x[:, None] - B[None]).norm(dim=-1), min=1e-4)
+        w = 1.0 / d
+        w = w / w.sum(1, keepdim=True)
+        moved = torch.einsum("pbk,bjk->pbj", x[:, None] - B[None], R) + M[None] + B[None]
+        want_xyz[s0:s0 + 10000] = (moved * w[..., None]).sum(1)
+        want_q[s0:s0 + 10000] = quat_multiply(torch.nn.functional.normalize((bq[None] * w[..., None]).sum(1), dim=-1),
+                                              quat[s0:s0 + 10000].double())
+    np.testing.assert_allclose(a[0].cpu().numpy(), want_xyz.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(a[1].cpu().numpy(), want_q.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_rollout_step_feeds_the_rasterizer(dev, golden_dir):
+    """One step of the predict.py path on the device: sample bones, build relations, GNN, move the Gaussians, render."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    from gsdyn.dynamics import DynamicsPredictor, farthest_point_sampler, fps_radius, rollout_step
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    P = 20000
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04)
+    with torch.no_grad():
+        rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+    idx1 = farthest_point_sampler(rv["means3D"][None], 100, start_idx=0)[0]
+    bones0, idx2 = fps_radius(rv["means3D"][idx1], 0.3, start_idx=0)
+    nobj = bones0.shape[0]
+    hist = bones0[None].repeat(3, 1, 1)
+    eef = torch.tensor([[[0.0, 0.0, 0.0]]], device=dev).repeat(3, 1, 1)
+    pred, xyz_new, quat_new, _ = rollout_step(model, hist, eef, eef[-1] + 0.05, rv["means3D"], rv["rotations"], 0.6, 5)
+    assert pred.shape == (nobj, 3) and torch.isfinite(xyz_new).all() and torch.isfinite(quat_new).all()
+    cam = synth_ring_cameras(4, 160, 120, device=dev)[0]
+    im, radii, depth = GaussianRasterizer(raster_settings=cam)(means3D=xyz_new, means2D=torch.zeros_like(xyz_new), opacities=rv["opacities"],
+                                                               colors_precomp=rv["colors_precomp"], scales=rv["scales"],
+                                                               rotations=torch.nn.functional.normalize(quat_new, dim=-1))
+    assert im.shape == (3, 120, 160) and torch.isfinite(im).all() and int((radii > 0).sum()) > 0
