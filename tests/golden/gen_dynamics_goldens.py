@@ -107,6 +107,36 @@ def main():
         np.random.randint = orig
     out["fpsr_pts"], out["fpsr_idx"], out["fpsr_sel"] = pts.numpy(), idx.numpy(), sel.numpy()
 
+    # ---- BASELINE.json configs[0]: the rope demo cloud (assets/demo/pcd.ply, 3 491 points), 100 bones, ONE GNN step at the
+    # rope.yaml width (512) with seed-0 weights.  The weights are NOT stored (14 MB): a module that creates its Linear layers
+    # in the same order draws the same initial values from torch.manual_seed(0).
+    raw = open("/root/reference/assets/demo/pcd.ply", "rb").read()
+    body = raw[raw.index(b"end_header\n") + len(b"end_header\n"):]
+    rec = np.frombuffer(body, dtype=np.dtype([("xyz", "<f8", 3), ("rgb", "u1", 3)]), count=3491)
+    cloud = torch.tensor(rec["xyz"].astype(np.float32))
+    pick = [0]                                            # farthest point sampling, first maximum (DGL is absent)
+    mind = torch.full((cloud.shape[0],), float("inf"))
+    for _ in range(99):
+        mind = torch.minimum(mind, ((cloud - cloud[pick[-1]]) ** 2).sum(-1))
+        pick.append(int(torch.argmax(mind)))
+    bones = cloud[torch.tensor(pick)]
+    eef = bones.mean(0, keepdim=True) + torch.tensor([[0.0, 0.0, 0.05]])
+    st = torch.cat([bones, eef])
+    Nn = st.shape[0]
+    m1 = torch.ones(Nn, dtype=torch.bool); tm = torch.zeros(Nn, dtype=torch.bool); tm[-1] = True
+    Rr1, Rs1 = construct_edges(st.clone(), 0.08, mask=m1, tool_mask=tm, topk=5, connect_all=False)
+    cfg1 = dict(cfg, nf_particle=512, nf_relation=512, nf_effect=512)
+    torch.manual_seed(0)
+    model1 = DynamicsPredictor(dict(cfg1), "cpu").eval()
+    hist1 = st[None, None].repeat(1, n_his, 1, 1)
+    act1 = torch.zeros(1, Nn, 3); act1[0, -1] = torch.tensor([0.01, 0.0, -0.005])
+    at1 = torch.zeros(1, Nn, 2); at1[0, :-1, 0] = 1; at1[0, -1, 1] = 1
+    with torch.no_grad():
+        pp1, pm1 = model1(state=hist1, attrs=at1, Rr=Rr1[None], Rs=Rs1[None], p_instance=torch.ones(1, Nn - 1, 1), action=act1)
+    out["cfg1_cloud"], out["cfg1_pick"], out["cfg1_eef"], out["cfg1_action"] = cloud.numpy(), np.array(pick), eef.numpy(), act1.numpy()
+    out["cfg1_n_rel"] = np.array([Rr1.shape[0]])
+    out["cfg1_pred_pos"], out["cfg1_pred_motion"] = pp1.numpy(), pm1.numpy()
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(out), "arrays")
 

@@ -114,3 +114,31 @@ def test_rollout_step_runs_and_is_consistent(gold):
     assert pred.shape == (nobj, 3) and xyz_new.shape == xyz.shape and quat_new.shape == quat.shape
     assert torch.isfinite(xyz_new).all() and torch.allclose(quat_new.norm(dim=-1), torch.ones(500), atol=1e-5)
     assert recv.shape == send.shape and recv.numel() > nobj          # at least the self relations
+
+
+def test_baseline_config1_rope_demo_step(gold):
+    """BASELINE.json configs[0]: rope demo cloud -> 100 bones -> relations -> ONE DynamicsPredictor step at the rope.yaml
+    width with seed-0 weights (same Linear creation order => same initial values as the reference's module)."""
+    from gsdyn.dynamics import DynamicsPredictor, construct_edges, farthest_point_sampler
+    cloud = torch.tensor(gold["cfg1_cloud"])
+    pick = farthest_point_sampler(cloud[None], 100, start_idx=0)[0]
+    assert np.array_equal(pick.numpy(), gold["cfg1_pick"])
+    st = torch.cat([cloud[pick], torch.tensor(gold["cfg1_eef"])])
+    N = st.shape[0]
+    mask = torch.ones(N, dtype=torch.bool)
+    tool = torch.zeros(N, dtype=torch.bool)
+    tool[-1] = True
+    recv, send = construct_edges(st, 0.08, mask, tool, topk=5, connect_all=False)
+    assert recv.numel() == int(gold["cfg1_n_rel"][0])
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    cfg.update(nf_particle=512, nf_relation=512, nf_effect=512)
+    torch.manual_seed(0)
+    model = DynamicsPredictor(cfg).eval()
+    attrs = torch.zeros(1, N, 2)
+    attrs[0, :-1, 0] = 1
+    attrs[0, -1, 1] = 1
+    with torch.no_grad():
+        pos, mot = model(state=st[None, None].repeat(1, cfg["n_his"], 1, 1), attrs=attrs, p_instance=torch.ones(1, N - 1, 1),
+                         action=torch.tensor(gold["cfg1_action"]), receivers=recv, senders=send)
+    np.testing.assert_allclose(pos.numpy(), gold["cfg1_pred_pos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mot.numpy(), gold["cfg1_pred_motion"], rtol=2e-4, atol=2e-6)
