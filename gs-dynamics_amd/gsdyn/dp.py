@@ -72,8 +72,13 @@ class ViewShardedStep:
     """One optimiser step over a set of views, sharded over the ranks of ``group``."""
 
     def __init__(self, params, optimizer: Optional[torch.optim.Optimizer], weights: LossWeights = LossWeights(),
-                 group=None, batched: Optional[bool] = None):
+                 group=None, batched: Optional[bool] = None, density_control: Optional[dict] = None):
+        """``density_control``: dict(remove_thresh, remove_thresh_5k, scale_scene_radius) switches on the reference's
+        adaptive density control for first-timestep calls that pass ``iteration`` (``variables`` then needs
+        ``scene_radius``); every rank runs it on the all-reduced statistics with the same random seed, so replicas
+        stay identical."""
         self.params, self.optimizer, self.weights, self.group = params, optimizer, weights, group
+        self.density_control = density_control
         if batched is None:   # the multi-view entry point exists in the HIP package (not in the CPU test double)
             import diff_gaussian_rasterization as dgr
             batched = hasattr(dgr, "rasterize_gaussians_views")
@@ -83,7 +88,7 @@ class ViewShardedStep:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def __call__(self, views: Sequence[dict], variables: dict, is_initial_timestep: bool = True,
-                 local_only: bool = False):
+                 local_only: bool = False, iteration: Optional[int] = None):
         """``views``: all views of the step (every rank passes the same list) unless ``local_only``, in
         which case ``views`` is already this rank's shard.  Returns (sum of local losses, variables)."""
         mine = list(views) if local_only else [views[i] for i in shard_views(len(views), self.rank, self.world)]
@@ -127,6 +132,16 @@ class ViewShardedStep:
                 variables["denom"] += stat[1]
             variables["max_2D_radius"] = rad
             variables["seen"] = stat[1] > 0
+        if self.density_control is not None and is_initial_timestep and iteration is not None and self.optimizer is not None:
+            # between backward and the optimiser step, as in /root/reference/src/tracking/train_gs.py:31-37
+            from .densify import densify
+            torch.manual_seed(0x5EED + int(iteration))       # same split offsets on every rank
+            before = [id(p) for p in self.bucket.params]
+            dc = self.density_control
+            densify(self.params, variables, self.optimizer, int(iteration), dc["remove_thresh"], dc["remove_thresh_5k"],
+                    dc["scale_scene_radius"], accumulate=False)
+            if [id(self.params[k]) for k in self.bucket.names] != before:
+                self.bucket = GradBucket(self.params)        # parameters were replaced (cloned / split / pruned / reset)
         if self.optimizer is not None:
             self.optimizer.step()
         return total, variables

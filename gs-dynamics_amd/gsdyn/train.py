@@ -15,8 +15,8 @@ The reference's driver, /root/reference/src/tracking/train_gs.py:10-46, does not
 
 With ``views_per_step > 1`` (or world_size > 1) one optimiser step sums the gradients of several views -- the
 view-sharded data-parallel step of ``gsdyn.dp`` -- instead of the reference's one view per step.  Densification
-(/root/reference/src/tracking/external.py:229-299) is plain torch bookkeeping outside the rasterizer path and is
-not reproduced; the statistics it consumes (means2D gradient norms, radii, seen) are maintained.
+(/root/reference/src/tracking/external.py:229-299) is ``gsdyn.densify`` (golden-tested against the imported
+reference); pass ``density_control`` to switch it on for the first timestep.
 """
 from __future__ import annotations
 
@@ -91,14 +91,17 @@ def save_params(output_params: List[Dict[str, np.ndarray]], path: str) -> str:
 
 def train_timestep(params, variables, optimizer, dataset: Sequence[dict], iters: int, is_initial_timestep: bool,
                    weights: LossWeights = LossWeights(), views_per_step: int = 1, seed: Optional[int] = None,
-                   progress_every: int = 0, group=None):
-    """One timestep of the loop.  ``dataset``: list of dict(cam, im, seg, id).  Returns the list of PSNR probes."""
+                   progress_every: int = 0, group=None, density_control: Optional[dict] = None):
+    """One timestep of the loop.  ``dataset``: list of dict(cam, im, seg, id).  Returns the list of PSNR probes.
+    ``density_control`` (first timestep only): dict(remove_thresh, remove_thresh_5k, scale_scene_radius) -- the reference's
+    adaptive density control (gsdyn/densify.py); ``variables['scene_radius']`` must be set."""
     rng = random.Random(seed)
-    stepper = ViewShardedStep(params, optimizer, weights, group=group)
+    stepper = ViewShardedStep(params, optimizer, weights, group=group,
+                              density_control=density_control if is_initial_timestep else None)
     psnrs = []
     for i in range(iters):
         batch = [dataset[rng.randint(0, len(dataset) - 1)] for _ in range(views_per_step * stepper.world)]
-        stepper(batch, variables, is_initial_timestep=is_initial_timestep)
+        _, variables = stepper(batch, variables, is_initial_timestep=is_initial_timestep, iteration=i)
         if progress_every and i % progress_every == 0:
             psnrs.append(float(report_psnr(params, dataset[0])))
     return psnrs
@@ -106,17 +109,21 @@ def train_timestep(params, variables, optimizer, dataset: Sequence[dict], iters:
 
 def train(params, optimizer, timesteps: Sequence[Sequence[dict]], iters_first: int = 10000, iters_next: int = 2000,
           weights: LossWeights = LossWeights(), num_knn: int = 20, views_per_step: int = 1, out_path: Optional[str] = None,
-          seed: Optional[int] = 0):
-    """The whole loop over timesteps (``timesteps[t]`` = that timestep's views).  Returns (params, variables, outputs)."""
+          seed: Optional[int] = 0, density_control: Optional[dict] = None, scene_radius: Optional[float] = None):
+    """The whole loop over timesteps (``timesteps[t]`` = that timestep's views).  Returns (params, variables, outputs).
+    ``density_control`` + ``scene_radius`` switch on the adaptive density control of the first timestep."""
     P = params["means3D"].shape[0]
     variables = init_variables(P, params["means3D"].device)
+    if scene_radius is not None:
+        variables["scene_radius"] = float(scene_radius)
     outputs = []
     for t, dataset in enumerate(timesteps):
         first = t == 0
         if not first:
             params, variables = initialize_per_timestep(params, variables, optimizer)
         train_timestep(params, variables, optimizer, dataset, iters_first if first else iters_next, first, weights,
-                       views_per_step=views_per_step, seed=None if seed is None else seed + t)
+                       views_per_step=views_per_step, seed=None if seed is None else seed + t,
+                       density_control=density_control if first else None)
         outputs.append(params2cpu(params, first))
         if first:
             variables = initialize_post_first_timestep(params, variables, optimizer, num_knn)
