@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import torch
 
-from diff_gaussian_rasterization import GaussianRasterizer
+from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
 
 from .camera import setup_camera
 
@@ -26,9 +26,22 @@ class Renderer:
 
     @torch.no_grad()
     def render_with_mask(self, w2c, k, timestep_data, bg=(0.0, 0.0, 0.0)):
-        """Colour render + the all-ones 'mask' render of predict.py."""
-        im, depth = self.render(w2c, k, timestep_data, bg=bg)
-        ones = dict(timestep_data)
-        ones["colors_precomp"] = torch.ones_like(timestep_data["colors_precomp"])
-        mask, _ = self.render(w2c, k, ones, bg=(0.0, 0.0, 0.0))
-        return im, depth, mask
+        """Colour render + the all-ones 'mask' render of predict.py, as ONE multi-view call: the two renders share the
+        camera, so the second one reuses the first one's tile lists (per-view colours, ``geometry_of``)."""
+        ims, depths, masks = self.render_cameras_with_mask([(w2c, k)], timestep_data, bg=bg)
+        return ims[0], depths[0], masks[0]
+
+    @torch.no_grad()
+    def render_cameras_with_mask(self, cameras, timestep_data, bg=(0.0, 0.0, 0.0)):
+        """All cameras of a frame, colour + mask each, in one rasterizer call (predict.py renders 4 cameras x 2 per
+        frame, /root/reference/src/predict.py:100-123).  ``cameras``: list of (w2c, k).  Returns image, depth and mask lists."""
+        d = {key: v.to(self.device) for key, v in timestep_data.items()}
+        cams = [setup_camera(self.w, self.h, k, w2c, near=self.near, far=self.far, bg=bg, device=self.device) for w2c, k in cameras]
+        views = [c for c in cams for _ in (0, 1)]
+        col = d["colors_precomp"].float()
+        colours = torch.stack([col, torch.ones_like(col)]).repeat(len(cams), 1, 1)
+        P = d["means3D"].shape[0]
+        out, _, depth = rasterize_gaussians_views(views, d["means3D"], torch.zeros((len(views), P, 3), device=self.device),
+                                                  d["opacities"], colors_precomp=colours, scales=d["scales"], rotations=d["rotations"])
+        n = len(cams)
+        return [out[2 * i] for i in range(n)], [depth[2 * i] for i in range(n)], [out[2 * i + 1] for i in range(n)]

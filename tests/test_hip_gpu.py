@@ -634,6 +634,30 @@ def test_more_views_than_one_library_call(dev):
         assert (ga - gb).abs().max().item() <= 4e-6 * ga.abs().max().item(), k
 
 
+def test_forward_only_renderer_colour_and_mask_in_one_call(dev):
+    """Row A11: the predict.py pattern (colour render + all-ones mask render per camera) as one multi-view call equals the
+    reference-shaped two calls per camera."""
+    from gsdyn import params2rendervar, synth_scene_params
+    from gsdyn.camera import look_at_w2c
+    from gsdyn.render import Renderer
+    P = 8000
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.05)
+    with torch.no_grad():
+        data = {k: v.detach() for k, v in params2rendervar(params).items()}
+    r = Renderer(dev, w=320, h=180)
+    k = np.array([[300.0, 0, 160], [0, 300.0, 90], [0, 0, 1]])
+    cams = [(look_at_w2c(np.array([3.5 * np.cos(a), 0.6, 3.5 * np.sin(a)]), np.zeros(3)), k) for a in (0.3, 1.9)]
+    ims, depths, masks = r.render_cameras_with_mask(cams, data, bg=(0.0, 0.0, 0.0))
+    ones = dict(data)
+    ones["colors_precomp"] = torch.ones_like(data["colors_precomp"])
+    for i, (w2c, kk) in enumerate(cams):
+        im, depth = r.render(w2c, kk, data, bg=(0.0, 0.0, 0.0))
+        mask, _ = r.render(w2c, kk, ones, bg=(0.0, 0.0, 0.0))
+        assert torch.equal(ims[i], im) and torch.equal(depths[i], depth) and torch.equal(masks[i], mask)
+    a, d, m = r.render_with_mask(cams[0][0], k, data)
+    assert torch.equal(a, ims[0]) and torch.equal(m, masks[0]) and float(m.max()) <= 1.0 + 1e-5
+
+
 # ------------------------------------------------------------------ fused image loss (row N2)
 @pytest.mark.parametrize("H,W", [(64, 48), (37, 53), (800, 800)])
 def test_fused_image_loss_matches_torch_formula(dev, H, W):
