@@ -439,12 +439,13 @@ int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int
 
 int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
                             const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
-                            float w_l1, float w_ssim, float* d_pred, void* stream) {
+                            int32_t channels_per_image, float w_l1, float w_ssim, float* d_pred, void* stream) {
   if (!window11_host || !pred || !target || !fA || !fC || !fE || !grad_loss || !d_pred || C <= 0 || H <= 0 || W <= 0) {
     gsr_set_error("gsr_image_loss_backward: bad argument");
     return -2;
   }
-  return gsr_launch_image_loss_bwd(window11_host, C, H, W, pred, target, fA, fC, fE, grad_loss, w_l1, w_ssim, d_pred,
+  if (channels_per_image <= 0 || C % channels_per_image != 0) { gsr_set_error("gsr_image_loss_backward: C must be a multiple of channels_per_image"); return -2; }
+  return gsr_launch_image_loss_bwd(window11_host, C, H, W, pred, target, fA, fC, fE, grad_loss, channels_per_image, w_l1, w_ssim, d_pred,
                                    (hipStream_t)stream);
 }
 

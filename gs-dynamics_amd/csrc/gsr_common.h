@@ -224,7 +224,7 @@ int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_mo
 int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, float* fA,
                               float* fC, float* fE, float* block_l1, float* block_ssim, hipStream_t st);
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
-                              const float* fC, const float* fE, const float* grad_loss, float w_l1, float w_ssim, float* dx,
+                              const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st);
 int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,

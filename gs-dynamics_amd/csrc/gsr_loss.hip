@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, int C, int
                                                              const float* __restrict__ y_img,
                                                              const float* __restrict__ fA, const float* __restrict__ fC,
                                                              const float* __restrict__ fE,
-                                                             const float* __restrict__ grad_loss, float w_l1, float w_ssim,
+                                                             const float* __restrict__ grad_loss, int cpi, float w_l1, float w_ssim,
                                                              float* __restrict__ dx) {
   __shared__ float s0[PT][PT + 1];
   __shared__ float s1[PT][PT + 1];
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, int C, int
   if (gx < W && gy < H) {
     const size_t o = coff + (size_t)gy * W + gx;
     const float xv = x_img[o], yv = y_img[o];
-    const float invN = 1.0f / ((float)C * (float)H * (float)W);
+    const float invN = 1.0f / ((float)cpi * (float)H * (float)W);   // a batch of C / cpi images of cpi channels each
     const float dssim = bA + 2.0f * xv * bC + yv * bE;            // d(sum of SSIM map)/dx
     const float dl1 = xv > yv ? 1.0f : (xv < yv ? -1.0f : 0.0f);  // torch: sign(x - y), 0 at ties
-    dx[o] = grad_loss[0] * invN * (w_l1 * dl1 - w_ssim * dssim);
+    dx[o] = grad_loss[ch / cpi] * invN * (w_l1 * dl1 - w_ssim * dssim);
   }
 }
 
@@ -153,13 +153,13 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
 }
 
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
-                              const float* fC, const float* fE, const float* grad_loss, float w_l1, float w_ssim, float* dx,
+                              const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st) {
   Win w;
   for (int i = 0; i < 11; ++i) w.g[i] = win11_host[i];
   const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
   { GSR_PROF("image_loss_bwd", st);
-    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, st, w, C, H, W, x, y, fA, fC, fE, grad_loss, w_l1, w_ssim,
+    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, st, w, C, H, W, x, y, fA, fC, fE, grad_loss, cpi, w_l1, w_ssim,
                        dx); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;

@@ -89,7 +89,7 @@ def load_library():
     lib.gsr_image_loss_forward.restype = C.c_int
     lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
     lib.gsr_image_loss_backward.restype = C.c_int
-    lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [C.c_float, C.c_float, vp, vp]
+    lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [i32, C.c_float, C.c_float, vp, vp]
     lib.gsr_fps.restype = C.c_int
     lib.gsr_fps.argtypes = [i32, vp, i32, i32, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
@@ -470,30 +470,36 @@ def profile_end():
 
 
 def image_loss_forward(window11, pred, target):
-    """Fused 0.8 L1 + 0.2 (1 - SSIM) building blocks: returns (l1_sum, ssim_sum, fA, fC, fE) device tensors."""
+    """Fused 0.8 L1 + 0.2 (1 - SSIM) building blocks for one image [C,H,W] or a batch [N,C,H,W]:
+    returns (l1_sum, ssim_sum, fA, fC, fE); the sums are scalars, or [N] tensors for a batch (one reduction for all)."""
     lib = load_library()
     _require_device(pred)
     dev = pred.device
-    Cc, H, W = (int(d) for d in pred.shape)
+    batched = pred.dim() == 4
+    N = int(pred.shape[0]) if batched else 1
+    Cc, H, W = (int(d) for d in pred.shape[-3:])
     win = (C.c_float * 11)(*[float(v) for v in window11])
     with torch.cuda.device(dev):
-        nb = int(lib.gsr_image_loss_blocks(Cc, H, W))
+        nb = int(lib.gsr_image_loss_blocks(N * Cc, H, W))
         f32 = dict(dtype=torch.float32, device=dev)
-        fA, fC, fE = (torch.empty((Cc, H, W), **f32) for _ in range(3))
-        bl1, bss = torch.empty((nb,), **f32), torch.empty((nb,), **f32)
-        _check(lib.gsr_image_loss_forward(win, Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(bl1),
-                                          _ptr(bss), _stream(dev)), "gsr_image_loss_forward")
-    return bl1.sum(), bss.sum(), fA, fC, fE
+        fA, fC, fE = (torch.empty(tuple(pred.shape), **f32) for _ in range(3))
+        part = torch.empty((2, nb), **f32)
+        _check(lib.gsr_image_loss_forward(win, N * Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(part[0]),
+                                          _ptr(part[1]), _stream(dev)), "gsr_image_loss_forward")
+    sums = part.view(2, N, nb // N).sum(2)          # block partials are channel-major: contiguous per image
+    return (sums[0], sums[1], fA, fC, fE) if batched else (sums[0, 0], sums[1, 0], fA, fC, fE)
 
 
 def image_loss_backward(window11, pred, target, fA, fC, fE, grad_loss, w_l1, w_ssim):
+    """``grad_loss``: scalar for one image, [N] for a batch [N,C,H,W]."""
     lib = load_library()
     dev = pred.device
-    Cc, H, W = (int(d) for d in pred.shape)
+    N = int(pred.shape[0]) if pred.dim() == 4 else 1
+    Cc, H, W = (int(d) for d in pred.shape[-3:])
     win = (C.c_float * 11)(*[float(v) for v in window11])
     with torch.cuda.device(dev):
-        g = grad_loss.to(dtype=torch.float32, device=dev).reshape(1).contiguous()
+        g = grad_loss.to(dtype=torch.float32, device=dev).reshape(N).contiguous()
         d_pred = torch.empty_like(pred)
-        _check(lib.gsr_image_loss_backward(win, Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(g),
+        _check(lib.gsr_image_loss_backward(win, N * Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(g), Cc,
                                            float(w_l1), float(w_ssim), _ptr(d_pred), _stream(dev)), "gsr_image_loss_backward")
     return d_pred

@@ -111,7 +111,7 @@ class _FusedImageLoss(torch.autograd.Function):
         t = target.contiguous().float()
         win = _window_1d()
         l1_sum, ssim_sum, fA, fC, fE = _hip.image_loss_forward(win, p, t)
-        n = float(p.numel())
+        n = float(p[0].numel()) if p.dim() == 4 else float(p.numel())   # a batch [N,C,H,W] gives one loss per image
         ctx.save_for_backward(p, t, fA, fC, fE)
         ctx.win, ctx.w = win, (float(w_l1), float(w_ssim))
         return w_l1 * (l1_sum / n) + w_ssim * (1.0 - ssim_sum / n)
@@ -126,7 +126,10 @@ class _FusedImageLoss(torch.autograd.Function):
 
 def image_loss(pred, target, w_l1: float = 0.8, w_ssim: float = 0.2):
     """The image term of the tracking loss (/root/reference/src/tracking/train_utils.py:185,195).
-    HIP tensors take the fused kernels; CPU tensors (host-logic tests) evaluate the reference's own torch formula."""
+    HIP tensors take the fused kernels; CPU tensors (host-logic tests) evaluate the reference's own torch formula.
+    ``pred`` / ``target`` [C,H,W] -> scalar, or a batch [N,C,H,W] -> [N] (one kernel launch for all images)."""
     if pred.is_cuda:
         return _FusedImageLoss.apply(pred, target, w_l1, w_ssim)
+    if pred.dim() == 4:
+        return torch.stack([w_l1 * l1_loss_v1(p, t) + w_ssim * (1.0 - calc_ssim(p, t)) for p, t in zip(pred, target)])
     return w_l1 * l1_loss_v1(pred, target) + w_ssim * (1.0 - calc_ssim(pred, target))

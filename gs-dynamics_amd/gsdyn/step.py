@@ -142,11 +142,13 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     m2 = torch.zeros((2 * V, P, 3), device=rendervar["means3D"].device, requires_grad=True)
     ims, radii, _ = rasterize_gaussians_views(cams, rendervar["means3D"], m2, rendervar["opacities"], colors_precomp=colours,
                                               scales=rendervar["scales"], rotations=rendervar["rotations"])
-    total = 0.0
-    for v, d in enumerate(datas):
-        cid = d["id"]
-        im = torch.exp(params["cam_m"][cid])[:, None, None] * ims[2 * v] + params["cam_c"][cid][:, None, None]
-        total = total + w.im * _image_term(im, d["im"]) + w.seg * _image_term(ims[2 * v + 1], d["seg"])
+    # both image terms of all cameras as two batched loss evaluations (one fused kernel pair each)
+    ids = [int(d["id"]) for d in datas]          # python indices: no host->device index tensor, no sync
+    cam_m = torch.stack([params["cam_m"][i] for i in ids])
+    cam_c = torch.stack([params["cam_c"][i] for i in ids])
+    col = torch.exp(cam_m)[:, :, None, None] * ims[0::2] + cam_c[:, :, None, None]
+    total = w.im * _image_term(col, torch.stack([d["im"] for d in datas])).sum() + \
+        w.seg * _image_term(ims[1::2], torch.stack([d["seg"] for d in datas])).sum()
     if not is_initial_timestep:
         losses = {}
         _shared_terms(params, rendervar, variables, losses)

@@ -157,13 +157,15 @@ int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotatio
  *   /root/reference/src/tracking/train_utils.py:185,195 with w_l1 = 0.8, w_ssim = 0.2.
  * forward: writes one partial sum of |.| and of the SSIM map per block (gsr_image_loss_blocks of them; the caller
  * adds them up) and the three per-pixel partials fA/fC/fE ([C,H,W] each) the backward needs.
- * backward: d_pred[C,H,W] = grad_loss[0] * d loss / d pred.  `window11_host` = the 11 normalised 1-D weights (host). */
+ * backward: d_pred[C,H,W] = grad_loss[c / channels_per_image] * d loss / d pred.  A batch of N images is passed as C = N *
+ * channels_per_image channels (the means then run over one image each; block partial sums are channel-major, so the caller
+ * adds them up per image); grad_loss has N entries.  `window11_host` = the 11 normalised 1-D weights (host). */
 int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W);
 int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,
                            float* fA, float* fC, float* fE, float* block_l1, float* block_ssim, void* stream);
 int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
                             const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
-                            float w_l1, float w_ssim, float* d_pred, void* stream);
+                            int32_t channels_per_image, float w_l1, float w_ssim, float* d_pred, void* stream);
 
 /* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);

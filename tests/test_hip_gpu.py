@@ -675,6 +675,26 @@ def test_fused_image_loss_matches_torch_formula(dev, H, W):
     assert (ggot - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
 
 
+def test_fused_image_loss_batch_equals_per_image(dev):
+    """A batch [N,3,H,W] through one kernel pair gives the per-image losses and gradients of N separate calls."""
+    from gsdyn import losses as L
+    rng = np.random.default_rng(11)
+    N, H, W = 5, 72, 100
+    x = torch.tensor(rng.uniform(0, 1, (N, 3, H, W)).astype(np.float32), device=dev)
+    y = torch.tensor(rng.uniform(0, 1, (N, 3, H, W)).astype(np.float32), device=dev)
+    wts = torch.tensor([1.0, -2.0, 0.5, 3.0, 0.25], device=dev)
+    xb = x.clone().requires_grad_(True)
+    lb = L.image_loss(xb, y)
+    assert lb.shape == (N,)
+    (lb * wts).sum().backward()
+    for i in range(N):
+        xi = x[i].clone().requires_grad_(True)
+        li = L.image_loss(xi, y[i])
+        (li * wts[i]).backward()
+        assert torch.equal(li, lb[i]) or abs(li.item() - lb[i].item()) <= 1e-6 * abs(li.item())
+        assert (xi.grad - xb.grad[i]).abs().max().item() <= 1e-6 * xi.grad.abs().max().item()
+
+
 def test_fused_image_loss_matches_reference_golden(dev, golden_dir):
     """Against vectors captured from the imported reference (calc_ssim value and input gradient)."""
     from gsdyn import losses as L

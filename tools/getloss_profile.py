@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gs-dynamics_amd")):
     sys.path.insert(0, p)
-from gsdyn import LossWeights, get_loss, synth_ring_cameras, synth_scene_params, synth_targets
+from gsdyn import LossWeights, get_loss, get_loss_views, synth_ring_cameras, synth_scene_params, synth_targets
 from gsdyn.dp import init_variables
 from gsdyn.step import make_rigidity_variables
 dev = torch.device("cuda:0")
@@ -16,9 +16,14 @@ variables = init_variables(P, dev)
 variables.update(make_rigidity_variables(params, num_knn=20))
 w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)
 views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
+BATCHED = os.environ.get("GETLOSS_SEPARATE") != "1"
 def step(initial):
     for p in params.values():
         p.grad = None
+    if BATCHED:
+        loss, _, _ = get_loss_views(params, views, variables, initial, w)
+        loss.backward()
+        return
     for d in views:
         loss, _ = get_loss(params, d, variables, initial, w)
         loss.backward()
