@@ -340,6 +340,24 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                     "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only"}
     except Exception as e:  # noqa: BLE001
         out["forward_only_cfg2"] = {"error": repr(e)}
+    try:   # BASELINE.json configs[0]-shaped rollout step on the device (row N4): rope.yaml GNN dims, random weights
+        from gsdyn.dynamics import DynamicsPredictor, farthest_point_sampler, fps_radius, rollout_step
+        cfg = dict(nf_particle=512, nf_relation=512, nf_effect=512, attr_dim=2, state_dim=0, action_dim=3, pstep=3,
+                   rel_attr_dim=2, rel_group_dim=1, rel_distance_dim=3, n_his=3)
+        torch.manual_seed(0)
+        model = DynamicsPredictor(cfg, device=dev).eval()
+        with torch.no_grad():
+            rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+        t_fps = _time_ms(lambda: farthest_point_sampler(rv["means3D"][None], 1000, start_idx=0), 5, 2)
+        pick = farthest_point_sampler(rv["means3D"][None], 100, start_idx=0)[0]
+        bones = rv["means3D"][pick]
+        hist, eef = bones[None].repeat(3, 1, 1), torch.zeros((3, 1, 3), device=dev)
+        t_step = _time_ms(lambda: rollout_step(model, hist, eef, eef[-1] + 0.02, rv["means3D"], rv["rotations"], 0.5, 5), 5, 2)
+        out["rollout_step_cfg1"] = {"ms_per_step": t_step, "fps_1000_of_100k_ms": t_fps,
+                                    "what": "row N4: relations + DynamicsPredictor (rope.yaml width 512, random weights, 100 bones) + "
+                                            "bone fitting (host SVD) + skinning of 100k Gaussians (gsr_lbs); FPS timed separately (gsr_fps)"}
+    except Exception as e:  # noqa: BLE001
+        out["rollout_step_cfg1"] = {"error": repr(e)}
     return out
 
 
