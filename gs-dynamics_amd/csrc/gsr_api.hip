@@ -411,6 +411,36 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                                          dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, st);
 }
 
+int32_t gsr_rigidity_blocks(int32_t n_fg) { return n_fg > 0 ? (n_fg + 255) / 256 : 0; }
+
+int gsr_rigidity_forward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                         const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
+                         const float* prev_inv_rot_fg, const float* prev_offset, float* block_partials, void* stream) {
+  if (n_fg < 0 || K <= 0 || (n_fg > 0 && (!means3D || !rotations || !fg_idx || !neighbor_indices || !neighbor_weight || !neighbor_dist ||
+                                          !prev_inv_rot_fg || !prev_offset || !block_partials))) {
+    gsr_set_error("gsr_rigidity_forward: bad argument");
+    return -2;
+  }
+  return gsr_launch_rigidity_fwd(n_fg, K, means3D, rotations, fg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
+                                 prev_offset, block_partials, (hipStream_t)stream);
+}
+
+int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                          const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
+                          const float* prev_inv_rot_fg, const float* prev_offset, const float* grad3, const int32_t* rev_ptr,
+                          const int32_t* rev_edge, float* scratch, float* d_means3D, float* d_rotations, void* stream) {
+  if (n_fg < 0 || K <= 0 || (n_fg > 0 && (!means3D || !rotations || !fg_idx || !neighbor_indices || !neighbor_weight || !neighbor_dist ||
+                                          !prev_inv_rot_fg || !prev_offset || !grad3 || !rev_ptr || !rev_edge || !scratch || !d_means3D ||
+                                          !d_rotations))) {
+    gsr_set_error("gsr_rigidity_backward: bad argument");
+    return -2;
+  }
+  float* self7 = scratch;
+  float* edge7 = scratch + (size_t)7 * n_fg;
+  return gsr_launch_rigidity_bwd(n_fg, K, means3D, rotations, fg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
+                                 prev_offset, grad3, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rotations, (hipStream_t)stream);
+}
+
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }
   if (npoints > N || (N > 0 && (start_idx < 0 || start_idx >= N))) { gsr_set_error("gsr_fps: npoints / start_idx out of range"); return -2; }

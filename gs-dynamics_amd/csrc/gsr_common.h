@@ -226,6 +226,13 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
                               const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st);
+int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
+                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* partial,
+                            hipStream_t st);
+int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
+                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, const float* g,
+                            const int32_t* rev_ptr, const int32_t* rev_edge, float* self7, float* edge7, float* d_means3D,
+                            float* d_rot, hipStream_t st);
 int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st);

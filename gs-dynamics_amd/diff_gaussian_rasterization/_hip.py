@@ -44,7 +44,8 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_backward_batch", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs")
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
+           "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward")
 
 
 def load_library():
@@ -90,6 +91,12 @@ def load_library():
     lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
     lib.gsr_image_loss_backward.restype = C.c_int
     lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [i32, C.c_float, C.c_float, vp, vp]
+    lib.gsr_rigidity_blocks.restype = i32
+    lib.gsr_rigidity_blocks.argtypes = [i32]
+    lib.gsr_rigidity_forward.restype = C.c_int
+    lib.gsr_rigidity_forward.argtypes = [i32, i32] + [vp] * 9 + [vp]
+    lib.gsr_rigidity_backward.restype = C.c_int
+    lib.gsr_rigidity_backward.argtypes = [i32, i32] + [vp] * 14 + [vp]
     lib.gsr_fps.restype = C.c_int
     lib.gsr_fps.argtypes = [i32, vp, i32, i32, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
@@ -376,6 +383,37 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
     return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None
+
+
+def rigidity_forward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_off):
+    """Sums of the rigid / rot / iso terms over all (foreground point, neighbour) pairs: tensor [3] (gsr_rigidity_forward)."""
+    lib = load_library()
+    _require_device(means3D)
+    dev = means3D.device
+    nfg, K = int(nbr.shape[0]), int(nbr.shape[1])
+    with torch.cuda.device(dev):
+        nb = int(lib.gsr_rigidity_blocks(nfg))
+        part = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)
+        if nb == 0:
+            part.zero_()
+        _check(lib.gsr_rigidity_forward(nfg, K, _ptr(means3D), _ptr(rotations), _ptr(fg_idx), _ptr(nbr), _ptr(nw), _ptr(nd),
+                                        _ptr(prev_inv), _ptr(prev_off), _ptr(part), _stream(dev)), "gsr_rigidity_forward")
+    return part.sum(1)
+
+
+def rigidity_backward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_off, grad3, rev_ptr, rev_edge):
+    """grad3 [3]: upstream gradients of the three MEANS divided by n_fg * K.  Returns (d_means3D [P,3], d_rotations [P,4])."""
+    lib = load_library()
+    dev = means3D.device
+    nfg, K = int(nbr.shape[0]), int(nbr.shape[1])
+    with torch.cuda.device(dev):
+        scratch = torch.empty((7 * (nfg + nfg * K),), dtype=torch.float32, device=dev)
+        d_m = torch.zeros_like(means3D)
+        d_r = torch.zeros_like(rotations)
+        _check(lib.gsr_rigidity_backward(nfg, K, _ptr(means3D), _ptr(rotations), _ptr(fg_idx), _ptr(nbr), _ptr(nw), _ptr(nd),
+                                         _ptr(prev_inv), _ptr(prev_off), _ptr(grad3), _ptr(rev_ptr), _ptr(rev_edge), _ptr(scratch),
+                                         _ptr(d_m), _ptr(d_r), _stream(dev)), "gsr_rigidity_backward")
+    return d_m, d_r
 
 
 def farthest_point_sampling(pos: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:

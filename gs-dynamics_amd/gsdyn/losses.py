@@ -124,6 +124,46 @@ class _FusedImageLoss(torch.autograd.Function):
         return d_pred, None, None, None
 
 
+class _FusedRigidity(torch.autograd.Function):
+    """rigid / rot / iso means of the t > 0 loss as one forward and two backward HIP kernels (gsr_rigidity.hip)."""
+
+    @staticmethod
+    def forward(ctx, means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_off, rev_ptr, rev_edge):
+        from diff_gaussian_rasterization import _hip
+        m, r = means3D.contiguous().float(), rotations.contiguous().float()
+        sums = _hip.rigidity_forward(m, r, fg_idx, nbr, nw, nd, prev_inv, prev_off)
+        ctx.save_for_backward(m, r, fg_idx, nbr, nw, nd, prev_inv, prev_off, rev_ptr, rev_edge)
+        return sums / float(max(nbr.numel(), 1))
+
+    @staticmethod
+    def backward(ctx, grad):
+        from diff_gaussian_rasterization import _hip
+        m, r, fg_idx, nbr, nw, nd, prev_inv, prev_off, rev_ptr, rev_edge = ctx.saved_tensors
+        g = (grad.float() / float(max(nbr.numel(), 1))).contiguous()
+        d_m, d_r = _hip.rigidity_backward(m, r, fg_idx, nbr, nw, nd, prev_inv, prev_off, g, rev_ptr, rev_edge)
+        return (d_m, d_r) + (None,) * 8
+
+
+def rigidity_terms(means3D, rotations, variables):
+    """(rigid, rot, iso) of /root/reference/src/tracking/train_utils.py:198-222 through the fused kernels.  ``variables``
+    must carry the tensors of ``make_rigidity_variables`` incl. fg_idx / rev_ptr / rev_edge."""
+    v = variables
+    out = _FusedRigidity.apply(means3D, rotations, v["fg_idx"], v["neighbor_indices"], v["neighbor_weight"], v["neighbor_dist"],
+                               v["prev_inv_rot_fg"].contiguous(), v["prev_offset"].contiguous(), v["rev_ptr"], v["rev_edge"])
+    return out[0], out[1], out[2]
+
+
+def reverse_adjacency(nbr: torch.Tensor):
+    """CSR of the incoming edges of every foreground point (edge id = i * K + k, target nbr[i,k]) as int32 (ptr, edges)."""
+    n = nbr.shape[0]
+    tgt = nbr.reshape(-1)
+    order = torch.argsort(tgt, stable=True)
+    counts = torch.bincount(tgt, minlength=n)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=nbr.device)
+    ptr[1:] = torch.cumsum(counts, 0)
+    return ptr.to(torch.int32).contiguous(), order.to(torch.int32).contiguous()
+
+
 def image_loss(pred, target, w_l1: float = 0.8, w_ssim: float = 0.2):
     """The image term of the tracking loss (/root/reference/src/tracking/train_utils.py:185,195).
     HIP tensors take the fused kernels; CPU tensors (host-logic tests) evaluate the reference's own torch formula.

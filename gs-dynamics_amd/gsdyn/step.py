@@ -13,8 +13,8 @@ import torch
 
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 
-from .losses import (build_rotation, calc_psnr, image_loss, l1_loss_v2, quat_mult, weighted_l2_loss_v1,
-                     weighted_l2_loss_v2)
+from .losses import (build_rotation, calc_psnr, image_loss, l1_loss_v2, quat_mult, reverse_adjacency, rigidity_terms,
+                     weighted_l2_loss_v1, weighted_l2_loss_v2)
 
 
 @dataclass
@@ -69,27 +69,10 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
     losses["seg"] = _image_term(seg, curr_data["seg"])
 
     if not is_initial_timestep:
-        is_fg = (params["seg_colors"][:, 0] > 0.5).detach()
-        fg_pts = rendervar["means3D"][is_fg]
-        fg_rot = rendervar["rotations"][is_fg]
-        rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
-        rot = build_rotation(rel_rot)
-        nbr = variables["neighbor_indices"]
-        curr_offset = fg_pts[nbr] - fg_pts[:, None]
-        # R^T applied to every neighbour offset.  The reference writes this as a batched 3x3 @ 3x1 matmul
-        # (train_utils.py:207), which on ROCm dispatches ~1.4 M tiny GEMMs (18 + 12 + 11 ms fwd+bwd at 70 k
-        # foreground points x 20 neighbours); the same contraction as a broadcast multiply + sum is ~0.1 ms.
-        offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)
-        nw = variables["neighbor_weight"]
-        losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
-        losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
-        offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
-        losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
-        losses["floor"] = torch.clamp(fg_pts[:, 1], min=0).mean()
-        bg_pts = rendervar["means3D"][~is_fg]
-        bg_rot = rendervar["rotations"][~is_fg]
-        losses["bg"] = l1_loss_v2(bg_pts, variables["init_bg_pts"]) + l1_loss_v2(bg_rot, variables["init_bg_rot"])
-        losses["soft_col_cons"] = 0.0
+        # R^T applied to every neighbour offset: the reference writes this as a batched 3x3 @ 3x1 matmul
+        # (train_utils.py:207), which on ROCm dispatches ~1.4 M tiny GEMMs (18 + 12 + 11 ms fwd+bwd at 70 k foreground
+        # points x 20 neighbours); _shared_terms uses the fused kernels on a HIP device, a broadcast multiply + sum otherwise.
+        _shared_terms(params, rendervar, variables, losses)
 
     weights = {"im": w.im, "seg": w.seg, "rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg,
                "soft_col_cons": w.soft_col_cons}
@@ -105,22 +88,34 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
 
 def _shared_terms(params, rendervar, variables, losses):
     """View-independent terms of the t > 0 loss (/root/reference/src/tracking/train_utils.py:198-232)."""
-    is_fg = (params["seg_colors"][:, 0] > 0.5).detach()
-    fg_pts = rendervar["means3D"][is_fg]
-    fg_rot = rendervar["rotations"][is_fg]
-    rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
-    rot = build_rotation(rel_rot)
-    nbr = variables["neighbor_indices"]
-    curr_offset = fg_pts[nbr] - fg_pts[:, None]
-    offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)   # see get_loss
-    nw = variables["neighbor_weight"]
-    losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
-    losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
-    offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
-    losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
+    if "fg_idx" in variables:     # index tensors prepared once per timestep: boolean-mask indexing costs a host sync per call
+        fg_idx, bg_idx = variables["fg_idx"], variables["bg_idx"]
+        fg_pts = rendervar["means3D"].index_select(0, fg_idx)
+        pick_fg = lambda t: t.index_select(0, fg_idx)   # noqa: E731
+        pick_bg = lambda t: t.index_select(0, bg_idx)   # noqa: E731
+    else:
+        is_fg = (params["seg_colors"][:, 0] > 0.5).detach()
+        fg_pts = rendervar["means3D"][is_fg]
+        pick_fg = lambda t: t[is_fg]                    # noqa: E731
+        pick_bg = lambda t: t[~is_fg]                   # noqa: E731
+    if rendervar["means3D"].is_cuda and "rev_ptr" in variables:
+        # the three neighbour terms in three fused kernels (gsr_rigidity.hip) instead of ~100 torch kernels
+        losses["rigid"], losses["rot"], losses["iso"] = rigidity_terms(rendervar["means3D"], rendervar["rotations"], variables)
+    else:
+        fg_rot = pick_fg(rendervar["rotations"])
+        rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
+        rot = build_rotation(rel_rot)
+        nbr = variables["neighbor_indices"]
+        curr_offset = fg_pts[nbr] - fg_pts[:, None]
+        offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)   # see get_loss
+        nw = variables["neighbor_weight"]
+        losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
+        losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
+        offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
+        losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
     losses["floor"] = torch.clamp(fg_pts[:, 1], min=0).mean()
-    bg_pts = rendervar["means3D"][~is_fg]
-    bg_rot = rendervar["rotations"][~is_fg]
+    bg_pts = pick_bg(rendervar["means3D"])
+    bg_rot = pick_bg(rendervar["rotations"])
     losses["bg"] = l1_loss_v2(bg_pts, variables["init_bg_pts"]) + l1_loss_v2(bg_rot, variables["init_bg_rot"])
     losses["soft_col_cons"] = 0.0
 
@@ -189,7 +184,10 @@ def make_rigidity_variables(params, num_knn: int = 20, device=None):
         sq = torch.cat(d_chunks) if d_chunks else torch.zeros((0, k), device=fg.device)
         inv = rot[is_fg].clone()
         inv[:, 1:] = -inv[:, 1:]
-        return dict(neighbor_indices=nbr.long().contiguous(), neighbor_weight=torch.exp(-2000 * sq).contiguous(),
+        rev_ptr, rev_edge = reverse_adjacency(nbr.long())
+        return dict(fg_idx=is_fg.nonzero().squeeze(1).contiguous(), bg_idx=(~is_fg).nonzero().squeeze(1).contiguous(),
+                    rev_ptr=rev_ptr, rev_edge=rev_edge,
+                    neighbor_indices=nbr.long().contiguous(), neighbor_weight=torch.exp(-2000 * sq).contiguous(),
                     neighbor_dist=torch.sqrt(sq).contiguous(), init_bg_pts=params["means3D"][~is_fg].detach().clone(),
                     init_bg_rot=rot[~is_fg].detach().clone(), prev_inv_rot_fg=inv.detach(),
                     prev_offset=(fg[nbr] - fg[:, None]).detach())

@@ -140,6 +140,23 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        float* const* dL_dmeans2D, float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity,
                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
 
+/* ---- neighbour terms of the t > 0 tracking loss, fused (caller side of the path):
+ *   rigid, rot, iso of /root/reference/src/tracking/train_utils.py:198-222 as three means over (foreground point, neighbour).
+ * All per-point arrays are indexed by foreground rank; fg_idx[n_fg] (int64) maps rank -> Gaussian; neighbor_* are [n_fg,K];
+ * rotations are the NORMALISED quaternions (w,x,y,z) of all P Gaussians.
+ * forward: block_partials[3][gsr_rigidity_blocks(n_fg)] = per-block sums of the three terms (caller: sum / (n_fg K)).
+ * backward: grad3[3] (device) = upstream gradients of the three means ALREADY divided by n_fg K; rev_ptr[n_fg+1] / rev_edge[n_fg K]
+ *   (int32) = reverse adjacency (edges sorted by neighbour); scratch = 7 (n_fg + n_fg K) floats; writes the foreground rows of
+ *   d_means3D[P,3] and d_rotations[P,4] (the caller zero-fills the rest).  No float atomics: deterministic. */
+int32_t gsr_rigidity_blocks(int32_t n_fg);
+int gsr_rigidity_forward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                         const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
+                         const float* prev_inv_rot_fg, const float* prev_offset, float* block_partials, void* stream);
+int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                          const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
+                          const float* prev_inv_rot_fg, const float* prev_offset, const float* grad3, const int32_t* rev_ptr,
+                          const int32_t* rev_edge, float* scratch, float* d_means3D, float* d_rotations, void* stream);
+
 /* ---- rollout plumbing (callers: gsdyn/dynamics.py)
  * gsr_fps: farthest point sampling of pos[N,3] -> out_idx[npoints] (int64), first pick start_idx, every further pick the
  *   point with the largest squared distance to the picked set (first maximum on ties).  Stands in for
