@@ -246,6 +246,24 @@ def main():
         except Exception:  # noqa: BLE001
             pass
 
+    # VALU issue occupancy of the blend kernels from the committed SQ counters (tools/prof_sq.sh): what actually bounds them
+    spath = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(spath):
+        try:
+            sj = json.load(open(spath))
+            occ = {}
+            for kname in ("render_fwd", "render_bwd"):
+                if kname in sj and kname in per_launch_us and sj.get("views_per_launch", 1) == views_per_launch:
+                    slots = per_launch_us[kname] * 1e-6 * 2.4e9 / 4.0 * 1024.0      # 256 CUs x 4 SIMDs, one wave-64 VALU op per 4 cycles
+                    occ[kname] = {"valu_wave_instructions": sj[kname].get("SQ_INSTS_VALU"),
+                                  "active_valu_quad_cycles": sj[kname].get("SQ_ACTIVE_INST_VALU"),
+                                  "issue_slots_in_launch_at_2.4GHz": slots,
+                                  "valu_issue_occupancy": sj[kname].get("SQ_ACTIVE_INST_VALU", 0.0) / slots}
+            roofline["valu"]["measured"] = occ
+            roofline["valu"]["measured_source"] = sj.get("source")
+        except Exception:  # noqa: BLE001
+            pass
+
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params)

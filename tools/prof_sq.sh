@@ -25,6 +25,10 @@ for d in ("prof_sq1", "prof_sq2"):
             k = "render_fwd" if "render_fwd" in r["Kernel_Name"] else "render_bwd" if "render_bwd" in r["Kernel_Name"] else None
             if k:
                 c = acc[k][r["Counter_Name"]]; c[0] += 1; c[1] += float(r["Counter_Value"])
+import json
+json.dump({k: {n: t / max(c, 1) for n, (c, t) in v.items()} for k, v in acc.items()} | {"views_per_launch": 4,
+          "source": "rocprofv3 --pmc SQ_* (two passes), tools/prof_sq.sh; means per dispatch; *_CYCLES / ACTIVE / WAIT in quad-cycles"},
+          open(os.path.join(O, "sq_counters.json"), "w"), indent=1)
 print("# derived (means per dispatch)")
 for k, v in acc.items():
     m = {n: t / max(c, 1) for n, (c, t) in v.items()}
