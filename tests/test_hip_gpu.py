@@ -838,3 +838,30 @@ def test_fused_rigidity_terms_match_torch_autograd(dev):
         err = (got.double() - want).abs().max().item()
         assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
     assert torch.all(m1.grad[~is_fg] == 0) and torch.all(r1.grad[~is_fg] == 0)
+
+
+def test_density_control_on_device(dev):
+    """A first-timestep step at a density iteration on the GPU: clone / split / prune between backward and the optimiser
+    step, then the grown cloud keeps training through the batched get_loss path."""
+    from gsdyn import LossWeights, initialize_optimizer, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import ViewShardedStep, init_variables
+    P, W, H = 5000, 160, 120
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.15)
+    cams = synth_ring_cameras(3, W, H, device=dev)
+    views = []
+    for i, cam in enumerate(cams):
+        im, seg = synth_targets(W, H, seed=3 + i, device=dev)
+        views.append(dict(cam=cam, im=im, seg=seg, id=i))
+    opt = initialize_optimizer(params, scene_radius=4.0)
+    variables = init_variables(P, dev)
+    variables["scene_radius"] = 4.0
+    step = ViewShardedStep(params, opt, LossWeights(), density_control=dict(remove_thresh=0.005, remove_thresh_5k=0.25,
+                                                                           scale_scene_radius=0.01))
+    step(views, variables, is_initial_timestep=True, iteration=10)
+    assert params["means3D"].shape[0] == P and float(variables["denom"].sum()) > 0
+    variables["means2D_gradient_accum"] += 1.0
+    step(views, variables, is_initial_timestep=True, iteration=600)
+    n = params["means3D"].shape[0]
+    assert n > P and variables["denom"].shape[0] == n
+    total, variables = step(views, variables, is_initial_timestep=True, iteration=601)
+    assert torch.isfinite(total) and params["means3D"].shape[0] == n
