@@ -181,9 +181,6 @@ __device__ __forceinline__ void fwd_tile(
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
       // One list entry: evaluate, then blend predicated.
-      // (the plain 2-instruction exp would save 5 of ~30 VALU slots per pair here -- measured 35.3 -> 33.2 us per view, all
-      // parity tests still green -- but the backward re-evaluates alpha with gsr_exp, and the two must take the same
-      // alpha >= 1/255 decisions)
 #define GSR_FWD_ENTRY(ea, eb, ec)                                                                   \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \

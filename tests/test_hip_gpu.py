@@ -168,9 +168,13 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
     assert mixed_err(color[:, ok], o2.color[:, ok]) < TOL, "colour"
     assert mixed_err(depth[:, ok], o2.depth[:, ok]) < TOL, "depth"
     gr = o2.backward(dL)
+    worst = {}
     for k, v in grads.items():
         e = rel_err(v, gr[k])
+        worst[k] = e
         assert e < TOL, f"grad {k}: rel err {e:.3e}"
+    if os.environ.get("GSR_TEST_VERBOSE"):
+        print("parity margins:", {k: f"{e:.2e}" for k, e in worst.items()}, "colour", f"{mixed_err(color[:, ok], o2.color[:, ok]):.2e}")
     rg = views["ranges"].cpu().numpy().astype(np.int64)
     o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max())        # longest per-tile list the HIP path sorted
     return o2
