@@ -869,3 +869,34 @@ def test_density_control_on_device(dev):
     assert n > P and variables["denom"].shape[0] == n
     total, variables = step(views, variables, is_initial_timestep=True, iteration=601)
     assert torch.isfinite(total) and params["means3D"].shape[0] == n
+
+
+def test_batch_with_a_view_that_sees_nothing(dev):
+    """One camera of a multi-view call looks away from the scene (no entries at all for it): background image, zero depth,
+    and the summed gradients equal those of the other views alone."""
+    from diff_gaussian_rasterization import rasterize_gaussians_views
+    from gsdyn import params2rendervar, setup_camera, synth_ring_cameras, synth_scene_params
+    from gsdyn.camera import look_at_w2c
+    P, W, H = 4000, 128, 96
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cams = synth_ring_cameras(2, W, H, device=dev)
+    k = np.array([[float(W), 0, W / 2], [0, float(W), H / 2], [0, 0, 1]])
+    away = setup_camera(W, H, k, look_at_w2c(np.array([4.0, 0.8, 0.0]), np.array([8.0, 0.8, 0.0])), bg=(0.2, 0.4, 0.6), device=dev)
+    dL = torch.tensor(np.random.default_rng(6).uniform(-1, 1, (3, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {kk: v.detach().clone() for kk, v in params2rendervar(params).items() if kk != "means2D"}
+
+    def run(views, g):
+        leaves = {kk: v.clone().requires_grad_(True) for kk, v in rv.items()}
+        m2 = torch.zeros((len(views), P, 3), device=dev, requires_grad=True)
+        im, radii, depth = rasterize_gaussians_views(views, leaves["means3D"], m2, leaves["opacities"], colors_precomp=leaves["colors_precomp"],
+                                                     scales=leaves["scales"], rotations=leaves["rotations"])
+        im.backward(gradient=g)
+        return im.detach(), radii, depth.detach(), {kk: v.grad for kk, v in leaves.items()}, m2.grad
+    im3, rad3, dep3, g3, m3 = run([cams[0], away, cams[1]], dL)
+    im2, rad2, dep2, g2, m2_ = run([cams[0], cams[1]], dL[[0, 2]])
+    assert int((rad3[1] > 0).sum()) == 0 and torch.all(dep3[1] == 0)
+    assert torch.allclose(im3[1], torch.tensor([0.2, 0.4, 0.6], device=dev)[:, None, None].expand(3, H, W))
+    assert torch.equal(im3[0], im2[0]) and torch.equal(im3[2], im2[1]) and torch.all(m3[1] == 0)
+    for kk in g2:
+        assert (g3[kk] - g2[kk]).abs().max().item() <= 1e-6 * g2[kk].abs().max().item(), kk
