@@ -166,7 +166,9 @@ __device__ __forceinline__ void fwd_tile(
       if ((mask >> w) & 1u) {
         uint32_t pos = (uint32_t)__popcll(bal[w] & gsr_lanemask_lt());
         for (int v = 0; v < wv; ++v) pos += L.cnt[v][w];
-        L.sA[w][pos] = a; L.sB[w][pos] = b; L.sC[w][pos] = c;
+        L.sA[w][pos] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);   // conic pre-scaled for the blend loop: hA, nB
+        L.sB[w][pos] = make_float4(-0.5f * b.x, b.y, b.z, b.w);    // hC
+        L.sC[w][pos] = c;
       }
     }
     // readfirstlane makes the trip count a scalar
@@ -184,7 +186,7 @@ __device__ __forceinline__ void fwd_tile(
 #define GSR_FWD_ENTRY(ea, eb, ec)                                                                   \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
-        const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;             \
+        const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
         const float alpha = fminf(GSR_ALPHA_MAX, eb.y * gsr_exp(power));                            \
         const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                          \
         const float test_T = T * (1.0f - alpha);                                                    \
@@ -337,7 +339,9 @@ __device__ __forceinline__ void bwd_tile(
       if ((mask >> w) & 1u) {
         uint32_t p = (uint32_t)__popcll(bal[w] & gsr_lanemask_lt());
         for (int v = 0; v < wv; ++v) p += L.cnt[v][w];
-        L.sA[w][p] = a; L.sB[w][p] = b; L.sC[w][p] = c;
+        L.sA[w][p] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);     // hA = -A/2, nB = -B (see fwd_tile)
+        L.sB[w][p] = make_float4(-0.5f * b.x, b.y, b.z, b.w);      // hC = -C/2
+        L.sC[w][p] = c;
       }
     }
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
@@ -355,7 +359,7 @@ __device__ __forceinline__ void bwd_tile(
       const int pos = max_last - 1 - (base + j);                                                              \
       const float blue = ec.x;                                                                                \
       const float dx = ea.x - pxf, dy = ea.y - pyf;                                                           \
-      const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;                         \
+      const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);        \
       const float G0 = gsr_exp(power);                                                                        \
       const bool hit = (pos < last) && power <= 0.0f && fminf(GSR_ALPHA_MAX, eb.y * G0) >= GSR_ALPHA_MIN;     \
       if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
@@ -381,8 +385,8 @@ __device__ __forceinline__ void bwd_tile(
         const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                          \
         const float gdx = G * dx, gdy = G * dy;                                                               \
         const float hG = -0.5f * dL_dG;                                                                       \
-        const float v0 = dL_dG * (-(gdx * ea.z) - gdy * ea.w);                                                \
-        const float v1 = dL_dG * (-(gdy * eb.x) - gdx * ea.w);                                                \
+        const float v0 = dL_dG * __builtin_fmaf(2.0f * gdx, ea.z, gdy * ea.w);  /* -(gdx A) - gdy B */               \
+        const float v1 = dL_dG * __builtin_fmaf(2.0f * gdy, eb.x, gdx * ea.w);  /* -(gdy C) - gdx B */               \
         const float v2 = hG * (gdx * dx);                                                                     \
         const float v3 = -dL_dG * (gdx * dy);                                                                 \
         const float v4 = hG * (gdy * dy);                                                                     \
