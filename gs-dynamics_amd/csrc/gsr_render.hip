@@ -266,7 +266,9 @@ __device__ __forceinline__ void bwd_tile(
   if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
   const float nTfbg = -T_final * (bg[0] * dL0 + bg[1] * dL1 + bg[2] * dL2);
   float T = T_final;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+  // Colour accumulated behind the current entry, only ever used dotted with this pixel's dL/dcolour: kept as that dot
+  // product (acc_dot), with the previous entry's colour . dL (last_cdot) pending -- 6 VALU per entry instead of 12.
+  float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;
 
   GSR_T0();
   if (tid == 0) L.sMaxLast = 0;
@@ -373,14 +375,11 @@ __device__ __forceinline__ void bwd_tile(
         const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);                                                \
         T = T * rcp;                                                                                          \
         const float w = alpha * T;                                                                            \
-        acc0 = __builtin_fmaf(last_alpha, lc0 - acc0, acc0);                                                  \
-        acc1 = __builtin_fmaf(last_alpha, lc1 - acc1, acc1);                                                  \
-        acc2 = __builtin_fmaf(last_alpha, lc2 - acc2, acc2);                                                  \
-        lc0 = eb.z; lc1 = eb.w; lc2 = blue;                                                                   \
+        acc_dot = __builtin_fmaf(last_alpha, last_cdot - acc_dot, acc_dot);                                   \
+        const float cdot = __builtin_fmaf(blue, dL2, __builtin_fmaf(eb.w, dL1, eb.z * dL0));                  \
+        last_cdot = cdot;                                                                                     \
         last_alpha = alpha;                                                                                   \
-        float dL_dalpha = (eb.z - acc0) * dL0;                                                                \
-        dL_dalpha = __builtin_fmaf(eb.w - acc1, dL1, dL_dalpha);                                              \
-        dL_dalpha = __builtin_fmaf(blue - acc2, dL2, dL_dalpha);                                              \
+        float dL_dalpha = cdot - acc_dot;                                                                     \
         dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                                \
         const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                          \
         const float gdx = G * dx, gdy = G * dy;                                                               \
