@@ -107,7 +107,8 @@ __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__
     r2x += q2x;
   }
   PartialSum ps;
-  ps.gmx = r0.x; ps.gmy = r0.y; ps.gA = r0.z; ps.gB = r0.w; ps.gC = r1.x; ps.gop = r1.y;
+  // the blend backward stores the conic partials without their constant factors (dA: -1/2, dB: -1, dC: -1/2)
+  ps.gmx = r0.x; ps.gmy = r0.y; ps.gA = -0.5f * r0.z; ps.gB = -r0.w; ps.gC = -0.5f * r1.x; ps.gop = r1.y;
   ps.dr = r1.z; ps.dg = r1.w; ps.db = r2x;
   return ps;
 }

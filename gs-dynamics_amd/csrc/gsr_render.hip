@@ -381,15 +381,14 @@ __device__ __forceinline__ void bwd_tile(
         last_alpha = alpha;                                                                                   \
         float dL_dalpha = cdot - acc_dot;                                                                     \
         dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                                \
-        const float dL_dG = eb.y * dL_dalpha; /* min(0.99, .) is straight-through */                          \
-        const float gdx = G * dx, gdy = G * dy;                                                               \
-        const float hG = -0.5f * dL_dG;                                                                       \
-        const float v0 = dL_dG * __builtin_fmaf(2.0f * gdx, ea.z, gdy * ea.w);  /* -(gdx A) - gdy B */               \
-        const float v1 = dL_dG * __builtin_fmaf(2.0f * gdy, eb.x, gdx * ea.w);  /* -(gdy C) - gdx B */               \
-        const float v2 = hG * (gdx * dx);                                                                     \
-        const float v3 = -dL_dG * (gdx * dy);                                                                 \
-        const float v4 = hG * (gdy * dy);                                                                     \
+        /* t = dL/dG * G with dL/dG = opacity * dL/dalpha (min(0.99, .) is straight-through).  The conic partials are     \
+           stored WITHOUT their constant factors (-1/2, -1, -1/2: preprocess_bwd applies them to the per-Gaussian sums). */ \
         const float v5 = G * dL_dalpha;                                                                       \
+        const float t = eb.y * v5;                                                                            \
+        const float tx = t * dx, ty = t * dy;                                                                 \
+        const float v0 = __builtin_fmaf(tx, ea.z + ea.z, ty * ea.w);  /* -(A tx) - B ty  (ea.z = -A/2, ea.w = -B) */   \
+        const float v1 = __builtin_fmaf(ty, eb.x + eb.x, tx * ea.w);  /* -(C ty) - B tx */                            \
+        const float v2 = tx * dx, v3 = tx * dy, v4 = ty * dy;                                                 \
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \
         if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
