@@ -199,8 +199,12 @@ __device__ __forceinline__ void view_chain(const float* __restrict__ view, const
   const float dtx = xm * -fx * itz2 * dJ02;
   const float dty = ym * -fy * itz2 * dJ12;
   const float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
-  gm2[0] = ps.gmx * 0.5f * (float)W;
-  gm2[1] = ps.gmy * 0.5f * (float)H;
+  // the blend backward hands over the raw sums of t*dx and t*dy (ps.gmx, ps.gmy); with the conic
+  // (A, B, C) = (cc, -b, a) / det:  d/d mean2D.x = -(A sx + B sy),  d/d mean2D.y = -(C sy + B sx)
+  const float det_inv = 1.0f / det;
+  const float cA = cc * det_inv, cB = -b * det_inv, cC = a * det_inv;
+  gm2[0] = -(cA * ps.gmx + cB * ps.gmy) * 0.5f * (float)W;
+  gm2[1] = -(cC * ps.gmy + cB * ps.gmx) * 0.5f * (float)H;
   const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
   const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
   const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];

@@ -386,8 +386,9 @@ __device__ __forceinline__ void bwd_tile(
         const float v5 = G * dL_dalpha;                                                                       \
         const float t = eb.y * v5;                                                                            \
         const float tx = t * dx, ty = t * dy;                                                                 \
-        const float v0 = __builtin_fmaf(tx, ea.z + ea.z, ty * ea.w);  /* -(A tx) - B ty  (ea.z = -A/2, ea.w = -B) */   \
-        const float v1 = __builtin_fmaf(ty, eb.x + eb.x, tx * ea.w);  /* -(C ty) - B tx */                            \
+        /* mean2D: d/dmx = -(A tx + B ty), d/dmy = -(C ty + B tx) is linear in (tx, ty) with per-Gaussian constants, so    \
+           the raw sums of tx and ty travel and preprocess_bwd applies the conic once per Gaussian */                    \
+        const float v0 = tx, v1 = ty;                                                                         \
         const float v2 = tx * dx, v3 = tx * dy, v4 = ty * dy;                                                 \
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \

@@ -461,7 +461,8 @@ def test_batched_views_equal_per_view_calls(dev):
     torch.cuda.synchronize()
     assert torch.equal(imb.detach(), torch.stack(ims)) and torch.equal(radb, torch.stack(rads))
     assert torch.equal(depb.detach(), torch.stack(deps))
-    assert torch.equal(m2v.grad, torch.stack(m2g))
+    # (two different kernels evaluate the same per-Gaussian chain: equal up to instruction contraction)
+    assert (m2v.grad - torch.stack(m2g)).abs().max().item() <= 2e-6 * torch.stack(m2g).abs().max().item()
     for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
         ga, gb = a[k].grad, b[k].grad
         scale = ga.abs().max().item()
