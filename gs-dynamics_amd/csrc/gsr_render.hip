@@ -52,6 +52,8 @@ namespace {
 
 #define GSR_QW 8   // pixel region of one wave inside the 16x16 tile: 8x8 quad (2 x 2 quads per tile)
 #define GSR_QH 8
+#define GSR_HALF_LOG2E (-0.5f * 1.44269502162933349609375f)
+#define GSR_NEG_LOG2E (-1.44269502162933349609375f)
 #ifndef FWD_BATCH
 #define FWD_BATCH 128
 #endif
@@ -166,8 +168,9 @@ __device__ __forceinline__ void fwd_tile(
       if ((mask >> w) & 1u) {
         uint32_t pos = (uint32_t)__popcll(bal[w] & gsr_lanemask_lt());
         for (int v = 0; v < wv; ++v) pos += L.cnt[v][w];
-        L.sA[w][pos] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);   // conic pre-scaled for the blend loop: hA, nB
-        L.sB[w][pos] = make_float4(-0.5f * b.x, b.y, b.z, b.w);    // hC
+        // conic pre-scaled for the blend loop: (-A/2, -B, -C/2) * log2(e), so that the quadratic form IS the exponent of v_exp_f32
+        L.sA[w][pos] = make_float4(a.x, a.y, GSR_HALF_LOG2E * a.z, GSR_NEG_LOG2E * a.w);
+        L.sB[w][pos] = make_float4(GSR_HALF_LOG2E * b.x, b.y, b.z, b.w);
         L.sC[w][pos] = c;
       }
     }
@@ -187,7 +190,7 @@ __device__ __forceinline__ void fwd_tile(
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
         const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
-        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * gsr_exp(power));                            \
+        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * __builtin_amdgcn_exp2f(power));  /* power is in log2 units */ \
         const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                          \
         const float test_T = T * (1.0f - alpha);                                                    \
         const bool stop = hit && test_T < GSR_T_EPS;                                                \
@@ -341,8 +344,8 @@ __device__ __forceinline__ void bwd_tile(
       if ((mask >> w) & 1u) {
         uint32_t p = (uint32_t)__popcll(bal[w] & gsr_lanemask_lt());
         for (int v = 0; v < wv; ++v) p += L.cnt[v][w];
-        L.sA[w][p] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);     // hA = -A/2, nB = -B (see fwd_tile)
-        L.sB[w][p] = make_float4(-0.5f * b.x, b.y, b.z, b.w);      // hC = -C/2
+        L.sA[w][p] = make_float4(a.x, a.y, GSR_HALF_LOG2E * a.z, GSR_NEG_LOG2E * a.w);   // (-A/2, -B) * log2(e), see fwd_tile
+        L.sB[w][p] = make_float4(GSR_HALF_LOG2E * b.x, b.y, b.z, b.w);                   // -C/2 * log2(e)
         L.sC[w][p] = c;
       }
     }
@@ -362,7 +365,7 @@ __device__ __forceinline__ void bwd_tile(
       const float blue = ec.x;                                                                                \
       const float dx = ea.x - pxf, dy = ea.y - pyf;                                                           \
       const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);        \
-      const float G0 = gsr_exp(power);                                                                        \
+      const float G0 = __builtin_amdgcn_exp2f(power);  /* power is in log2 units (pre-scaled conic) */        \
       const bool hit = (pos < last) && power <= 0.0f && fminf(GSR_ALPHA_MAX, eb.y * G0) >= GSR_ALPHA_MIN;     \
       if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
         /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
