@@ -456,7 +456,7 @@ int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotatio
   return gsr_launch_lbs(P, n_bones, bones, rotations, translations, bone_quats, xyz, quat, out_xyz, out_quat, (hipStream_t)stream);
 }
 
-int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * ((H + 15) / 16) * ((W + 15) / 16); }
+int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * gsr_loss_blocks_per_channel(H, W); }
 
 int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,
                            float* fA, float* fC, float* fE, float* block_l1, float* block_ssim, void* stream) {
@@ -477,6 +477,43 @@ int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, in
   if (channels_per_image <= 0 || C % channels_per_image != 0) { gsr_set_error("gsr_image_loss_backward: C must be a multiple of channels_per_image"); return -2; }
   return gsr_launch_image_loss_bwd(window11_host, C, H, W, pred, target, fA, fC, fE, grad_loss, channels_per_image, w_l1, w_ssim, d_pred,
                                    (hipStream_t)stream);
+}
+
+int32_t gsr_views_loss_blocks(int32_t n_images, int32_t channels, int32_t H, int32_t W) {
+  return n_images * channels * gsr_loss_blocks_per_channel(H, W);
+}
+
+static int views_loss_check(const char* who, const gsr_loss_views* v, int32_t H, int32_t W, const float* cam_m, const float* cam_c) {
+  if (!v || v->n_images <= 0 || v->n_images > GSR_LOSS_MAX_IMAGES || v->channels <= 0 || v->channels > 4 || H <= 0 || W <= 0) {
+    gsr_set_error("%s: bad view table (1..%d images of 1..4 channels)", who, GSR_LOSS_MAX_IMAGES);
+    return -2;
+  }
+  for (int i = 0; i < v->n_images; ++i) {
+    if (!v->target[i]) { gsr_set_error("%s: target[%d] is NULL", who, i); return -2; }
+    if (v->cam_row[i] >= 0 && (!cam_m || !cam_c)) { gsr_set_error("%s: image %d has a camera row but cam_m / cam_c is NULL", who, i); return -2; }
+  }
+  return 0;
+}
+
+int gsr_views_loss_forward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
+                           const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
+                           float* partials, float* losses, void* stream) {
+  if (int e = views_loss_check("gsr_views_loss_forward", views, H, W, cam_m, cam_c)) return e;
+  if (!window11_host || !renders || !fA || !fC || !fE || !partials || !losses) { gsr_set_error("gsr_views_loss_forward: NULL argument"); return -2; }
+  return gsr_launch_views_loss_fwd(window11_host, views, H, W, renders, cam_m, cam_c, w_l1, w_ssim, fA, fC, fE, partials, losses,
+                                   (hipStream_t)stream);
+}
+
+int gsr_views_loss_backward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
+                            const float* cam_m, const float* cam_c, int32_t n_cams, const float* fA, const float* fC,
+                            const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders, float* partials,
+                            float* d_cam_m, float* d_cam_c, void* stream) {
+  if (int e = views_loss_check("gsr_views_loss_backward", views, H, W, cam_m, cam_c)) return e;
+  if (!window11_host || !renders || !fA || !fC || !fE || !grad_total || !d_renders || !partials) { gsr_set_error("gsr_views_loss_backward: NULL argument"); return -2; }
+  for (int i = 0; i < views->n_images; ++i)
+    if (views->cam_row[i] >= n_cams && d_cam_m) { gsr_set_error("gsr_views_loss_backward: cam_row[%d] = %d >= n_cams = %d", i, views->cam_row[i], n_cams); return -2; }
+  return gsr_launch_views_loss_bwd(window11_host, views, H, W, renders, cam_m, cam_c, n_cams, fA, fC, fE, grad_total, w_l1, w_ssim,
+                                   d_renders, partials, d_cam_m, d_cam_c, (hipStream_t)stream);
 }
 
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {

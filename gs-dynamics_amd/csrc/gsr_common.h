@@ -226,6 +226,14 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
                               const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st);
+int gsr_loss_blocks_per_channel(int H, int W);
+int gsr_launch_views_loss_fwd(const float* win11_host, const gsr_loss_views* v, int H, int W, const float* renders,
+                              const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
+                              float* partials, float* losses, hipStream_t st);
+int gsr_launch_views_loss_bwd(const float* win11_host, const gsr_loss_views* v, int H, int W, const float* renders,
+                              const float* cam_m, const float* cam_c, int n_cams, const float* fA, const float* fC,
+                              const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders,
+                              float* partials, float* d_cam_m, float* d_cam_c, hipStream_t st);
 int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* partial,
                             hipStream_t st);

@@ -1,153 +1,363 @@
-// gsr_loss.hip -- fused image loss of the tracking step for gfx950:
-//     loss = 0.8 * mean|x - y| + 0.2 * (1 - mean SSIM(x, y))
-// exactly the term the reference evaluates twice per iteration with PyTorch ops
-// (/root/reference/src/tracking/train_utils.py:185,195; SSIM = five zero-padded depthwise 11x11 Gaussian
-// convolutions, /root/reference/src/tracking/external.py:101-135).  Here: one forward and one backward kernel.
+// gsr_loss.hip -- fused image terms of the tracking step for gfx950:
+//     loss_i = w_l1 * mean|pred_i - target_i| + w_ssim * (1 - mean SSIM(pred_i, target_i)),   total = sum_i weight_i loss_i
+// with pred_i = exp(cam_m[row_i]) * render_i + cam_c[row_i] for the colour renders (the per-camera affine of
+// /root/reference/src/tracking/train_utils.py:181-183) and pred_i = render_i for the segmentation renders -- exactly the
+// terms the reference evaluates twice per iteration with PyTorch ops (train_utils.py:185,195; SSIM = five zero-padded
+// depthwise 11x11 Gaussian convolutions, /root/reference/src/tracking/external.py:101-135).  Here: one forward and one
+// backward kernel for ALL images of a step, reading the rasterizer's output batch in place and writing the gradient batch
+// the rasterizer's backward consumes, plus two single-workgroup finishing kernels (losses / camera-affine gradients).
 //
-// A 256-thread workgroup owns a 16x16 output tile of one channel.  The 26x26 input patch (halo 5, zeros
-// outside the image, as conv2d's zero padding) of x and y goes to LDS; the 11-tap Gaussian is applied
-// separably (horizontal pass into LDS for the five moments x, y, xx, yy, xy; vertical pass in registers).
-// Forward also stores, per pixel, the three partials of the SSIM map w.r.t. the blurred moments that depend
-// on x: f_A (d/d blur(x)), f_C (d/d blur(xx)), f_E (d/d blur(xy)); because the window is symmetric,
-//     d loss / d x(q) = [blur(f_A) + 2 x blur(f_C) + y blur(f_E)](q) * (-0.2 / N) + 0.8 sign(x - y) / N,
-// which the backward kernel evaluates with the same separable machinery.  Block partial sums are written
-// to an array and summed by the caller: no atomics, deterministic.
+// A 256-thread workgroup owns a 32 x 54 output tile of one channel of one image.  The 42 x 64 input patch (halo 5, zeros
+// outside the image, as conv2d's zero padding) goes to LDS; the 11-tap Gaussian is applied separably with register blocking:
+//   horizontal: 64 patch rows x 4 segments of 8 outputs = 256 items; an item reads its 18 inputs once (5 ds_read_b128 per
+//               map) and produces 8 outputs per moment, written back over the patch (all reads are in registers by then);
+//   vertical:   32 columns x 8 segments of 7 rows = 256 items; 17 reads per moment for 7 outputs.
+// ~130 VALU lane-operations and ~25 LDS dwords per pixel, against ~200 and ~90 for one output per thread.
+// Forward also stores, per pixel, the three partials of the SSIM map w.r.t. the blurred moments that depend on pred:
+// f_A (d/d blur(x)), f_C (d/d blur(xx)), f_E (d/d blur(xy)); because the window is symmetric,
+//     d loss / d x(q) = [blur(f_A) + 2 x blur(f_C) + y blur(f_E)](q) * (-w_ssim / N) + w_l1 sign(x - y) / N,
+// which the backward kernel evaluates with the same machinery.  Block partial sums go to arrays that the finishing kernels
+// (or the caller) add up in a fixed order: no atomics, deterministic.
 #include "gsr_common.h"
 
 namespace {
 
-#define LT 16          // output tile edge
+#define TW 32               // output tile width
+#define TH 54               // output tile height
 #define HALO 5
-#define PT (LT + 2 * HALO)  // 26
-
-__device__ __forceinline__ float load_px(const float* __restrict__ img, int H, int W, int y, int x) {
-  return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
-}
+#define PW (TW + 2 * HALO)  // 42 patch columns
+#define PH (TH + 2 * HALO)  // 64 patch rows
+#define PS 44               // patch row stride in floats (16-byte aligned rows, >= 3 * 8 + 20)
+#define VSEG 7              // output rows per vertical item (8 segments cover 56 >= TH)
 
 struct Win { float g[11]; };
 
-__global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, int C, int H, int W, const float* __restrict__ x_img,
-                                                             const float* __restrict__ y_img,
+struct LossTab {                 // one entry per image, passed by value
+  int n_images, channels;
+  int cam_row[GSR_LOSS_MAX_IMAGES];
+  int grad_idx[GSR_LOSS_MAX_IMAGES];
+  float weight[GSR_LOSS_MAX_IMAGES];
+  const float* target[GSR_LOSS_MAX_IMAGES];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// 8 outputs of the 11-tap filter over 18 inputs
+#define GSR_FIR8(out, in, g)                                  \
+  _Pragma("unroll") for (int o_ = 0; o_ < 8; ++o_) {          \
+    float s_ = 0.f;                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 11; ++k_) s_ = fmaf((g)[k_], (in)[o_ + k_], s_); \
+    (out)[o_] = s_;                                           \
+  }
+
+__device__ __forceinline__ void load20(const float* __restrict__ row, float* __restrict__ v) {
+  const float4* __restrict__ p = reinterpret_cast<const float4*>(row);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { const float4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+}
+
+__device__ __forceinline__ void store8(float* __restrict__ dst, const float* __restrict__ v) {
+  float4* __restrict__ p = reinterpret_cast<float4*>(dst);
+  p[0] = make_float4(v[0], v[1], v[2], v[3]);
+  p[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab tab, int H, int W, const float* __restrict__ x_img,
+                                                             const float* __restrict__ cam_m, const float* __restrict__ cam_c,
                                                              float* __restrict__ fA, float* __restrict__ fC,
                                                              float* __restrict__ fE, float* __restrict__ block_l1,
                                                              float* __restrict__ block_ssim) {
-  __shared__ float sx[PT][PT + 1];
-  __shared__ float sy[PT][PT + 1];
-  __shared__ float hb[5][PT][LT + 1];   // horizontally blurred moments
+  __shared__ __attribute__((aligned(16))) float smem[5 * PH * TW];   // patch x|y (2 * 64 * 44), then the 5 blurred moments
   __shared__ float red[2][4];
-  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-  const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
-  const float* __restrict__ xc = x_img + (size_t)ch * H * W;
-  const float* __restrict__ yc = y_img + (size_t)ch * H * W;
-  for (int i = tid; i < PT * PT; i += 256) {
-    const int py = i / PT, px = i % PT;
-    sx[py][px] = load_px(xc, H, W, ty0 + py - HALO, tx0 + px - HALO);
-    sy[py][px] = load_px(yc, H, W, ty0 + py - HALO, tx0 + px - HALO);
-  }
-  __syncthreads();
-  for (int i = tid; i < PT * LT; i += 256) {   // horizontal pass: 26 rows x 16 columns
-    const int py = i / LT, ox = i % LT;
-    float a = 0.f, b = 0.f, c = 0.f, d = 0.f, e = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float xv = sx[py][ox + k], yv = sy[py][ox + k], w = win.g[k];
-      a += w * xv; b += w * yv; c += w * xv * xv; d += w * yv * yv; e += w * xv * yv;
+  float* __restrict__ sx = smem;
+  float* __restrict__ sy = smem + PH * PS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, ch = blockIdx.z;
+  const int img = ch / tab.channels, c = ch - img * tab.channels;
+  const size_t HW = (size_t)H * W;
+  const float* __restrict__ xc = x_img + (size_t)ch * HW;
+  const float* __restrict__ yc = tab.target[img] + (size_t)c * HW;
+  float a = 1.0f, b = 0.0f;
+  const int row = tab.cam_row[img];
+  if (row >= 0) { a = expf(cam_m[row * tab.channels + c]); b = cam_c[row * tab.channels + c]; }
+
+  for (int r = wave; r < PH; r += 4) {
+    const int gy = ty0 + r - HALO, gx = tx0 + lane - HALO;
+    if (lane < PW) {
+      float xv = 0.f, yv = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const size_t o = (size_t)gy * W + gx;
+        xv = fmaf(a, xc[o], b);
+        yv = yc[o];
+      }
+      sx[r * PS + lane] = xv;
+      sy[r * PS + lane] = yv;
     }
-    hb[0][py][ox] = a; hb[1][py][ox] = b; hb[2][py][ox] = c; hb[3][py][ox] = d; hb[4][py][ox] = e;
   }
   __syncthreads();
-  float A = 0.f, B = 0.f, Cc = 0.f, D = 0.f, E = 0.f;
+  // horizontal pass
+  const int hr = tid >> 2, hs = tid & 3;
+  float xr[20], yr[20];
+  load20(sx + hr * PS + hs * 8, xr);
+  load20(sy + hr * PS + hs * 8, yr);
+  float l1 = 0.f;
+  if (hr >= HALO && hr < HALO + TH) {
 #pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = win.g[k];
-    A += w * hb[0][ly + k][lx]; B += w * hb[1][ly + k][lx]; Cc += w * hb[2][ly + k][lx];
-    D += w * hb[3][ly + k][lx]; E += w * hb[4][ly + k][lx];
+    for (int o = 0; o < 8; ++o) l1 += fabsf(xr[o + HALO] - yr[o + HALO]);   // pixels outside the image are 0 - 0
   }
-  const int gx = tx0 + lx, gy = ty0 + ly;
-  const bool inside = gx < W && gy < H;
-  float ssim = 0.f, l1 = 0.f;
-  if (inside) {
-    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-    const float num1 = 2.0f * A * B + c1, num2 = 2.0f * (E - A * B) + c2;
-    const float den1 = A * A + B * B + c1, den2 = (Cc - A * A) + (D - B * B) + c2;
-    const float inv = 1.0f / (den1 * den2);
-    ssim = num1 * num2 * inv;
-    const size_t o = (size_t)ch * H * W + (size_t)gy * W + gx;
-    fA[o] = 2.0f * B * (num2 - num1) * inv - ssim * 2.0f * A * (1.0f / den1 - 1.0f / den2);
-    fC[o] = -ssim / den2;
-    fE[o] = 2.0f * num1 * inv;
-    l1 = fabsf(sx[ly + HALO][lx + HALO] - sy[ly + HALO][lx + HALO]);
-  }
-  // block sums (wave shuffle + LDS), one partial per block
+  __syncthreads();                      // every row is in registers: the moments may overwrite the patch
+  {
+    float out[8], prod[18];
+    float* __restrict__ dst = smem + hr * TW + hs * 8;
+    GSR_FIR8(out, xr, win.g); store8(dst, out);
+    GSR_FIR8(out, yr, win.g); store8(dst + PH * TW, out);
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { ssim += __shfl_xor(ssim, m, 64); l1 += __shfl_xor(l1, m, 64); }
-  if ((tid & 63) == 0) { red[0][tid >> 6] = ssim; red[1][tid >> 6] = l1; }
+    for (int j = 0; j < 18; ++j) prod[j] = xr[j] * xr[j];
+    GSR_FIR8(out, prod, win.g); store8(dst + 2 * PH * TW, out);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) prod[j] = yr[j] * yr[j];
+    GSR_FIR8(out, prod, win.g); store8(dst + 3 * PH * TW, out);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) prod[j] = xr[j] * yr[j];
+    GSR_FIR8(out, prod, win.g); store8(dst + 4 * PH * TW, out);
+  }
+  __syncthreads();
+  // vertical pass + SSIM map
+  const int vc = tid & 31, vs = tid >> 5, r0 = vs * VSEG;
+  float mom[5][VSEG];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    float v[VSEG + 10];
+#pragma unroll
+    for (int i = 0; i < VSEG + 10; ++i) v[i] = smem[m * PH * TW + min(r0 + i, PH - 1) * TW + vc];
+#pragma unroll
+    for (int o = 0; o < VSEG; ++o) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) s = fmaf(win.g[k], v[o + k], s);
+      mom[m][o] = s;
+    }
+  }
+  float ssim_sum = 0.f;
+  const int gx = tx0 + vc;
+#pragma unroll
+  for (int o = 0; o < VSEG; ++o) {
+    const int gy = ty0 + r0 + o;
+    if (r0 + o < TH && gx < W && gy < H) {
+      const float A = mom[0][o], B = mom[1][o], Cc = mom[2][o], D = mom[3][o], E = mom[4][o];
+      const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+      const float num1 = 2.0f * A * B + c1, num2 = 2.0f * (E - A * B) + c2;
+      const float den1 = A * A + B * B + c1, den2 = (Cc - A * A) + (D - B * B) + c2;
+      const float i1 = 1.0f / den1, i2 = 1.0f / den2, inv = i1 * i2;
+      const float ssim = num1 * num2 * inv;
+      const size_t q = (size_t)ch * HW + (size_t)gy * W + gx;
+      fA[q] = 2.0f * B * (num2 - num1) * inv - ssim * 2.0f * A * (i1 - i2);
+      fC[q] = -ssim * i2;
+      fE[q] = 2.0f * num1 * inv;
+      ssim_sum += ssim;
+    }
+  }
+  ssim_sum = wave_sum(ssim_sum);
+  l1 = wave_sum(l1);
+  if (lane == 0) { red[0][wave] = ssim_sum; red[1][wave] = l1; }
   __syncthreads();
   if (tid == 0) {
-    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_ssim[b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    block_l1[b] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const int bidx = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_ssim[bidx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    block_l1[bidx] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
 
-__global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, int C, int H, int W, const float* __restrict__ x_img,
-                                                             const float* __restrict__ y_img,
+__global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab tab, int H, int W, const float* __restrict__ x_img,
+                                                             const float* __restrict__ cam_m, const float* __restrict__ cam_c,
                                                              const float* __restrict__ fA, const float* __restrict__ fC,
-                                                             const float* __restrict__ fE,
-                                                             const float* __restrict__ grad_loss, int cpi, float w_l1, float w_ssim,
-                                                             float* __restrict__ dx) {
-  __shared__ float s0[PT][PT + 1];
-  __shared__ float s1[PT][PT + 1];
-  __shared__ float s2[PT][PT + 1];
-  __shared__ float hb[3][PT][LT + 1];
-  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-  const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
-  const size_t coff = (size_t)ch * H * W;
-  for (int i = tid; i < PT * PT; i += 256) {
-    const int py = i / PT, px = i % PT;
-    const int yy = ty0 + py - HALO, xx = tx0 + px - HALO;
-    s0[py][px] = load_px(fA + coff, H, W, yy, xx);
-    s1[py][px] = load_px(fC + coff, H, W, yy, xx);
-    s2[py][px] = load_px(fE + coff, H, W, yy, xx);
-  }
-  __syncthreads();
-  for (int i = tid; i < PT * LT; i += 256) {
-    const int py = i / LT, ox = i % LT;
-    float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k];
-      a += w * s0[py][ox + k]; b += w * s1[py][ox + k]; c += w * s2[py][ox + k];
+                                                             const float* __restrict__ fE, const float* __restrict__ grad,
+                                                             float invN, float w_l1, float w_ssim, float* __restrict__ dx,
+                                                             float* __restrict__ block_dm, float* __restrict__ block_dc) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * PH * PS];   // three patches, then the 3 blurred maps (3 * 64 * 32)
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, ch = blockIdx.z;
+  const int img = ch / tab.channels, c = ch - img * tab.channels;
+  const size_t HW = (size_t)H * W, coff = (size_t)ch * HW;
+  float a = 1.0f, b = 0.0f;
+  const int row = tab.cam_row[img];
+  if (row >= 0) { a = expf(cam_m[row * tab.channels + c]); b = cam_c[row * tab.channels + c]; }
+  const float g = grad[tab.grad_idx[img]] * tab.weight[img] * invN;
+
+  for (int r = wave; r < PH; r += 4) {
+    const int gy = ty0 + r - HALO, gx = tx0 + lane - HALO;
+    if (lane < PW) {
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const size_t o = coff + (size_t)gy * W + gx;
+        v0 = fA[o]; v1 = fC[o]; v2 = fE[o];
+      }
+      smem[r * PS + lane] = v0;
+      smem[PH * PS + r * PS + lane] = v1;
+      smem[2 * PH * PS + r * PS + lane] = v2;
     }
-    hb[0][py][ox] = a; hb[1][py][ox] = b; hb[2][py][ox] = c;
   }
   __syncthreads();
-  float bA = 0.f, bC = 0.f, bE = 0.f;
-#pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = win.g[k];
-    bA += w * hb[0][ly + k][lx]; bC += w * hb[1][ly + k][lx]; bE += w * hb[2][ly + k][lx];
+  const int hr = tid >> 2, hs = tid & 3;
+  float r0v[20], r1v[20], r2v[20];
+  load20(smem + hr * PS + hs * 8, r0v);
+  load20(smem + PH * PS + hr * PS + hs * 8, r1v);
+  load20(smem + 2 * PH * PS + hr * PS + hs * 8, r2v);
+  __syncthreads();
+  {
+    float out[8];
+    float* __restrict__ dst = smem + hr * TW + hs * 8;
+    GSR_FIR8(out, r0v, win.g); store8(dst, out);
+    GSR_FIR8(out, r1v, win.g); store8(dst + PH * TW, out);
+    GSR_FIR8(out, r2v, win.g); store8(dst + 2 * PH * TW, out);
   }
-  const int gx = tx0 + lx, gy = ty0 + ly;
-  if (gx < W && gy < H) {
-    const size_t o = coff + (size_t)gy * W + gx;
-    const float xv = x_img[o], yv = y_img[o];
-    const float invN = 1.0f / ((float)cpi * (float)H * (float)W);   // a batch of C / cpi images of cpi channels each
-    const float dssim = bA + 2.0f * xv * bC + yv * bE;            // d(sum of SSIM map)/dx
-    const float dl1 = xv > yv ? 1.0f : (xv < yv ? -1.0f : 0.0f);  // torch: sign(x - y), 0 at ties
-    dx[o] = grad_loss[ch / cpi] * invN * (w_l1 * dl1 - w_ssim * dssim);
+  __syncthreads();
+  const int vc = tid & 31, vs = tid >> 5, r0 = vs * VSEG;
+  float bl[3][VSEG];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    float v[VSEG + 10];
+#pragma unroll
+    for (int i = 0; i < VSEG + 10; ++i) v[i] = smem[m * PH * TW + min(r0 + i, PH - 1) * TW + vc];
+#pragma unroll
+    for (int o = 0; o < VSEG; ++o) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) s = fmaf(win.g[k], v[o + k], s);
+      bl[m][o] = s;
+    }
+  }
+  const float* __restrict__ yc = tab.target[img] + (size_t)c * HW;
+  const int gx = tx0 + vc;
+  float sum_dm = 0.f, sum_dc = 0.f;
+#pragma unroll
+  for (int o = 0; o < VSEG; ++o) {
+    const int gy = ty0 + r0 + o;
+    if (r0 + o < TH && gx < W && gy < H) {
+      const size_t p = (size_t)gy * W + gx;
+      const float xraw = x_img[coff + p], yv = yc[p];
+      const float xv = fmaf(a, xraw, b);
+      const float dssim = bl[0][o] + 2.0f * xv * bl[1][o] + yv * bl[2][o];   // d(sum of SSIM map)/d pred
+      const float dl1 = xv > yv ? 1.0f : (xv < yv ? -1.0f : 0.0f);           // torch: sign(x - y), 0 at ties
+      const float dpred = g * (w_l1 * dl1 - w_ssim * dssim);
+      const float dr = a * dpred;
+      dx[coff + p] = dr;
+      sum_dm += dr * xraw;       // d/d cam_m: pred = exp(m) render + c
+      sum_dc += dpred;
+    }
+  }
+  if (block_dm) {
+    sum_dm = wave_sum(sum_dm);
+    sum_dc = wave_sum(sum_dc);
+    if (lane == 0) { red[0][wave] = sum_dm; red[1][wave] = sum_dc; }
+    __syncthreads();
+    if (tid == 0) {
+      const int bidx = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      block_dm[bidx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      block_dc[bidx] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
   }
 }
+
+// one wave per image: loss_i from the block partials; then the weighted total.  Fixed summation order.
+__global__ __launch_bounds__(256) void loss_finish_fwd_kernel(LossTab tab, int per_image, const float* __restrict__ block_l1,
+                                                              const float* __restrict__ block_ssim, float invN, float w_l1,
+                                                              float w_ssim, float* __restrict__ losses) {
+  __shared__ float li[GSR_LOSS_MAX_IMAGES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < tab.n_images; i += 4) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < per_image; j += 64) { s1 += block_l1[(size_t)i * per_image + j]; s2 += block_ssim[(size_t)i * per_image + j]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+      const float l = w_l1 * (s1 * invN) + w_ssim * (1.0f - s2 * invN);
+      li[i] = l;
+      losses[i] = l;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < tab.n_images; ++i) t += tab.weight[i] * li[i];
+    losses[tab.n_images] = t;
+  }
+}
+
+// d_cam_m / d_cam_c [n_cams, channels]: one wave per (image, channel) sum, then a serial scatter in image order (duplicates add up)
+__global__ __launch_bounds__(256) void loss_finish_bwd_kernel(LossTab tab, int per_channel, const float* __restrict__ block_dm,
+                                                              const float* __restrict__ block_dc, int n_cams,
+                                                              float* __restrict__ d_cam_m, float* __restrict__ d_cam_c) {
+  __shared__ float sm[GSR_LOSS_MAX_IMAGES * 4], sc[GSR_LOSS_MAX_IMAGES * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = tab.channels, pairs = tab.n_images * nch;
+  for (int i = threadIdx.x; i < n_cams * nch; i += 256) { d_cam_m[i] = 0.f; d_cam_c[i] = 0.f; }
+  for (int p = wave; p < pairs; p += 4) {
+    float s1 = 0.f, s2 = 0.f;
+    if (tab.cam_row[p / nch] >= 0)
+      for (int j = lane; j < per_channel; j += 64) { s1 += block_dm[(size_t)p * per_channel + j]; s2 += block_dc[(size_t)p * per_channel + j]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { sm[p] = s1; sc[p] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < nch) {
+    const int c = threadIdx.x;
+    for (int i = 0; i < tab.n_images; ++i) {
+      const int row = tab.cam_row[i];
+      if (row >= 0 && row < n_cams) { d_cam_m[row * nch + c] += sm[i * nch + c]; d_cam_c[row * nch + c] += sc[i * nch + c]; }
+    }
+  }
+}
+
+Win make_win(const float* w11) {
+  Win w;
+  for (int i = 0; i < 11; ++i) w.g[i] = w11[i];
+  return w;
+}
+
+LossTab make_tab(const gsr_loss_views* v) {
+  LossTab t;
+  t.n_images = v->n_images;
+  t.channels = v->channels;
+  for (int i = 0; i < GSR_LOSS_MAX_IMAGES; ++i) {
+    const bool on = i < v->n_images;
+    t.cam_row[i] = on ? v->cam_row[i] : -1;
+    t.grad_idx[i] = 0;
+    t.weight[i] = on ? v->weight[i] : 0.f;
+    t.target[i] = on ? v->target[i] : nullptr;
+  }
+  return t;
+}
+
+inline dim3 loss_grid(int C, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, C); }
 
 }  // namespace
 
+int gsr_loss_blocks_per_channel(int H, int W) { return ((W + TW - 1) / TW) * ((H + TH - 1) / TH); }
+
+// plain batch of C channels (C / cpi images): the original entry points, chunked through the table kernels
 int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, float* fA,
                               float* fC, float* fE, float* block_l1, float* block_ssim, hipStream_t st) {
-  Win w;
-  for (int i = 0; i < 11; ++i) w.g[i] = win11_host[i];
-  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
-  { GSR_PROF("image_loss_fwd", st);
-    hipLaunchKernelGGL(image_loss_fwd_kernel, grid, dim3(256), 0, st, w, C, H, W, x, y, fA, fC, fE, block_l1, block_ssim); }
+  const Win w = make_win(win11_host);
+  const size_t HW = (size_t)H * W;
+  const int nb = gsr_loss_blocks_per_channel(H, W);
+  for (int c0 = 0; c0 < C; c0 += GSR_LOSS_MAX_IMAGES) {
+    const int n = C - c0 < GSR_LOSS_MAX_IMAGES ? C - c0 : GSR_LOSS_MAX_IMAGES;
+    LossTab t;
+    t.n_images = n; t.channels = 1;
+    for (int i = 0; i < GSR_LOSS_MAX_IMAGES; ++i) {
+      t.cam_row[i] = -1; t.grad_idx[i] = 0; t.weight[i] = 1.f;
+      t.target[i] = i < n ? y + (size_t)(c0 + i) * HW : nullptr;
+    }
+    { GSR_PROF("image_loss_fwd", st);
+      hipLaunchKernelGGL(image_loss_fwd_kernel, loss_grid(n, H, W), dim3(256), 0, st, w, t, H, W, x + (size_t)c0 * HW,
+                         (const float*)nullptr, (const float*)nullptr, fA + (size_t)c0 * HW, fC + (size_t)c0 * HW,
+                         fE + (size_t)c0 * HW, block_l1 + (size_t)c0 * nb, block_ssim + (size_t)c0 * nb); }
+  }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -155,12 +365,64 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
 int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, const float* x, const float* y, const float* fA,
                               const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st) {
-  Win w;
-  for (int i = 0; i < 11; ++i) w.g[i] = win11_host[i];
-  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  const Win w = make_win(win11_host);
+  const size_t HW = (size_t)H * W;
+  const float invN = 1.0f / ((float)cpi * (float)H * (float)W);   // a batch of C / cpi images of cpi channels each
+  for (int c0 = 0; c0 < C; c0 += GSR_LOSS_MAX_IMAGES) {
+    const int n = C - c0 < GSR_LOSS_MAX_IMAGES ? C - c0 : GSR_LOSS_MAX_IMAGES;
+    LossTab t;
+    t.n_images = n; t.channels = 1;
+    for (int i = 0; i < GSR_LOSS_MAX_IMAGES; ++i) {
+      t.cam_row[i] = -1; t.grad_idx[i] = i < n ? (c0 + i) / cpi : 0; t.weight[i] = 1.f;
+      t.target[i] = i < n ? y + (size_t)(c0 + i) * HW : nullptr;
+    }
+    { GSR_PROF("image_loss_bwd", st);
+      hipLaunchKernelGGL(image_loss_bwd_kernel, loss_grid(n, H, W), dim3(256), 0, st, w, t, H, W, x + (size_t)c0 * HW,
+                         (const float*)nullptr, (const float*)nullptr, fA + (size_t)c0 * HW, fC + (size_t)c0 * HW,
+                         fE + (size_t)c0 * HW, grad_loss, invN, w_l1, w_ssim, dx + (size_t)c0 * HW, (float*)nullptr, (float*)nullptr); }
+  }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_views_loss_fwd(const float* win11_host, const gsr_loss_views* v, int H, int W, const float* renders,
+                              const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
+                              float* partials, float* losses, hipStream_t st) {
+  const Win w = make_win(win11_host);
+  const LossTab t = make_tab(v);
+  const int C = v->n_images * v->channels, nb = gsr_loss_blocks_per_channel(H, W);
+  float* block_l1 = partials;
+  float* block_ssim = partials + (size_t)C * nb;
+  { GSR_PROF("image_loss_fwd", st);
+    hipLaunchKernelGGL(image_loss_fwd_kernel, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC, fE,
+                       block_l1, block_ssim); }
+  const float invN = 1.0f / ((float)v->channels * (float)H * (float)W);
+  { GSR_PROF("loss_finish_fwd", st);
+    hipLaunchKernelGGL(loss_finish_fwd_kernel, dim3(1), dim3(256), 0, st, t, v->channels * nb, (const float*)block_l1,
+                       (const float*)block_ssim, invN, w_l1, w_ssim, losses); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_views_loss_bwd(const float* win11_host, const gsr_loss_views* v, int H, int W, const float* renders,
+                              const float* cam_m, const float* cam_c, int n_cams, const float* fA, const float* fC,
+                              const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders,
+                              float* partials, float* d_cam_m, float* d_cam_c, hipStream_t st) {
+  const Win w = make_win(win11_host);
+  const LossTab t = make_tab(v);
+  const int C = v->n_images * v->channels, nb = gsr_loss_blocks_per_channel(H, W);
+  const bool cams = d_cam_m && d_cam_c && n_cams > 0;
+  float* block_dm = cams ? partials : nullptr;
+  float* block_dc = cams ? partials + (size_t)C * nb : nullptr;
+  const float invN = 1.0f / ((float)v->channels * (float)H * (float)W);
   { GSR_PROF("image_loss_bwd", st);
-    hipLaunchKernelGGL(image_loss_bwd_kernel, grid, dim3(256), 0, st, w, C, H, W, x, y, fA, fC, fE, grad_loss, cpi, w_l1, w_ssim,
-                       dx); }
+    hipLaunchKernelGGL(image_loss_bwd_kernel, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC, fE,
+                       grad_total, invN, w_l1, w_ssim, d_renders, block_dm, block_dc); }
+  if (cams) {
+    GSR_PROF("loss_finish_bwd", st);
+    hipLaunchKernelGGL(loss_finish_bwd_kernel, dim3(1), dim3(256), 0, st, t, nb, (const float*)block_dm, (const float*)block_dc,
+                       n_cams, d_cam_m, d_cam_c);
+  }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -35,6 +35,14 @@ class GsrDebugViews(C.Structure):
                                           "point_list", "ranges", "final_T", "n_contrib")]
 
 
+LOSS_MAX_IMAGES = 32
+
+
+class GsrLossViews(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("channels", C.c_int32), ("cam_row", C.c_int32 * LOSS_MAX_IMAGES),
+                ("weight", C.c_float * LOSS_MAX_IMAGES), ("target", C.c_void_p * LOSS_MAX_IMAGES)]
+
+
 class GsrKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64)]
 
@@ -45,7 +53,8 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
-           "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward")
+           "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
+           "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward")
 
 
 def load_library():
@@ -91,6 +100,14 @@ def load_library():
     lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
     lib.gsr_image_loss_backward.restype = C.c_int
     lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [i32, C.c_float, C.c_float, vp, vp]
+    lib.gsr_views_loss_blocks.restype = i32
+    lib.gsr_views_loss_blocks.argtypes = [i32] * 4
+    lib.gsr_views_loss_forward.restype = C.c_int
+    lib.gsr_views_loss_forward.argtypes = ([C.POINTER(C.c_float), C.POINTER(GsrLossViews), i32, i32, vp, vp, vp, C.c_float, C.c_float]
+                                           + [vp] * 6)
+    lib.gsr_views_loss_backward.restype = C.c_int
+    lib.gsr_views_loss_backward.argtypes = ([C.POINTER(C.c_float), C.POINTER(GsrLossViews), i32, i32, vp, vp, vp, i32, vp, vp, vp, vp,
+                                             C.c_float, C.c_float] + [vp] * 5)
     lib.gsr_rigidity_blocks.restype = i32
     lib.gsr_rigidity_blocks.argtypes = [i32]
     lib.gsr_rigidity_forward.restype = C.c_int
@@ -526,6 +543,64 @@ def image_loss_forward(window11, pred, target):
                                           _ptr(part[1]), _stream(dev)), "gsr_image_loss_forward")
     sums = part.view(2, N, nb // N).sum(2)          # block partials are channel-major: contiguous per image
     return (sums[0], sums[1], fA, fC, fE) if batched else (sums[0, 0], sums[1, 0], fA, fC, fE)
+
+
+def _loss_table(targets, cam_rows, weights, channels):
+    tab = GsrLossViews()
+    tab.n_images, tab.channels = len(targets), channels
+    for i, (t, r, w) in enumerate(zip(targets, cam_rows, weights)):
+        tab.cam_row[i], tab.weight[i], tab.target[i] = int(r), float(w), t.data_ptr()
+    return tab
+
+
+def views_loss_forward(window11, renders, targets, cam_rows, weights, cam_m, cam_c, w_l1, w_ssim):
+    """Image terms of all renders of a step (gsr_views_loss_forward): ``renders`` [n,C,H,W] (the rasterizer's output batch),
+    ``targets`` n tensors [C,H,W], ``cam_rows`` n ints (row of cam_m / cam_c, or -1), ``weights`` n floats.
+    Returns (losses[n+1] with the weighted total last, state for the backward)."""
+    lib = load_library()
+    _require_device(renders)
+    dev = renders.device
+    n, Cc, H, W = (int(d) for d in renders.shape)
+    if n > LOSS_MAX_IMAGES or len(targets) != n or len(cam_rows) != n or len(weights) != n:
+        raise RuntimeError(f"views_loss_forward: 1..{LOSS_MAX_IMAGES} images with one target / camera row / weight each")
+    if not renders.is_contiguous() or renders.dtype != torch.float32:
+        raise RuntimeError("views_loss_forward: renders must be a contiguous float32 batch")
+    targets = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t in targets]
+    for t in targets:
+        if tuple(t.shape) != (Cc, H, W) or t.device != dev:
+            raise RuntimeError("views_loss_forward: every target must be [C,H,W] on the renders' device")
+    win = (C.c_float * 11)(*[float(v) for v in window11])
+    tab = _loss_table(targets, cam_rows, weights, Cc)
+    with torch.cuda.device(dev):
+        nb = int(lib.gsr_views_loss_blocks(n, Cc, H, W))
+        f32 = dict(dtype=torch.float32, device=dev)
+        maps = torch.empty((3,) + tuple(renders.shape), **f32)
+        part = torch.empty((2, nb), **f32)
+        losses = torch.empty((n + 1,), **f32)
+        _check(lib.gsr_views_loss_forward(win, C.byref(tab), H, W, _ptr(renders), _ptr(cam_m), _ptr(cam_c), float(w_l1), float(w_ssim),
+                                          _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]), _ptr(part), _ptr(losses), _stream(dev)),
+               "gsr_views_loss_forward")
+    return losses, (win, tab, targets, maps, part)
+
+
+def views_loss_backward(state, renders, cam_m, cam_c, grad_total, w_l1, w_ssim, want_cam_grads=True):
+    """Returns (d_renders like renders, d_cam_m, d_cam_c like cam_m / None)."""
+    lib = load_library()
+    win, tab, _targets, maps, part = state
+    dev = renders.device
+    _n, _Cc, H, W = (int(d) for d in renders.shape)
+    with torch.cuda.device(dev):
+        g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
+        d_renders = torch.empty_like(renders)
+        d_m = d_c = None
+        n_cams = 0
+        if want_cam_grads and cam_m is not None:
+            n_cams = int(cam_m.shape[0])
+            d_m, d_c = torch.empty_like(cam_m), torch.empty_like(cam_c)
+        _check(lib.gsr_views_loss_backward(win, C.byref(tab), H, W, _ptr(renders), _ptr(cam_m), _ptr(cam_c), n_cams, _ptr(maps[0]),
+                                           _ptr(maps[1]), _ptr(maps[2]), _ptr(g), float(w_l1), float(w_ssim), _ptr(d_renders), _ptr(part),
+                                           _ptr(d_m), _ptr(d_c), _stream(dev)), "gsr_views_loss_backward")
+    return d_renders, d_m, d_c
 
 
 def image_loss_backward(window11, pred, target, fA, fC, fE, grad_loss, w_l1, w_ssim):

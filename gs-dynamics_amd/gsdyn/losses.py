@@ -124,6 +124,51 @@ class _FusedImageLoss(torch.autograd.Function):
         return d_pred, None, None, None
 
 
+class _FusedViewsLoss(torch.autograd.Function):
+    """Weighted sum of the image terms of ALL renders of a step, camera affine included, as one forward and one backward
+    HIP kernel (gsr_views_loss_*): reads the rasterizer's output batch in place, writes the gradient batch its backward takes."""
+
+    @staticmethod
+    def forward(ctx, renders, cam_m, cam_c, targets, cam_rows, weights, w_l1, w_ssim):
+        from diff_gaussian_rasterization import _hip
+        r = renders if (renders.is_contiguous() and renders.dtype == torch.float32) else renders.contiguous().float()
+        m = None if cam_m is None else cam_m.detach().contiguous().float()
+        c = None if cam_c is None else cam_c.detach().contiguous().float()
+        losses, state = _hip.views_loss_forward(_window_1d(), r.detach(), targets, cam_rows, weights, m, c, w_l1, w_ssim)
+        ctx.state, ctx.w = state, (float(w_l1), float(w_ssim))
+        ctx.save_for_backward(r, m, c)
+        per_image = losses[:-1]
+        ctx.mark_non_differentiable(per_image)
+        return losses[-1], per_image
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_losses):
+        from diff_gaussian_rasterization import _hip
+        r, m, c = ctx.saved_tensors
+        want = m is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        d_r, d_m, d_c = _hip.views_loss_backward(ctx.state, r, m, c, grad_total, ctx.w[0], ctx.w[1], want_cam_grads=want)
+        return d_r, d_m, d_c, None, None, None, None, None
+
+
+def views_image_loss(renders, targets, cam_rows, weights, cam_m=None, cam_c=None, w_l1: float = 0.8, w_ssim: float = 0.2):
+    """total = sum_i weights[i] * image_loss(pred_i, targets[i]) with pred_i = exp(cam_m[cam_rows[i]])[:,None,None] * renders[i] +
+    cam_c[cam_rows[i]][:,None,None] (cam_rows[i] < 0: pred_i = renders[i]) -- the image terms of the reference's ``get_loss``
+    (/root/reference/src/tracking/train_utils.py:181-195) for every render of a step at once.
+    Returns (total, per-image losses [n] detached).  HIP tensors take the fused kernels; CPU tensors (host-logic tests) the torch formula."""
+    if renders.is_cuda:
+        total, losses = _FusedViewsLoss.apply(renders, cam_m, cam_c, list(targets), [int(r) for r in cam_rows],
+                                              [float(w) for w in weights], w_l1, w_ssim)
+        return total, losses
+    per = []
+    for i, (t, row) in enumerate(zip(targets, cam_rows)):
+        pred = renders[i]
+        if row >= 0:
+            pred = torch.exp(cam_m[row])[:, None, None] * pred + cam_c[row][:, None, None]
+        per.append(w_l1 * l1_loss_v1(pred, t) + w_ssim * (1.0 - calc_ssim(pred, t)))
+    total = sum(w * l for w, l in zip(weights, per))
+    return total, torch.stack([l.detach() for l in per])
+
+
 class _FusedRigidity(torch.autograd.Function):
     """rigid / rot / iso means of the t > 0 loss as one forward and two backward HIP kernels (gsr_rigidity.hip)."""
 

@@ -14,7 +14,7 @@ import torch
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 
 from .losses import (build_rotation, calc_psnr, image_loss, l1_loss_v2, quat_mult, reverse_adjacency, rigidity_terms,
-                     weighted_l2_loss_v1, weighted_l2_loss_v2)
+                     views_image_loss, weighted_l2_loss_v1, weighted_l2_loss_v2)
 
 
 @dataclass
@@ -137,13 +137,11 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     m2 = torch.zeros((2 * V, P, 3), device=rendervar["means3D"].device, requires_grad=True)
     ims, radii, _ = rasterize_gaussians_views(cams, rendervar["means3D"], m2, rendervar["opacities"], colors_precomp=colours,
                                               scales=rendervar["scales"], rotations=rendervar["rotations"])
-    # both image terms of all cameras as two batched loss evaluations (one fused kernel pair each)
-    ids = [int(d["id"]) for d in datas]          # python indices: no host->device index tensor, no sync
-    cam_m = torch.stack([params["cam_m"][i] for i in ids])
-    cam_c = torch.stack([params["cam_c"][i] for i in ids])
-    col = torch.exp(cam_m)[:, :, None, None] * ims[0::2] + cam_c[:, :, None, None]
-    total = w.im * _image_term(col, torch.stack([d["im"] for d in datas])).sum() + \
-        w.seg * _image_term(ims[1::2], torch.stack([d["seg"] for d in datas])).sum()
+    # both image terms of all cameras, camera affine included, as ONE fused loss evaluation on the render batch
+    ids = [int(d["id"]) for d in datas]
+    targets = [t for d in datas for t in (d["im"], d["seg"])]
+    rows = [r for i in ids for r in (i, -1)]
+    total, _ = views_image_loss(ims, targets, rows, [w.im, w.seg] * V, params["cam_m"], params["cam_c"], 0.8, 0.2)
     if not is_initial_timestep:
         losses = {}
         _shared_terms(params, rendervar, variables, losses)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 110 /* 0.1.10: multi-view tables, batch_state, per-view colours */
+#define GSR_VERSION 111 /* 0.1.11: + image terms of all views of a step in one call (gsr_views_loss_*) */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -183,6 +183,33 @@ int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int
 int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
                             const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
                             int32_t channels_per_image, float w_l1, float w_ssim, float* d_pred, void* stream);
+
+/* ---- image terms of ALL renders of a tracking step in one call (SURVEY.md section 8f rows N1 + N2; caller: gsdyn/step.py
+ * get_loss_views).  `renders` is the rasterizer's output batch [n_images, channels, H, W] read in place; image i is compared with
+ * target[i] after the per-camera affine of /root/reference/src/tracking/train_utils.py:181-183,
+ *     pred_i = exp(cam_m[cam_row[i]]) * render_i + cam_c[cam_row[i]]        (per channel; cam_row[i] < 0: pred_i = render_i),
+ * and  losses[i] = w_l1 mean|pred_i - target_i| + w_ssim (1 - mean SSIM(pred_i, target_i)),  losses[n_images] = sum_i weight[i] losses[i]
+ * (train_utils.py:185,195 and the weighted sum at :235-241).
+ * forward: fA/fC/fE [n_images, channels, H, W] keep the per-pixel SSIM partials; partials = 2 * gsr_views_loss_blocks floats.
+ * backward: d_renders = grad_total[0] * d losses[n_images] / d renders, laid out like `renders` (what gsr_backward_batch takes as
+ *   dL_dcolor); d_cam_m / d_cam_c [n_cams, channels] (zero-filled, rows hit by several images add up in image order; both may be
+ *   NULL when no image has a camera row).  No float atomics: deterministic. */
+#define GSR_LOSS_MAX_IMAGES 32
+typedef struct gsr_loss_views {
+  int32_t n_images;                            /* <= GSR_LOSS_MAX_IMAGES */
+  int32_t channels;                            /* per image, <= 4 */
+  int32_t cam_row[GSR_LOSS_MAX_IMAGES];
+  float weight[GSR_LOSS_MAX_IMAGES];
+  const float* target[GSR_LOSS_MAX_IMAGES];    /* DEVICE [channels,H,W] each */
+} gsr_loss_views;
+int32_t gsr_views_loss_blocks(int32_t n_images, int32_t channels, int32_t H, int32_t W);
+int gsr_views_loss_forward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
+                           const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
+                           float* partials, float* losses, void* stream);
+int gsr_views_loss_backward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
+                            const float* cam_m, const float* cam_c, int32_t n_cams, const float* fA, const float* fC,
+                            const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders, float* partials,
+                            float* d_cam_m, float* d_cam_c, void* stream);
 
 /* ---- mark_visible  (replaces `mark_visible`; GaussianRasterizer.markVisible).  present[P] = view z > 0.2 */
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream);

@@ -700,6 +700,83 @@ def test_fused_image_loss_batch_equals_per_image(dev):
         assert (xi.grad - xb.grad[i]).abs().max().item() <= 1e-6 * xi.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("H,W", [(61, 45), (120, 200)])
+def test_views_loss_matches_torch_formula(dev, H, W):
+    """gsr_views_loss_*: the image terms of all renders of a step (camera affine included, one camera used twice) vs the
+    torch restatement of /root/reference/src/tracking/train_utils.py:181-195 -- total, per-image losses, and the gradients to
+    the render batch, cam_m and cam_c."""
+    from gsdyn import losses as L
+    rng = np.random.default_rng(H + W)
+    n, ncam = 6, 5
+    mk = lambda *sh: torch.tensor(rng.uniform(0, 1, sh).astype(np.float32), device=dev)   # noqa: E731
+    renders = mk(n, 3, H, W)
+    targets = [mk(3, H, W) for _ in range(n)]
+    rows = [3, -1, 0, -1, 3, -1]
+    weights = [50.0, 200.0, 50.0, 200.0, 50.0, 200.0]
+    cam_m = (mk(ncam, 3) * 0.4 - 0.2).requires_grad_(True)
+    cam_c = (mk(ncam, 3) * 0.2 - 0.1).requires_grad_(True)
+
+    def torch_total(r, m, c):
+        per = []
+        for i in range(n):
+            pred = r[i] if rows[i] < 0 else torch.exp(m[rows[i]])[:, None, None] * r[i] + c[rows[i]][:, None, None]
+            per.append(0.8 * L.l1_loss_v1(pred, targets[i]) + 0.2 * (1.0 - L.calc_ssim(pred, targets[i])))
+        return sum(w * l for w, l in zip(weights, per)), torch.stack(per)
+
+    r1 = renders.clone().requires_grad_(True)
+    ref, ref_per = torch_total(r1, cam_m, cam_c)
+    g_ref = torch.autograd.grad(ref * 0.7, (r1, cam_m, cam_c))
+    r2 = renders.clone().requires_grad_(True)
+    got, got_per = L.views_image_loss(r2, targets, rows, weights, cam_m, cam_c)
+    g_got = torch.autograd.grad(got * 0.7, (r2, cam_m, cam_c))
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert (got_per - ref_per.detach()).abs().max().item() <= 1e-5
+    for a_, b_ in zip(g_got, g_ref):
+        assert a_.shape == b_.shape
+        assert (a_ - b_).abs().max().item() <= 1e-4 * b_.abs().max().item()
+    assert float(g_got[1][1].abs().max()) == 0.0 and float(g_got[1][3].abs().max()) > 0.0    # unused / doubly used camera rows
+    # deterministic: a second evaluation gives the same bits
+    r3 = renders.clone().requires_grad_(True)
+    got2, _ = L.views_image_loss(r3, targets, rows, weights, cam_m, cam_c)
+    g2 = torch.autograd.grad(got2 * 0.7, (r3, cam_m, cam_c))
+    assert torch.equal(got, got2) and all(torch.equal(x_, y_) for x_, y_ in zip(g_got, g2))
+
+
+def test_get_loss_views_equals_sum_of_get_loss(dev):
+    """The fused multi-camera step (one rasterizer call + one loss call) against the per-camera ``get_loss`` sum: value and
+    every parameter gradient, cam_m / cam_c included (a camera sampled twice)."""
+    from gsdyn import LossWeights, get_loss, get_loss_views, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    P, W, H = 3000, 160, 120
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.08)
+    with torch.no_grad():
+        params["cam_m"].add_(0.05 * torch.randn_like(params["cam_m"]))
+        params["cam_c"].add_(0.02 * torch.randn_like(params["cam_c"]))
+    cams = synth_ring_cameras(4, W, H, device=dev)
+    im_gt, seg_gt = synth_targets(W, H, device=dev)
+    w = LossWeights()
+    ids = [2, 0, 2]
+    views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in ids]
+    for p_ in params.values():
+        p_.grad = None
+    total = 0.0
+    for d in views:
+        loss, _ = get_loss(params, d, init_variables(P, dev), True, w)
+        loss.backward()
+        total += float(loss.detach())
+    ref = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+    for p_ in params.values():
+        p_.grad = None
+    loss, _, _ = get_loss_views(params, views, init_variables(P, dev), True, w)
+    loss.backward()
+    assert abs(float(loss) - total) <= 2e-5 * abs(total)
+    assert "cam_m" in ref and "cam_c" in ref and float(ref["cam_m"].abs().max()) > 0
+    for k, g in ref.items():
+        got = params[k].grad
+        assert got is not None, k
+        assert (got - g).abs().max().item() <= 2e-4 * g.abs().max().item() + 1e-12, k
+
+
 def test_fused_image_loss_matches_reference_golden(dev, golden_dir):
     """Against vectors captured from the imported reference (calc_ssim value and input gradient)."""
     from gsdyn import losses as L
