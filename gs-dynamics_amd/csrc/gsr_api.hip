@@ -411,7 +411,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                                          dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, st);
 }
 
-int32_t gsr_rigidity_blocks(int32_t n_fg) { return n_fg > 0 ? (n_fg + 255) / 256 : 0; }
+int32_t gsr_rigidity_blocks(int32_t n_fg) { return gsr_rigidity_fwd_blocks(n_fg); }
 
 int gsr_rigidity_forward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
                          const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
@@ -438,7 +438,67 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
   float* self7 = scratch;
   float* edge7 = scratch + (size_t)7 * n_fg;
   return gsr_launch_rigidity_bwd(n_fg, K, means3D, rotations, fg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
-                                 prev_offset, grad3, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rotations, (hipStream_t)stream);
+                                 prev_offset, grad3, 1, 1.0f, 1.0f, 1.0f, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rotations, (hipStream_t)stream);
+}
+
+int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
+                         float* rotations, float* opacities, float* scales, void* stream) {
+  if (P < 0 || (P > 0 && (!unnorm_rotations || !logit_opacities || !log_scales || !rotations || !opacities || !scales))) {
+    gsr_set_error("gsr_activate_forward: bad argument");
+    return -2;
+  }
+  return gsr_launch_activate_fwd(P, unnorm_rotations, logit_opacities, log_scales, rotations, opacities, scales, (hipStream_t)stream);
+}
+
+int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float* opacities, const float* scales,
+                          const float* d_rotations, const float* d_opacities, const float* d_scales, float* d_unnorm_rotations,
+                          float* d_logit_opacities, float* d_log_scales, void* stream) {
+  if (P < 0 || (P > 0 && (!unnorm_rotations || !opacities || !scales || !d_unnorm_rotations || !d_logit_opacities || !d_log_scales))) {
+    gsr_set_error("gsr_activate_backward: bad argument");
+    return -2;
+  }
+  return gsr_launch_activate_bwd(P, unnorm_rotations, opacities, scales, d_rotations, d_opacities, d_scales, d_unnorm_rotations,
+                                 d_logit_opacities, d_log_scales, (hipStream_t)stream);
+}
+
+int32_t gsr_shared_terms_partials(int32_t n_fg, int32_t n_bg) {
+  return 3 * (gsr_rigidity_fwd_blocks(n_fg) + gsr_shared_terms_point_blocks(n_fg, n_bg));
+}
+
+static int shared_terms_check(const char* who, int32_t n_fg, int32_t K, int32_t n_bg, const void* const* ptrs, int n) {
+  if (n_fg < 0 || n_bg < 0 || K <= 0) { gsr_set_error("%s: bad sizes", who); return -2; }
+  for (int i = 0; i < n; ++i)
+    if (!ptrs[i]) { gsr_set_error("%s: NULL argument (#%d)", who, i); return -2; }
+  return 0;
+}
+
+int gsr_shared_terms_forward(int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                             const int64_t* bg_idx, const int64_t* neighbor_indices, const float* neighbor_weight,
+                             const float* neighbor_dist, const float* prev_inv_rot_fg, const float* prev_offset,
+                             const float* init_bg_pts, const float* init_bg_rot, const float* weights5_host, float* partials,
+                             float* terms6, void* stream) {
+  const void* ptrs[] = {means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
+                        prev_offset, init_bg_pts, init_bg_rot, weights5_host, partials, terms6};
+  if (int e = shared_terms_check("gsr_shared_terms_forward", n_fg, K, n_bg, ptrs, 14)) return e;
+  return gsr_launch_shared_terms_fwd(n_fg, K, n_bg, means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight,
+                                     neighbor_dist, prev_inv_rot_fg, prev_offset, init_bg_pts, init_bg_rot, weights5_host, partials,
+                                     terms6, (hipStream_t)stream);
+}
+
+int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations,
+                              const int64_t* fg_idx, const int64_t* bg_idx, const int64_t* neighbor_indices,
+                              const float* neighbor_weight, const float* neighbor_dist, const float* prev_inv_rot_fg,
+                              const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
+                              const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
+                              float* scratch, float* d_means3D, float* d_rotations, void* stream) {
+  const void* ptrs[] = {means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
+                        prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total, rev_ptr, rev_edge, scratch, d_means3D,
+                        d_rotations};
+  if (int e = shared_terms_check("gsr_shared_terms_backward", n_fg, K, n_bg, ptrs, 18)) return e;
+  if (P < n_fg + n_bg) { gsr_set_error("gsr_shared_terms_backward: P < n_fg + n_bg"); return -2; }
+  return gsr_launch_shared_terms_bwd(P, n_fg, K, n_bg, means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight,
+                                     neighbor_dist, prev_inv_rot_fg, prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total,
+                                     rev_ptr, rev_edge, scratch, d_means3D, d_rotations, (hipStream_t)stream);
 }
 
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {

@@ -85,17 +85,25 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
   const int row = tab.cam_row[img];
   if (row >= 0) { a = expf(cam_m[row * tab.channels + c]); b = cam_c[row * tab.channels + c]; }
 
-  for (int r = wave; r < PH; r += 4) {
-    const int gy = ty0 + r - HALO, gx = tx0 + lane - HALO;
+  {  // patch load: all 32 global loads of a lane are issued before the first LDS store (addresses clamped, values masked)
+    const int gx = tx0 + lane - HALO, cx = min(max(gx, 0), W - 1);
+    const bool okx = gx >= 0 && gx < W && lane < PW;
+    float xv[PH / 4], yv[PH / 4];
+#pragma unroll
+    for (int i = 0; i < PH / 4; ++i) {
+      const int gy = ty0 + wave + 4 * i - HALO, cy = min(max(gy, 0), H - 1);
+      const size_t o = (size_t)cy * W + cx;
+      xv[i] = xc[o];
+      yv[i] = yc[o];
+    }
     if (lane < PW) {
-      float xv = 0.f, yv = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        const size_t o = (size_t)gy * W + gx;
-        xv = fmaf(a, xc[o], b);
-        yv = yc[o];
+#pragma unroll
+      for (int i = 0; i < PH / 4; ++i) {
+        const int gy = ty0 + wave + 4 * i - HALO;
+        const bool ok = okx && gy >= 0 && gy < H;
+        sx[(wave + 4 * i) * PS + lane] = ok ? fmaf(a, xv[i], b) : 0.f;
+        sy[(wave + 4 * i) * PS + lane] = ok ? yv[i] : 0.f;
       }
-      sx[r * PS + lane] = xv;
-      sy[r * PS + lane] = yv;
     }
   }
   __syncthreads();
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
       const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
       const float num1 = 2.0f * A * B + c1, num2 = 2.0f * (E - A * B) + c2;
       const float den1 = A * A + B * B + c1, den2 = (Cc - A * A) + (D - B * B) + c2;
-      const float i1 = 1.0f / den1, i2 = 1.0f / den2, inv = i1 * i2;
+      const float i1 = __builtin_amdgcn_rcpf(den1), i2 = __builtin_amdgcn_rcpf(den2), inv = i1 * i2;   // 1 ulp: den >= c1, c2
       const float ssim = num1 * num2 * inv;
       const size_t q = (size_t)ch * HW + (size_t)gy * W + gx;
       fA[q] = 2.0f * B * (num2 - num1) * inv - ssim * 2.0f * A * (i1 - i2);
@@ -189,17 +197,28 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
   if (row >= 0) { a = expf(cam_m[row * tab.channels + c]); b = cam_c[row * tab.channels + c]; }
   const float g = grad[tab.grad_idx[img]] * tab.weight[img] * invN;
 
-  for (int r = wave; r < PH; r += 4) {
-    const int gy = ty0 + r - HALO, gx = tx0 + lane - HALO;
-    if (lane < PW) {
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        const size_t o = coff + (size_t)gy * W + gx;
-        v0 = fA[o]; v1 = fC[o]; v2 = fE[o];
+  {
+    const int gx = tx0 + lane - HALO, cx = min(max(gx, 0), W - 1);
+    const bool okx = gx >= 0 && gx < W && lane < PW;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {      // 2 x 24 loads in flight per lane
+      float v0[PH / 8], v1[PH / 8], v2[PH / 8];
+#pragma unroll
+      for (int i = 0; i < PH / 8; ++i) {
+        const int gy = ty0 + wave + 4 * (i + half * (PH / 8)) - HALO, cy = min(max(gy, 0), H - 1);
+        const size_t o = coff + (size_t)cy * W + cx;
+        v0[i] = fA[o]; v1[i] = fC[o]; v2[i] = fE[o];
       }
-      smem[r * PS + lane] = v0;
-      smem[PH * PS + r * PS + lane] = v1;
-      smem[2 * PH * PS + r * PS + lane] = v2;
+      if (lane < PW) {
+#pragma unroll
+        for (int i = 0; i < PH / 8; ++i) {
+          const int r = wave + 4 * (i + half * (PH / 8)), gy = ty0 + r - HALO;
+          const bool ok = okx && gy >= 0 && gy < H;
+          smem[r * PS + lane] = ok ? v0[i] : 0.f;
+          smem[PH * PS + r * PS + lane] = ok ? v1[i] : 0.f;
+          smem[2 * PH * PS + r * PS + lane] = ok ? v2[i] : 0.f;
+        }
+      }
     }
   }
   __syncthreads();
@@ -264,16 +283,24 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
   }
 }
 
+// strided sum of n floats by one wave, four loads in flight per lane, fixed order
+__device__ __forceinline__ float wave_strided_sum(const float* __restrict__ p, int n, int lane) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int j = lane;
+  for (; j + 192 < n; j += 256) { s0 += p[j]; s1 += p[j + 64]; s2 += p[j + 128]; s3 += p[j + 192]; }
+  for (; j < n; j += 64) s0 += p[j];
+  return wave_sum((s0 + s1) + (s2 + s3));
+}
+
 // one wave per image: loss_i from the block partials; then the weighted total.  Fixed summation order.
-__global__ __launch_bounds__(256) void loss_finish_fwd_kernel(LossTab tab, int per_image, const float* __restrict__ block_l1,
-                                                              const float* __restrict__ block_ssim, float invN, float w_l1,
-                                                              float w_ssim, float* __restrict__ losses) {
+__global__ __launch_bounds__(1024) void loss_finish_fwd_kernel(LossTab tab, int per_image, const float* __restrict__ block_l1,
+                                                               const float* __restrict__ block_ssim, float invN, float w_l1,
+                                                               float w_ssim, float* __restrict__ losses) {
   __shared__ float li[GSR_LOSS_MAX_IMAGES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < tab.n_images; i += 4) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int j = lane; j < per_image; j += 64) { s1 += block_l1[(size_t)i * per_image + j]; s2 += block_ssim[(size_t)i * per_image + j]; }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
+  for (int i = wave; i < tab.n_images; i += 16) {
+    const float s1 = wave_strided_sum(block_l1 + (size_t)i * per_image, per_image, lane);
+    const float s2 = wave_strided_sum(block_ssim + (size_t)i * per_image, per_image, lane);
     if (lane == 0) {
       const float l = w_l1 * (s1 * invN) + w_ssim * (1.0f - s2 * invN);
       li[i] = l;
@@ -289,18 +316,19 @@ __global__ __launch_bounds__(256) void loss_finish_fwd_kernel(LossTab tab, int p
 }
 
 // d_cam_m / d_cam_c [n_cams, channels]: one wave per (image, channel) sum, then a serial scatter in image order (duplicates add up)
-__global__ __launch_bounds__(256) void loss_finish_bwd_kernel(LossTab tab, int per_channel, const float* __restrict__ block_dm,
-                                                              const float* __restrict__ block_dc, int n_cams,
-                                                              float* __restrict__ d_cam_m, float* __restrict__ d_cam_c) {
+__global__ __launch_bounds__(1024) void loss_finish_bwd_kernel(LossTab tab, int per_channel, const float* __restrict__ block_dm,
+                                                               const float* __restrict__ block_dc, int n_cams,
+                                                               float* __restrict__ d_cam_m, float* __restrict__ d_cam_c) {
   __shared__ float sm[GSR_LOSS_MAX_IMAGES * 4], sc[GSR_LOSS_MAX_IMAGES * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = tab.channels, pairs = tab.n_images * nch;
-  for (int i = threadIdx.x; i < n_cams * nch; i += 256) { d_cam_m[i] = 0.f; d_cam_c[i] = 0.f; }
-  for (int p = wave; p < pairs; p += 4) {
+  for (int i = threadIdx.x; i < n_cams * nch; i += 1024) { d_cam_m[i] = 0.f; d_cam_c[i] = 0.f; }
+  for (int p = wave; p < pairs; p += 16) {
     float s1 = 0.f, s2 = 0.f;
-    if (tab.cam_row[p / nch] >= 0)
-      for (int j = lane; j < per_channel; j += 64) { s1 += block_dm[(size_t)p * per_channel + j]; s2 += block_dc[(size_t)p * per_channel + j]; }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (tab.cam_row[p / nch] >= 0) {
+      s1 = wave_strided_sum(block_dm + (size_t)p * per_channel, per_channel, lane);
+      s2 = wave_strided_sum(block_dc + (size_t)p * per_channel, per_channel, lane);
+    }
     if (lane == 0) { sm[p] = s1; sc[p] = s2; }
   }
   __syncthreads();
@@ -398,7 +426,7 @@ int gsr_launch_views_loss_fwd(const float* win11_host, const gsr_loss_views* v, 
                        block_l1, block_ssim); }
   const float invN = 1.0f / ((float)v->channels * (float)H * (float)W);
   { GSR_PROF("loss_finish_fwd", st);
-    hipLaunchKernelGGL(loss_finish_fwd_kernel, dim3(1), dim3(256), 0, st, t, v->channels * nb, (const float*)block_l1,
+    hipLaunchKernelGGL(loss_finish_fwd_kernel, dim3(1), dim3(1024), 0, st, t, v->channels * nb, (const float*)block_l1,
                        (const float*)block_ssim, invN, w_l1, w_ssim, losses); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -420,7 +448,7 @@ int gsr_launch_views_loss_bwd(const float* win11_host, const gsr_loss_views* v, 
                        grad_total, invN, w_l1, w_ssim, d_renders, block_dm, block_dc); }
   if (cams) {
     GSR_PROF("loss_finish_bwd", st);
-    hipLaunchKernelGGL(loss_finish_bwd_kernel, dim3(1), dim3(256), 0, st, t, nb, (const float*)block_dm, (const float*)block_dc,
+    hipLaunchKernelGGL(loss_finish_bwd_kernel, dim3(1), dim3(1024), 0, st, t, nb, (const float*)block_dm, (const float*)block_dc,
                        n_cams, d_cam_m, d_cam_c);
   }
   GSR_HIP_CHECK(hipGetLastError());

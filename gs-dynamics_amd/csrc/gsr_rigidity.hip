@@ -10,8 +10,9 @@
 //     rigid += sqrt(|R_i^T off - prev_offset[i,k]|^2 w + 1e-20)
 //     rot   += sqrt(|q_j - q_i|^2 w + 1e-20)
 //     iso   += sqrt((sqrt(|off|^2 + 1e-20) - dist[i,k])^2 w + 1e-20)
-// each divided by N_fg * K (torch .mean()).  Forward writes one partial sum per block and term (the caller adds them up:
-// no atomics).  Backward: kernel 2 recomputes the edge terms, keeps what flows to point i itself and writes what flows to
+// each divided by N_fg * K (torch .mean()).  Forward: one thread per EDGE, one partial sum per block and term (added up by the
+// caller or the finishing kernel: no atomics).  Backward: kernel 2 (a lane group per point, a lane per edge) recomputes the
+// edge terms, reduces over the group what flows to point i itself and writes what flows to
 // the neighbour j (d/dp_j: 3 floats, d/dq_j: 4 floats) into an edge-major buffer; kernel 3 gathers a point's incoming edges
 // through a reverse adjacency (CSR, built once per timestep by the caller) and applies the chain rule to the rotation
 // input -- deterministic, no float atomics.
@@ -35,36 +36,49 @@ __device__ __forceinline__ void rotmat(const Quat u, float R[9]) {   // u is a u
 }
 
 #define RG_BLOCK 256
+#define RG_PTS 32          // foreground points per forward block (their K edges are contiguous)
+
+struct PointFrame { float px, py, pz; Quat q; float inv; float R[9]; };
+
+__device__ __forceinline__ PointFrame point_frame(const float* __restrict__ means3D, const float* __restrict__ rot,
+                                                  const int64_t* __restrict__ fg_idx, const float* __restrict__ prev_inv, int i) {
+  PointFrame f;
+  const size_t gi = (size_t)fg_idx[i];
+  f.px = means3D[3 * gi]; f.py = means3D[3 * gi + 1]; f.pz = means3D[3 * gi + 2];
+  f.q = qmul(load_q(rot, gi), load_q(prev_inv, i));
+  f.inv = 1.0f / sqrtf(f.q.w * f.q.w + f.q.x * f.q.x + f.q.y * f.q.y + f.q.z * f.q.z);
+  rotmat(Quat{f.q.w * f.inv, f.q.x * f.inv, f.q.y * f.inv, f.q.z * f.inv}, f.R);
+  return f;
+}
+
+// Forward: one thread per EDGE (the point's frame is recomputed per edge: its loads are shared by the K adjacent lanes,
+// and ~1.4 M independent threads hide the latency of the neighbour gathers, which one thread per point with a serial
+// K loop cannot).  A block owns RG_PTS consecutive points, i.e. RG_PTS * K consecutive edges.
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_fwd_kernel(
     int nfg, int K, const float* __restrict__ means3D, const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
     const int64_t* __restrict__ nbr, const float* __restrict__ nw, const float* __restrict__ nd,
     const float* __restrict__ prev_inv, const float* __restrict__ prev_off, float* __restrict__ partial /*[3][blocks]*/) {
   __shared__ float red[3][RG_BLOCK / 64];
-  const int i = blockIdx.x * RG_BLOCK + threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * RG_PTS * K;
+  const size_t e1 = min(e0 + (size_t)RG_PTS * K, (size_t)nfg * K);
   float l1 = 0.f, l2 = 0.f, l3 = 0.f;
-  if (i < nfg) {
-    const size_t gi = (size_t)fg_idx[i];
-    const float px = means3D[3 * gi], py = means3D[3 * gi + 1], pz = means3D[3 * gi + 2];
-    const Quat q = qmul(load_q(rot, gi), load_q(prev_inv, i));
-    const float inv = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    float R[9];
-    rotmat(Quat{q.w * inv, q.x * inv, q.y * inv, q.z * inv}, R);
-    for (int k = 0; k < K; ++k) {
-      const size_t e = (size_t)i * K + k;
-      const int j = (int)nbr[e];
-      const size_t gj = (size_t)fg_idx[j];
-      const float ox = means3D[3 * gj] - px, oy = means3D[3 * gj + 1] - py, oz = means3D[3 * gj + 2] - pz;
-      const float w = nw[e];
-      const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
-      const float dy = (ox * R[1] + oy * R[4] + oz * R[7]) - prev_off[3 * e + 1];
-      const float dz = (ox * R[2] + oy * R[5] + oz * R[8]) - prev_off[3 * e + 2];
-      l1 += sqrtf((dx * dx + dy * dy + dz * dz) * w + 1e-20f);
-      const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
-      const float ew = qj.w - q.w, ex = qj.x - q.x, ey = qj.y - q.y, ez = qj.z - q.z;
-      l2 += sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
-      const float t = sqrtf(ox * ox + oy * oy + oz * oz + 1e-20f) - nd[e];
-      l3 += sqrtf(t * t * w + 1e-20f);
-    }
+  for (size_t e = e0 + threadIdx.x; e < e1; e += RG_BLOCK) {
+    const int i = (int)(e / K);
+    const PointFrame f = point_frame(means3D, rot, fg_idx, prev_inv, i);
+    const float* R = f.R;
+    const int j = (int)nbr[e];
+    const size_t gj = (size_t)fg_idx[j];
+    const float ox = means3D[3 * gj] - f.px, oy = means3D[3 * gj + 1] - f.py, oz = means3D[3 * gj + 2] - f.pz;
+    const float w = nw[e];
+    const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
+    const float dy = (ox * R[1] + oy * R[4] + oz * R[7]) - prev_off[3 * e + 1];
+    const float dz = (ox * R[2] + oy * R[5] + oz * R[8]) - prev_off[3 * e + 2];
+    l1 += sqrtf((dx * dx + dy * dy + dz * dz) * w + 1e-20f);
+    const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
+    const float ew = qj.w - f.q.w, ex = qj.x - f.q.x, ey = qj.y - f.q.y, ez = qj.z - f.q.z;
+    l2 += sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
+    const float t = sqrtf(ox * ox + oy * oy + oz * oz + 1e-20f) - nd[e];
+    l3 += sqrtf(t * t * w + 1e-20f);
   }
   l1 = gsr_wave_sum_shfl(l1); l2 = gsr_wave_sum_shfl(l2); l3 = gsr_wave_sum_shfl(l3);
   const int wv = threadIdx.x >> 6;
@@ -77,87 +91,107 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_fwd_kernel(
   }
 }
 
-// Kernel 2: edge terms again, now for the gradient.  g[3] = upstream gradients of the three means, already divided by
-// N_fg * K.  self[i] = {d/dp_i (3), d/dq_i (4)} from point i's own edges; edge[e] = {d/dp_j (3), d/dq_j (4)}.
+// Kernel 2: edge terms again, now for the gradient, GRP lanes per point (GRP = power of two >= K up to 64; longer lists are
+// strided).  g1..g3 = upstream gradients of the three means, already divided by N_fg * K.
+// self[i] = {d/dp_i (3), d/dq_i (4)} from point i's own edges; edge[e] = {d/dp_j (3), d/dq_j (4)}.
+template <int GRP>
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
     int nfg, int K, const float* __restrict__ means3D, const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
     const int64_t* __restrict__ nbr, const float* __restrict__ nw, const float* __restrict__ nd,
-    const float* __restrict__ prev_inv, const float* __restrict__ prev_off, const float* __restrict__ g,
-    float* __restrict__ self7, float* __restrict__ edge7) {
-  const int i = blockIdx.x * RG_BLOCK + threadIdx.x;
-  if (i >= nfg) return;
-  const float g1 = g[0], g2 = g[1], g3 = g[2];
-  const size_t gi = (size_t)fg_idx[i];
-  const float px = means3D[3 * gi], py = means3D[3 * gi + 1], pz = means3D[3 * gi + 2];
-  const Quat q = qmul(load_q(rot, gi), load_q(prev_inv, i));
-  const float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-  const float inv = 1.0f / sqrtf(n2);
-  const Quat u{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
-  float R[9];
-  rotmat(u, R);
-  float G[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d loss / d R_i
-  float sp[3] = {0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < K; ++k) {
-    const size_t e = (size_t)i * K + k;
-    const int j = (int)nbr[e];
-    const size_t gj = (size_t)fg_idx[j];
-    const float ox = means3D[3 * gj] - px, oy = means3D[3 * gj + 1] - py, oz = means3D[3 * gj + 2] - pz;
-    const float w = nw[e];
-    // rigid
-    const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
-    const float dy = (ox * R[1] + oy * R[4] + oz * R[7]) - prev_off[3 * e + 1];
-    const float dz = (ox * R[2] + oy * R[5] + oz * R[8]) - prev_off[3 * e + 2];
-    const float c1 = g1 * w / sqrtf((dx * dx + dy * dy + dz * dz) * w + 1e-20f);
-    const float ax = c1 * dx, ay = c1 * dy, az = c1 * dz;              // d/d(R^T off)
-    float fx = R[0] * ax + R[1] * ay + R[2] * az;                        // d/d off = R ga
-    float fy = R[3] * ax + R[4] * ay + R[5] * az;
-    float fz = R[6] * ax + R[7] * ay + R[8] * az;
-    G[0] += ox * ax; G[1] += ox * ay; G[2] += ox * az;
-    G[3] += oy * ax; G[4] += oy * ay; G[5] += oy * az;
-    G[6] += oz * ax; G[7] += oz * ay; G[8] += oz * az;
-    // iso
-    const float mag = sqrtf(ox * ox + oy * oy + oz * oz + 1e-20f);
-    const float t = mag - nd[e];
-    const float c3 = g3 * w * t / sqrtf(t * t * w + 1e-20f) / mag;
-    fx += c3 * ox; fy += c3 * oy; fz += c3 * oz;
-    // rot
-    const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
-    const float ew = qj.w - q.w, ex = qj.x - q.x, ey = qj.y - q.y, ez = qj.z - q.z;
-    const float c2 = g2 * w / sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
-    const float hw = c2 * ew, hx = c2 * ex, hy = c2 * ey, hz = c2 * ez;
-    float* E = edge7 + 7 * e;
-    E[0] = fx; E[1] = fy; E[2] = fz; E[3] = hw; E[4] = hx; E[5] = hy; E[6] = hz;
-    sp[0] -= fx; sp[1] -= fy; sp[2] -= fz;
-    sq[0] -= hw; sq[1] -= hx; sq[2] -= hy; sq[3] -= hz;
+    const float* __restrict__ prev_inv, const float* __restrict__ prev_off, const float* __restrict__ g, int gstride,
+    float s1, float s2, float s3, float* __restrict__ self7, float* __restrict__ edge7) {
+  const int i = (blockIdx.x * RG_BLOCK + threadIdx.x) / GRP, lg = threadIdx.x & (GRP - 1);
+  const bool live = i < nfg;                       // whole groups are live or dead; dead lanes still take part in the shuffles
+  const float g1 = g[0] * s1, g2 = g[gstride] * s2, g3 = g[2 * gstride] * s3;
+  PointFrame f{};
+  if (live) f = point_frame(means3D, rot, fg_idx, prev_inv, i);
+  const float* R = f.R;
+  float acc[16];                                   // G[9] = d loss / d R_i, sp[3], sq[4]
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  if (live) {
+    for (int k = lg; k < K; k += GRP) {
+      const size_t e = (size_t)i * K + k;
+      const int j = (int)nbr[e];
+      const size_t gj = (size_t)fg_idx[j];
+      const float ox = means3D[3 * gj] - f.px, oy = means3D[3 * gj + 1] - f.py, oz = means3D[3 * gj + 2] - f.pz;
+      const float w = nw[e];
+      // rigid
+      const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
+      const float dy = (ox * R[1] + oy * R[4] + oz * R[7]) - prev_off[3 * e + 1];
+      const float dz = (ox * R[2] + oy * R[5] + oz * R[8]) - prev_off[3 * e + 2];
+      const float c1 = g1 * w / sqrtf((dx * dx + dy * dy + dz * dz) * w + 1e-20f);
+      const float ax = c1 * dx, ay = c1 * dy, az = c1 * dz;              // d/d(R^T off)
+      float fx = R[0] * ax + R[1] * ay + R[2] * az;                        // d/d off = R ga
+      float fy = R[3] * ax + R[4] * ay + R[5] * az;
+      float fz = R[6] * ax + R[7] * ay + R[8] * az;
+      acc[0] += ox * ax; acc[1] += ox * ay; acc[2] += ox * az;
+      acc[3] += oy * ax; acc[4] += oy * ay; acc[5] += oy * az;
+      acc[6] += oz * ax; acc[7] += oz * ay; acc[8] += oz * az;
+      // iso
+      const float mag = sqrtf(ox * ox + oy * oy + oz * oz + 1e-20f);
+      const float t = mag - nd[e];
+      const float c3 = g3 * w * t / sqrtf(t * t * w + 1e-20f) / mag;
+      fx += c3 * ox; fy += c3 * oy; fz += c3 * oz;
+      // rot
+      const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
+      const float ew = qj.w - f.q.w, ex = qj.x - f.q.x, ey = qj.y - f.q.y, ez = qj.z - f.q.z;
+      const float c2 = g2 * w / sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
+      const float hw = c2 * ew, hx = c2 * ex, hy = c2 * ey, hz = c2 * ez;
+      float* E = edge7 + 7 * e;
+      E[0] = fx; E[1] = fy; E[2] = fz; E[3] = hw; E[4] = hx; E[5] = hy; E[6] = hz;
+      acc[9] -= fx; acc[10] -= fy; acc[11] -= fz;
+      acc[12] -= hw; acc[13] -= hx; acc[14] -= hy; acc[15] -= hz;
+    }
   }
+#pragma unroll
+  for (int m = GRP / 2; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] += __shfl_xor(acc[c], m, 64);
+  }
+  if (!live || lg != 0) return;
   // d loss / d u from G (R as a function of the unit quaternion u), then through the normalisation q -> q / |q|
-  const float r = u.w, x = u.x, y = u.y, z = u.z;
+  const float* G = acc;
+  const float inv = f.inv;
+  const float r = f.q.w * inv, x = f.q.x * inv, y = f.q.y * inv, z = f.q.z * inv;
   const float dr = 2.f * (-z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7]);
   const float dxq = 2.f * (y * G[1] + z * G[2] + y * G[3] - 2.f * x * G[4] - r * G[5] + z * G[6] + r * G[7] - 2.f * x * G[8]);
   const float dyq = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
   const float dzq = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
   const float dot = r * dr + x * dxq + y * dyq + z * dzq;
-  sq[0] += (dr - r * dot) * inv; sq[1] += (dxq - x * dot) * inv; sq[2] += (dyq - y * dot) * inv; sq[3] += (dzq - z * dot) * inv;
   float* S = self7 + 7 * (size_t)i;
-  S[0] = sp[0]; S[1] = sp[1]; S[2] = sp[2]; S[3] = sq[0]; S[4] = sq[1]; S[5] = sq[2]; S[6] = sq[3];
+  S[0] = acc[9]; S[1] = acc[10]; S[2] = acc[11];
+  S[3] = acc[12] + (dr - r * dot) * inv; S[4] = acc[13] + (dxq - x * dot) * inv;
+  S[5] = acc[14] + (dyq - y * dot) * inv; S[6] = acc[15] + (dzq - z * dot) * inv;
 }
 
-// Kernel 3: total gradient of point j = its own part + its incoming edges; d/dq_j -> d/d rot (q = rot * c is linear in rot).
-// Writes the rows of the foreground Gaussians (the caller zero-fills the others).
+// Kernel 3: total gradient of point j = its own part + its incoming edges (8 lanes per point stride over the reverse
+// adjacency); d/dq_j -> d/d rot (q = rot * c is linear in rot).  Writes the rows of the foreground Gaussians (the caller
+// zero-fills the others).  Fixed lane assignment and reduction order: deterministic.
+#define RG_GATHER 8
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
     int nfg, const int64_t* __restrict__ fg_idx, const int32_t* __restrict__ rev_ptr, const int32_t* __restrict__ rev_edge,
     const float* __restrict__ prev_inv, const float* __restrict__ self7, const float* __restrict__ edge7,
     float* __restrict__ d_means3D, float* __restrict__ d_rot) {
-  const int j = blockIdx.x * RG_BLOCK + threadIdx.x;
-  if (j >= nfg) return;
-  float a[7];
+  const int j = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_GATHER, lg = threadIdx.x & (RG_GATHER - 1);
+  const bool live = j < nfg;
+  float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const int t1 = rev_ptr[j + 1];
+    for (int t = rev_ptr[j] + lg; t < t1; t += RG_GATHER) {
+      const float* E = edge7 + 7 * (size_t)rev_edge[t];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) a[c] = self7[7 * (size_t)j + c];
-  for (int t = rev_ptr[j]; t < rev_ptr[j + 1]; ++t) {
-    const float* E = edge7 + 7 * (size_t)rev_edge[t];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a[c] += E[c];
+      for (int c = 0; c < 7; ++c) a[c] += E[c];
+    }
   }
+#pragma unroll
+  for (int m = RG_GATHER / 2; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a[c] += __shfl_xor(a[c], m, 64);
+  }
+  if (!live || lg != 0) return;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) a[c] += self7[7 * (size_t)j + c];
   const size_t gj = (size_t)fg_idx[j];
   d_means3D[3 * gj] = a[0]; d_means3D[3 * gj + 1] = a[1]; d_means3D[3 * gj + 2] = a[2];
   const Quat c = load_q(prev_inv, j);
@@ -170,12 +204,14 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
 
 }  // namespace
 
+int gsr_rigidity_fwd_blocks(int nfg) { return nfg > 0 ? (nfg + RG_PTS - 1) / RG_PTS : 0; }
+
 int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* partial,
                             hipStream_t st) {
   if (nfg <= 0) return 0;
   { GSR_PROF("rigidity_fwd", st);
-    hipLaunchKernelGGL(rigidity_fwd_kernel, dim3((nfg + RG_BLOCK - 1) / RG_BLOCK), dim3(RG_BLOCK), 0, st, nfg, K, means3D, rot, fg_idx,
+    hipLaunchKernelGGL(rigidity_fwd_kernel, dim3(gsr_rigidity_fwd_blocks(nfg)), dim3(RG_BLOCK), 0, st, nfg, K, means3D, rot, fg_idx,
                        nbr, nw, nd, prev_inv, prev_off, partial); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -183,17 +219,21 @@ int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* r
 
 int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, const float* g,
-                            const int32_t* rev_ptr, const int32_t* rev_edge, float* self7, float* edge7, float* d_means3D,
-                            float* d_rot, hipStream_t st) {
+                            int gstride, float s1, float s2, float s3, const int32_t* rev_ptr, const int32_t* rev_edge,
+                            float* self7, float* edge7, float* d_means3D, float* d_rot, hipStream_t st) {
   if (nfg <= 0) return 0;
-  const dim3 grid((nfg + RG_BLOCK - 1) / RG_BLOCK), block(RG_BLOCK);
+  const int grp = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
+  const dim3 block(RG_BLOCK), grid(((size_t)nfg * grp + RG_BLOCK - 1) / RG_BLOCK);
   { GSR_PROF("rigidity_bwd_edges", st);
-    hipLaunchKernelGGL(rigidity_bwd_edges_kernel, grid, block, 0, st, nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, g,
-                       self7, edge7); }
+#define GSR_RG_LAUNCH(G_) hipLaunchKernelGGL(rigidity_bwd_edges_kernel<G_>, grid, block, 0, st, nfg, K, means3D, rot, fg_idx, nbr, nw, nd, \
+                                             prev_inv, prev_off, g, gstride, s1, s2, s3, self7, edge7)
+    if (grp == 8) GSR_RG_LAUNCH(8); else if (grp == 16) GSR_RG_LAUNCH(16); else if (grp == 32) GSR_RG_LAUNCH(32); else GSR_RG_LAUNCH(64);
+#undef GSR_RG_LAUNCH
+  }
   GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("rigidity_bwd_gather", st);
-    hipLaunchKernelGGL(rigidity_bwd_gather_kernel, grid, block, 0, st, nfg, fg_idx, rev_ptr, rev_edge, prev_inv, self7, edge7,
-                       d_means3D, d_rot); }
+    hipLaunchKernelGGL(rigidity_bwd_gather_kernel, dim3(((size_t)nfg * RG_GATHER + RG_BLOCK - 1) / RG_BLOCK), block, 0, st, nfg, fg_idx,
+                       rev_ptr, rev_edge, prev_inv, self7, edge7, d_means3D, d_rot); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,222 @@
+// gsr_step.hip -- the small per-Gaussian pieces of the tracking step around the rasterizer (caller side of the path,
+// SURVEY.md section 8a row A9), each a handful of PyTorch element-wise / indexing / reduction kernels in the reference and
+// host-launch-bound there (~5 us of GPU work behind ~15 us of dispatch each):
+//   * activations  (/root/reference/src/tracking/helpers.py:36-45, params2rendervar):
+//         rotations = normalize(unnorm_rotations), opacities = sigmoid(logit_opacities), scales = exp(log_scales)
+//     one forward and one backward kernel instead of ~6 + ~12;
+//   * the view-independent terms of the t > 0 loss (/root/reference/src/tracking/train_utils.py:198-241): the three neighbour
+//     terms (gsr_rigidity.hip) plus floor = mean(clamp(y_fg, min=0)) and bg = mean|p_bg - p_bg0|_1 + mean|q_bg - q_bg0|_1, their
+//     weighted sum formed on the device -> two kernels + one finishing kernel forward, three kernels backward, where the
+//     reference runs ~40 + ~60.
+// No float atomics anywhere: block partials + fixed-order finishing sums.
+#include "gsr_common.h"
+
+namespace {
+
+#define ST_BLOCK 256
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(ST_BLOCK) void activate_fwd_kernel(int P, const float* __restrict__ unnorm, const float* __restrict__ logit,
+                                                                const float* __restrict__ logs, float* __restrict__ rot,
+                                                                float* __restrict__ op, float* __restrict__ sc) {
+  const int i = blockIdx.x * ST_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const float4 q = reinterpret_cast<const float4*>(unnorm)[i];
+  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float d = fmaxf(n, 1e-12f);                    // torch.nn.functional.normalize: x / max(|x|, eps)
+  reinterpret_cast<float4*>(rot)[i] = make_float4(q.x / d, q.y / d, q.z / d, q.w / d);
+  op[i] = 1.0f / (1.0f + expf(-logit[i]));
+  sc[3 * (size_t)i] = expf(logs[3 * (size_t)i]);
+  sc[3 * (size_t)i + 1] = expf(logs[3 * (size_t)i + 1]);
+  sc[3 * (size_t)i + 2] = expf(logs[3 * (size_t)i + 2]);
+}
+
+// any of the incoming gradients may be NULL (that output was not used): its parameter gradient is zero
+__global__ __launch_bounds__(ST_BLOCK) void activate_bwd_kernel(int P, const float* __restrict__ unnorm, const float* __restrict__ op,
+                                                                const float* __restrict__ sc, const float* __restrict__ d_rot,
+                                                                const float* __restrict__ d_op, const float* __restrict__ d_sc,
+                                                                float* __restrict__ d_unnorm, float* __restrict__ d_logit,
+                                                                float* __restrict__ d_logs) {
+  const int i = blockIdx.x * ST_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d_rot) {
+    const float4 q = reinterpret_cast<const float4*>(unnorm)[i];
+    const float4 dr = reinterpret_cast<const float4*>(d_rot)[i];
+    const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    if (n > 1e-12f) {
+      const float inv = 1.0f / n;
+      const float rx = q.x * inv, ry = q.y * inv, rz = q.z * inv, rw = q.w * inv;
+      const float dot = rx * dr.x + ry * dr.y + rz * dr.z + rw * dr.w;
+      g = make_float4((dr.x - rx * dot) * inv, (dr.y - ry * dot) * inv, (dr.z - rz * dot) * inv, (dr.w - rw * dot) * inv);
+    } else {
+      g = make_float4(dr.x * 1e12f, dr.y * 1e12f, dr.z * 1e12f, dr.w * 1e12f);   // clamped denominator: a constant
+    }
+  }
+  reinterpret_cast<float4*>(d_unnorm)[i] = g;
+  const float o = op[i];
+  d_logit[i] = d_op ? d_op[i] * o * (1.0f - o) : 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d_logs[3 * (size_t)i + c] = d_sc ? d_sc[3 * (size_t)i + c] * sc[3 * (size_t)i + c] : 0.f;
+}
+
+// floor / background terms: item < n_fg -> foreground point (floor), else background point (two L1 terms)
+__global__ __launch_bounds__(ST_BLOCK) void point_terms_fwd_kernel(int nfg, int nbg, const float* __restrict__ means3D,
+                                                                   const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
+                                                                   const int64_t* __restrict__ bg_idx,
+                                                                   const float* __restrict__ init_pts, const float* __restrict__ init_rot,
+                                                                   float* __restrict__ partial /*[3][blocks]*/) {
+  __shared__ float red[3][ST_BLOCK / 64];
+  const int t = blockIdx.x * ST_BLOCK + threadIdx.x;
+  float l_floor = 0.f, l_pts = 0.f, l_rot = 0.f;
+  if (t < nfg) {
+    l_floor = fmaxf(means3D[3 * (size_t)fg_idx[t] + 1], 0.f);
+  } else if (t < nfg + nbg) {
+    const int b = t - nfg;
+    const size_t gb = (size_t)bg_idx[b];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) l_pts += fabsf(means3D[3 * gb + c] - init_pts[3 * (size_t)b + c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l_rot += fabsf(rot[4 * gb + c] - init_rot[4 * (size_t)b + c]);
+  }
+  l_floor = wave_sum(l_floor); l_pts = wave_sum(l_pts); l_rot = wave_sum(l_rot);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = l_floor; red[1][wv] = l_pts; red[2][wv] = l_rot; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int w = 0; w < ST_BLOCK / 64; ++w) s += red[threadIdx.x][w];
+    partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// runs after the neighbour-term gather (which WROTE the foreground rows): adds the floor gradient there, writes the background rows
+__global__ __launch_bounds__(ST_BLOCK) void point_terms_bwd_kernel(int nfg, int nbg, const float* __restrict__ means3D,
+                                                                   const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
+                                                                   const int64_t* __restrict__ bg_idx,
+                                                                   const float* __restrict__ init_pts, const float* __restrict__ init_rot,
+                                                                   const float* __restrict__ grad_total, float s_floor, float s_bg,
+                                                                   float* __restrict__ d_means3D, float* __restrict__ d_rot) {
+  const int t = blockIdx.x * ST_BLOCK + threadIdx.x;
+  const float g = grad_total[0];
+  if (t < nfg) {
+    const size_t gi = (size_t)fg_idx[t];
+    if (means3D[3 * gi + 1] >= 0.f) d_means3D[3 * gi + 1] += g * s_floor;      // torch.clamp passes the gradient at the bound
+  } else if (t < nfg + nbg) {
+    const int b = t - nfg;
+    const size_t gb = (size_t)bg_idx[b];
+    const float gs = g * s_bg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = means3D[3 * gb + c] - init_pts[3 * (size_t)b + c];
+      d_means3D[3 * gb + c] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = rot[4 * gb + c] - init_rot[4 * (size_t)b + c];
+      d_rot[4 * gb + c] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_strided_sum(const float* __restrict__ p, int n, int lane) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int j = lane;
+  for (; j + 192 < n; j += 256) { s0 += p[j]; s1 += p[j + 64]; s2 += p[j + 128]; s3 += p[j + 192]; }
+  for (; j < n; j += 64) s0 += p[j];
+  return wave_sum((s0 + s1) + (s2 + s3));
+}
+
+struct TermScales { float inv_edges, inv_fg, inv_bg, w[5]; };
+
+// terms[0..4] = rigid, rot, iso, floor, bg;  terms[5] = sum_k w_k terms[k].  One wave per partial array.
+__global__ __launch_bounds__(384) void shared_terms_finish_kernel(TermScales sc, int nbe, const float* __restrict__ edge_partial,
+                                                                  int nbp, const float* __restrict__ point_partial,
+                                                                  float* __restrict__ terms) {
+  __shared__ float s[6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float v = wave < 3 ? wave_strided_sum(edge_partial + (size_t)wave * nbe, nbe, lane)
+                           : wave_strided_sum(point_partial + (size_t)(wave - 3) * nbp, nbp, lane);
+  if (lane == 0) s[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t0 = s[0] * sc.inv_edges, t1 = s[1] * sc.inv_edges, t2 = s[2] * sc.inv_edges;
+    const float t3 = s[3] * sc.inv_fg, t4 = (s[4] + s[5]) * sc.inv_bg;
+    terms[0] = t0; terms[1] = t1; terms[2] = t2; terms[3] = t3; terms[4] = t4;
+    terms[5] = sc.w[0] * t0 + sc.w[1] * t1 + sc.w[2] * t2 + sc.w[3] * t3 + sc.w[4] * t4;
+  }
+}
+
+inline int blocks_for(int n) { return (n + ST_BLOCK - 1) / ST_BLOCK; }
+
+}  // namespace
+
+int gsr_launch_activate_fwd(int P, const float* unnorm, const float* logit, const float* logs, float* rot, float* op, float* sc,
+                            hipStream_t st) {
+  if (P <= 0) return 0;
+  { GSR_PROF("activate_fwd", st);
+    hipLaunchKernelGGL(activate_fwd_kernel, dim3(blocks_for(P)), dim3(ST_BLOCK), 0, st, P, unnorm, logit, logs, rot, op, sc); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_activate_bwd(int P, const float* unnorm, const float* op, const float* sc, const float* d_rot, const float* d_op,
+                            const float* d_sc, float* d_unnorm, float* d_logit, float* d_logs, hipStream_t st) {
+  if (P <= 0) return 0;
+  { GSR_PROF("activate_bwd", st);
+    hipLaunchKernelGGL(activate_bwd_kernel, dim3(blocks_for(P)), dim3(ST_BLOCK), 0, st, P, unnorm, op, sc, d_rot, d_op, d_sc, d_unnorm,
+                       d_logit, d_logs); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_shared_terms_point_blocks(int nfg, int nbg) { return blocks_for(nfg + nbg > 0 ? nfg + nbg : 1); }
+
+int gsr_launch_shared_terms_fwd(int nfg, int K, int nbg, const float* means3D, const float* rot, const int64_t* fg_idx,
+                                const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
+                                const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
+                                float* partials, float* terms, hipStream_t st) {
+  const int nbe = gsr_rigidity_fwd_blocks(nfg), nbp = gsr_shared_terms_point_blocks(nfg, nbg);
+  float* edge_partial = partials;
+  float* point_partial = partials + 3 * (size_t)nbe;
+  if (int e = gsr_launch_rigidity_fwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, edge_partial, st)) return e;
+  { GSR_PROF("point_terms_fwd", st);
+    hipLaunchKernelGGL(point_terms_fwd_kernel, dim3(nbp), dim3(ST_BLOCK), 0, st, nfg, nbg, means3D, rot, fg_idx, bg_idx, init_pts,
+                       init_rot, point_partial); }
+  TermScales sc;
+  sc.inv_edges = nfg > 0 && K > 0 ? 1.0f / ((float)nfg * (float)K) : 0.f;
+  sc.inv_fg = nfg > 0 ? 1.0f / (float)nfg : 0.f;
+  sc.inv_bg = nbg > 0 ? 1.0f / (float)nbg : 0.f;
+  for (int k = 0; k < 5; ++k) sc.w[k] = w5[k];
+  { GSR_PROF("shared_terms_finish", st);
+    hipLaunchKernelGGL(shared_terms_finish_kernel, dim3(1), dim3(384), 0, st, sc, nbe, (const float*)edge_partial, nbp,
+                       (const float*)point_partial, terms); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_shared_terms_bwd(int P, int nfg, int K, int nbg, const float* means3D, const float* rot, const int64_t* fg_idx,
+                                const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
+                                const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
+                                const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge, float* scratch,
+                                float* d_means3D, float* d_rot, hipStream_t st) {
+  GSR_HIP_CHECK(hipMemsetAsync(d_means3D, 0, sizeof(float) * 3 * (size_t)P, st));
+  GSR_HIP_CHECK(hipMemsetAsync(d_rot, 0, sizeof(float) * 4 * (size_t)P, st));
+  const float inv_edges = nfg > 0 && K > 0 ? 1.0f / ((float)nfg * (float)K) : 0.f;
+  float* self7 = scratch;
+  float* edge7 = scratch + 7 * (size_t)nfg;
+  if (int e = gsr_launch_rigidity_bwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, grad_total, 0, w5[0] * inv_edges,
+                                      w5[1] * inv_edges, w5[2] * inv_edges, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rot, st))
+    return e;
+  { GSR_PROF("point_terms_bwd", st);
+    hipLaunchKernelGGL(point_terms_bwd_kernel, dim3(gsr_shared_terms_point_blocks(nfg, nbg)), dim3(ST_BLOCK), 0, st, nfg, nbg, means3D,
+                       rot, fg_idx, bg_idx, init_pts, init_rot, grad_total, nfg > 0 ? w5[3] / (float)nfg : 0.f,
+                       nbg > 0 ? w5[4] / (float)nbg : 0.f, d_means3D, d_rot); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}

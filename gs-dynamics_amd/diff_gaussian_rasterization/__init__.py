@@ -151,9 +151,10 @@ def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=No
     per_view_col = colors_precomp is not None and colors_precomp.dim() == 3
 
     def call(lo, hi):
+        whole = lo == 0 and hi == V          # no slice nodes in the graph (their backward is a zero-fill + copy each)
         return _RasterizeGaussiansViews.apply(
-            means3D, means2D[lo:hi], empty if shs is None else shs,
-            empty if colors_precomp is None else (colors_precomp[lo:hi] if per_view_col else colors_precomp), opacities,
+            means3D, means2D if whole else means2D[lo:hi], empty if shs is None else shs,
+            empty if colors_precomp is None else (colors_precomp[lo:hi] if (per_view_col and not whole) else colors_precomp), opacities,
             empty if scales is None else scales, empty if rotations is None else rotations,
             empty if cov3D_precomp is None else cov3D_precomp, settings_list[lo:hi])
     if V <= _hip.MAX_BATCH:

@@ -54,7 +54,9 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
-           "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward")
+           "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward",
+           "gsr_shared_terms_partials", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
+           "gsr_activate_forward", "gsr_activate_backward")
 
 
 def load_library():
@@ -108,6 +110,16 @@ def load_library():
     lib.gsr_views_loss_backward.restype = C.c_int
     lib.gsr_views_loss_backward.argtypes = ([C.POINTER(C.c_float), C.POINTER(GsrLossViews), i32, i32, vp, vp, vp, i32, vp, vp, vp, vp,
                                              C.c_float, C.c_float] + [vp] * 5)
+    lib.gsr_shared_terms_partials.restype = i32
+    lib.gsr_shared_terms_partials.argtypes = [i32, i32]
+    lib.gsr_shared_terms_forward.restype = C.c_int
+    lib.gsr_shared_terms_forward.argtypes = [i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float), vp, vp, vp]
+    lib.gsr_shared_terms_backward.restype = C.c_int
+    lib.gsr_shared_terms_backward.argtypes = [i32, i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float)] + [vp] * 7
+    lib.gsr_activate_forward.restype = C.c_int
+    lib.gsr_activate_forward.argtypes = [i32] + [vp] * 7
+    lib.gsr_activate_backward.restype = C.c_int
+    lib.gsr_activate_backward.argtypes = [i32] + [vp] * 10
     lib.gsr_rigidity_blocks.restype = i32
     lib.gsr_rigidity_blocks.argtypes = [i32]
     lib.gsr_rigidity_forward.restype = C.c_int
@@ -431,6 +443,69 @@ def rigidity_backward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_of
                                          _ptr(prev_inv), _ptr(prev_off), _ptr(grad3), _ptr(rev_ptr), _ptr(rev_edge), _ptr(scratch),
                                          _ptr(d_m), _ptr(d_r), _stream(dev)), "gsr_rigidity_backward")
     return d_m, d_r
+
+
+def _shared_args(v):
+    return (_ptr(v["fg_idx"]), _ptr(v["bg_idx"]), _ptr(v["neighbor_indices"]), _ptr(v["neighbor_weight"]), _ptr(v["neighbor_dist"]),
+            _ptr(v["prev_inv_rot_fg"]), _ptr(v["prev_offset"]), _ptr(v["init_bg_pts"]), _ptr(v["init_bg_rot"]))
+
+
+def shared_terms_forward(means3D, rotations, v, weights5):
+    """View-independent terms of the t > 0 loss (gsr_shared_terms_forward).  ``v``: the contiguous tensors of
+    gsdyn.step.make_rigidity_variables.  Returns terms[6] = rigid, rot, iso, floor, bg, weighted sum."""
+    lib = load_library()
+    _require_device(means3D)
+    dev = means3D.device
+    nfg, K = (int(d) for d in v["neighbor_indices"].shape)
+    nbg = int(v["bg_idx"].shape[0])
+    w5 = (C.c_float * 5)(*[float(x) for x in weights5])
+    with torch.cuda.device(dev):
+        part = torch.empty((max(int(lib.gsr_shared_terms_partials(nfg, nbg)), 1),), dtype=torch.float32, device=dev)
+        terms = torch.empty((6,), dtype=torch.float32, device=dev)
+        _check(lib.gsr_shared_terms_forward(nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5, _ptr(part), _ptr(terms),
+                                            _stream(dev)), "gsr_shared_terms_forward")
+    return terms
+
+
+def shared_terms_backward(means3D, rotations, v, weights5, grad_total):
+    lib = load_library()
+    dev = means3D.device
+    nfg, K = (int(d) for d in v["neighbor_indices"].shape)
+    nbg = int(v["bg_idx"].shape[0])
+    w5 = (C.c_float * 5)(*[float(x) for x in weights5])
+    with torch.cuda.device(dev):
+        g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
+        scratch = torch.empty((max(7 * (nfg + nfg * K), 1),), dtype=torch.float32, device=dev)
+        d_m, d_r = torch.empty_like(means3D), torch.empty_like(rotations)
+        _check(lib.gsr_shared_terms_backward(int(means3D.shape[0]), nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5,
+                                             _ptr(g), _ptr(v["rev_ptr"]), _ptr(v["rev_edge"]), _ptr(scratch), _ptr(d_m), _ptr(d_r),
+                                             _stream(dev)), "gsr_shared_terms_backward")
+    return d_m, d_r
+
+
+def activate_forward(unnorm_rotations, logit_opacities, log_scales):
+    lib = load_library()
+    _require_device(unnorm_rotations)
+    dev = unnorm_rotations.device
+    P = int(unnorm_rotations.shape[0])
+    with torch.cuda.device(dev):
+        rot, op, sc = torch.empty_like(unnorm_rotations), torch.empty_like(logit_opacities), torch.empty_like(log_scales)
+        _check(lib.gsr_activate_forward(P, _ptr(unnorm_rotations), _ptr(logit_opacities), _ptr(log_scales), _ptr(rot), _ptr(op), _ptr(sc),
+                                        _stream(dev)), "gsr_activate_forward")
+    return rot, op, sc
+
+
+def activate_backward(unnorm_rotations, opacities, scales, d_rot, d_op, d_sc):
+    lib = load_library()
+    dev = unnorm_rotations.device
+    P = int(unnorm_rotations.shape[0])
+    with torch.cuda.device(dev):
+        d_u, d_l, d_s = torch.empty_like(unnorm_rotations), torch.empty_like(opacities), torch.empty_like(scales)
+        c = lambda t: None if t is None else t.contiguous()   # noqa: E731
+        d_rot, d_op, d_sc = c(d_rot), c(d_op), c(d_sc)
+        _check(lib.gsr_activate_backward(P, _ptr(unnorm_rotations), _ptr(opacities), _ptr(scales), _ptr(d_rot), _ptr(d_op), _ptr(d_sc),
+                                         _ptr(d_u), _ptr(d_l), _ptr(d_s), _stream(dev)), "gsr_activate_backward")
+    return d_u, d_l, d_s
 
 
 def farthest_point_sampling(pos: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:

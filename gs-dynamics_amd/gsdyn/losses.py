@@ -189,6 +189,69 @@ class _FusedRigidity(torch.autograd.Function):
         return (d_m, d_r) + (None,) * 8
 
 
+_SHARED_KEYS = ("fg_idx", "bg_idx", "neighbor_indices", "neighbor_weight", "neighbor_dist", "prev_inv_rot_fg", "prev_offset",
+                "init_bg_pts", "init_bg_rot", "rev_ptr", "rev_edge")
+
+
+class _FusedSharedTerms(torch.autograd.Function):
+    """rigid / rot / iso / floor / bg and their weighted sum: 3 kernels forward, 3 backward (gsr_rigidity.hip, gsr_step.hip)."""
+
+    @staticmethod
+    def forward(ctx, means3D, rotations, weights5, *tensors):
+        from diff_gaussian_rasterization import _hip
+        m, r = means3D.detach().contiguous().float(), rotations.detach().contiguous().float()
+        v = dict(zip(_SHARED_KEYS, tensors))
+        terms = _hip.shared_terms_forward(m, r, v, weights5)
+        ctx.v, ctx.w = v, tuple(weights5)
+        ctx.save_for_backward(m, r)
+        each = terms[:5]
+        ctx.mark_non_differentiable(each)
+        return terms[5], each
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_each):
+        from diff_gaussian_rasterization import _hip
+        m, r = ctx.saved_tensors
+        d_m, d_r = _hip.shared_terms_backward(m, r, ctx.v, ctx.w, grad_total)
+        return (d_m, d_r, None) + (None,) * len(_SHARED_KEYS)
+
+
+def shared_terms(means3D, rotations, variables, weights5):
+    """Weighted sum of the view-independent t > 0 terms (rigid, rot, iso, floor, bg -- /root/reference/src/tracking/train_utils.py:198-241)
+    through the fused kernels.  Returns (weighted sum, the five terms detached)."""
+    tensors = []
+    for k in _SHARED_KEYS:
+        t = variables[k]
+        tensors.append(t if t.is_contiguous() else t.contiguous())
+    return _FusedSharedTerms.apply(means3D, rotations, tuple(float(x) for x in weights5), *tensors)
+
+
+class _FusedActivations(torch.autograd.Function):
+    """normalize / sigmoid / exp of the raw parameters as one kernel each way (gsr_step.hip)."""
+
+    @staticmethod
+    def forward(ctx, unnorm_rotations, logit_opacities, log_scales):
+        from diff_gaussian_rasterization import _hip
+        u = unnorm_rotations.detach().contiguous().float()
+        rot, op, sc = _hip.activate_forward(u, logit_opacities.detach().contiguous().float(), log_scales.detach().contiguous().float())
+        ctx.save_for_backward(u, op, sc)
+        ctx.set_materialize_grads(False)
+        return rot, op, sc
+
+    @staticmethod
+    def backward(ctx, d_rot, d_op, d_sc):
+        from diff_gaussian_rasterization import _hip
+        u, op, sc = ctx.saved_tensors
+        return _hip.activate_backward(u, op, sc, d_rot, d_op, d_sc)
+
+
+def activate(unnorm_rotations, logit_opacities, log_scales):
+    """(rotations, opacities, scales) of params2rendervar (/root/reference/src/tracking/helpers.py:36-45): fused on a HIP device."""
+    if unnorm_rotations.is_cuda:
+        return _FusedActivations.apply(unnorm_rotations, logit_opacities, log_scales)
+    return F.normalize(unnorm_rotations), torch.sigmoid(logit_opacities), torch.exp(log_scales)
+
+
 def rigidity_terms(means3D, rotations, variables):
     """(rigid, rot, iso) of /root/reference/src/tracking/train_utils.py:198-222 through the fused kernels.  ``variables``
     must carry the tensors of ``make_rigidity_variables`` incl. fg_idx / rev_ptr / rev_edge."""

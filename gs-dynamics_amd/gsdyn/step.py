@@ -13,7 +13,7 @@ import torch
 
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 
-from .losses import (build_rotation, calc_psnr, image_loss, l1_loss_v2, quat_mult, reverse_adjacency, rigidity_terms,
+from .losses import (activate, build_rotation, calc_psnr, image_loss, l1_loss_v2, quat_mult, reverse_adjacency, shared_terms,
                      views_image_loss, weighted_l2_loss_v1, weighted_l2_loss_v2)
 
 
@@ -68,15 +68,15 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
     seg, _, _ = Renderer(raster_settings=curr_data["cam"])(**segrendervar)
     losses["seg"] = _image_term(seg, curr_data["seg"])
 
+    weights = {"im": w.im, "seg": w.seg, "rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg,
+               "soft_col_cons": w.soft_col_cons}
+    loss = sum(weights[k] * v for k, v in losses.items())
     if not is_initial_timestep:
         # R^T applied to every neighbour offset: the reference writes this as a batched 3x3 @ 3x1 matmul
         # (train_utils.py:207), which on ROCm dispatches ~1.4 M tiny GEMMs (18 + 12 + 11 ms fwd+bwd at 70 k foreground
         # points x 20 neighbours); _shared_terms uses the fused kernels on a HIP device, a broadcast multiply + sum otherwise.
-        _shared_terms(params, rendervar, variables, losses)
-
-    weights = {"im": w.im, "seg": w.seg, "rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg,
-               "soft_col_cons": w.soft_col_cons}
-    loss = sum(weights[k] * v for k, v in losses.items())
+        shared, _ = _shared_terms(params, rendervar, variables, weights)
+        loss = loss + shared
     # Same values as the reference's `max_2D_radius[seen] = max(radius[seen], max_2D_radius[seen])`
     # (train_utils.py:243-245) without boolean-mask indexing, which costs a device->host sync per call.
     seen = radius > 0
@@ -86,8 +86,16 @@ def get_loss(params, curr_data, variables, is_initial_timestep: bool, w: LossWei
     return loss, variables
 
 
-def _shared_terms(params, rendervar, variables, losses):
-    """View-independent terms of the t > 0 loss (/root/reference/src/tracking/train_utils.py:198-232)."""
+_SHARED_NAMES = ("rigid", "rot", "iso", "floor", "bg")
+
+
+def _shared_terms(params, rendervar, variables, weights, scale: float = 1.0):
+    """View-independent terms of the t > 0 loss (/root/reference/src/tracking/train_utils.py:198-232).
+    Returns (scale * sum_k weights[k] * term_k, the five terms rigid / rot / iso / floor / bg as a detached [5] tensor)."""
+    if rendervar["means3D"].is_cuda and all(k in variables for k in ("fg_idx", "bg_idx", "rev_ptr", "rev_edge")):
+        # all of it in 3 + 3 fused kernels (gsr_rigidity.hip, gsr_step.hip) instead of ~100 + ~100 torch kernels
+        return shared_terms(rendervar["means3D"], rendervar["rotations"], variables, [scale * weights[k] for k in _SHARED_NAMES])
+    losses = {}
     if "fg_idx" in variables:     # index tensors prepared once per timestep: boolean-mask indexing costs a host sync per call
         fg_idx, bg_idx = variables["fg_idx"], variables["bg_idx"]
         fg_pts = rendervar["means3D"].index_select(0, fg_idx)
@@ -98,26 +106,43 @@ def _shared_terms(params, rendervar, variables, losses):
         fg_pts = rendervar["means3D"][is_fg]
         pick_fg = lambda t: t[is_fg]                    # noqa: E731
         pick_bg = lambda t: t[~is_fg]                   # noqa: E731
-    if rendervar["means3D"].is_cuda and "rev_ptr" in variables:
-        # the three neighbour terms in three fused kernels (gsr_rigidity.hip) instead of ~100 torch kernels
-        losses["rigid"], losses["rot"], losses["iso"] = rigidity_terms(rendervar["means3D"], rendervar["rotations"], variables)
-    else:
-        fg_rot = pick_fg(rendervar["rotations"])
-        rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
-        rot = build_rotation(rel_rot)
-        nbr = variables["neighbor_indices"]
-        curr_offset = fg_pts[nbr] - fg_pts[:, None]
-        offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)   # see get_loss
-        nw = variables["neighbor_weight"]
-        losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
-        losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
-        offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
-        losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
+    fg_rot = pick_fg(rendervar["rotations"])
+    rel_rot = quat_mult(fg_rot, variables["prev_inv_rot_fg"])
+    rot = build_rotation(rel_rot)
+    nbr = variables["neighbor_indices"]
+    curr_offset = fg_pts[nbr] - fg_pts[:, None]
+    offset_prev_frame = (curr_offset[:, :, :, None] * rot[:, None, :, :]).sum(2)   # see get_loss
+    nw = variables["neighbor_weight"]
+    losses["rigid"] = weighted_l2_loss_v2(offset_prev_frame, variables["prev_offset"], nw)
+    losses["rot"] = weighted_l2_loss_v2(rel_rot[nbr], rel_rot[:, None], nw)
+    offset_mag = torch.sqrt((curr_offset ** 2).sum(-1) + 1e-20)
+    losses["iso"] = weighted_l2_loss_v1(offset_mag, variables["neighbor_dist"], nw)
     losses["floor"] = torch.clamp(fg_pts[:, 1], min=0).mean()
     bg_pts = pick_bg(rendervar["means3D"])
     bg_rot = pick_bg(rendervar["rotations"])
     losses["bg"] = l1_loss_v2(bg_pts, variables["init_bg_pts"]) + l1_loss_v2(bg_rot, variables["init_bg_rot"])
-    losses["soft_col_cons"] = 0.0
+    total = scale * sum(weights[k] * losses[k] for k in _SHARED_NAMES)
+    return total, torch.stack([losses[k].detach() for k in _SHARED_NAMES])
+
+
+def params2rendervar_fused(params, colors_key: str = "rgb_colors"):
+    """``params2rendervar`` with the three activations as one fused kernel each way (same values; gsr_step.hip)."""
+    rot, op, sc = activate(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
+    return {"means3D": params["means3D"], "colors_precomp": params[colors_key], "rotations": rot, "opacities": op, "scales": sc}
+
+
+def _view_colours(params, variables, V: int):
+    """[rgb, seg] x V as one [2V,P,3] array; rebuilt only when a colour tensor changed (they are frozen while tracking:
+    lr 0, /root/reference/src/tracking/train_utils.py:152-164) or would need a gradient."""
+    rgb, seg = params["rgb_colors"], params["seg_colors"]
+    if rgb.requires_grad or seg.requires_grad:
+        return torch.stack([rgb, seg]).repeat(V, 1, 1)
+    key = (rgb.data_ptr(), rgb._version, seg.data_ptr(), seg._version, V, tuple(rgb.shape))
+    hit = variables.get("_view_colours")
+    if hit is None or hit[0] != key:
+        hit = (key, torch.stack([rgb, seg]).repeat(V, 1, 1))
+        variables["_view_colours"] = hit
+    return hit[1]
 
 
 def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights):
@@ -130,10 +155,10 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     radii=[V,P] of the colour renders)."""
     from diff_gaussian_rasterization import rasterize_gaussians_views
     V = len(datas)
-    rendervar = params2rendervar(params)
+    rendervar = params2rendervar_fused(params)
     P = rendervar["means3D"].shape[0]
     cams = [d["cam"] for d in datas for _ in (0, 1)]
-    colours = torch.stack([params["rgb_colors"], params["seg_colors"]]).repeat(V, 1, 1)        # [2V,P,3]
+    colours = _view_colours(params, variables, V)                                               # [2V,P,3]
     m2 = torch.zeros((2 * V, P, 3), device=rendervar["means3D"].device, requires_grad=True)
     ims, radii, _ = rasterize_gaussians_views(cams, rendervar["means3D"], m2, rendervar["opacities"], colors_precomp=colours,
                                               scales=rendervar["scales"], rotations=rendervar["rotations"])
@@ -143,10 +168,9 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     rows = [r for i in ids for r in (i, -1)]
     total, _ = views_image_loss(ims, targets, rows, [w.im, w.seg] * V, params["cam_m"], params["cam_c"], 0.8, 0.2)
     if not is_initial_timestep:
-        losses = {}
-        _shared_terms(params, rendervar, variables, losses)
-        weights = {"rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg, "soft_col_cons": w.soft_col_cons}
-        total = total + V * sum(weights[k] * val for k, val in losses.items())   # every per-camera get_loss adds them once
+        weights = {"rigid": w.rigid, "iso": w.iso, "rot": w.rot, "floor": w.floor, "bg": w.bg}
+        shared, _ = _shared_terms(params, rendervar, variables, weights, scale=float(V))   # every per-camera get_loss adds them once
+        total = total + shared
     rad = radii[0::2]                                                             # colour renders
     m2r = variables["max_2D_radius"]
     variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))

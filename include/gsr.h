@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 111 /* 0.1.11: + image terms of all views of a step in one call (gsr_views_loss_*) */
+#define GSR_VERSION 111 /* 0.1.11: + image terms of all views of a step in one call (gsr_views_loss_*), shared terms, activations */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -156,6 +156,35 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
                           const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
                           const float* prev_inv_rot_fg, const float* prev_offset, const float* grad3, const int32_t* rev_ptr,
                           const int32_t* rev_edge, float* scratch, float* d_means3D, float* d_rotations, void* stream);
+
+/* ---- the whole view-independent part of the t > 0 loss in one call (train_utils.py:198-241): the three neighbour terms above plus
+ *   floor = mean(clamp(means3D[fg].y, min=0))                                                     (train_utils.py:225)
+ *   bg    = mean_b sum_c |means3D[bg] - init_bg_pts| + mean_b sum_c |rotations[bg] - init_bg_rot| (train_utils.py:227-229)
+ * and their weighted sum.  bg_idx[n_bg] (int64) lists the background Gaussians; init_bg_* are indexed by background rank.
+ * forward: terms6 (device) = rigid, rot, iso, floor, bg, sum_k weights5_host[k] * term_k;  partials = gsr_shared_terms_partials floats.
+ * backward: d_means3D[P,3] / d_rotations[P,4] (fully written) = grad_total[0] (device) * d terms6[5] / d input;
+ *   scratch = 7 (n_fg + n_fg K) floats; rev_ptr / rev_edge as for gsr_rigidity_backward. */
+int32_t gsr_shared_terms_partials(int32_t n_fg, int32_t n_bg);
+int gsr_shared_terms_forward(int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations, const int64_t* fg_idx,
+                             const int64_t* bg_idx, const int64_t* neighbor_indices, const float* neighbor_weight,
+                             const float* neighbor_dist, const float* prev_inv_rot_fg, const float* prev_offset,
+                             const float* init_bg_pts, const float* init_bg_rot, const float* weights5_host, float* partials,
+                             float* terms6, void* stream);
+int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations,
+                              const int64_t* fg_idx, const int64_t* bg_idx, const int64_t* neighbor_indices,
+                              const float* neighbor_weight, const float* neighbor_dist, const float* prev_inv_rot_fg,
+                              const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
+                              const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
+                              float* scratch, float* d_means3D, float* d_rotations, void* stream);
+
+/* ---- activations of the raw parameters (replaces the torch ops of params2rendervar, /root/reference/src/tracking/helpers.py:36-45):
+ *   rotations[P,4] = unnorm_rotations / max(|unnorm_rotations|, 1e-12), opacities[P,1] = sigmoid(logit_opacities), scales[P,3] = exp(log_scales).
+ * backward: any of d_rotations / d_opacities / d_scales may be NULL (treated as zero); the three outputs are always written. */
+int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
+                         float* rotations, float* opacities, float* scales, void* stream);
+int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float* opacities, const float* scales,
+                          const float* d_rotations, const float* d_opacities, const float* d_scales, float* d_unnorm_rotations,
+                          float* d_logit_opacities, float* d_log_scales, void* stream);
 
 /* ---- rollout plumbing (callers: gsdyn/dynamics.py)
  * gsr_fps: farthest point sampling of pos[N,3] -> out_idx[npoints] (int64), first pick start_idx, every further pick the

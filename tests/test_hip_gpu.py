@@ -769,7 +769,7 @@ def test_get_loss_views_equals_sum_of_get_loss(dev):
         p_.grad = None
     loss, _, _ = get_loss_views(params, views, init_variables(P, dev), True, w)
     loss.backward()
-    assert abs(float(loss) - total) <= 2e-5 * abs(total)
+    assert abs(float(loss.detach()) - total) <= 2e-5 * abs(total)
     assert "cam_m" in ref and "cam_c" in ref and float(ref["cam_m"].abs().max()) > 0
     for k, g in ref.items():
         got = params[k].grad
@@ -920,6 +920,72 @@ def test_fused_rigidity_terms_match_torch_autograd(dev):
         err = (got.double() - want).abs().max().item()
         assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
     assert torch.all(m1.grad[~is_fg] == 0) and torch.all(r1.grad[~is_fg] == 0)
+
+
+def test_fused_shared_terms_match_torch(dev):
+    """All five view-independent t > 0 terms and their weighted sum in the fused kernels (gsr_shared_terms_*) against the torch
+    path of ``_shared_terms`` evaluated in fp64: value and the gradients w.r.t. means3D and the normalised rotations."""
+    from gsdyn import synth_scene_params
+    from gsdyn.step import _SHARED_NAMES, _shared_terms, make_rigidity_variables
+    P = 7000
+    params = synth_scene_params(P, device=dev)
+    variables = make_rigidity_variables(params, num_knn=20)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    means = params["means3D"].detach() + 0.01 * torch.randn(P, 3, generator=g).to(dev)
+    with torch.no_grad():
+        means[::7, 1] = means[::7, 1].abs() + 0.01          # some foreground points above the floor
+    rots = torch.nn.functional.normalize(params["unnorm_rotations"].detach() + 0.05 * torch.randn(P, 4, generator=g).to(dev))
+    weights = dict(rigid=200.0, rot=4.0, iso=1000.0, floor=2.0, bg=200.0)
+    m1, r1 = means.clone().requires_grad_(True), rots.clone().requires_grad_(True)
+    total, each = _shared_terms(params, dict(means3D=m1, rotations=r1), variables, weights, scale=3.0)
+    (total * 0.5).backward()
+    v64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in variables.items()
+           if k not in ("rev_ptr", "rev_edge")}
+    m2, r2 = means.double().clone().requires_grad_(True), rots.double().clone().requires_grad_(True)
+    ref_total, ref_each = _shared_terms(params, dict(means3D=m2, rotations=r2), v64, weights, scale=3.0)
+    (ref_total * 0.5).backward()
+    assert abs(total.item() - ref_total.item()) <= 2e-5 * abs(ref_total.item())
+    for i, k in enumerate(_SHARED_NAMES):
+        assert abs(each[i].item() - ref_each[i].item()) <= 2e-5 * abs(ref_each[i].item()) + 1e-9, k
+    assert float(ref_each[3]) > 0
+    for got, want, name in ((m1.grad, m2.grad, "means3D"), (r1.grad, r2.grad, "rotations")):
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
+    # deterministic
+    m3, r3 = means.clone().requires_grad_(True), rots.clone().requires_grad_(True)
+    total3, _ = _shared_terms(params, dict(means3D=m3, rotations=r3), variables, weights, scale=3.0)
+    (total3 * 0.5).backward()
+    assert torch.equal(total, total3) and torch.equal(m1.grad, m3.grad) and torch.equal(r1.grad, r3.grad)
+
+
+def test_fused_activations_match_torch(dev):
+    """normalize / sigmoid / exp in one kernel each way (gsr_activate_*) vs the torch ops of params2rendervar, incl. a zero quaternion
+    and an unused output (its incoming gradient is None)."""
+    from gsdyn.losses import activate
+    g = torch.Generator(device="cpu").manual_seed(9)
+    P = 5003
+    u = torch.randn(P, 4, generator=g).to(dev)
+    u[5] = 0.0
+    lo, ls = torch.randn(P, 1, generator=g).to(dev) * 3, torch.randn(P, 3, generator=g).to(dev)
+    wr, wo, ws = torch.randn(P, 4, generator=g).to(dev), torch.randn(P, 1, generator=g).to(dev), torch.randn(P, 3, generator=g).to(dev)
+    a = [t.clone().requires_grad_(True) for t in (u, lo, ls)]
+    b = [t.clone().requires_grad_(True) for t in (u, lo, ls)]
+    rot, op, sc = activate(*a)
+    rot_t, op_t, sc_t = torch.nn.functional.normalize(b[0]), torch.sigmoid(b[1]), torch.exp(b[2])
+    for x_, y_ in ((rot, rot_t), (op, op_t), (sc, sc_t)):
+        assert (x_ - y_).abs().max().item() <= 2e-6 * max(1.0, y_.abs().max().item())
+    ((rot * wr).sum() + (op * wo).sum() + (sc * ws).sum()).backward()
+    ((rot_t * wr).sum() + (op_t * wo).sum() + (sc_t * ws).sum()).backward()
+    for x_, y_ in zip(a, b):
+        ok = torch.ones(P, dtype=torch.bool, device=dev)
+        ok[5] = False                                         # the zero quaternion: 1e12-scaled gradient, compared relatively below
+        assert (x_.grad[ok] - y_.grad[ok]).abs().max().item() <= 1e-5 * max(1.0, y_.grad[ok].abs().max().item())
+    assert torch.allclose(a[0].grad[5], b[0].grad[5], rtol=1e-5)
+    c = [t.clone().requires_grad_(True) for t in (u, lo, ls)]
+    _, op_c, _ = activate(*c)
+    (op_c * wo).sum().backward()
+    assert float(c[0].grad.abs().max()) == 0.0 and float(c[2].grad.abs().max()) == 0.0
+    assert (c[1].grad - b[1].grad).abs().max().item() <= 1e-6
 
 
 def test_density_control_on_device(dev):
