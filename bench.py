@@ -322,23 +322,26 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
             def getloss_step():
                 for p in params.values():
                     p.grad = None
-                if mode == "all":            # all cameras, colour + seg renders: ONE rasterizer call (8 views)
-                    loss, _, _ = get_loss_views(params, views, variables, initial, w)
+                if mode in ("all", "all_colour_grads"):   # all cameras, colour + seg renders: ONE rasterizer call (8 views)
+                    # colour groups have lr 0 in the tracking schedule (train_utils.py:152-164): their gradient is skipped,
+                    # which keeps each colour + seg pair one fused tile pass in the backward too
+                    loss, _, _ = get_loss_views(params, views, variables, initial, w, frozen_colours=(mode == "all"))
                     loss.backward()
                     return
                 for d in views:
                     if mode == "pair":       # the reference's pattern, one camera per iteration: colour + seg as a 2-view call
-                        loss, _, _ = get_loss_views(params, [d], variables, initial, w)
+                        loss, _, _ = get_loss_views(params, [d], variables, initial, w, frozen_colours=True)
                     else:                    # two separate GaussianRasterizer calls per camera, as train_utils.py writes it
                         loss, _ = get_loss(params, d, variables, initial, w)
                     loss.backward()
             return getloss_step
         for name, initial in (("getloss_step_t0", True), ("getloss_step", False)):
             res = {}
-            for mode in ("separate", "pair", "all"):
+            for mode in ("separate", "pair", "all_colour_grads", "all"):
                 ms = _time_ms(make_step(initial, mode), 5, 2)
                 res[mode] = {"ms_per_step": ms, "ms_per_view": ms / len(views)}
-            out[name] = {"views": len(views), **res["all"], "per_camera_2view_call": res["pair"], "separate_calls": res["separate"],
+            out[name] = {"views": len(views), **res["all"], "with_seg_colour_gradient": res["all_colour_grads"],
+                         "per_camera_2view_call": res["pair"], "separate_calls": res["separate"],
                          "what": "train_gs.py get_loss (colour+seg renders, fused 0.8 L1 + 0.2 (1-SSIM)"
                                  + ("" if initial else ", rigid/rot/iso/floor/bg terms") + ") + backward, "
                                  + ("t = 0" if initial else "t > 0") + "; headline = all cameras in one rasterizer call"}

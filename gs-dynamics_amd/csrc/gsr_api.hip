@@ -73,7 +73,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
-  o.shares_lists = 0;
+  o.shares_lists = 0; o.fused_alias = 0;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
   o.offsets = g.offsets;
@@ -85,7 +85,19 @@ void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, c
                       float* out_color, float* out_depth, const float* dL_dcolor, float4* partials) {
   o.point_list = bs.point_list; o.rec = g.rec; o.bg = cam.bg; o.final_T = im.final_T; o.n_contrib = im.n_contrib;
   o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
-  o.partials = partials; o.ranges = im.ranges;
+  o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0;
+}
+
+// Fused pairs: the FIRST alias of a view (same camera, other colours) is blended inside its owner's tile pass instead of
+// getting tile tickets of its own; further aliases of the same owner keep the plain shared-list path.
+void pair_up(int V, const int32_t* geometry_of, const uint32_t* num_rendered, int partner[GSR_MAX_BATCH], int fused[GSR_MAX_BATCH]) {
+  static const bool off = [] { const char* e = getenv("GSR_NO_PAIR_FUSION"); return e && *e && atoi(e) != 0; }();
+  for (int v = 0; v < V; ++v) { partner[v] = -1; fused[v] = 0; }
+  if (!geometry_of || off) return;
+  for (int v = 0; v < V; ++v) {
+    const int u = geometry_of[v];
+    if (u != v && partner[u] < 0 && num_rendered[u] > 0) { partner[u] = v; fused[v] = 1; }
+  }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
   t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue;
@@ -193,6 +205,8 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
+  int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH];
+  pair_up(V, geometry_of, num_rendered, partner, fused);
   const uint32_t nblk = (uint32_t)(((P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK);
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
@@ -221,6 +235,8 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
       bt.v[v].shares_lists = 1; bt.v[v].D = 0; bt.v[v].nblocks = 0; bt.v[v].ranges = im_owner.ranges;
       rt.v[v].ranges = im_owner.ranges;
     }
+    bt.v[v].fused_alias = (uint32_t)fused[v];
+    rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
   return gsr_launch_render_fwd(rt, st);
@@ -382,7 +398,18 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
   GsrBwdViews vw;
   vw.V = V;
   GsrRenderViews rt;
+  GsrBinViews bt;          // only for a tile_order rebuild (ranges + flags)
   bool any = false;
+  // Pairs fused by the forward (pair_up) stay fused in the backward when no colour gradient is wanted (the pair pass carries
+  // none); otherwise every view takes its own pass.  Either way the LPT order is rebuilt for the mode that runs -- a pair call
+  // cannot tell which order an earlier backward left behind -- at the cost of one tile_order launch.
+  int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH];
+  pair_up(V, geometry_of, num_rendered, partner, fused);
+  bool pairs_fwd = false;
+  for (int v = 0; v < V; ++v) pairs_fwd = pairs_fwd || fused[v];
+  const bool fuse_bwd = pairs_fwd && !dL_dcolors && !dL_dcolors_views;
+  if (!fuse_bwd)
+    for (int v = 0; v < V; ++v) { partner[v] = -1; fused[v] = 0; }
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
     if (int rc = make_cam(&s[v], &cam)) return rc;
@@ -396,14 +423,21 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     if (v == 0) render_header(rt, V, cam, b.order, b.queue);
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
+    rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; }
+    bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
     w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
     w.dL_dcolors = dL_dcolors_views ? dL_dcolors_views[v] : nullptr;
+    w.partner_dL_dmeans2D = partner[v] >= 0 ? dL_dmeans2D[partner[v]] : nullptr;
+    w.fused_alias = fused[v];
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
   if (any) {
+    if (pairs_fwd)
+      if (int rc = gsr_launch_tile_order(bt, st)) return rc;
     if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
   }
   (void)colors_precomp;
@@ -654,6 +688,9 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   const int l = threadIdx.x & 63;
   const float zexp = ((l & 8) == 0) ? (float)((l & 7) + 1) * b : 9.f * b;
   bool okz = __ballot(z != zexp) == 0ull;
+  // eight-value form of the fused pair backward: lane & 7 = i holds the total of value i
+  const float z8 = gsr_wave_sum8_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v);
+  okz = okz && __ballot(z8 != (float)((l & 7) + 1) * b) == 0ull;
   // the blend backward runs unused lanes with alpha = 0 and relies on 1 / (1 - 0) being exactly 1 (v_rcp_f32)
   const float alpha0 = fminf(0.99f, 0.7f * (v * 0.0f));
   okz = okz && __ballot(__builtin_amdgcn_rcpf(1.0f - alpha0) != 1.0f) == 0ull;

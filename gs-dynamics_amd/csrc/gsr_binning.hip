@@ -423,8 +423,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
     }
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
+      const int k = k0 + u;
       const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
-      if (bucket != 255u) atomicAdd(&cnt[bucket], 1u);   // empty tiles (and padding): not counted, no hot LDS word
+      // empty tiles (and padding): not counted, no hot LDS word; the busy tiles of a fused alias view ride on its owner's tickets
+      if (bucket != 255u && !(k < n_items && tab.v[k / n_it].fused_alias)) atomicAdd(&cnt[bucket], 1u);
     }
   }
   __syncthreads();
@@ -463,8 +465,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
         // empty tiles go behind the busy ones in any order: a wave-aggregated slot (one LDS atomic per wave).
         // (Aggregating the busy buckets too -- 8 ballots per item -- was measured slower than the plain atomics.)
         uint32_t slot;
-        if (bucket != 255u) slot = atomicAdd(&start[bucket], 1u);
-        else {
+        if (bucket != 255u) {
+          if (tab.v[k / n_it].fused_alias) continue;   // uniform per item: no ticket of its own
+          slot = atomicAdd(&start[bucket], 1u);
+        } else {
           const uint64_t m = __ballot(1);
           const int leader = __ffsll((long long)m) - 1;
           uint32_t base = 0;
@@ -476,8 +480,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
       }
     }
   }
-  // the empty tiles (bucket 255) are sorted last and never enter the queues
-  if (tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; }
+  // the empty tiles (bucket 255) are sorted last and never enter the queues; queue[7] = entries of the order array
+  __syncthreads();
+  if (tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; queue[7] = start[255]; }
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
@@ -776,9 +781,7 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((maxD + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur); }
     GSR_HIP_CHECK(hipGetLastError());
   }
-  { GSR_PROF("tile_order", st);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
-  GSR_HIP_CHECK(hipGetLastError());
+  if (int rc = gsr_launch_tile_order(tab, st)) return rc;
   if (maxD > 0 && P > 0) {
     { GSR_PROF("tile_sort", st);
     const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
@@ -789,5 +792,12 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
       hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur); }
     GSR_HIP_CHECK(hipGetLastError());
   }
+  return 0;
+}
+
+int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st) {
+  { GSR_PROF("tile_order", st);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
+  GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

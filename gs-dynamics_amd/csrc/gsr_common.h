@@ -161,6 +161,7 @@ struct GsrBinView {            // emit .. tile_sort
   uint2* ranges;
   uint32_t D, nblocks;
   uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
+  uint32_t fused_alias;    // 1: additionally blended INSIDE its owner's tile pass (GsrRenderView::partner): no tickets for its busy tiles
 };
 struct GsrBinViews { int V, T, gx; uint4* order; uint32_t* queue; GsrBinView v[GSR_MAX_BATCH]; };
 struct GsrRenderView {         // blend forward / backward
@@ -168,6 +169,8 @@ struct GsrRenderView {         // blend forward / backward
   float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
   const float* dL_dcolor; const uint2* rect; const uint32_t* offsets; float4* partials;
   const uint2* ranges;
+  int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
+  int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
 };
 struct GsrRenderViews { int V, W, H, gx, T; const uint4* order; uint32_t* queue; GsrRenderView v[GSR_MAX_BATCH]; };
 
@@ -194,6 +197,7 @@ int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, cons
                           const float* shs, const float* cov3D_precomp, hipStream_t st);
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
 int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
+int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);   // uses only V, T, order, queue, v[].ranges, v[].fused_alias
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
@@ -210,6 +214,9 @@ struct GsrBwdView {
   const float4* partials;
   float* dL_dmeans2D;
   float* dL_dcolors;      // per-view colour gradient [P,3] (views with their own colours), else nullptr: summed
+  float* partner_dL_dmeans2D;   // != nullptr: fused pair backward -- the records carry both views (layout in gsr_render.hip), the
+                                // partner's screen-space gradient goes here
+  int fused_alias;        // 1: handled by its owner (see partner_dL_dmeans2D): nothing to do for this view
   int W, H;
   float tanfovx, tanfovy;
 };
@@ -354,6 +361,25 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
   // issue occupancy, so the crossbar round trips are already hidden by the other waves and VALU slots are what count.)  Every lane ends up
   // with the total of "its" value: lane & 15 in 0..7 -> v_(lane & 7), lane & 8 set -> v8.
   z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
+  z += __shfl_xor(z, 32, 64);
+  return z;
+}
+
+// Eight values (fused pair backward without colour gradients): 9 -> 4 -> 2 -> 1 registers, 27 instructions.
+// Result z (in every lane): lane with (lane & 7) = i holds the wave total of v_i.
+__device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float v2, float v3, float v4, float v5,
+                                                      float v6, float v7) {
+  const int lane = gsr_lane();
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
+  const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
+  const float r45 = (b0 ? v5 : v4) + gsr_dpp_get<0xB1>(b0 ? v4 : v5);
+  const float r67 = (b0 ? v7 : v6) + gsr_dpp_get<0xB1>(b0 ? v6 : v7);
+  const float q03 = (b1 ? r23 : r01) + gsr_dpp_get<0x4E>(b1 ? r01 : r23);
+  const float q47 = (b1 ? r67 : r45) + gsr_dpp_get<0x4E>(b1 ? r45 : r67);
+  float z = (b2 ? q47 : q03) + gsr_swz_xor4(b2 ? q03 : q47);
+  z += gsr_dpp_get<0x128>(z);                                                        // xor 8 (row_ror:8)
+  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));       // xor 16
   z += __shfl_xor(z, 32, 64);
   return z;
 }

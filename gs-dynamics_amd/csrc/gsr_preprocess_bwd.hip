@@ -149,7 +149,8 @@ __device__ __forceinline__ void build_cov3(int i, float mod, const float* __rest
 // gcov[6] and gm3[3]; returns this view's dL/d(NDC mean) in gm2.
 __device__ __forceinline__ void view_chain(const float* __restrict__ view, const float* __restrict__ proj, int W, int H,
                                            float tanfovx, float tanfovy, float3 p, const float c[6],
-                                           const PartialSum& ps, float gcov[6], float gm3[3], float gm2[2]) {
+                                           const PartialSum& ps, float gcov[6], float gm3[3], float gm2[2],
+                                           float sx_first = 0.f, float sy_first = 0.f, float* gm2_first = nullptr) {
   const float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
   const float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
   const float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
@@ -205,6 +206,10 @@ __device__ __forceinline__ void view_chain(const float* __restrict__ view, const
   const float cA = cc * det_inv, cB = -b * det_inv, cC = a * det_inv;
   gm2[0] = -(cA * ps.gmx + cB * ps.gmy) * 0.5f * (float)W;
   gm2[1] = -(cC * ps.gmy + cB * ps.gmx) * 0.5f * (float)H;
+  if (gm2_first) {   // fused pair: the share of the first view of the pair (ps.gmx / gmy are the sums over both)
+    gm2_first[0] = -(cA * sx_first + cB * sy_first) * 0.5f * (float)W;
+    gm2_first[1] = -(cC * sy_first + cB * sx_first) * 0.5f * (float)H;
+  }
   const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
   const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
   const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
@@ -303,18 +308,30 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
   bool any = false;
   for (int v = 0; v < vw.V; ++v) {
     const GsrBwdView& w = vw.v[v];
-    float gm2[2] = {0.f, 0.f};
+    if (w.fused_alias) continue;      // its owner's records carry it (fused pair): the owner writes its dL_dmeans2D too
+    float gm2[2] = {0.f, 0.f}, gm2a[2] = {0.f, 0.f};
+    const bool pair = w.partner_dL_dmeans2D != nullptr;
     if (w.radii[i] > 0) {
       any = true;
       const PartialSum ps = reduce_partials(w.partials, w.offsets[i], w.offsets[i + 1]);
       gop += ps.gop;
-      if (w.dL_dcolors) { w.dL_dcolors[3 * i] = ps.dr; w.dL_dcolors[3 * i + 1] = ps.dg; w.dL_dcolors[3 * i + 2] = ps.db; }
-      else { gcol[0] += ps.dr; gcol[1] += ps.dg; gcol[2] += ps.db; }
-      view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+      if (pair) {   // record layout of the pair backward: geometry sums of both views, then (sum t dx, sum t dy) of this view alone
+        view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2, ps.dr, ps.dg, gm2a);
+      } else {
+        if (w.dL_dcolors) { w.dL_dcolors[3 * i] = ps.dr; w.dL_dcolors[3 * i + 1] = ps.dg; w.dL_dcolors[3 * i + 2] = ps.db; }
+        else { gcol[0] += ps.dr; gcol[1] += ps.dg; gcol[2] += ps.db; }
+        view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+      }
     } else if (w.dL_dcolors) {
       w.dL_dcolors[3 * i] = 0.f; w.dL_dcolors[3 * i + 1] = 0.f; w.dL_dcolors[3 * i + 2] = 0.f;
     }
-    w.dL_dmeans2D[3 * i] = gm2[0]; w.dL_dmeans2D[3 * i + 1] = gm2[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+    if (pair) {
+      w.dL_dmeans2D[3 * i] = gm2a[0]; w.dL_dmeans2D[3 * i + 1] = gm2a[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+      float* m2b = w.partner_dL_dmeans2D;
+      m2b[3 * i] = gm2[0] - gm2a[0]; m2b[3 * i + 1] = gm2[1] - gm2a[1]; m2b[3 * i + 2] = 0.f;
+    } else {
+      w.dL_dmeans2D[3 * i] = gm2[0]; w.dL_dmeans2D[3 * i + 1] = gm2[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+    }
   }
   if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];

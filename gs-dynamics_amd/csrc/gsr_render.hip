@@ -101,18 +101,30 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
 }
 
 // Per-strip compacted entry lists of one staged batch (stable: list order is preserved).
-struct FwdLds {
+// PAIR: the tile pass also blends a partner view that shares this view's camera and differs only in its colours (the
+// segmentation render next to the colour render of get_loss, the mask render next to the colour render of predict.py):
+// geometry, alpha and transmittance are evaluated once, three more colour accumulators ride along (3 of ~25 VALU per
+// pixel-entry pair instead of a second pass).
+template <bool PAIR>
+struct FwdLdsT {
   float4 sA[4][FWD_BATCH + 1];   // mean2D.x, mean2D.y, conic A, conic B   (+1: the loop prefetches entry j+1)
   float4 sB[4][FWD_BATCH + 1];   // conic C, opacity, r, g
-  float4 sC[4][FWD_BATCH + 1];   // b, depth, bits(1-based list position), -
+  float4 sC[4][FWD_BATCH + 1];   // b, depth, bits(1-based list position), partner r
+  float2 sD[4][PAIR ? FWD_BATCH + 1 : 1];   // partner g, b
   uint32_t cnt[4][4];        // [staging wave][strip]
 };
 
+// the partner's side of a fused pair (all nullptr / unused when !PAIR)
+struct FwdPartner {
+  const float4* rec; const float* bg; float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
+};
+
+template <bool PAIR>
 __device__ __forceinline__ void fwd_tile(
-    const int tile, const uint2 rg, FwdLds& L, int W, int H, int gx,
+    const int tile, const uint2 rg, FwdLdsT<PAIR>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth) {
+    float* __restrict__ out_depth, const FwdPartner pt) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
   const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
@@ -121,6 +133,7 @@ __device__ __forceinline__ void fwd_tile(
   const int n = (int)(rg.y - rg.x);
 
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+  float C3 = 0.f, C4 = 0.f, C5 = 0.f;   // PAIR: the partner's colour
   uint32_t last = 0;
   bool done = !inside;
   GSR_T0();
@@ -129,11 +142,13 @@ __device__ __forceinline__ void fwd_tile(
   // latency (point_list -> record arrays, two dependent trips to L2/HBM) hides behind the blend loop.
   float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
   float2 nc = make_float2(0.f, 0.f);
+  float3 np = make_float3(0.f, 0.f, 0.f);   // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
   if (tid < FWD_BATCH && tid < n) {
     const uint32_t g = point_list[rg.x + tid];
     { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+    if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
   }
   GSR_TP(0);
   for (int base = 0; base < n; base += FWD_BATCH) {
@@ -142,7 +157,8 @@ __device__ __forceinline__ void fwd_tile(
     // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
     const float4 a = na, b = nb;
     const int idx = base + tid;
-    const float4 c = make_float4(nc.x, nc.y, __uint_as_float((uint32_t)(idx + 1)), 0.f);
+    const float4 c = make_float4(nc.x, nc.y, __uint_as_float((uint32_t)(idx + 1)), np.x);
+    const float2 d = make_float2(np.y, np.z);
     uint32_t mask = 0;
     if (tid < FWD_BATCH && idx < n) mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
     {
@@ -151,6 +167,7 @@ __device__ __forceinline__ void fwd_tile(
         const uint32_t g = point_list[rg.x + nidx];
         { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+        if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
       }
     }
     uint64_t bal[4];
@@ -172,6 +189,7 @@ __device__ __forceinline__ void fwd_tile(
         L.sA[w][pos] = make_float4(a.x, a.y, GSR_HALF_LOG2E * a.z, GSR_NEG_LOG2E * a.w);
         L.sB[w][pos] = make_float4(GSR_HALF_LOG2E * b.x, b.y, b.z, b.w);
         L.sC[w][pos] = c;
+        if (PAIR) L.sD[w][pos] = d;
       }
     }
     // readfirstlane makes the trip count a scalar
@@ -185,8 +203,9 @@ __device__ __forceinline__ void fwd_tile(
       const float4* __restrict__ wA = L.sA[wv];
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
+      const float2* __restrict__ wD = L.sD[wv];
       // One list entry: evaluate, then blend predicated.
-#define GSR_FWD_ENTRY(ea, eb, ec)                                                                   \
+#define GSR_FWD_ENTRY(ea, eb, ec, ed)                                                               \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
         const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
@@ -199,6 +218,7 @@ __device__ __forceinline__ void fwd_tile(
         const float w = blend ? alpha * T : 0.0f;                                                   \
         C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                         \
         C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                         \
+        if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
         T = blend ? test_T : T;                                                                     \
         last = blend ? __float_as_uint(ec.z) : last;                                                \
       }
@@ -206,15 +226,18 @@ __device__ __forceinline__ void fwd_tile(
       // (j+1) is evaluated, and no register copies are needed to rotate the prefetch (they were 6 of ~40 VALU
       // slots per entry, and the blend kernels run at the VALU issue limit).
       float4 ea = wA[0], eb = wB[0], ec = wC[0];
+      float2 ed = PAIR ? wD[0] : make_float2(0.f, 0.f);
       int j = 0;
       for (; j + 1 < m; j += 2) {
         const float4 xa = wA[j + 1], xb = wB[j + 1], xc = wC[j + 1];
-        GSR_FWD_ENTRY(ea, eb, ec)
+        const float2 xd = PAIR ? wD[j + 1] : make_float2(0.f, 0.f);
+        GSR_FWD_ENTRY(ea, eb, ec, ed)
         ea = wA[j + 2]; eb = wB[j + 2]; ec = wC[j + 2];
-        GSR_FWD_ENTRY(xa, xb, xc)
+        if (PAIR) ed = wD[j + 2];
+        GSR_FWD_ENTRY(xa, xb, xc, xd)
         if ((j & 6) == 6 && __ballot(!done) == 0ull) { j = m; break; }
       }
-      if (j < m) GSR_FWD_ENTRY(ea, eb, ec)
+      if (j < m) GSR_FWD_ENTRY(ea, eb, ec, ed)
 #undef GSR_FWD_ENTRY
     }
     GSR_TP(5);
@@ -229,16 +252,31 @@ __device__ __forceinline__ void fwd_tile(
     out_color[N + pix] = C1 + T * bg[1];
     out_color[2 * N + pix] = C2 + T * bg[2];
     out_depth[pix] = Dp;
+    if (PAIR) {   // same geometry: same transmittance, contributor count and depth
+      pt.final_T[pix] = T;
+      pt.n_contrib[pix] = last;
+      pt.out_color[pix] = C3 + T * pt.bg[0];
+      pt.out_color[N + pix] = C4 + T * pt.bg[1];
+      pt.out_color[2 * N + pix] = C5 + T * pt.bg[2];
+      pt.out_depth[pix] = Dp;
+    }
   }
   GSR_TP(6);
   GSR_TFLUSH();
 }
 
 // ------------------------------------------------------------------------------------------ backward
-struct BwdLds {
+// PAIR (fused pair, see FwdLdsT): both views' dL/dcolour drive ONE replay of the list.  Only used when no colour gradient is
+// wanted (colours are frozen while tracking): the record then carries
+//   { sum t dx, sum t dy, sum tx dx, sum tx dy, sum ty dy, sum G dL/dalpha }  of both views together  (the Gaussian's geometry
+//   gradients only ever need the sum over views)  and  { sum t_A dx, sum t_A dy }  of this view alone, from which preprocess_bwd
+//   forms the two per-view screen-space gradients -- eight sums instead of 2 x 9, one alpha evaluation instead of two.
+template <bool PAIR>
+struct BwdLdsT {
   float4 sA[4][BWD_BATCH + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
   float4 sB[4][BWD_BATCH + 1];                 // C, opacity, r, g
   float2 sC[4][BWD_BATCH + 1];                 // b, bits(batch index j)
+  float4 sD[4][PAIR ? BWD_BATCH + 1 : 1];      // partner r, g, b, -
   float sRed[4][BWD_BATCH][9];                 // per-wave totals of the 9 partials, by batch index (36 B stride: odd
                                                // word count, so both the 9-lane write and the per-entry read are conflict-free)
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
@@ -247,11 +285,14 @@ struct BwdLds {
   int sMaxLast;
 };
 
+struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; };
+
+template <bool PAIR>
 __device__ __forceinline__ void bwd_tile(
-    const int tile, const uint2 rg, BwdLds& L, int W, int H, int gx,
+    const int tile, const uint2 rg, BwdLdsT<PAIR>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials) {
+    const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials, const BwdPartner pt) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx = tile % gx, ty = tile / gx;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
@@ -272,6 +313,13 @@ __device__ __forceinline__ void bwd_tile(
   // Colour accumulated behind the current entry, only ever used dotted with this pixel's dL/dcolour: kept as that dot
   // product (acc_dot), with the previous entry's colour . dL (last_cdot) pending -- 6 VALU per entry instead of 12.
   float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;
+  // PAIR: the partner's dL/dcolour and its own dot-product state (the two views' dL/dalpha are needed separately for the
+  // per-view screen-space gradients, and together for everything else)
+  float dL3 = 0.f, dL4 = 0.f, dL5 = 0.f, nTfbg2 = 0.f, acc_dot2 = 0.f, last_cdot2 = 0.f;
+  if (PAIR) {
+    if (inside) { dL3 = pt.dL_dcolor[pix]; dL4 = pt.dL_dcolor[N + pix]; dL5 = pt.dL_dcolor[2 * N + pix]; }
+    nTfbg2 = -T_final * (pt.bg[0] * dL3 + pt.bg[1] * dL4 + pt.bg[2] * dL5);
+  }
 
   GSR_T0();
   if (tid == 0) L.sMaxLast = 0;
@@ -296,6 +344,7 @@ __device__ __forceinline__ void bwd_tile(
   float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
   float nblue = 0.f;
   float4 nslot = na;   // record word 3: rect bits, offsets[g]
+  float4 np = na;      // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
   uint32_t ng = 0;
   if (tid < BWD_BATCH && tid < max_last) {
@@ -303,12 +352,13 @@ __device__ __forceinline__ void bwd_tile(
     { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+    if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * ng + 1]; np = make_float4(q1.z, q1.w, pt.rec[GSR_REC_F4 * ng + 2].x, 0.f); }
   }
   GSR_TP(0);
   for (int base = 0; base < max_last; base += BWD_BATCH) {
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
     const int m_all = min(BWD_BATCH, max_last - base);
-    const float4 a = na, b = nb;
+    const float4 a = na, b = nb, d = np;
     const float2 c = make_float2(nblue, __uint_as_float((uint32_t)tid));
     uint32_t mask = 0;
     if (tid < m_all) {
@@ -327,6 +377,7 @@ __device__ __forceinline__ void bwd_tile(
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
+        if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * ng + 1]; np = make_float4(q1.z, q1.w, pt.rec[GSR_REC_F4 * ng + 2].x, 0.f); }
       }
     }
     uint64_t bal[4];
@@ -347,6 +398,7 @@ __device__ __forceinline__ void bwd_tile(
         L.sA[w][p] = make_float4(a.x, a.y, GSR_HALF_LOG2E * a.z, GSR_NEG_LOG2E * a.w);   // (-A/2, -B) * log2(e), see fwd_tile
         L.sB[w][p] = make_float4(GSR_HALF_LOG2E * b.x, b.y, b.z, b.w);                   // -C/2 * log2(e)
         L.sC[w][p] = c;
+        if (PAIR) L.sD[w][p] = d;
       }
     }
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
@@ -356,9 +408,10 @@ __device__ __forceinline__ void bwd_tile(
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
+    const float4* __restrict__ wD = L.sD[wv];
     // One list entry: re-evaluate alpha; when some pixel of the quad used the entry, back out T, form the nine partials,
     // reduce them over the wave and park the totals.
-#define GSR_BWD_ENTRY(ea, eb, ec)                                                                             \
+#define GSR_BWD_ENTRY(ea, eb, ec, ed)                                                                           \
     {                                                                                                         \
       const int j = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ec.y)); /* batch index, wave-uniform */ \
       const int pos = max_last - 1 - (base + j);                                                              \
@@ -377,13 +430,27 @@ __device__ __forceinline__ void bwd_tile(
         const float alpha = fminf(GSR_ALPHA_MAX, eb.y * G);                                                   \
         const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);                                                \
         T = T * rcp;                                                                                          \
-        const float w = alpha * T;                                                                            \
         acc_dot = __builtin_fmaf(last_alpha, last_cdot - acc_dot, acc_dot);                                   \
         const float cdot = __builtin_fmaf(blue, dL2, __builtin_fmaf(eb.w, dL1, eb.z * dL0));                  \
         last_cdot = cdot;                                                                                     \
-        last_alpha = alpha;                                                                                   \
         float dL_dalpha = cdot - acc_dot;                                                                     \
         dL_dalpha = __builtin_fmaf(dL_dalpha, T, nTfbg * rcp);                                                \
+        if (PAIR) {                                                                                           \
+          /* the partner's dL/dalpha from its own colour recurrence; t_A (this view alone) and t (both) */     \
+          acc_dot2 = __builtin_fmaf(last_alpha, last_cdot2 - acc_dot2, acc_dot2);                             \
+          const float cdot2 = __builtin_fmaf(ed.z, dL5, __builtin_fmaf(ed.y, dL4, ed.x * dL3));               \
+          last_cdot2 = cdot2;                                                                                 \
+          last_alpha = alpha;                                                                                 \
+          const float dL_dalpha2 = __builtin_fmaf(cdot2 - acc_dot2, T, nTfbg2 * rcp);                         \
+          const float u1 = G * dL_dalpha;                                                                     \
+          const float v5 = __builtin_fmaf(G, dL_dalpha2, u1);                                                 \
+          const float tA = eb.y * u1, t = eb.y * v5;                                                          \
+          const float tx = t * dx, ty = t * dy;                                                               \
+          const float z = gsr_wave_sum8_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5, tA * dx, tA * dy);      \
+          if (lane >= 48 && lane <= 55) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                  \
+        } else {                                                                                              \
+        last_alpha = alpha;                                                                                   \
+        const float w = alpha * T;                                                                            \
         /* t = dL/dG * G with dL/dG = opacity * dL/dalpha (min(0.99, .) is straight-through).  The conic partials are     \
            stored WITHOUT their constant factors (-1/2, -1, -1/2: preprocess_bwd applies them to the per-Gaussian sums). */ \
         const float v5 = G * dL_dalpha;                                                                       \
@@ -396,21 +463,25 @@ __device__ __forceinline__ void bwd_tile(
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \
         if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
+        }                                                                                                     \
         if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));                           \
       }                                                                                                       \
     }
     // two entries per trip on ping-pong registers (see fwd_tile): no copies to rotate the LDS prefetch
     float4 ea = wA[0], eb = wB[0];
     float2 ec = wC[0];
+    float4 ed = wD[0];
     int jj = 0;
     for (; jj + 1 < m; jj += 2) {
       const float4 xa = wA[jj + 1], xb = wB[jj + 1];
       const float2 xc = wC[jj + 1];
-      GSR_BWD_ENTRY(ea, eb, ec)
+      const float4 xd = PAIR ? wD[jj + 1] : ed;
+      GSR_BWD_ENTRY(ea, eb, ec, ed)
       ea = wA[jj + 2]; eb = wB[jj + 2]; ec = wC[jj + 2];
-      GSR_BWD_ENTRY(xa, xb, xc)
+      if (PAIR) ed = wD[jj + 2];
+      GSR_BWD_ENTRY(xa, xb, xc, xd)
     }
-    if (jj < m) GSR_BWD_ENTRY(ea, eb, ec)
+    if (jj < m) GSR_BWD_ENTRY(ea, eb, ec, ed)
 #undef GSR_BWD_ENTRY
     if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
     GSR_TP(4);
@@ -424,7 +495,7 @@ __device__ __forceinline__ void bwd_tile(
           const float* q = L.sRed[w][tid];
           r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
           r1.x += q[4]; r1.y += q[5]; r1.z += q[6]; r1.w += q[7];
-          r2.x += q[8];
+          if (!PAIR) r2.x += q[8];
         }
       }
       const uint32_t e = L.sSlot[tid];
@@ -444,20 +515,32 @@ __device__ __forceinline__ void bwd_tile(
 #define GSR_BWD_PASS(vw) \
   tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).rect, (vw).offsets, (vw).partials
 
+__device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
+  return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth};
+}
+
+// PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the
+// plain path.  A call without pairs runs the PAIRS = false build (smaller LDS footprint: one more workgroup per CU).
+template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
-  __shared__ FwdLds L;
+  __shared__ FwdLdsT<PAIRS> L;
   const GsrRenderView& vw = tab.v[blockIdx.y];
-  fwd_tile((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_FWD_PASS(vw));
+  if (vw.fused_alias) return;                       // rendered by its owner's workgroup
+  if (PAIRS && vw.partner >= 0)
+    fwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]));
+  else
+    fwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{});
 }
 
 // Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
 // (grid-stride over the tail of the order array), then pop busy tiles longest-first.
+template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persistent(GsrRenderViews tab) {
-  __shared__ FwdLds L;
+  __shared__ FwdLdsT<PAIRS> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
-  const uint32_t n_busy = queue[4];
+  const uint32_t n_busy = queue[4], n_all = queue[7];   // n_all < V * T when fused pairs took their partners' busy tiles along
   // Tickets: the first one is implicit (blockIdx.x, no atomic: no thundering herd at kernel start); later ones
   // are gridDim.x + atomicAdd(head), popped after the tile.  (Popping the next ticket one tile ahead -- even from
   // wave 3, which stages nothing, so the returning atomic blocks no gather wait -- was measured 30 % slower: a
@@ -465,7 +548,7 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
   {  // background of the empty tiles
     const int W = tab.W, H = tab.H, gx = tab.gx;
     const size_t N = (size_t)H * W;
-    for (uint32_t i = n_busy + blockIdx.x; i < (uint32_t)(tab.V * tab.T); i += gridDim.x) {
+    for (uint32_t i = n_busy + blockIdx.x; i < n_all; i += gridDim.x) {
       const uint4 ord = tile_order[i];
       const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
       const int tile = (int)ord.x;
@@ -482,7 +565,10 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
-    fwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw));
+    if (PAIRS && vw.partner >= 0)
+      fwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]));
+    else
+      fwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{});
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
@@ -496,14 +582,22 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
   }
 }
 
+__device__ __forceinline__ BwdPartner bwd_partner(const GsrRenderView& p) { return BwdPartner{p.rec, p.bg, p.dL_dcolor}; }
+
+template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews tab) {   // grid (T, V)
-  __shared__ BwdLds L;
+  __shared__ BwdLdsT<PAIRS> L;
   const GsrRenderView& vw = tab.v[blockIdx.y];
-  bwd_tile((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_BWD_PASS(vw));
+  if (vw.fused_alias) return;
+  if (PAIRS && vw.partner >= 0)
+    bwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
+  else
+    bwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 }
 
+template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
-  __shared__ BwdLds L;
+  __shared__ BwdLdsT<PAIRS> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
@@ -514,7 +608,10 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
-    bwd_tile((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS(vw));
+    if (PAIRS && vw.partner >= 0)
+      bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
+    else
+      bwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
     __syncthreads();  // also: the tile's LDS (incl. sMaxLast) is dead before the next tile reuses it
     ticket = s_ticket;
@@ -559,17 +656,27 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+static bool has_pairs(const GsrRenderViews& tab) {
+  for (int v = 0; v < tab.V; ++v)
+    if (tab.v[v].partner >= 0) return true;
+  return false;
+}
+
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 6);
+  const bool pairs = has_pairs(tab);
   { GSR_PROF("render_fwd", st);
     if (use_static) {
-      hipLaunchKernelGGL(render_fwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      if (pairs) hipLaunchKernelGGL(render_fwd_static<true>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL(render_fwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
       const int tiles = tab.T * tab.V;
-      const int grid = tiles < 256 * wg_per_cu ? tiles : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_fwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      const int per_cu = pairs ? (wg_per_cu < 5 ? wg_per_cu : 5) : wg_per_cu;   // the pair build's LDS fits 5 workgroups per CU
+      const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+      if (pairs) hipLaunchKernelGGL(render_fwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL(render_fwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());
@@ -580,13 +687,18 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
+  static const int pair_wg_per_cu = env_int("GSR_BWD_PAIR_WG_PER_CU", 3);   // the pair build's LDS fits 3 workgroups per CU
+  const bool pairs = has_pairs(tab);
   { GSR_PROF("render_bwd", st);
     if (use_static) {
-      hipLaunchKernelGGL(render_bwd_static, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      if (pairs) hipLaunchKernelGGL(render_bwd_static<true>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL(render_bwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
       const int tiles = tab.T * tab.V;
-      const int grid = tiles < 256 * wg_per_cu ? tiles : 256 * wg_per_cu;
-      hipLaunchKernelGGL(render_bwd_persistent, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      const int per_cu = pairs ? pair_wg_per_cu : wg_per_cu;
+      const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+      if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());

@@ -128,7 +128,8 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             grad_color = torch.zeros((V, 3, ctx.states[0].H, ctx.states[0].W), device=m3.device)
         d3, d2, dc, do, ds, dr, dcov, dsh = _hip.rasterize_backward_batch(
             ctx.states, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
-            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
+            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None,
+            want_color_grad=bool(has_col and ctx.needs_input_grad[3]))
         # gradients arrive already summed over views (means2D stays per view); the state stays on ctx so that a
         # second backward (retain_graph=True) works, and is released with the graph
         return (d3, d2, dsh if has_sh else None, dc if has_col else None, do, ds if has_sc else None,

@@ -372,7 +372,8 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
     return color, radii, depth, states
 
 
-def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
+def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
+                             want_color_grad: bool = True):
     """Backward of all views.  Returns gradients already SUMMED over views (dmeans3D[P,3], dcolors, dopacity[P,1],
     dscales, drotations, dcov3D, dsh) plus the per-view means2D gradients [V,P,3]."""
     lib = load_library()
@@ -408,10 +409,12 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
                                       _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
                                       _ptr(states[0].batch), states[0].geometry_of, per_view(g), _ptr_array(scratch), _ptr(d_means3D),
                                       per_view(d_means2D),
-                                      _ptr(None if per_view_col else d_colors), per_view(d_colors) if per_view_col else None,
+                                      _ptr(None if (per_view_col or not want_color_grad) else d_colors),
+                                      per_view(d_colors) if (per_view_col and want_color_grad) else None,
                                       _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
                "gsr_backward_batch")
-    return d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, None
+    # without a colour gradient, views that share a camera stay fused in the backward (one replay of the tile lists for both)
+    return d_means3D, d_means2D, (d_colors if want_color_grad else None), d_opacity, d_scales, d_rot, d_cov, None
 
 
 def rigidity_forward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_off):

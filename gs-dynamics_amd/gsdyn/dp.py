@@ -84,6 +84,9 @@ class ViewShardedStep:
             batched = hasattr(dgr, "rasterize_gaussians_views")
         self.batched = batched
         self.bucket = GradBucket(params)
+        # colour groups with lr 0 (the reference's tracking schedule): their gradient is never applied, so it is not computed
+        lrs = {g.get("name"): g["lr"] for g in optimizer.param_groups} if optimizer is not None else {}
+        self.frozen_colours = lrs.get("rgb_colors", 1.0) == 0.0 and lrs.get("seg_colors", 1.0) == 0.0
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
@@ -100,7 +103,8 @@ class ViewShardedStep:
         total = torch.zeros((), dtype=torch.float32, device=dev)
         if self.batched and mine:
             # all cameras of the shard, colour + segmentation renders, in ONE rasterizer call
-            loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights)
+            loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights,
+                                                  frozen_colours=self.frozen_colours)
             loss.backward()
             total += loss.detach()
             with torch.no_grad():

@@ -131,12 +131,12 @@ def params2rendervar_fused(params, colors_key: str = "rgb_colors"):
     return {"means3D": params["means3D"], "colors_precomp": params[colors_key], "rotations": rot, "opacities": op, "scales": sc}
 
 
-def _view_colours(params, variables, V: int):
-    """[rgb, seg] x V as one [2V,P,3] array; rebuilt only when a colour tensor changed (they are frozen while tracking:
-    lr 0, /root/reference/src/tracking/train_utils.py:152-164) or would need a gradient."""
+def _view_colours(params, variables, V: int, frozen: bool):
+    """[rgb, seg] x V as one [2V,P,3] array; rebuilt only when a colour tensor changed or needs a gradient."""
     rgb, seg = params["rgb_colors"], params["seg_colors"]
-    if rgb.requires_grad or seg.requires_grad:
+    if not frozen and (rgb.requires_grad or seg.requires_grad):
         return torch.stack([rgb, seg]).repeat(V, 1, 1)
+    rgb, seg = rgb.detach(), seg.detach()
     key = (rgb.data_ptr(), rgb._version, seg.data_ptr(), seg._version, V, tuple(rgb.shape))
     hit = variables.get("_view_colours")
     if hit is None or hit[0] != key:
@@ -145,12 +145,16 @@ def _view_colours(params, variables, V: int):
     return hit[1]
 
 
-def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights):
+def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights, frozen_colours: bool = False):
     """``get_loss`` for several cameras at once, equal to the SUM of the per-camera ``get_loss`` values, with ONE
     rasterizer call: the colour and the segmentation render of every camera (2 V renders) share the Gaussians'
     geometry and differ only in their colour array, so they go through ``rasterize_gaussians_views`` as 2 V views
     with per-view colours -- one kernel launch per stage for all of them.  Even the
     reference's own pattern (one camera per iteration, /root/reference/src/tracking/train_gs.py:25-39) becomes a 2-view batch.
+    ``frozen_colours``: no gradient for rgb_colors / seg_colors.  The reference leaves ``seg_colors.requires_grad`` on but
+    gives both colour groups lr 0 (/root/reference/src/tracking/train_utils.py:133,152-164), i.e. computes that gradient and
+    never applies it; without it the backward of a colour + segmentation pair stays ONE replay of the tile lists
+    (fused pair, gsr_render.hip) -- callers that own the optimiser (``ViewShardedStep``) switch it on when both lrs are 0.
     Returns (loss, variables, aux) with aux = dict(means2D=[2V,P,3] gradient holder (rows 0, 2, ... = colour renders),
     radii=[V,P] of the colour renders)."""
     from diff_gaussian_rasterization import rasterize_gaussians_views
@@ -158,7 +162,7 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     rendervar = params2rendervar_fused(params)
     P = rendervar["means3D"].shape[0]
     cams = [d["cam"] for d in datas for _ in (0, 1)]
-    colours = _view_colours(params, variables, V)                                               # [2V,P,3]
+    colours = _view_colours(params, variables, V, frozen_colours)                                               # [2V,P,3]
     m2 = torch.zeros((2 * V, P, 3), device=rendervar["means3D"].device, requires_grad=True)
     ims, radii, _ = rasterize_gaussians_views(cams, rendervar["means3D"], m2, rendervar["opacities"], colors_precomp=colours,
                                               scales=rendervar["scales"], rotations=rendervar["rotations"])

@@ -45,7 +45,8 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             [o[3] for o in outs])
 
 
-def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
+def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
+                             want_color_grad=True):
     per_view = colors_precomp is not None and colors_precomp.dim() == 3
     outs = [rasterize_backward(st, grad_color[v], means3D, radii[v], colors_precomp[v] if per_view else colors_precomp, shs,
                                scales, rotations, cov3D_precomp) for v, st in enumerate(states)]

@@ -610,6 +610,62 @@ def test_per_view_colours_share_geometry(dev):
         assert (ga - gb).abs().max().item() <= 2e-6 * ga.abs().max().item(), k
 
 
+def test_fused_pair_backward_with_frozen_colours(dev):
+    """Views that share a camera are blended in ONE tile pass (6 channels); with frozen colours (tracking: lr 0) the backward
+    stays fused too -- one replay of the lists driven by both views' dL/dcolour.  Against one GaussianRasterizer call per
+    view: identical images, summed geometry gradients, and the per-view screen-space gradients (densification reads the colour
+    render's alone).  Camera 0 is used three times (pair + a plain alias), camera 1 twice, camera 2 once."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H = 12000, 240, 176
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.06)
+    cams = synth_ring_cameras(3, W, H, device=dev)
+    cam_of = [0, 0, 1, 1, 0, 2]
+    V = len(cam_of)
+    rng = np.random.default_rng(19)
+    dL = torch.tensor(rng.uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    cols = torch.tensor(rng.uniform(0, 1, (V, P, 3)).astype(np.float32), device=dev)          # frozen: no gradient
+    cols[0], cols[1] = rv["colors_precomp"], params["seg_colors"].detach()
+    a = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    ims, m2s = [], []
+    for v in range(V):
+        holder = torch.zeros((P, 3), device=dev, requires_grad=True)
+        im, _, _ = GaussianRasterizer(raster_settings=cams[cam_of[v]])(
+            means3D=a["means3D"], means2D=holder, opacities=a["opacities"], colors_precomp=cols[v], scales=a["scales"],
+            rotations=a["rotations"])
+        im.backward(gradient=dL[v])
+        ims.append(im.detach())
+        m2s.append(holder.grad.clone())
+    b = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    m2 = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+    imb, radb, depb = rasterize_gaussians_views([cams[c] for c in cam_of], b["means3D"], m2, b["opacities"], colors_precomp=cols,
+                                                scales=b["scales"], rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    torch.cuda.synchronize()
+    assert torch.equal(imb.detach(), torch.stack(ims))
+    assert torch.equal(depb[0], depb[1]) and torch.equal(depb[0], depb[4]) and torch.equal(radb[2], radb[3])
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        ga, gb = a[k].grad, b[k].grad
+        assert (ga - gb).abs().max().item() <= 5e-6 * ga.abs().max().item(), k
+    for v in range(V):
+        want = m2s[v]
+        assert (m2.grad[v] - want).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-12, v
+    # a second backward over the same graph state gives the same bits (queue re-armed, order rebuilt)
+    b2 = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    m2b = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+    imb2, _, _ = rasterize_gaussians_views([cams[c] for c in cam_of], b2["means3D"], m2b, b2["opacities"], colors_precomp=cols,
+                                           scales=b2["scales"], rotations=b2["rotations"])
+    imb2.backward(gradient=dL, retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in b2.items()}
+    for v_ in b2.values():
+        v_.grad = None
+    imb2.backward(gradient=dL)
+    for k in g1:
+        assert torch.equal(g1[k], b2[k].grad) and torch.equal(g1[k], b[k].grad), k
+
+
 def test_more_views_than_one_library_call(dev):
     """18 views (> GSR_MAX_BATCH = 16): the Python entry point splits the call; results equal per-view calls."""
     from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views

@@ -17,11 +17,12 @@ variables.update(make_rigidity_variables(params, num_knn=20))
 w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)
 views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
 BATCHED = os.environ.get("GETLOSS_SEPARATE") != "1"
+FROZEN = os.environ.get("GETLOSS_COLOUR_GRADS") != "1"     # the tracking schedule: both colour groups have lr 0
 def step(initial):
     for p in params.values():
         p.grad = None
     if BATCHED:
-        loss, _, _ = get_loss_views(params, views, variables, initial, w)
+        loss, _, _ = get_loss_views(params, views, variables, initial, w, frozen_colours=FROZEN)
         loss.backward()
         return
     for d in views:
