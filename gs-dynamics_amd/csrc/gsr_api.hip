@@ -401,8 +401,9 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
   GsrBinViews bt;          // only for a tile_order rebuild (ranges + flags)
   bool any = false;
   // Pairs fused by the forward (pair_up) stay fused in the backward when no colour gradient is wanted (the pair pass carries
-  // none); otherwise every view takes its own pass.  Either way the LPT order is rebuilt for the mode that runs -- a pair call
-  // cannot tell which order an earlier backward left behind -- at the cost of one tile_order launch.
+  // none); otherwise every view takes its own pass over an LPT order rebuilt WITH the partners' tickets, and the fused order is
+  // put back afterwards (batch_state always holds the forward's order between calls: two tile_order launches on the rare path,
+  // none on the common one).
   int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH];
   pair_up(V, geometry_of, num_rendered, partner, fused);
   bool pairs_fwd = false;
@@ -436,9 +437,15 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
   if (any) {
-    if (pairs_fwd)
+    const bool rebuild = pairs_fwd && !fuse_bwd;
+    if (rebuild)
       if (int rc = gsr_launch_tile_order(bt, st)) return rc;
     if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
+    if (rebuild) {
+      pair_up(V, geometry_of, num_rendered, partner, fused);
+      for (int v = 0; v < V; ++v) bt.v[v].fused_alias = (uint32_t)fused[v];
+      if (int rc = gsr_launch_tile_order(bt, st)) return rc;
+    }
   }
   (void)colors_precomp;
   return gsr_launch_preprocess_bwd_views(vw, P, s[0].scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D,

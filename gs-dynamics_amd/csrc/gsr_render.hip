@@ -271,16 +271,20 @@ __device__ __forceinline__ void fwd_tile(
 //   { sum t dx, sum t dy, sum tx dx, sum tx dy, sum ty dy, sum G dL/dalpha }  of both views together  (the Gaussian's geometry
 //   gradients only ever need the sum over views)  and  { sum t_A dx, sum t_A dy }  of this view alone, from which preprocess_bwd
 //   forms the two per-view screen-space gradients -- eight sums instead of 2 x 9, one alpha evaluation instead of two.
+// The pair build stages 96 entries per batch instead of 128 and keeps 8 sums per entry: with the partner colours its LDS
+// footprint then still allows four workgroups per CU (3 -> 4 measured +4 % on the get_loss step).
+#define GSR_BWD_BB(PAIR) ((PAIR) ? 96 : BWD_BATCH)
 template <bool PAIR>
 struct BwdLdsT {
-  float4 sA[4][BWD_BATCH + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
-  float4 sB[4][BWD_BATCH + 1];                 // C, opacity, r, g
-  float2 sC[4][BWD_BATCH + 1];                 // b, bits(batch index j)
-  float4 sD[4][PAIR ? BWD_BATCH + 1 : 1];      // partner r, g, b, -
-  float sRed[4][BWD_BATCH][9];                 // per-wave totals of the 9 partials, by batch index (36 B stride: odd
+  static constexpr int BB = GSR_BWD_BB(PAIR);
+  float4 sA[4][BB + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
+  float4 sB[4][BB + 1];                 // C, opacity, r, g
+  float2 sC[4][BB + 1];                 // b, bits(batch index j)
+  float4 sD[4][PAIR ? BB + 1 : 1];      // partner r, g, b, -
+  float sRed[4][BB][9];                        // per-wave totals of the 9 partials, by batch index (36 B stride: odd
                                                // word count, so both the 9-lane write and the per-entry read are conflict-free)
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
-  uint32_t sSlot[BWD_BATCH];                   // by batch index: the entry's record slot in the Gaussian-major scratch
+  uint32_t sSlot[BB];                          // by batch index: the entry's record slot in the Gaussian-major scratch
   uint32_t cnt[4][4];                          // [staging wave][strip]
   int sMaxLast;
 };
@@ -293,6 +297,7 @@ __device__ __forceinline__ void bwd_tile(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials, const BwdPartner pt) {
+  constexpr int BB = GSR_BWD_BB(PAIR);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx = tile % gx, ty = tile / gx;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
@@ -347,7 +352,7 @@ __device__ __forceinline__ void bwd_tile(
   float4 np = na;      // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
   uint32_t ng = 0;
-  if (tid < BWD_BATCH && tid < max_last) {
+  if (tid < BB && tid < max_last) {
     ng = point_list[rg.x + (max_last - 1 - tid)];
     { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
@@ -355,9 +360,9 @@ __device__ __forceinline__ void bwd_tile(
     if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * ng + 1]; np = make_float4(q1.z, q1.w, pt.rec[GSR_REC_F4 * ng + 2].x, 0.f); }
   }
   GSR_TP(0);
-  for (int base = 0; base < max_last; base += BWD_BATCH) {
+  for (int base = 0; base < max_last; base += BB) {
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
-    const int m_all = min(BWD_BATCH, max_last - base);
+    const int m_all = min(BB, max_last - base);
     const float4 a = na, b = nb, d = np;
     const float2 c = make_float2(nblue, __uint_as_float((uint32_t)tid));
     uint32_t mask = 0;
@@ -371,8 +376,8 @@ __device__ __forceinline__ void bwd_tile(
       mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
     }
     {
-      const int nj = base + BWD_BATCH + tid;
-      if (tid < BWD_BATCH && nj < max_last) {
+      const int nj = base + BB + tid;
+      if (tid < BB && nj < max_last) {
         ng = point_list[rg.x + (max_last - 1 - nj)];
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
@@ -521,6 +526,7 @@ __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
 
 // PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the
 // plain path.  A call without pairs runs the PAIRS = false build (smaller LDS footprint: one more workgroup per CU).
+static_assert(sizeof(FwdLdsT<true>) >= sizeof(FwdLdsT<false>), "the pair build's LDS must hold the plain layout too");
 template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
   __shared__ FwdLdsT<PAIRS> L;
@@ -584,20 +590,27 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
 
 __device__ __forceinline__ BwdPartner bwd_partner(const GsrRenderView& p) { return BwdPartner{p.rec, p.bg, p.dL_dcolor}; }
 
+// LDS of a backward workgroup: the pair build also runs plain tickets (views without a partner), whose layout is the larger one
+template <bool PAIRS>
+struct BwdLdsAny {
+  static constexpr size_t BYTES = PAIRS && sizeof(BwdLdsT<true>) > sizeof(BwdLdsT<false>) ? sizeof(BwdLdsT<true>) : sizeof(BwdLdsT<false>);
+  alignas(16) unsigned char raw[BYTES];
+};
+
 template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews tab) {   // grid (T, V)
-  __shared__ BwdLdsT<PAIRS> L;
+  __shared__ BwdLdsAny<PAIRS> L;
   const GsrRenderView& vw = tab.v[blockIdx.y];
   if (vw.fused_alias) return;
   if (PAIRS && vw.partner >= 0)
-    bwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
+    bwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
   else
     bwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 }
 
 template <bool PAIRS>
 __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
-  __shared__ BwdLdsT<PAIRS> L;
+  __shared__ BwdLdsAny<PAIRS> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
@@ -609,7 +622,7 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     if (PAIRS && vw.partner >= 0)
-      bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
+      bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
     else
       bwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
@@ -687,7 +700,7 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
-  static const int pair_wg_per_cu = env_int("GSR_BWD_PAIR_WG_PER_CU", 3);   // the pair build's LDS fits 3 workgroups per CU
+  static const int pair_wg_per_cu = env_int("GSR_BWD_PAIR_WG_PER_CU", 4);
   const bool pairs = has_pairs(tab);
   { GSR_PROF("render_bwd", st);
     if (use_static) {
