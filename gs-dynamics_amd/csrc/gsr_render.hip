@@ -286,7 +286,7 @@ struct BwdLdsT {
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
   uint32_t sSlot[BB];                          // by batch index: the entry's record slot in the Gaussian-major scratch
   uint32_t cnt[4][4];                          // [staging wave][strip]
-  int sMaxLast;
+  int sQuadLast[4];                            // per wave: the deepest list position any of its 64 pixels used
 };
 
 struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; };
@@ -327,11 +327,15 @@ __device__ __forceinline__ void bwd_tile(
   }
 
   GSR_T0();
-  if (tid == 0) L.sMaxLast = 0;
+  {  // per-quad and per-tile maxima of `last`: a wave reduction, then four words in LDS
+    int wl = last;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wl = max(wl, __shfl_xor(wl, m, 64));
+    if (lane == 0) L.sQuadLast[wv] = wl;
+  }
   __syncthreads();
-  atomicMax(&L.sMaxLast, last);
-  __syncthreads();
-  const int max_last = L.sMaxLast;  // entries [max_last, n) are used by no pixel of this tile
+  const int ql0 = L.sQuadLast[0], ql1 = L.sQuadLast[1], ql2 = L.sQuadLast[2], ql3 = L.sQuadLast[3];
+  const int max_last = max(max(ql0, ql1), max(ql2, ql3));  // entries [max_last, n) are used by no pixel of this tile
 
   // entries nobody reached still own a slot in the Gaussian-major partial buffer: zero them
   for (int k = max_last + tid; k < n; k += GSR_BLOCK) {
@@ -374,6 +378,9 @@ __device__ __forceinline__ void bwd_tile(
                                                                 ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
       }
       mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
+      // a quad whose pixels all stopped before this list position has nothing to add for it
+      const int pos = max_last - 1 - (base + tid);
+      mask &= (pos < ql0 ? 1u : 0u) | (pos < ql1 ? 2u : 0u) | (pos < ql2 ? 4u : 0u) | (pos < ql3 ? 8u : 0u);
     }
     {
       const int nj = base + BB + tid;
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
     else
       bwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
-    __syncthreads();  // also: the tile's LDS (incl. sMaxLast) is dead before the next tile reuses it
+    __syncthreads();  // also: the tile's LDS (incl. sQuadLast) is dead before the next tile reuses it
     ticket = s_ticket;
     __syncthreads();
   }
