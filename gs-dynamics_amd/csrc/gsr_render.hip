@@ -213,7 +213,7 @@ __device__ __forceinline__ void fwd_tile(
         const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                          \
         const float test_T = T * (1.0f - alpha);                                                    \
         const bool stop = hit && test_T < GSR_T_EPS;                                                \
-        const bool blend = hit && !stop;                                                            \
+        const bool blend = hit != stop;  /* = hit && !stop, from the ONE compare above (a second v_cmp otherwise) */ \
         done = done || stop;                                                                        \
         const float w = blend ? alpha * T : 0.0f;                                                   \
         C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                         \
