@@ -156,9 +156,13 @@ def views_image_loss(renders, targets, cam_rows, weights, cam_m=None, cam_c=None
     (/root/reference/src/tracking/train_utils.py:181-195) for every render of a step at once.
     Returns (total, per-image losses [n] detached).  HIP tensors take the fused kernels; CPU tensors (host-logic tests) the torch formula."""
     if renders.is_cuda:
-        total, losses = _FusedViewsLoss.apply(renders, cam_m, cam_c, list(targets), [int(r) for r in cam_rows],
-                                              [float(w) for w in weights], w_l1, w_ssim)
-        return total, losses
+        n, cap = renders.shape[0], 32                      # GSR_LOSS_MAX_IMAGES per library call
+        parts = [_FusedViewsLoss.apply(renders[lo:lo + cap] if n > cap else renders, cam_m, cam_c, list(targets[lo:lo + cap]),
+                                       [int(r) for r in cam_rows[lo:lo + cap]], [float(w) for w in weights[lo:lo + cap]], w_l1, w_ssim)
+                 for lo in range(0, n, cap)]
+        if len(parts) == 1:
+            return parts[0]
+        return sum(p[0] for p in parts), torch.cat([p[1] for p in parts])
     per = []
     for i, (t, row) in enumerate(zip(targets, cam_rows)):
         pred = renders[i]

@@ -798,6 +798,29 @@ def test_views_loss_matches_torch_formula(dev, H, W):
     assert torch.equal(got, got2) and all(torch.equal(x_, y_) for x_, y_ in zip(g_got, g2))
 
 
+def test_views_loss_more_images_than_one_library_call(dev):
+    """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
+    from gsdyn import losses as L
+    rng = np.random.default_rng(3)
+    n, H, W = 40, 33, 47
+    mk = lambda *sh: torch.tensor(rng.uniform(0, 1, sh).astype(np.float32), device=dev)   # noqa: E731
+    renders, targets = mk(n, 3, H, W).requires_grad_(True), [mk(3, H, W) for _ in range(n)]
+    rows = [i % 3 if i % 2 == 0 else -1 for i in range(n)]
+    weights = [1.0 + 0.1 * i for i in range(n)]
+    cam_m, cam_c = (mk(3, 3) * 0.2).requires_grad_(True), (mk(3, 3) * 0.1).requires_grad_(True)
+    total, per = L.views_image_loss(renders, targets, rows, weights, cam_m, cam_c)
+    g = torch.autograd.grad(total, (renders, cam_m, cam_c))
+    r2 = renders.detach().clone().requires_grad_(True)
+    ref = 0.0
+    for i in range(n):
+        pred = r2[i] if rows[i] < 0 else torch.exp(cam_m[rows[i]])[:, None, None] * r2[i] + cam_c[rows[i]][:, None, None]
+        ref = ref + weights[i] * L.image_loss(pred, targets[i])
+    g_ref = torch.autograd.grad(ref, (r2, cam_m, cam_c))
+    assert per.shape == (n,) and abs(total.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    for a_, b_ in zip(g, g_ref):
+        assert (a_ - b_).abs().max().item() <= 1e-5 * b_.abs().max().item()
+
+
 def test_get_loss_views_equals_sum_of_get_loss(dev):
     """The fused multi-camera step (one rasterizer call + one loss call) against the per-camera ``get_loss`` sum: value and
     every parameter gradient, cam_m / cam_c included (a camera sampled twice)."""
