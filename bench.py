@@ -307,7 +307,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
     """Reported beside the headline: the full get_loss-shaped step of train_gs.py
     (2 renders + SSIM/L1 + rigidity terms + backward, per view) and BASELINE configs[1] (forward only)."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    from gsdyn import LossWeights, get_loss, get_loss_views, params2rendervar, synth_targets
+    from gsdyn import LossWeights, get_loss, get_loss_views, loss_and_grads_views, params2rendervar, synth_targets
     from gsdyn.dp import init_variables
     from gsdyn.step import make_rigidity_variables
     out = {}
@@ -322,6 +322,9 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
             def getloss_step():
                 for p in params.values():
                     p.grad = None
+                if mode == "all_direct":     # the same library calls back to back, no autograd graph
+                    loss_and_grads_views(params, views, variables, initial, w)
+                    return
                 if mode in ("all", "all_colour_grads"):   # all cameras, colour + seg renders: ONE rasterizer call (8 views)
                     # colour groups have lr 0 in the tracking schedule (train_utils.py:152-164): their gradient is skipped,
                     # which keeps each colour + seg pair one fused tile pass in the backward too
@@ -329,6 +332,9 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                     loss.backward()
                     return
                 for d in views:
+                    if mode == "pair_direct":
+                        loss_and_grads_views(params, [d], variables, initial, w)
+                        continue
                     if mode == "pair":       # the reference's pattern, one camera per iteration: colour + seg as a 2-view call
                         loss, _, _ = get_loss_views(params, [d], variables, initial, w, frozen_colours=True)
                     else:                    # two separate GaussianRasterizer calls per camera, as train_utils.py writes it
@@ -337,14 +343,16 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
             return getloss_step
         for name, initial in (("getloss_step_t0", True), ("getloss_step", False)):
             res = {}
-            for mode in ("separate", "pair", "all_colour_grads", "all"):
+            for mode in ("separate", "pair", "pair_direct", "all_colour_grads", "all", "all_direct"):
                 ms = _time_ms(make_step(initial, mode), 5, 2)
                 res[mode] = {"ms_per_step": ms, "ms_per_view": ms / len(views)}
-            out[name] = {"views": len(views), **res["all"], "with_seg_colour_gradient": res["all_colour_grads"],
-                         "per_camera_2view_call": res["pair"], "separate_calls": res["separate"],
+            out[name] = {"views": len(views), **res["all_direct"], "through_autograd": res["all"],
+                         "with_seg_colour_gradient": res["all_colour_grads"],
+                         "per_camera_2view_call": res["pair_direct"], "per_camera_2view_call_through_autograd": res["pair"],
+                         "separate_calls": res["separate"],
                          "what": "train_gs.py get_loss (colour+seg renders, fused 0.8 L1 + 0.2 (1-SSIM)"
                                  + ("" if initial else ", rigid/rot/iso/floor/bg terms") + ") + backward, "
-                                 + ("t = 0" if initial else "t > 0") + "; headline = all cameras in one rasterizer call"}
+                                 + ("t = 0" if initial else "t > 0") + "; headline = all cameras in one rasterizer call, library calls back to back (gsdyn.step.loss_and_grads_views)"}
     except Exception as e:  # noqa: BLE001
         out["getloss_step"] = {"error": repr(e)}
     try:

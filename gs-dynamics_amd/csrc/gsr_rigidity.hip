@@ -172,7 +172,7 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
     int nfg, const int64_t* __restrict__ fg_idx, const int32_t* __restrict__ rev_ptr, const int32_t* __restrict__ rev_edge,
     const float* __restrict__ prev_inv, const float* __restrict__ self7, const float* __restrict__ edge7,
-    float* __restrict__ d_means3D, float* __restrict__ d_rot) {
+    float* __restrict__ d_means3D, float* __restrict__ d_rot, int accumulate) {
   const int j = (blockIdx.x * RG_BLOCK + threadIdx.x) / RG_GATHER, lg = threadIdx.x & (RG_GATHER - 1);
   const bool live = j < nfg;
   float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -193,13 +193,18 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
 #pragma unroll
   for (int c = 0; c < 7; ++c) a[c] += self7[7 * (size_t)j + c];
   const size_t gj = (size_t)fg_idx[j];
-  d_means3D[3 * gj] = a[0]; d_means3D[3 * gj + 1] = a[1]; d_means3D[3 * gj + 2] = a[2];
   const Quat c = load_q(prev_inv, j);
   const float gw = a[3], gx = a[4], gy = a[5], gz = a[6];
-  d_rot[4 * gj + 0] = gw * c.w + gx * c.x + gy * c.y + gz * c.z;
-  d_rot[4 * gj + 1] = -gw * c.x + gx * c.w - gy * c.z + gz * c.y;
-  d_rot[4 * gj + 2] = -gw * c.y + gx * c.z + gy * c.w - gz * c.x;
-  d_rot[4 * gj + 3] = -gw * c.z - gx * c.y + gy * c.x + gz * c.w;
+  float o[7] = {a[0], a[1], a[2], gw * c.w + gx * c.x + gy * c.y + gz * c.z, -gw * c.x + gx * c.w - gy * c.z + gz * c.y,
+                -gw * c.y + gx * c.z + gy * c.w - gz * c.x, -gw * c.z - gx * c.y + gy * c.x + gz * c.w};
+  if (accumulate) {   // on top of what the caller already holds there (the rasterizer's gradient)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] += d_means3D[3 * gj + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[3 + k] += d_rot[4 * gj + k];
+  }
+  d_means3D[3 * gj] = o[0]; d_means3D[3 * gj + 1] = o[1]; d_means3D[3 * gj + 2] = o[2];
+  d_rot[4 * gj + 0] = o[3]; d_rot[4 * gj + 1] = o[4]; d_rot[4 * gj + 2] = o[5]; d_rot[4 * gj + 3] = o[6];
 }
 
 }  // namespace
@@ -220,7 +225,7 @@ int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* r
 int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, const float* g,
                             int gstride, float s1, float s2, float s3, const int32_t* rev_ptr, const int32_t* rev_edge,
-                            float* self7, float* edge7, float* d_means3D, float* d_rot, hipStream_t st) {
+                            float* self7, float* edge7, float* d_means3D, float* d_rot, int accumulate, hipStream_t st) {
   if (nfg <= 0) return 0;
   const int grp = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
   const dim3 block(RG_BLOCK), grid(((size_t)nfg * grp + RG_BLOCK - 1) / RG_BLOCK);
@@ -233,7 +238,7 @@ int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* r
   GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("rigidity_bwd_gather", st);
     hipLaunchKernelGGL(rigidity_bwd_gather_kernel, dim3(((size_t)nfg * RG_GATHER + RG_BLOCK - 1) / RG_BLOCK), block, 0, st, nfg, fg_idx,
-                       rev_ptr, rev_edge, prev_inv, self7, edge7, d_means3D, d_rot); }
+                       rev_ptr, rev_edge, prev_inv, self7, edge7, d_means3D, d_rot, accumulate); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

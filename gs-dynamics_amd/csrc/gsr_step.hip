@@ -101,7 +101,7 @@ __global__ __launch_bounds__(ST_BLOCK) void point_terms_bwd_kernel(int nfg, int 
                                                                    const int64_t* __restrict__ bg_idx,
                                                                    const float* __restrict__ init_pts, const float* __restrict__ init_rot,
                                                                    const float* __restrict__ grad_total, float s_floor, float s_bg,
-                                                                   float* __restrict__ d_means3D, float* __restrict__ d_rot) {
+                                                                   float* __restrict__ d_means3D, float* __restrict__ d_rot, int accumulate) {
   const int t = blockIdx.x * ST_BLOCK + threadIdx.x;
   const float g = grad_total[0];
   if (t < nfg) {
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(ST_BLOCK) void point_terms_bwd_kernel(int nfg, int 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float d = means3D[3 * gb + c] - init_pts[3 * (size_t)b + c];
-      d_means3D[3 * gb + c] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+      const float gv = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+      d_means3D[3 * gb + c] = accumulate ? d_means3D[3 * gb + c] + gv : gv;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float d = rot[4 * gb + c] - init_rot[4 * (size_t)b + c];
-      d_rot[4 * gb + c] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+      const float gv = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+      d_rot[4 * gb + c] = accumulate ? d_rot[4 * gb + c] + gv : gv;
     }
   }
 }
@@ -204,19 +206,21 @@ int gsr_launch_shared_terms_bwd(int P, int nfg, int K, int nbg, const float* mea
                                 const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
                                 const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
                                 const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge, float* scratch,
-                                float* d_means3D, float* d_rot, hipStream_t st) {
-  GSR_HIP_CHECK(hipMemsetAsync(d_means3D, 0, sizeof(float) * 3 * (size_t)P, st));
-  GSR_HIP_CHECK(hipMemsetAsync(d_rot, 0, sizeof(float) * 4 * (size_t)P, st));
+                                float* d_means3D, float* d_rot, int accumulate, hipStream_t st) {
+  if (!accumulate) {
+    GSR_HIP_CHECK(hipMemsetAsync(d_means3D, 0, sizeof(float) * 3 * (size_t)P, st));
+    GSR_HIP_CHECK(hipMemsetAsync(d_rot, 0, sizeof(float) * 4 * (size_t)P, st));
+  }
   const float inv_edges = nfg > 0 && K > 0 ? 1.0f / ((float)nfg * (float)K) : 0.f;
   float* self7 = scratch;
   float* edge7 = scratch + 7 * (size_t)nfg;
   if (int e = gsr_launch_rigidity_bwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, grad_total, 0, w5[0] * inv_edges,
-                                      w5[1] * inv_edges, w5[2] * inv_edges, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rot, st))
+                                      w5[1] * inv_edges, w5[2] * inv_edges, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rot, accumulate, st))
     return e;
   { GSR_PROF("point_terms_bwd", st);
     hipLaunchKernelGGL(point_terms_bwd_kernel, dim3(gsr_shared_terms_point_blocks(nfg, nbg)), dim3(ST_BLOCK), 0, st, nfg, nbg, means3D,
                        rot, fg_idx, bg_idx, init_pts, init_rot, grad_total, nfg > 0 ? w5[3] / (float)nfg : 0.f,
-                       nbg > 0 ? w5[4] / (float)nbg : 0.f, d_means3D, d_rot); }
+                       nbg > 0 ? w5[4] / (float)nbg : 0.f, d_means3D, d_rot, accumulate); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -115,7 +115,7 @@ def load_library():
     lib.gsr_shared_terms_forward.restype = C.c_int
     lib.gsr_shared_terms_forward.argtypes = [i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float), vp, vp, vp]
     lib.gsr_shared_terms_backward.restype = C.c_int
-    lib.gsr_shared_terms_backward.argtypes = [i32, i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float)] + [vp] * 7
+    lib.gsr_shared_terms_backward.argtypes = [i32, i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float)] + [vp] * 6 + [i32, vp]
     lib.gsr_activate_forward.restype = C.c_int
     lib.gsr_activate_forward.argtypes = [i32] + [vp] * 7
     lib.gsr_activate_backward.restype = C.c_int
@@ -470,7 +470,8 @@ def shared_terms_forward(means3D, rotations, v, weights5):
     return terms
 
 
-def shared_terms_backward(means3D, rotations, v, weights5, grad_total):
+def shared_terms_backward(means3D, rotations, v, weights5, grad_total, accumulate_into=None):
+    """``accumulate_into`` = (d_means3D, d_rotations): the gradients are ADDED to these tensors (and they are returned)."""
     lib = load_library()
     dev = means3D.device
     nfg, K = (int(d) for d in v["neighbor_indices"].shape)
@@ -479,10 +480,10 @@ def shared_terms_backward(means3D, rotations, v, weights5, grad_total):
     with torch.cuda.device(dev):
         g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
         scratch = torch.empty((max(7 * (nfg + nfg * K), 1),), dtype=torch.float32, device=dev)
-        d_m, d_r = torch.empty_like(means3D), torch.empty_like(rotations)
+        d_m, d_r = accumulate_into if accumulate_into is not None else (torch.empty_like(means3D), torch.empty_like(rotations))
         _check(lib.gsr_shared_terms_backward(int(means3D.shape[0]), nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5,
                                              _ptr(g), _ptr(v["rev_ptr"]), _ptr(v["rev_edge"]), _ptr(scratch), _ptr(d_m), _ptr(d_r),
-                                             _stream(dev)), "gsr_shared_terms_backward")
+                                             1 if accumulate_into is not None else 0, _stream(dev)), "gsr_shared_terms_backward")
     return d_m, d_r
 
 

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .step import LossWeights, get_loss, get_loss_views
+from .step import LossWeights, get_loss, get_loss_views, loss_and_grads_views
 
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:
@@ -103,13 +103,18 @@ class ViewShardedStep:
         total = torch.zeros((), dtype=torch.float32, device=dev)
         if self.batched and mine:
             # all cameras of the shard, colour + segmentation renders, in ONE rasterizer call
-            loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights,
-                                                  frozen_colours=self.frozen_colours)
-            loss.backward()
+            direct = self.frozen_colours and dev.type == "cuda" and 2 * len(mine) <= 16 and \
+                (is_initial_timestep or "rev_ptr" in variables)
+            if direct:   # the same kernels called back to back, no autograd graph (host time / 3)
+                loss, variables, aux = loss_and_grads_views(self.params, mine, variables, is_initial_timestep, self.weights)
+            else:
+                loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights,
+                                                      frozen_colours=self.frozen_colours)
+                loss.backward()
             total += loss.detach()
             with torch.no_grad():
                 seen_v = aux["radii"] > 0                                    # [V,P]
-                g2 = aux["means2D"].grad
+                g2 = aux["means2D_grad"] if direct else aux["means2D"].grad
                 if g2 is not None:
                     stat[0] += (torch.norm(g2[0::2, :, :2], dim=-1) * seen_v).sum(0)
                 stat[1] += seen_v.sum(0)

@@ -183,6 +183,72 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
     return total, variables, dict(means2D=m2, radii=rad)
 
 
+_ONES = {}
+
+
+def _acc_grad(p, g):
+    if g is None:
+        return
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad.add_(g)
+
+
+@torch.no_grad()
+def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights):
+    """``get_loss_views(..., frozen_colours=True)`` followed by ``loss.backward()``, as a straight sequence of library calls
+    (activations, rasterizer, image terms, shared terms and their backward passes in reverse) without the autograd engine:
+    same kernels, same values, about a third of the host time -- which is what bounds the reference's own loop shape, one camera
+    per iteration (/root/reference/src/tracking/train_gs.py:25-39: ~0.3 ms of GPU work per iteration).  The gradients are ADDED
+    to the ``.grad`` of means3D / unnorm_rotations / logit_opacities / log_scales / cam_m / cam_c (colours are frozen: lr 0 in
+    the tracking schedule).  Needs a HIP device, at most 8 cameras per call, and at t > 0 the tensors of ``make_rigidity_variables``.
+    Returns (loss, variables, aux) with aux = dict(means2D_grad=[2V,P,3] (rows 0, 2, ... = colour renders), radii=[V,P])."""
+    from diff_gaussian_rasterization import _hip
+    from .losses import _SHARED_KEYS, _window_1d
+    V = len(datas)
+    m3 = params["means3D"]
+    dev = m3.device
+    if not m3.is_cuda or 2 * V > _hip.MAX_BATCH:
+        raise RuntimeError("loss_and_grads_views: needs a HIP device and at most %d cameras per call" % (_hip.MAX_BATCH // 2))
+    rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
+    cams = [d["cam"] for d in datas for _ in (0, 1)]
+    colours = _view_colours(params, variables, V, True)
+    ims, radii, _depth, states = _hip.rasterize_forward_batch(cams, m3, op, colours, None, sc, rot, None, prepare_backward=True)
+    ids = [int(d["id"]) for d in datas]
+    targets = [t for d in datas for t in (d["im"], d["seg"])]
+    rows = [r for i in ids for r in (i, -1)]
+    win = _window_1d()
+    cam_m, cam_c = params["cam_m"], params["cam_c"]
+    losses, lstate = _hip.views_loss_forward(win, ims, targets, rows, [w.im, w.seg] * V, cam_m, cam_c, 0.8, 0.2)
+    total = losses[-1]
+    one = _ONES.get(dev)
+    if one is None:
+        one = _ONES[dev] = torch.ones((1,), dtype=torch.float32, device=dev)
+    shared = None
+    if not is_initial_timestep:
+        shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
+        w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
+        terms = _hip.shared_terms_forward(m3, rot, shared, w5)
+        total = total + terms[5]
+    # ---- backward, in reverse
+    d_ims, d_cm, d_cc = _hip.views_loss_backward(lstate, ims, cam_m, cam_c, one, 0.8, 0.2)
+    d3, d2, _dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, d_ims, m3, radii, colours, None, sc, rot, None,
+                                                                              want_color_grad=False)
+    if shared is not None:
+        _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot))
+    d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
+    for k, g in (("means3D", d3), ("unnorm_rotations", d_un), ("logit_opacities", d_lo), ("log_scales", d_ls), ("cam_m", d_cm),
+                 ("cam_c", d_cc)):
+        if params[k].requires_grad:
+            _acc_grad(params[k], g)
+    rad = radii[0::2]
+    m2r = variables["max_2D_radius"]
+    variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))
+    variables["seen"] = (rad > 0).any(0)
+    return total, variables, dict(means2D_grad=d2, radii=rad)
+
+
 @torch.no_grad()
 def report_psnr(params, data):
     """The extra forward render of /root/reference/src/tracking/train_utils.py:377-384."""

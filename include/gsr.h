@@ -162,7 +162,8 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
  *   bg    = mean_b sum_c |means3D[bg] - init_bg_pts| + mean_b sum_c |rotations[bg] - init_bg_rot| (train_utils.py:227-229)
  * and their weighted sum.  bg_idx[n_bg] (int64) lists the background Gaussians; init_bg_* are indexed by background rank.
  * forward: terms6 (device) = rigid, rot, iso, floor, bg, sum_k weights5_host[k] * term_k;  partials = gsr_shared_terms_partials floats.
- * backward: d_means3D[P,3] / d_rotations[P,4] (fully written) = grad_total[0] (device) * d terms6[5] / d input;
+ * backward: d_means3D[P,3] / d_rotations[P,4] = grad_total[0] (device) * d terms6[5] / d input -- fully written, or, with
+ *   accumulate != 0, ADDED to what the buffers hold (rows in neither index list are left alone);
  *   scratch = 7 (n_fg + n_fg K) floats; rev_ptr / rev_edge as for gsr_rigidity_backward. */
 int32_t gsr_shared_terms_partials(int32_t n_fg, int32_t n_bg);
 int gsr_shared_terms_forward(int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations, const int64_t* fg_idx,
@@ -175,7 +176,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
                               const float* neighbor_weight, const float* neighbor_dist, const float* prev_inv_rot_fg,
                               const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
                               const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
-                              float* scratch, float* d_means3D, float* d_rotations, void* stream);
+                              float* scratch, float* d_means3D, float* d_rotations, int32_t accumulate, void* stream);
 
 /* ---- activations of the raw parameters (replaces the torch ops of params2rendervar, /root/reference/src/tracking/helpers.py:36-45):
  *   rotations[P,4] = unnorm_rotations / max(|unnorm_rotations|, 1e-12), opacities[P,1] = sigmoid(logit_opacities), scales[P,3] = exp(log_scales).

@@ -798,6 +798,49 @@ def test_views_loss_matches_torch_formula(dev, H, W):
     assert torch.equal(got, got2) and all(torch.equal(x_, y_) for x_, y_ in zip(g_got, g2))
 
 
+@pytest.mark.parametrize("initial", [True, False])
+def test_direct_step_equals_autograd_step(dev, initial):
+    """``loss_and_grads_views`` (the library calls back to back, no autograd graph) == ``get_loss_views(frozen_colours=True)`` +
+    ``backward()``: loss, every parameter gradient, the per-view screen-space gradients and the bookkeeping tensors."""
+    from gsdyn import LossWeights, get_loss_views, loss_and_grads_views, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    from gsdyn.step import make_rigidity_variables
+    P, W, H = 4000, 160, 120
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.08)
+    with torch.no_grad():
+        params["cam_m"].add_(0.05 * torch.randn_like(params["cam_m"]))
+        params["means3D"].add_(0.002 * torch.randn_like(params["means3D"]))
+    cams = synth_ring_cameras(3, W, H, device=dev)
+    im_gt, seg_gt = synth_targets(W, H, device=dev)
+    w = LossWeights()
+    views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in (1, 0, 1)]
+    rig = make_rigidity_variables(params, num_knn=8)
+
+    def fresh_variables():
+        v = init_variables(P, dev)
+        v.update(rig)
+        return v
+    for p_ in params.values():
+        p_.grad = None
+    loss_a, var_a, aux_a = get_loss_views(params, views, fresh_variables(), initial, w, frozen_colours=True)
+    loss_a.backward()
+    ga = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+    m2a = aux_a["means2D"].grad.clone()
+    for p_ in params.values():
+        p_.grad = None
+    loss_b, var_b, aux_b = loss_and_grads_views(params, views, fresh_variables(), initial, w)
+    gb = {k: v.grad for k, v in params.items() if v.grad is not None}
+    assert abs(float(loss_a.detach()) - float(loss_b)) <= 1e-6 * abs(float(loss_b))
+    assert set(ga) == set(gb) and "cam_m" in ga and "seg_colors" not in ga
+    for k in ga:
+        assert (ga[k] - gb[k]).abs().max().item() <= 1e-6 * ga[k].abs().max().item() + 1e-20, k
+    assert (m2a - aux_b["means2D_grad"]).abs().max().item() <= 1e-6 * m2a.abs().max().item() + 1e-20
+    assert torch.equal(var_a["max_2D_radius"], var_b["max_2D_radius"]) and torch.equal(var_a["seen"], var_b["seen"])
+    # a second call accumulates
+    loss_and_grads_views(params, views, fresh_variables(), initial, w)
+    assert (params["means3D"].grad - 2 * ga["means3D"]).abs().max().item() <= 1e-5 * ga["means3D"].abs().max().item()
+
+
 def test_views_loss_more_images_than_one_library_call(dev):
     """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
     from gsdyn import losses as L

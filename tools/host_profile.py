@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gs-dynamics_amd")):
     sys.path.insert(0, p)
-from gsdyn import LossWeights, get_loss_views, synth_ring_cameras, synth_scene_params, synth_targets
+from gsdyn import LossWeights, get_loss_views, loss_and_grads_views, synth_ring_cameras, synth_scene_params, synth_targets
 from gsdyn.dp import init_variables
 from gsdyn.step import make_rigidity_variables
 dev = torch.device("cuda:0")
@@ -20,6 +20,9 @@ initial = os.environ.get("GETLOSS_MODE", "t1") == "t0"
 def step(i):
     for p in params.values():
         p.grad = None
+    if os.environ.get("DIRECT", "1") == "1":
+        loss_and_grads_views(params, [views[i % 4]], variables, initial, w)
+        return
     loss, _, _ = get_loss_views(params, [views[i % 4]], variables, initial, w, frozen_colours=True)
     loss.backward()
 for i in range(20):
