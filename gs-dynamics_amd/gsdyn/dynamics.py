@@ -20,6 +20,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -247,22 +248,81 @@ def quat_multiply(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ motion interpolation
+def _bone_moment_matrices(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):
+    """F_i = sum_j (new_j - new_i)(old_j - old_i)^T over the bones j related to i (device), and the neighbour counts."""
+    nb = bones.shape[0]
+    rel = relations.to(torch.bool)
+    i_idx, j_idx = rel.nonzero(as_tuple=True)
+    old = (bones[j_idx] - bones[i_idx]).float()
+    new = ((bones[j_idx] + motions[j_idx]) - (bones[i_idx] + motions[i_idx])).float()
+    F = torch.zeros((nb, 3, 3), dtype=torch.float32, device=bones.device)
+    F.index_add_(0, i_idx, new[:, :, None] * old[:, None, :])
+    return F, rel.sum(1)
+
+
 def fit_bone_rotations(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor) -> torch.Tensor:
     """One rotation per bone from how its related bones move around it (/root/reference/src/render/utils.py:147-205):
     F_i = sum_j (new_j - new_i)(old_j - old_i)^T over the bones j related to i, then by the rank of F_i
       0 neighbours -> identity;  rank 1 -> the rotation taking the x axis onto the dominant left singular vector;
       otherwise the Kabsch rotation U S V^T, with the reference's quirks kept: for a full-rank F with negative determinant
       its index error falls back to the identity, and a result with det = -1 is repaired by flipping S[rank, rank].
-    The 3x3 problems are solved on the host in one batched SVD (see the module docstring)."""
+    The 3x3 problems are solved on the host in one batched SVD (see the module docstring); the per-bone decision tree is
+    evaluated for all bones at once with numpy masks (a Python loop of torch CPU ops over 100 bones cost 20 ms per step --
+    ``_fit_bone_rotations_loop`` keeps that literal form for the tests)."""
+    F_dev, n_adj_dev = _bone_moment_matrices(bones, motions, relations)
+    nb = bones.shape[0]
+    packed = torch.cat([F_dev.reshape(nb, 9), n_adj_dev.to(torch.float32)[:, None]], 1).cpu()      # one D2H copy
+    F_t = packed[:, :9].reshape(nb, 3, 3).contiguous()
+    n_adj = packed[:, 9].numpy()
+    U_t, S_t, Vh_t = torch.linalg.svd(F_t)               # same LAPACK driver as the literal form
+    F, U, S, Vh = F_t.numpy(), U_t.numpy(), S_t.numpy(), Vh_t.numpy()
+    eps = np.finfo(np.float32).eps
+    rank = (S > S.max(axis=1, keepdims=True) * 3 * eps).sum(1)
+    detF = torch.linalg.det(F_t).numpy()                 # float32, as the literal form: its SIGN picks the branch
+    eye = np.eye(3, dtype=np.float32)
+    R = np.broadcast_to(eye, (nb, 3, 3)).copy()
+    has = n_adj > 0
+    # rank 1: x axis -> dominant left singular vector
+    r1 = has & (rank == 1)
+    if r1.any():
+        axis = U[r1][:, :, 0]
+        x = np.broadcast_to(np.array([1.0, 0.0, 0.0], np.float32), axis.shape)
+        perp = np.cross(axis, x)
+        nrm = np.linalg.norm(perp, axis=1)
+        ok = nrm >= 1e-6
+        perp = perp / np.where(ok, nrm, 1.0)[:, None]
+        X = np.stack([x, perp, np.cross(x, perp)], 2)
+        Y = np.stack([axis, perp, np.cross(axis, perp)], 2)
+        Rr = np.where(ok[:, None, None], Y @ X.transpose(0, 2, 1), eye)
+        R[r1] = Rr.astype(np.float32)
+    # Kabsch with the reference's sign handling
+    kb = has & (rank != 1)
+    neg = detF < 0
+    kb_identity = kb & neg & (rank > 2)                   # S[3,3] does not exist: the reference's try/except yields the identity
+    kb = kb & ~kb_identity
+    if kb.any():
+        idx = np.nonzero(kb)[0]
+        r = rank[idx]
+        Sg = np.broadcast_to(eye, (idx.size, 3, 3)).copy()
+        flip = neg[idx]
+        rr = np.minimum(r, 2)                              # r <= 2 wherever flip is set
+        Sg[np.arange(idx.size)[flip], rr[flip], rr[flip]] = -1.0
+        Ri = U[idx] @ Sg @ Vh[idx]
+        d = np.linalg.det(Ri.astype(np.float64))
+        again = (np.abs(d - 1) > 1e-3) & (np.abs(d + 1) < 1e-3) & (r <= 2)
+        if again.any():
+            Sg[np.arange(idx.size)[again], rr[again], rr[again]] *= -1.0
+            Ri[again] = U[idx][again] @ Sg[again] @ Vh[idx][again]
+        R[idx] = Ri.astype(np.float32)
+    return torch.from_numpy(R).to(bones.device)
+
+
+def _fit_bone_rotations_loop(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor) -> torch.Tensor:
+    """The literal per-bone form of ``fit_bone_rotations`` (the reference's control flow, one bone at a time)."""
     nb = bones.shape[0]
     dev = bones.device
-    rel = relations.to(torch.bool)
-    i_idx, j_idx = rel.nonzero(as_tuple=True)
-    old = (bones[j_idx] - bones[i_idx]).float()
-    new = ((bones[j_idx] + motions[j_idx]) - (bones[i_idx] + motions[i_idx])).float()
-    F = torch.zeros((nb, 3, 3), dtype=torch.float32, device=dev)
-    F.index_add_(0, i_idx, new[:, :, None] * old[:, None, :])
-    n_adj = rel.sum(1).cpu()
+    F, n_adj = _bone_moment_matrices(bones, motions, relations)
+    n_adj = n_adj.cpu()
     F = F.cpu()
     U, S, Vh = torch.linalg.svd(F)
     V = Vh.transpose(1, 2)
@@ -271,7 +331,7 @@ def fit_bone_rotations(bones: torch.Tensor, motions: torch.Tensor, relations: to
     detF = torch.linalg.det(F)
     eye = torch.eye(3)
     R = torch.empty((nb, 3, 3))
-    for i in range(nb):                               # decision tree per bone; the linear algebra above is batched
+    for i in range(nb):
         if int(n_adj[i]) == 0:
             R[i] = eye
             continue

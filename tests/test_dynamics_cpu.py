@@ -142,3 +142,36 @@ def test_baseline_config1_rope_demo_step(gold):
                          action=torch.tensor(gold["cfg1_action"]), receivers=recv, senders=send)
     np.testing.assert_allclose(pos.numpy(), gold["cfg1_pred_pos"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mot.numpy(), gold["cfg1_pred_motion"], rtol=2e-4, atol=2e-6)
+
+
+def test_fit_bone_rotations_vectorised_equals_literal_form():
+    """The masked numpy evaluation of the per-bone decision tree against the literal one-bone-at-a-time form, on random chains
+    plus the degenerate cases: no neighbours, one neighbour (rank 1), collinear neighbours, planar neighbours (rank 2),
+    a reflection (negative determinant)."""
+    import numpy as np
+    import torch
+    from gsdyn.dynamics import _fit_bone_rotations_loop, fit_bone_rotations
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        nb = 40
+        bones = torch.tensor(rng.normal(0, 1, (nb, 3)).astype(np.float32))
+        rel = torch.tensor((rng.uniform(0, 1, (nb, nb)) < 0.12).astype(np.int64))
+        rel.fill_diagonal_(0)
+        rel[0] = 0                                             # no neighbours
+        rel[1] = 0; rel[1, 5] = 1                              # one neighbour
+        rel[2] = 0; rel[2, 6] = 1; rel[2, 7] = 1
+        bones[6] = bones[2] + torch.tensor([0.3, 0.0, 0.0]); bones[7] = bones[2] + torch.tensor([0.7, 0.0, 0.0])   # collinear
+        rel[3] = 0; rel[3, 8] = 1; rel[3, 9] = 1; rel[3, 10] = 1
+        for k, off in zip((8, 9, 10), ([0.3, 0.1, 0.0], [-0.2, 0.4, 0.0], [0.1, -0.5, 0.0])):                   # planar
+            bones[k] = bones[3] + torch.tensor(off)
+        ang = 0.3 * (trial + 1)
+        Rz = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=torch.float32)
+        new = bones @ Rz.T + torch.tensor(rng.normal(0, 0.02, (nb, 3)).astype(np.float32))
+        if trial % 2:
+            new[:, 2] = -new[:, 2]                             # a reflection: negative determinants
+        motions = new - bones
+        a = fit_bone_rotations(bones, motions, rel)
+        b = _fit_bone_rotations_loop(bones, motions, rel)
+        assert a.shape == b.shape == (nb, 3, 3)
+        assert float((a - b).abs().max()) <= 1e-6, trial
+        assert torch.equal(a[0], torch.eye(3))
