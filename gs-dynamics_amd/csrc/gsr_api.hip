@@ -463,7 +463,7 @@ int gsr_rigidity_forward(int32_t n_fg, int32_t K, const float* means3D, const fl
     return -2;
   }
   return gsr_launch_rigidity_fwd(n_fg, K, means3D, rotations, fg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
-                                 prev_offset, block_partials, (hipStream_t)stream);
+                                 prev_offset, nullptr, block_partials, (hipStream_t)stream);
 }
 
 int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
@@ -479,7 +479,7 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
   float* self7 = scratch;
   float* edge7 = scratch + (size_t)7 * n_fg;
   return gsr_launch_rigidity_bwd(n_fg, K, means3D, rotations, fg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
-                                 prev_offset, grad3, 1, 1.0f, 1.0f, 1.0f, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rotations, 0, (hipStream_t)stream);
+                                 prev_offset, grad3, 1, 1.0f, 1.0f, 1.0f, rev_ptr, rev_edge, nullptr, 0, self7, edge7, d_means3D, d_rotations, 0, (hipStream_t)stream);
 }
 
 int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
@@ -502,8 +502,13 @@ int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float*
                                  d_logit_opacities, d_log_scales, (hipStream_t)stream);
 }
 
+int32_t gsr_shared_terms_scratch(int32_t n_fg, int32_t K) {
+  const int64_t n = n_fg > 0 ? n_fg : 0;
+  return (int32_t)(16 * n + 8 * (n + n * (K > 0 ? K : 0)));
+}
+
 int32_t gsr_shared_terms_partials(int32_t n_fg, int32_t n_bg) {
-  return 3 * (gsr_rigidity_fwd_blocks(n_fg) + gsr_shared_terms_point_blocks(n_fg, n_bg));
+  return 16 * (n_fg > 0 ? n_fg : 0) + 3 * (gsr_rigidity_fwd_blocks(n_fg) + gsr_shared_terms_point_blocks(n_fg, n_bg));
 }
 
 static int shared_terms_check(const char* who, int32_t n_fg, int32_t K, int32_t n_bg, const void* const* ptrs, int n) {
@@ -531,7 +536,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
                               const float* neighbor_weight, const float* neighbor_dist, const float* prev_inv_rot_fg,
                               const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
                               const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
-                              float* scratch, float* d_means3D, float* d_rotations, int32_t accumulate, void* stream) {
+                              float* scratch, float* d_means3D, float* d_rotations, int32_t flags, void* stream) {
   const void* ptrs[] = {means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
                         prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total, rev_ptr, rev_edge, scratch, d_means3D,
                         d_rotations};
@@ -539,7 +544,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
   if (P < n_fg + n_bg) { gsr_set_error("gsr_shared_terms_backward: P < n_fg + n_bg"); return -2; }
   return gsr_launch_shared_terms_bwd(P, n_fg, K, n_bg, means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight,
                                      neighbor_dist, prev_inv_rot_fg, prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total,
-                                     rev_ptr, rev_edge, scratch, d_means3D, d_rotations, accumulate, (hipStream_t)stream);
+                                     rev_ptr, rev_edge, scratch, d_means3D, d_rotations, flags, (hipStream_t)stream);
 }
 
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {

@@ -242,12 +242,13 @@ int gsr_launch_views_loss_bwd(const float* win11_host, const gsr_loss_views* v, 
                               const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders,
                               float* partials, float* d_cam_m, float* d_cam_c, hipStream_t st);
 int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
-                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* partial,
-                            hipStream_t st);
+                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* frames,
+                            float* partial, hipStream_t st);   // frames: 16 nfg floats (16-byte aligned) or nullptr
 int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, const float* g,
                             int gstride, float s1, float s2, float s3, const int32_t* rev_ptr, const int32_t* rev_edge,
-                            float* self7, float* edge7, float* d_means3D, float* d_rot, int accumulate, hipStream_t st);
+                            float* frames, int frames_valid, float* self7, float* edge7, float* d_means3D, float* d_rot, int accumulate,
+                            hipStream_t st);   // frames != nullptr: 8-float records in self7 / edge7, else 7
 int gsr_rigidity_fwd_blocks(int nfg);
 int gsr_launch_activate_fwd(int P, const float* unnorm, const float* logit, const float* logs, float* rot, float* op, float* sc,
                             hipStream_t st);
@@ -262,7 +263,7 @@ int gsr_launch_shared_terms_bwd(int P, int nfg, int K, int nbg, const float* mea
                                 const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
                                 const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
                                 const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge, float* scratch,
-                                float* d_means3D, float* d_rot, int accumulate, hipStream_t st);
+                                float* d_means3D, float* d_rot, int flags, hipStream_t st);
 int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st);

@@ -51,30 +51,74 @@ __device__ __forceinline__ PointFrame point_frame(const float* __restrict__ mean
   return f;
 }
 
-// Forward: one thread per EDGE (the point's frame is recomputed per edge: its loads are shared by the K adjacent lanes,
-// and ~1.4 M independent threads hide the latency of the neighbour gathers, which one thread per point with a serial
-// K loop cannot).  A block owns RG_PTS consecutive points, i.e. RG_PTS * K consecutive edges.
+// Optional pre-pass: one 64-byte frame per foreground point -- {p, q.w | q.xyz, R0 | R1..R4 | R5..R8} with q = rot * prev_inv (not
+// normalised) and R the rotation matrix of q / |q| -- so that an edge thread reads its own point's frame (shared by the K
+// adjacent lanes) and half a line of its neighbour's (p, q) by foreground RANK: no fg_idx indirection (one dependent load less
+// per edge), no quaternion products per edge.
+__global__ __launch_bounds__(RG_BLOCK) void rigidity_frames_kernel(int nfg, const float* __restrict__ means3D, const float* __restrict__ rot,
+                                                                   const int64_t* __restrict__ fg_idx, const float* __restrict__ prev_inv,
+                                                                   float4* __restrict__ frames) {
+  const int i = blockIdx.x * RG_BLOCK + threadIdx.x;
+  if (i >= nfg) return;
+  const PointFrame f = point_frame(means3D, rot, fg_idx, prev_inv, i);
+  frames[4 * (size_t)i] = make_float4(f.px, f.py, f.pz, f.q.w);
+  frames[4 * (size_t)i + 1] = make_float4(f.q.x, f.q.y, f.q.z, f.R[0]);
+  frames[4 * (size_t)i + 2] = make_float4(f.R[1], f.R[2], f.R[3], f.R[4]);
+  frames[4 * (size_t)i + 3] = make_float4(f.R[5], f.R[6], f.R[7], f.R[8]);
+}
+
+__device__ __forceinline__ PointFrame load_frame(const float4* __restrict__ frames, int i) {
+  const float4 a = frames[4 * (size_t)i], b = frames[4 * (size_t)i + 1], c = frames[4 * (size_t)i + 2], d = frames[4 * (size_t)i + 3];
+  PointFrame f;
+  f.px = a.x; f.py = a.y; f.pz = a.z;
+  f.q = Quat{a.w, b.x, b.y, b.z};
+  f.inv = 1.0f / sqrtf(f.q.w * f.q.w + f.q.x * f.q.x + f.q.y * f.q.y + f.q.z * f.q.z);
+  f.R[0] = b.w; f.R[1] = c.x; f.R[2] = c.y; f.R[3] = c.z; f.R[4] = c.w; f.R[5] = d.x; f.R[6] = d.y; f.R[7] = d.z; f.R[8] = d.w;
+  return f;
+}
+
+// position and relative quaternion of neighbour j (foreground rank)
+template <bool FRAMES>
+__device__ __forceinline__ void load_neighbour(const float4* __restrict__ frames, const float* __restrict__ means3D,
+                                               const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
+                                               const float* __restrict__ prev_inv, int j, float& x, float& y, float& z, Quat& qj) {
+  if (FRAMES) {
+    const float4 a = frames[4 * (size_t)j], b = frames[4 * (size_t)j + 1];
+    x = a.x; y = a.y; z = a.z;
+    qj = Quat{a.w, b.x, b.y, b.z};
+  } else {
+    const size_t gj = (size_t)fg_idx[j];
+    x = means3D[3 * gj]; y = means3D[3 * gj + 1]; z = means3D[3 * gj + 2];
+    qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
+  }
+}
+
+// Forward: one thread per EDGE (~1.4 M independent threads hide the latency of the neighbour gathers, which one thread per
+// point with a serial K loop cannot).  A block owns RG_PTS consecutive points, i.e. RG_PTS * K consecutive edges.
+template <bool FRAMES>
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_fwd_kernel(
     int nfg, int K, const float* __restrict__ means3D, const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
     const int64_t* __restrict__ nbr, const float* __restrict__ nw, const float* __restrict__ nd,
-    const float* __restrict__ prev_inv, const float* __restrict__ prev_off, float* __restrict__ partial /*[3][blocks]*/) {
+    const float* __restrict__ prev_inv, const float* __restrict__ prev_off, const float4* __restrict__ frames,
+    float* __restrict__ partial /*[3][blocks]*/) {
   __shared__ float red[3][RG_BLOCK / 64];
   const size_t e0 = (size_t)blockIdx.x * RG_PTS * K;
   const size_t e1 = min(e0 + (size_t)RG_PTS * K, (size_t)nfg * K);
   float l1 = 0.f, l2 = 0.f, l3 = 0.f;
   for (size_t e = e0 + threadIdx.x; e < e1; e += RG_BLOCK) {
     const int i = (int)(e / K);
-    const PointFrame f = point_frame(means3D, rot, fg_idx, prev_inv, i);
+    const PointFrame f = FRAMES ? load_frame(frames, i) : point_frame(means3D, rot, fg_idx, prev_inv, i);
     const float* R = f.R;
     const int j = (int)nbr[e];
-    const size_t gj = (size_t)fg_idx[j];
-    const float ox = means3D[3 * gj] - f.px, oy = means3D[3 * gj + 1] - f.py, oz = means3D[3 * gj + 2] - f.pz;
+    float nx, ny, nz;
+    Quat qj;
+    load_neighbour<FRAMES>(frames, means3D, rot, fg_idx, prev_inv, j, nx, ny, nz, qj);
+    const float ox = nx - f.px, oy = ny - f.py, oz = nz - f.pz;
     const float w = nw[e];
     const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
     const float dy = (ox * R[1] + oy * R[4] + oz * R[7]) - prev_off[3 * e + 1];
     const float dz = (ox * R[2] + oy * R[5] + oz * R[8]) - prev_off[3 * e + 2];
     l1 += sqrtf((dx * dx + dy * dy + dz * dz) * w + 1e-20f);
-    const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
     const float ew = qj.w - f.q.w, ex = qj.x - f.q.x, ey = qj.y - f.q.y, ez = qj.z - f.q.z;
     l2 += sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
     const float t = sqrtf(ox * ox + oy * oy + oz * oz + 1e-20f) - nd[e];
@@ -94,17 +138,17 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_fwd_kernel(
 // Kernel 2: edge terms again, now for the gradient, GRP lanes per point (GRP = power of two >= K up to 64; longer lists are
 // strided).  g1..g3 = upstream gradients of the three means, already divided by N_fg * K.
 // self[i] = {d/dp_i (3), d/dq_i (4)} from point i's own edges; edge[e] = {d/dp_j (3), d/dq_j (4)}.
-template <int GRP>
+template <int GRP, bool FRAMES>
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
     int nfg, int K, const float* __restrict__ means3D, const float* __restrict__ rot, const int64_t* __restrict__ fg_idx,
     const int64_t* __restrict__ nbr, const float* __restrict__ nw, const float* __restrict__ nd,
     const float* __restrict__ prev_inv, const float* __restrict__ prev_off, const float* __restrict__ g, int gstride,
-    float s1, float s2, float s3, float* __restrict__ self7, float* __restrict__ edge7) {
+    float s1, float s2, float s3, const float4* __restrict__ frames, float* __restrict__ self7, float* __restrict__ edge7) {
   const int i = (blockIdx.x * RG_BLOCK + threadIdx.x) / GRP, lg = threadIdx.x & (GRP - 1);
   const bool live = i < nfg;                       // whole groups are live or dead; dead lanes still take part in the shuffles
   const float g1 = g[0] * s1, g2 = g[gstride] * s2, g3 = g[2 * gstride] * s3;
   PointFrame f{};
-  if (live) f = point_frame(means3D, rot, fg_idx, prev_inv, i);
+  if (live) f = FRAMES ? load_frame(frames, i) : point_frame(means3D, rot, fg_idx, prev_inv, i);
   const float* R = f.R;
   float acc[16];                                   // G[9] = d loss / d R_i, sp[3], sq[4]
 #pragma unroll
@@ -113,8 +157,10 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
     for (int k = lg; k < K; k += GRP) {
       const size_t e = (size_t)i * K + k;
       const int j = (int)nbr[e];
-      const size_t gj = (size_t)fg_idx[j];
-      const float ox = means3D[3 * gj] - f.px, oy = means3D[3 * gj + 1] - f.py, oz = means3D[3 * gj + 2] - f.pz;
+      float nx, ny, nz;
+      Quat qj;
+      load_neighbour<FRAMES>(frames, means3D, rot, fg_idx, prev_inv, j, nx, ny, nz, qj);
+      const float ox = nx - f.px, oy = ny - f.py, oz = nz - f.pz;
       const float w = nw[e];
       // rigid
       const float dx = (ox * R[0] + oy * R[3] + oz * R[6]) - prev_off[3 * e];
@@ -134,12 +180,17 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
       const float c3 = g3 * w * t / sqrtf(t * t * w + 1e-20f) / mag;
       fx += c3 * ox; fy += c3 * oy; fz += c3 * oz;
       // rot
-      const Quat qj = qmul(load_q(rot, gj), load_q(prev_inv, j));
       const float ew = qj.w - f.q.w, ex = qj.x - f.q.x, ey = qj.y - f.q.y, ez = qj.z - f.q.z;
       const float c2 = g2 * w / sqrtf((ew * ew + ex * ex + ey * ey + ez * ez) * w + 1e-20f);
       const float hw = c2 * ew, hx = c2 * ex, hy = c2 * ey, hz = c2 * ez;
-      float* E = edge7 + 7 * e;
-      E[0] = fx; E[1] = fy; E[2] = fz; E[3] = hw; E[4] = hx; E[5] = hy; E[6] = hz;
+      if (FRAMES) {   // fused path: 32-byte records, two aligned 16-byte stores (a record never straddles a 64-byte line)
+        float4* E = reinterpret_cast<float4*>(edge7) + 2 * e;
+        E[0] = make_float4(fx, fy, fz, hw);
+        E[1] = make_float4(hx, hy, hz, 0.f);
+      } else {
+        float* E = edge7 + 7 * e;
+        E[0] = fx; E[1] = fy; E[2] = fz; E[3] = hw; E[4] = hx; E[5] = hy; E[6] = hz;
+      }
       acc[9] -= fx; acc[10] -= fy; acc[11] -= fz;
       acc[12] -= hw; acc[13] -= hx; acc[14] -= hy; acc[15] -= hz;
     }
@@ -159,7 +210,7 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
   const float dyq = 2.f * (-2.f * y * G[0] + x * G[1] + r * G[2] + x * G[3] + z * G[5] - r * G[6] + z * G[7] - 2.f * y * G[8]);
   const float dzq = 2.f * (-2.f * z * G[0] - r * G[1] + x * G[2] + r * G[3] - 2.f * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
   const float dot = r * dr + x * dxq + y * dyq + z * dzq;
-  float* S = self7 + 7 * (size_t)i;
+  float* S = self7 + (FRAMES ? 8 : 7) * (size_t)i;
   S[0] = acc[9]; S[1] = acc[10]; S[2] = acc[11];
   S[3] = acc[12] + (dr - r * dot) * inv; S[4] = acc[13] + (dxq - x * dot) * inv;
   S[5] = acc[14] + (dyq - y * dot) * inv; S[6] = acc[15] + (dzq - z * dot) * inv;
@@ -169,6 +220,7 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_edges_kernel(
 // adjacency); d/dq_j -> d/d rot (q = rot * c is linear in rot).  Writes the rows of the foreground Gaussians (the caller
 // zero-fills the others).  Fixed lane assignment and reduction order: deterministic.
 #define RG_GATHER 8
+template <int REC>   // floats per record: 7 (standalone entry point) or 8 (fused path, 16-byte aligned)
 __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
     int nfg, const int64_t* __restrict__ fg_idx, const int32_t* __restrict__ rev_ptr, const int32_t* __restrict__ rev_edge,
     const float* __restrict__ prev_inv, const float* __restrict__ self7, const float* __restrict__ edge7,
@@ -179,9 +231,15 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
   if (live) {
     const int t1 = rev_ptr[j + 1];
     for (int t = rev_ptr[j] + lg; t < t1; t += RG_GATHER) {
-      const float* E = edge7 + 7 * (size_t)rev_edge[t];
+      if (REC == 8) {
+        const float4* E = reinterpret_cast<const float4*>(edge7) + 2 * (size_t)rev_edge[t];
+        const float4 e0 = E[0], e1 = E[1];
+        a[0] += e0.x; a[1] += e0.y; a[2] += e0.z; a[3] += e0.w; a[4] += e1.x; a[5] += e1.y; a[6] += e1.z;
+      } else {
+        const float* E = edge7 + 7 * (size_t)rev_edge[t];
 #pragma unroll
-      for (int c = 0; c < 7; ++c) a[c] += E[c];
+        for (int c = 0; c < 7; ++c) a[c] += E[c];
+      }
     }
   }
 #pragma unroll
@@ -191,7 +249,7 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
   }
   if (!live || lg != 0) return;
 #pragma unroll
-  for (int c = 0; c < 7; ++c) a[c] += self7[7 * (size_t)j + c];
+  for (int c = 0; c < 7; ++c) a[c] += self7[REC * (size_t)j + c];
   const size_t gj = (size_t)fg_idx[j];
   const Quat c = load_q(prev_inv, j);
   const float gw = a[3], gx = a[4], gy = a[5], gz = a[6];
@@ -212,12 +270,20 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
 int gsr_rigidity_fwd_blocks(int nfg) { return nfg > 0 ? (nfg + RG_PTS - 1) / RG_PTS : 0; }
 
 int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
-                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* partial,
-                            hipStream_t st) {
+                            const float* nw, const float* nd, const float* prev_inv, const float* prev_off, float* frames,
+                            float* partial, hipStream_t st) {
   if (nfg <= 0) return 0;
+  float4* fr = reinterpret_cast<float4*>(frames);
+  if (fr) {
+    GSR_PROF("rigidity_frames", st);
+    hipLaunchKernelGGL(rigidity_frames_kernel, dim3((nfg + RG_BLOCK - 1) / RG_BLOCK), dim3(RG_BLOCK), 0, st, nfg, means3D, rot, fg_idx,
+                       prev_inv, fr);
+  }
   { GSR_PROF("rigidity_fwd", st);
-    hipLaunchKernelGGL(rigidity_fwd_kernel, dim3(gsr_rigidity_fwd_blocks(nfg)), dim3(RG_BLOCK), 0, st, nfg, K, means3D, rot, fg_idx,
-                       nbr, nw, nd, prev_inv, prev_off, partial); }
+    if (fr) hipLaunchKernelGGL(rigidity_fwd_kernel<true>, dim3(gsr_rigidity_fwd_blocks(nfg)), dim3(RG_BLOCK), 0, st, nfg, K, means3D, rot,
+                               fg_idx, nbr, nw, nd, prev_inv, prev_off, (const float4*)fr, partial);
+    else hipLaunchKernelGGL(rigidity_fwd_kernel<false>, dim3(gsr_rigidity_fwd_blocks(nfg)), dim3(RG_BLOCK), 0, st, nfg, K, means3D, rot,
+                            fg_idx, nbr, nw, nd, prev_inv, prev_off, (const float4*)nullptr, partial); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -225,20 +291,36 @@ int gsr_launch_rigidity_fwd(int nfg, int K, const float* means3D, const float* r
 int gsr_launch_rigidity_bwd(int nfg, int K, const float* means3D, const float* rot, const int64_t* fg_idx, const int64_t* nbr,
                             const float* nw, const float* nd, const float* prev_inv, const float* prev_off, const float* g,
                             int gstride, float s1, float s2, float s3, const int32_t* rev_ptr, const int32_t* rev_edge,
-                            float* self7, float* edge7, float* d_means3D, float* d_rot, int accumulate, hipStream_t st) {
+                            float* frames, int frames_valid, float* self7, float* edge7, float* d_means3D, float* d_rot, int accumulate,
+                            hipStream_t st) {
   if (nfg <= 0) return 0;
+  float4* fr = reinterpret_cast<float4*>(frames);
+  if (fr && !frames_valid) {
+    GSR_PROF("rigidity_frames", st);
+    hipLaunchKernelGGL(rigidity_frames_kernel, dim3((nfg + RG_BLOCK - 1) / RG_BLOCK), dim3(RG_BLOCK), 0, st, nfg, means3D, rot, fg_idx,
+                       prev_inv, fr);
+  }
+  // a lane per edge (8 or 16 lanes per point striding over K = 20 edges measured 57 / 45 us against 42: gather latency, not issue, bounds it)
   const int grp = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
   const dim3 block(RG_BLOCK), grid(((size_t)nfg * grp + RG_BLOCK - 1) / RG_BLOCK);
   { GSR_PROF("rigidity_bwd_edges", st);
-#define GSR_RG_LAUNCH(G_) hipLaunchKernelGGL(rigidity_bwd_edges_kernel<G_>, grid, block, 0, st, nfg, K, means3D, rot, fg_idx, nbr, nw, nd, \
-                                             prev_inv, prev_off, g, gstride, s1, s2, s3, self7, edge7)
+#define GSR_RG_LAUNCH(G_)                                                                                                              \
+  do {                                                                                                                                 \
+    if (fr) hipLaunchKernelGGL((rigidity_bwd_edges_kernel<G_, true>), grid, block, 0, st, nfg, K, means3D, rot, fg_idx, nbr, nw, nd,   \
+                               prev_inv, prev_off, g, gstride, s1, s2, s3, (const float4*)fr, self7, edge7);                           \
+    else hipLaunchKernelGGL((rigidity_bwd_edges_kernel<G_, false>), grid, block, 0, st, nfg, K, means3D, rot, fg_idx, nbr, nw, nd,     \
+                            prev_inv, prev_off, g, gstride, s1, s2, s3, (const float4*)nullptr, self7, edge7);                         \
+  } while (0)
     if (grp == 8) GSR_RG_LAUNCH(8); else if (grp == 16) GSR_RG_LAUNCH(16); else if (grp == 32) GSR_RG_LAUNCH(32); else GSR_RG_LAUNCH(64);
 #undef GSR_RG_LAUNCH
   }
   GSR_HIP_CHECK(hipGetLastError());
   { GSR_PROF("rigidity_bwd_gather", st);
-    hipLaunchKernelGGL(rigidity_bwd_gather_kernel, dim3(((size_t)nfg * RG_GATHER + RG_BLOCK - 1) / RG_BLOCK), block, 0, st, nfg, fg_idx,
-                       rev_ptr, rev_edge, prev_inv, self7, edge7, d_means3D, d_rot, accumulate); }
+    const dim3 ggrid(((size_t)nfg * RG_GATHER + RG_BLOCK - 1) / RG_BLOCK);
+    if (fr) hipLaunchKernelGGL(rigidity_bwd_gather_kernel<8>, ggrid, block, 0, st, nfg, fg_idx, rev_ptr, rev_edge, prev_inv, self7, edge7,
+                               d_means3D, d_rot, accumulate);
+    else hipLaunchKernelGGL(rigidity_bwd_gather_kernel<7>, ggrid, block, 0, st, nfg, fg_idx, rev_ptr, rev_edge, prev_inv, self7, edge7,
+                            d_means3D, d_rot, accumulate); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -184,9 +184,10 @@ int gsr_launch_shared_terms_fwd(int nfg, int K, int nbg, const float* means3D, c
                                 const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
                                 float* partials, float* terms, hipStream_t st) {
   const int nbe = gsr_rigidity_fwd_blocks(nfg), nbp = gsr_shared_terms_point_blocks(nfg, nbg);
-  float* edge_partial = partials;
-  float* point_partial = partials + 3 * (size_t)nbe;
-  if (int e = gsr_launch_rigidity_fwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, edge_partial, st)) return e;
+  float* frames = partials;                                  // 16 nfg floats first (the buffer's base alignment carries over)
+  float* edge_partial = partials + 16 * (size_t)(nfg > 0 ? nfg : 0);
+  float* point_partial = edge_partial + 3 * (size_t)nbe;
+  if (int e = gsr_launch_rigidity_fwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, frames, edge_partial, st)) return e;
   { GSR_PROF("point_terms_fwd", st);
     hipLaunchKernelGGL(point_terms_fwd_kernel, dim3(nbp), dim3(ST_BLOCK), 0, st, nfg, nbg, means3D, rot, fg_idx, bg_idx, init_pts,
                        init_rot, point_partial); }
@@ -206,16 +207,19 @@ int gsr_launch_shared_terms_bwd(int P, int nfg, int K, int nbg, const float* mea
                                 const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
                                 const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,
                                 const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge, float* scratch,
-                                float* d_means3D, float* d_rot, int accumulate, hipStream_t st) {
+                                float* d_means3D, float* d_rot, int flags, hipStream_t st) {
+  const int accumulate = flags & GSR_SHARED_ACCUMULATE, frames_valid = (flags & GSR_SHARED_FRAMES_VALID) ? 1 : 0;
   if (!accumulate) {
     GSR_HIP_CHECK(hipMemsetAsync(d_means3D, 0, sizeof(float) * 3 * (size_t)P, st));
     GSR_HIP_CHECK(hipMemsetAsync(d_rot, 0, sizeof(float) * 4 * (size_t)P, st));
   }
   const float inv_edges = nfg > 0 && K > 0 ? 1.0f / ((float)nfg * (float)K) : 0.f;
-  float* self7 = scratch;
-  float* edge7 = scratch + 7 * (size_t)nfg;
+  float* frames = scratch;                                   // 16 nfg floats, then 8 (nfg + nfg K) of the neighbour terms
+  float* self7 = scratch + 16 * (size_t)(nfg > 0 ? nfg : 0);
+  float* edge7 = self7 + 8 * (size_t)nfg;
   if (int e = gsr_launch_rigidity_bwd(nfg, K, means3D, rot, fg_idx, nbr, nw, nd, prev_inv, prev_off, grad_total, 0, w5[0] * inv_edges,
-                                      w5[1] * inv_edges, w5[2] * inv_edges, rev_ptr, rev_edge, self7, edge7, d_means3D, d_rot, accumulate, st))
+                                      w5[1] * inv_edges, w5[2] * inv_edges, rev_ptr, rev_edge, frames, frames_valid, self7, edge7, d_means3D,
+                                      d_rot, accumulate, st))
     return e;
   { GSR_PROF("point_terms_bwd", st);
     hipLaunchKernelGGL(point_terms_bwd_kernel, dim3(gsr_shared_terms_point_blocks(nfg, nbg)), dim3(ST_BLOCK), 0, st, nfg, nbg, means3D,

@@ -55,7 +55,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward",
-           "gsr_shared_terms_partials", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
+           "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward")
 
 
@@ -112,6 +112,8 @@ def load_library():
                                              C.c_float, C.c_float] + [vp] * 5)
     lib.gsr_shared_terms_partials.restype = i32
     lib.gsr_shared_terms_partials.argtypes = [i32, i32]
+    lib.gsr_shared_terms_scratch.restype = i32
+    lib.gsr_shared_terms_scratch.argtypes = [i32, i32]
     lib.gsr_shared_terms_forward.restype = C.c_int
     lib.gsr_shared_terms_forward.argtypes = [i32, i32, i32] + [vp] * 11 + [C.POINTER(C.c_float), vp, vp, vp]
     lib.gsr_shared_terms_backward.restype = C.c_int
@@ -455,7 +457,8 @@ def _shared_args(v):
 
 def shared_terms_forward(means3D, rotations, v, weights5):
     """View-independent terms of the t > 0 loss (gsr_shared_terms_forward).  ``v``: the contiguous tensors of
-    gsdyn.step.make_rigidity_variables.  Returns terms[6] = rigid, rot, iso, floor, bg, weighted sum."""
+    gsdyn.step.make_rigidity_variables.  Returns (terms[6] = rigid, rot, iso, floor, bg, weighted sum; work buffer to hand to
+    ``shared_terms_backward``: it starts with the per-point frames the backward needs again)."""
     lib = load_library()
     _require_device(means3D)
     dev = means3D.device
@@ -463,15 +466,17 @@ def shared_terms_forward(means3D, rotations, v, weights5):
     nbg = int(v["bg_idx"].shape[0])
     w5 = (C.c_float * 5)(*[float(x) for x in weights5])
     with torch.cuda.device(dev):
-        part = torch.empty((max(int(lib.gsr_shared_terms_partials(nfg, nbg)), 1),), dtype=torch.float32, device=dev)
+        n = max(int(lib.gsr_shared_terms_partials(nfg, nbg)), int(lib.gsr_shared_terms_scratch(nfg, K)), 1)
+        work = torch.empty((n,), dtype=torch.float32, device=dev)
         terms = torch.empty((6,), dtype=torch.float32, device=dev)
-        _check(lib.gsr_shared_terms_forward(nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5, _ptr(part), _ptr(terms),
+        _check(lib.gsr_shared_terms_forward(nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5, _ptr(work), _ptr(terms),
                                             _stream(dev)), "gsr_shared_terms_forward")
-    return terms
+    return terms, work
 
 
-def shared_terms_backward(means3D, rotations, v, weights5, grad_total, accumulate_into=None):
-    """``accumulate_into`` = (d_means3D, d_rotations): the gradients are ADDED to these tensors (and they are returned)."""
+def shared_terms_backward(means3D, rotations, v, weights5, grad_total, accumulate_into=None, work=None):
+    """``accumulate_into`` = (d_means3D, d_rotations): the gradients are ADDED to these tensors (and they are returned).
+    ``work``: the buffer ``shared_terms_forward`` returned for the same inputs (saves recomputing the per-point frames)."""
     lib = load_library()
     dev = means3D.device
     nfg, K = (int(d) for d in v["neighbor_indices"].shape)
@@ -479,11 +484,16 @@ def shared_terms_backward(means3D, rotations, v, weights5, grad_total, accumulat
     w5 = (C.c_float * 5)(*[float(x) for x in weights5])
     with torch.cuda.device(dev):
         g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
-        scratch = torch.empty((max(7 * (nfg + nfg * K), 1),), dtype=torch.float32, device=dev)
+        need = max(int(lib.gsr_shared_terms_scratch(nfg, K)), 1)
+        flags = 1 if accumulate_into is not None else 0
+        if work is not None and work.numel() >= need:
+            scratch, flags = work, flags | 2
+        else:
+            scratch = torch.empty((need,), dtype=torch.float32, device=dev)
         d_m, d_r = accumulate_into if accumulate_into is not None else (torch.empty_like(means3D), torch.empty_like(rotations))
         _check(lib.gsr_shared_terms_backward(int(means3D.shape[0]), nfg, K, nbg, _ptr(means3D), _ptr(rotations), *_shared_args(v), w5,
                                              _ptr(g), _ptr(v["rev_ptr"]), _ptr(v["rev_edge"]), _ptr(scratch), _ptr(d_m), _ptr(d_r),
-                                             1 if accumulate_into is not None else 0, _stream(dev)), "gsr_shared_terms_backward")
+                                             flags, _stream(dev)), "gsr_shared_terms_backward")
     return d_m, d_r
 
 

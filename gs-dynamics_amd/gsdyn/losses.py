@@ -205,8 +205,8 @@ class _FusedSharedTerms(torch.autograd.Function):
         from diff_gaussian_rasterization import _hip
         m, r = means3D.detach().contiguous().float(), rotations.detach().contiguous().float()
         v = dict(zip(_SHARED_KEYS, tensors))
-        terms = _hip.shared_terms_forward(m, r, v, weights5)
-        ctx.v, ctx.w = v, tuple(weights5)
+        terms, work = _hip.shared_terms_forward(m, r, v, weights5)
+        ctx.v, ctx.w, ctx.work = v, tuple(weights5), work
         ctx.save_for_backward(m, r)
         each = terms[:5]
         ctx.mark_non_differentiable(each)
@@ -216,7 +216,7 @@ class _FusedSharedTerms(torch.autograd.Function):
     def backward(ctx, grad_total, _grad_each):
         from diff_gaussian_rasterization import _hip
         m, r = ctx.saved_tensors
-        d_m, d_r = _hip.shared_terms_backward(m, r, ctx.v, ctx.w, grad_total)
+        d_m, d_r = _hip.shared_terms_backward(m, r, ctx.v, ctx.w, grad_total, work=ctx.work)
         return (d_m, d_r, None) + (None,) * len(_SHARED_KEYS)
 
 

@@ -229,14 +229,14 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
     if not is_initial_timestep:
         shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
         w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
-        terms = _hip.shared_terms_forward(m3, rot, shared, w5)
+        terms, work = _hip.shared_terms_forward(m3, rot, shared, w5)
         total = total + terms[5]
     # ---- backward, in reverse
     d_ims, d_cm, d_cc = _hip.views_loss_backward(lstate, ims, cam_m, cam_c, one, 0.8, 0.2)
     d3, d2, _dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, d_ims, m3, radii, colours, None, sc, rot, None,
                                                                               want_color_grad=False)
     if shared is not None:
-        _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot))
+        _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot), work=work)
     d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
     for k, g in (("means3D", d3), ("unnorm_rotations", d_un), ("logit_opacities", d_lo), ("log_scales", d_ls), ("cam_m", d_cm),
                  ("cam_c", d_cc)):

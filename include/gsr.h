@@ -161,10 +161,15 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
  *   floor = mean(clamp(means3D[fg].y, min=0))                                                     (train_utils.py:225)
  *   bg    = mean_b sum_c |means3D[bg] - init_bg_pts| + mean_b sum_c |rotations[bg] - init_bg_rot| (train_utils.py:227-229)
  * and their weighted sum.  bg_idx[n_bg] (int64) lists the background Gaussians; init_bg_* are indexed by background rank.
- * forward: terms6 (device) = rigid, rot, iso, floor, bg, sum_k weights5_host[k] * term_k;  partials = gsr_shared_terms_partials floats.
+ * forward: terms6 (device) = rigid, rot, iso, floor, bg, sum_k weights5_host[k] * term_k;  partials = gsr_shared_terms_partials floats, 16-byte aligned.
  * backward: d_means3D[P,3] / d_rotations[P,4] = grad_total[0] (device) * d terms6[5] / d input -- fully written, or, with
- *   accumulate != 0, ADDED to what the buffers hold (rows in neither index list are left alone);
- *   scratch = 7 (n_fg + n_fg K) floats; rev_ptr / rev_edge as for gsr_rigidity_backward. */
+ *   GSR_SHARED_ACCUMULATE in `flags`, ADDED to what the buffers hold (rows in neither index list are left alone);
+ *   scratch = gsr_shared_terms_scratch(n_fg, K) floats, 16-byte aligned; its first 16 n_fg floats are the per-point frames the
+ *   forward left at the start of `partials`: pass that buffer (if large enough) with GSR_SHARED_FRAMES_VALID to skip their
+ *   recomputation.  rev_ptr / rev_edge as for gsr_rigidity_backward. */
+#define GSR_SHARED_ACCUMULATE 1
+#define GSR_SHARED_FRAMES_VALID 2
+int32_t gsr_shared_terms_scratch(int32_t n_fg, int32_t K);
 int32_t gsr_shared_terms_partials(int32_t n_fg, int32_t n_bg);
 int gsr_shared_terms_forward(int32_t n_fg, int32_t K, int32_t n_bg, const float* means3D, const float* rotations, const int64_t* fg_idx,
                              const int64_t* bg_idx, const int64_t* neighbor_indices, const float* neighbor_weight,
@@ -176,7 +181,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
                               const float* neighbor_weight, const float* neighbor_dist, const float* prev_inv_rot_fg,
                               const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
                               const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
-                              float* scratch, float* d_means3D, float* d_rotations, int32_t accumulate, void* stream);
+                              float* scratch, float* d_means3D, float* d_rotations, int32_t flags, void* stream);
 
 /* ---- activations of the raw parameters (replaces the torch ops of params2rendervar, /root/reference/src/tracking/helpers.py:36-45):
  *   rotations[P,4] = unnorm_rotations / max(|unnorm_rotations|, 1e-12), opacities[P,1] = sigmoid(logit_opacities), scales[P,3] = exp(log_scales).
