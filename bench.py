@@ -370,7 +370,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
     except Exception as e:  # noqa: BLE001
         out["forward_only_cfg2"] = {"error": repr(e)}
     try:   # BASELINE.json configs[0]-shaped rollout step on the device (row N4): rope.yaml GNN dims, random weights
-        from gsdyn.dynamics import DynamicsPredictor, farthest_point_sampler, fps_radius, rollout_step
+        from gsdyn.dynamics import DynamicsPredictor, farthest_point_sampler, rollout_step
         cfg = dict(nf_particle=512, nf_relation=512, nf_effect=512, attr_dim=2, state_dim=0, action_dim=3, pstep=3,
                    rel_attr_dim=2, rel_group_dim=1, rel_distance_dim=3, n_his=3)
         torch.manual_seed(0)

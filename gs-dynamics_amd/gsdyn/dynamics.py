@@ -18,7 +18,7 @@ are checked without a GPU); on a HIP device the two kernels take over.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 import torch
