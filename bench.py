@@ -369,6 +369,31 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                     "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only"}
     except Exception as e:  # noqa: BLE001
         out["forward_only_cfg2"] = {"error": repr(e)}
+    try:   # predict.py's frame (row A11): every camera rendered twice, colours and an all-ones mask (predict.py:100-123)
+        from gsdyn.camera import look_at_w2c
+        from gsdyn.render import Renderer
+        import math
+        rdr = Renderer(dev, w=W, h=H)
+        with torch.no_grad():
+            data = {k: v.detach() for k, v in params2rendervar(params).items()}      # incl. the means2D holder, as the reference passes it
+        kmat = [[float(W), 0.0, W / 2.0], [0.0, float(W), H / 2.0], [0.0, 0.0, 1.0]]
+        poses = [(look_at_w2c((4.0 * math.cos(0.3 + 1.57 * i), 0.8, 4.0 * math.sin(0.3 + 1.57 * i))), kmat) for i in range(4)]
+
+        def frame_fused():
+            rdr.render_cameras_with_mask(poses, data)
+
+        def frame_reference():
+            for w2c, k in poses:
+                rdr.render(w2c, k, data, bg=(0.0, 0.0, 0.0))
+                ones = dict(data)
+                ones["colors_precomp"] = torch.ones_like(data["colors_precomp"])
+                rdr.render(w2c, k, ones, bg=(0.0, 0.0, 0.0))
+        ms_f, ms_r = _time_ms(frame_fused, 10, 3), _time_ms(frame_reference, 5, 2)
+        out["predict_frame_4cams"] = {"ms_per_frame": ms_f, "ms_per_frame_reference_calls": ms_r, "Mpix_per_s": 8 * H * W / ms_f / 1e3,
+                                      "what": "predict.py frame: 4 cameras x (colour + all-ones mask render), 100k Gaussians, 800x800, forward only; "
+                                              "fused = one multi-view call, each camera's pair blended in one tile pass; reference_calls = 8 Renderer.render calls"}
+    except Exception as e:  # noqa: BLE001
+        out["predict_frame_4cams"] = {"error": repr(e)}
     try:   # BASELINE.json configs[0]-shaped rollout step on the device (row N4): rope.yaml GNN dims, random weights
         from gsdyn.dynamics import DynamicsPredictor, farthest_point_sampler, rollout_step
         cfg = dict(nf_particle=512, nf_relation=512, nf_effect=512, attr_dim=2, state_dim=0, action_dim=3, pstep=3,

@@ -4,6 +4,7 @@
 alpha mask (/root/reference/src/predict.py:115-123)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
@@ -16,11 +17,24 @@ class Renderer:
         self.near, self.far = near, far
         self.w, self.h = w, h
         self.device = device
+        self._cameras = {}
+
+    def _camera(self, w2c, k, bg):
+        """The settings record of a camera, built once per distinct (pose, intrinsics, background): ``setup_camera`` costs
+        three host->device copies and a device-side 4x4 inverse per call, which the reference pays on every render of every
+        frame although predict.py's cameras are fixed (/root/reference/src/render/renderer.py:25-50)."""
+        key = (np.asarray(w2c, dtype=np.float64).tobytes(), np.asarray(k, dtype=np.float64).tobytes(), tuple(float(b) for b in bg))
+        cam = self._cameras.get(key)
+        if cam is None:
+            if len(self._cameras) >= 256:
+                self._cameras.clear()
+            cam = self._cameras[key] = setup_camera(self.w, self.h, k, w2c, near=self.near, far=self.far, bg=bg, device=self.device)
+        return cam
 
     @torch.no_grad()
     def render(self, w2c, k, timestep_data, bg=(0.7, 0.7, 0.7)):
         timestep_data = {key: v.to(self.device) for key, v in timestep_data.items()}
-        cam = setup_camera(self.w, self.h, k, w2c, near=self.near, far=self.far, bg=bg, device=self.device)
+        cam = self._camera(w2c, k, bg)
         im, _, depth = GaussianRasterizer(raster_settings=cam)(**timestep_data)
         return im, depth
 
@@ -36,7 +50,7 @@ class Renderer:
         """All cameras of a frame, colour + mask each, in one rasterizer call (predict.py renders 4 cameras x 2 per
         frame, /root/reference/src/predict.py:100-123).  ``cameras``: list of (w2c, k).  Returns image, depth and mask lists."""
         d = {key: v.to(self.device) for key, v in timestep_data.items()}
-        cams = [setup_camera(self.w, self.h, k, w2c, near=self.near, far=self.far, bg=bg, device=self.device) for w2c, k in cameras]
+        cams = [self._camera(w2c, k, bg) for w2c, k in cameras]
         views = [c for c in cams for _ in (0, 1)]
         col = d["colors_precomp"].float()
         colours = torch.stack([col, torch.ones_like(col)]).repeat(len(cams), 1, 1)
