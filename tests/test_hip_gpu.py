@@ -896,6 +896,61 @@ def test_direct_step_equals_autograd_step(dev, initial):
     assert (params["means3D"].grad - 2 * ga["means3D"]).abs().max().item() <= 1e-5 * ga["means3D"].abs().max().item()
 
 
+def test_full_size_direct_step_against_literal_torch_step(dev):
+    """BASELINE-size end-to-end check of the most fused path against the most literal one, t > 0, 2 cameras at 800 x 800, 100 k
+    Gaussians: ``loss_and_grads_views`` (fused activations, pair passes, fused image terms with the camera affine, fused shared
+    terms, no autograd) vs one ``GaussianRasterizer`` call per render, the camera affine / 0.8 L1 + 0.2 (1 - SSIM) / rigid / rot /
+    iso / floor / bg terms as the reference's torch formulas, and autograd."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import LossWeights, loss_and_grads_views, params2rendervar, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn import losses as L
+    from gsdyn.dp import init_variables
+    from gsdyn.step import _SHARED_NAMES, _shared_terms, make_rigidity_variables
+    P, W, H = 100_000, 800, 800
+    params = synth_scene_params(P, device=dev)
+    with torch.no_grad():
+        params["cam_m"].add_(0.05 * torch.randn_like(params["cam_m"]))
+        params["cam_c"].add_(0.02 * torch.randn_like(params["cam_c"]))
+    cams = synth_ring_cameras(4, W, H, device=dev)
+    im_gt, seg_gt = synth_targets(W, H, device=dev)
+    w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)
+    views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in (0, 2)]
+    rig = make_rigidity_variables(params, num_knn=20)
+    with torch.no_grad():
+        params["means3D"].add_(0.003 * torch.randn_like(params["means3D"]))        # move away from the rest pose
+        params["unnorm_rotations"].add_(0.02 * torch.randn_like(params["unnorm_rotations"]))
+
+    for p_ in params.values():
+        p_.grad = None
+    v1 = init_variables(P, dev)
+    v1.update(rig)
+    loss_f, _, aux = loss_and_grads_views(params, views, v1, False, w)
+    g_f = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+
+    for p_ in params.values():
+        p_.grad = None
+    torch_vars = {k: v for k, v in rig.items() if k not in ("rev_ptr", "rev_edge")}     # no reverse adjacency -> torch formulas
+    weights = dict(rigid=w.rigid, rot=w.rot, iso=w.iso, floor=w.floor, bg=w.bg)
+    total = 0.0
+    for d in views:
+        rv = params2rendervar(params)
+        im, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**rv)
+        im = torch.exp(params["cam_m"][d["id"]])[:, None, None] * im + params["cam_c"][d["id"]][:, None, None]
+        l_im = 0.8 * L.l1_loss_v1(im, d["im"]) + 0.2 * (1.0 - L.calc_ssim(im, d["im"]))
+        sv = params2rendervar(params, colors_key="seg_colors")
+        seg, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**sv)
+        l_seg = 0.8 * L.l1_loss_v1(seg, d["seg"]) + 0.2 * (1.0 - L.calc_ssim(seg, d["seg"]))
+        shared, _ = _shared_terms(params, rv, torch_vars, weights)
+        loss = w.im * l_im + w.seg * l_seg + shared
+        loss.backward()
+        total += float(loss.detach())
+    assert abs(float(loss_f) - total) <= 2e-5 * abs(total)
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "cam_m", "cam_c"):
+        want, got = params[k].grad, g_f[k]
+        assert (got - want).abs().max().item() <= 3e-4 * want.abs().max().item(), (k, (got - want).abs().max().item(), want.abs().max().item())
+    assert len(_SHARED_NAMES) == 5 and aux["means2D_grad"].shape == (4, P, 3)
+
+
 def test_views_loss_more_images_than_one_library_call(dev):
     """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
     from gsdyn import losses as L
