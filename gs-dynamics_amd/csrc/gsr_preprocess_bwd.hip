@@ -2,13 +2,13 @@
 // reference extension's computeCov2D-backward + preprocess-backward kernels, fused into one).
 //
 // One lane per Gaussian:
-//   1. reduce its entry records (one 48-byte record per touched tile, contiguous, written by
+//   1. reduce its entry records (one 36-byte record per touched tile, contiguous, written by
 //      render_bwd) in ascending tile order -> dL/d{mean2D_pix, conic(A,B,C), opacity, rgb};
 //   2. conic -> cov2D -> (cov3D, view-space mean) -> (scale, rotation, mean3D);  the 3D covariance is
 //      recomputed from scale/rotation rather than stored by the forward (saves 24 B/Gaussian each way);
 //   3. 2D mean -> 3D mean through the 4x4 projection; SH backward when colours came from SH.
 // Every output element is written (zeros for culled Gaussians): callers need no memset.
-// HBM per Gaussian: reads 48*tiles + 12 + 12 + 16 + 8 + 4 + 4, writes 12+12+12+4+12+16+24 = 92 B.
+// HBM per Gaussian: reads 36*tiles + 12 + 12 + 16 + 8 + 4 + 4, writes 12+12+12+4+12+16+24 = 92 B.
 #include "gsr_common.h"
 
 namespace {

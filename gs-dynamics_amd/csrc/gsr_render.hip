@@ -18,8 +18,8 @@
 // conflict-free).  Early termination is per WAVE (`__ballot(!done) == 0`) and per workgroup.
 //
 // Backward: lanes replay their pixel back-to-front.  For every list entry the nine partial gradients are
-// summed over the wave's 64 pixels with a DPP reduction (no LDS traffic), lane 63 parks the wave total in
-// LDS, and after the batch one lane per entry adds the four wave totals and writes ONE 48-byte record to
+// summed over the wave's 64 pixels with a packed DPP / swizzle reduction (one value per lane at the end), nine lanes
+// park the wave totals in LDS, and after the batch one lane per entry adds the four wave totals and writes ONE 36-byte record to
 // the entry's Gaussian-major slot.  No global atomics on the data path: gradients are deterministic, and
 // the per-Gaussian reduce in gsr_preprocess_bwd.hip reads contiguous records.
 //
