@@ -35,6 +35,22 @@ def test_host_only_entry_points_work_without_a_gpu():
     assert lib.gsr_backward_scratch_bytes(100000, 460000) >= 460000 * 36
 
 
+def test_host_only_size_functions_of_the_step_kernels():
+    """Sizes the caller allocates for the fused step pieces (no GPU needed): image-term block partials, shared-term work buffers."""
+    from diff_gaussian_rasterization import _hip
+    lib = _hip.load_library()
+    per = lib.gsr_image_loss_blocks(1, 800, 800)
+    assert per == 25 * 15                                          # 32 x 54 output tiles
+    assert lib.gsr_image_loss_blocks(7, 33, 55) == 7 * 2 * 1
+    assert lib.gsr_views_loss_blocks(8, 3, 800, 800) == 24 * per
+    nfg, K, nbg = 70_000, 20, 30_000
+    assert lib.gsr_shared_terms_scratch(nfg, K) == 16 * nfg + 8 * (nfg + nfg * K)
+    assert lib.gsr_shared_terms_partials(nfg, nbg) >= 16 * nfg + 3 * lib.gsr_rigidity_blocks(nfg)
+    assert lib.gsr_shared_terms_scratch(0, K) == 0 and lib.gsr_rigidity_blocks(0) == 0
+    tab = _hip.GsrLossViews()
+    assert len(tab.cam_row) == _hip.LOSS_MAX_IMAGES == 32
+
+
 def test_settings_namedtuple_matches_reference_fields():
     """Field names/order constructed at /root/reference/src/tracking/helpers.py:20-32."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings as S
