@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gs-dynamics_amd")):
     sys.path.insert(0, p)
-from gsdyn import LossWeights, get_loss, get_loss_views, synth_ring_cameras, synth_scene_params, synth_targets
+from gsdyn import LossWeights, get_loss, get_loss_views, loss_and_grads_views, synth_ring_cameras, synth_scene_params, synth_targets
 from gsdyn.dp import init_variables
 from gsdyn.step import make_rigidity_variables
 dev = torch.device("cuda:0")
@@ -17,10 +17,14 @@ variables.update(make_rigidity_variables(params, num_knn=20))
 w = LossWeights(im=50.0, seg=200.0, rigid=200.0, iso=1000.0, rot=4.0, bg=200.0)
 views = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
 BATCHED = os.environ.get("GETLOSS_SEPARATE") != "1"
+DIRECT = os.environ.get("GETLOSS_AUTOGRAD") != "1"       # library calls back to back (gsdyn.step.loss_and_grads_views)
 FROZEN = os.environ.get("GETLOSS_COLOUR_GRADS") != "1"     # the tracking schedule: both colour groups have lr 0
 def step(initial):
     for p in params.values():
         p.grad = None
+    if BATCHED and DIRECT:
+        loss_and_grads_views(params, views, variables, initial, w)
+        return
     if BATCHED:
         loss, _, _ = get_loss_views(params, views, variables, initial, w, frozen_colours=FROZEN)
         loss.backward()
