@@ -419,14 +419,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
       r[u] = make_uint2(0u, 0u);
-      if (k < n_items && t < T) r[u] = tab.v[k / n_it].ranges[t];
+      // a fused alias view has no entry of its own in the order: its busy tiles ride on its owner's tickets and its empty
+      // tiles are painted together with the owner's (same ranges)
+      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) r[u] = tab.v[k / n_it].ranges[t];
     }
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
-      const int k = k0 + u;
       const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
-      // empty tiles (and padding): not counted, no hot LDS word; the busy tiles of a fused alias view ride on its owner's tickets
-      if (bucket != 255u && !(k < n_items && tab.v[k / n_it].fused_alias)) atomicAdd(&cnt[bucket], 1u);
+      if (bucket != 255u) atomicAdd(&cnt[bucket], 1u);   // empty tiles (and padding): not counted, no hot LDS word
     }
   }
   __syncthreads();
@@ -455,20 +455,18 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
       r[u] = make_uint2(0u, 0u);
-      if (k < n_items && t < T) r[u] = tab.v[k / n_it].ranges[t];
+      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) r[u] = tab.v[k / n_it].ranges[t];
     }
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
-      if (k < n_items && t < T) {
+      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) {
         const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
         // empty tiles go behind the busy ones in any order: a wave-aggregated slot (one LDS atomic per wave).
         // (Aggregating the busy buckets too -- 8 ballots per item -- was measured slower than the plain atomics.)
         uint32_t slot;
-        if (bucket != 255u) {
-          if (tab.v[k / n_it].fused_alias) continue;   // uniform per item: no ticket of its own
-          slot = atomicAdd(&start[bucket], 1u);
-        } else {
+        if (bucket != 255u) slot = atomicAdd(&start[bucket], 1u);
+        else {
           const uint64_t m = __ballot(1);
           const int leader = __ffsll((long long)m) - 1;
           uint32_t base = 0;

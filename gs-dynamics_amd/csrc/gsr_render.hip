@@ -571,6 +571,12 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
         vw.final_T[pix] = 1.0f; vw.n_contrib[pix] = 0u;
         vw.out_color[pix] = vw.bg[0]; vw.out_color[N + pix] = vw.bg[1]; vw.out_color[2 * N + pix] = vw.bg[2];
         vw.out_depth[pix] = 0.0f;
+        if (PAIRS && vw.partner >= 0) {   // the partner's tile is empty too (same lists): it has no order entry of its own
+          const GsrRenderView& pw = tab.v[vw.partner];
+          pw.final_T[pix] = 1.0f; pw.n_contrib[pix] = 0u;
+          pw.out_color[pix] = pw.bg[0]; pw.out_color[N + pix] = pw.bg[1]; pw.out_color[2 * N + pix] = pw.bg[2];
+          pw.out_depth[pix] = 0.0f;
+        }
       }
     }
   }
