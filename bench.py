@@ -355,6 +355,38 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                  + ("t = 0" if initial else "t > 0") + "; headline = all cameras in one rasterizer call, library calls back to back (gsdyn.step.loss_and_grads_views)"}
     except Exception as e:  # noqa: BLE001
         out["getloss_step"] = {"error": repr(e)}
+    try:   # one whole training iteration of the tracking loop, one camera per iteration as train_gs.py runs it: loss + backward + Adam
+        from gsdyn import initialize_optimizer
+        res = {}
+        for name, initial in (("t0", True), ("t>0", False)):
+            for mode in ("reference_shape", "fused"):
+                p3 = synth_scene_params(P_GAUSS, seed=0, device=dev)
+                v3 = init_variables(P_GAUSS, dev)
+                v3.update(make_rigidity_variables(p3, num_knn=20))
+                views3 = [dict(cam=c, im=im_gt, seg=seg_gt, id=i) for i, c in enumerate(cams)]
+                if mode == "fused":
+                    opt = initialize_optimizer(p3, 4.0)                    # gsdyn.optim.FusedAdam on a HIP device
+                else:
+                    lrs = {g["name"]: g["lr"] for g in initialize_optimizer(p3, 4.0).param_groups}
+                    opt = torch.optim.Adam([{"params": [v], "name": k, "lr": lrs[k]} for k, v in p3.items()], lr=0.0, eps=1e-15)
+                it = [0]
+
+                def iteration():
+                    d = views3[it[0] % len(views3)]
+                    it[0] += 1
+                    if mode == "fused":
+                        loss_and_grads_views(p3, [d], v3, initial, w)
+                    else:
+                        loss, _ = get_loss(p3, d, v3, initial, w)
+                        loss.backward()
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                res[name + " " + mode] = _time_ms(iteration, 20, 5)
+        out["train_iteration_one_camera"] = {"ms": res, "what": "train_gs.py iteration (one camera: colour + seg render, losses, backward, Adam step); "
+                                             "reference_shape = gsdyn.get_loss (two GaussianRasterizer calls, torch loss ops) + torch.optim.Adam; "
+                                             "fused = loss_and_grads_views + gsdyn.optim.FusedAdam"}
+    except Exception as e:  # noqa: BLE001
+        out["train_iteration_one_camera"] = {"error": repr(e)}
     try:
         p2 = synth_scene_params(50_000, seed=0, device=dev)
         with torch.no_grad():

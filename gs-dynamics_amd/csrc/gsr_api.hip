@@ -547,6 +547,19 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
                                      rev_ptr, rev_edge, scratch, d_means3D, d_rotations, flags, (hipStream_t)stream);
 }
 
+int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* stream) {
+  if (n_tensors < 0 || n_tensors > GSR_ADAM_MAX_TENSORS || (n_tensors > 0 && !tensors)) {
+    gsr_set_error("gsr_adam_step: 0..%d tensors per call", GSR_ADAM_MAX_TENSORS);
+    return -2;
+  }
+  for (int i = 0; i < n_tensors; ++i) {
+    const gsr_adam_tensor& t = tensors[i];
+    if (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) { gsr_set_error("gsr_adam_step: NULL pointer in tensor %d", i); return -2; }
+    if (t.n > 0 && !(t.bias_correction1 > 0.f && t.bias_correction2_sqrt > 0.f)) { gsr_set_error("gsr_adam_step: bias corrections of tensor %d must be positive (step >= 1)", i); return -2; }
+  }
+  return gsr_launch_adam_step(n_tensors, tensors, (hipStream_t)stream);
+}
+
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }
   if (npoints > N || (N > 0 && (start_idx < 0 || start_idx >= N))) { gsr_set_error("gsr_fps: npoints / start_idx out of range"); return -2; }

@@ -255,6 +255,7 @@ int gsr_launch_activate_fwd(int P, const float* unnorm, const float* logit, cons
 int gsr_launch_activate_bwd(int P, const float* unnorm, const float* op, const float* sc, const float* d_rot, const float* d_op,
                             const float* d_sc, float* d_unnorm, float* d_logit, float* d_logs, hipStream_t st);
 int gsr_shared_terms_point_blocks(int nfg, int nbg);
+int gsr_launch_adam_step(int n_tensors, const gsr_adam_tensor* t, hipStream_t st);
 int gsr_launch_shared_terms_fwd(int nfg, int K, int nbg, const float* means3D, const float* rot, const int64_t* fg_idx,
                                 const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,
                                 const float* prev_off, const float* init_pts, const float* init_rot, const float* w5,

@@ -43,6 +43,16 @@ class GsrLossViews(C.Structure):
                 ("weight", C.c_float * LOSS_MAX_IMAGES), ("target", C.c_void_p * LOSS_MAX_IMAGES)]
 
 
+ADAM_MAX_TENSORS = 16
+
+
+class GsrAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float),
+                ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float)]
+
+
 class GsrKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64)]
 
@@ -56,7 +66,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
-           "gsr_activate_forward", "gsr_activate_backward")
+           "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step")
 
 
 def load_library():
@@ -122,6 +132,8 @@ def load_library():
     lib.gsr_activate_forward.argtypes = [i32] + [vp] * 7
     lib.gsr_activate_backward.restype = C.c_int
     lib.gsr_activate_backward.argtypes = [i32] + [vp] * 10
+    lib.gsr_adam_step.restype = C.c_int
+    lib.gsr_adam_step.argtypes = [i32, C.POINTER(GsrAdamTensor), vp]
     lib.gsr_rigidity_blocks.restype = i32
     lib.gsr_rigidity_blocks.argtypes = [i32]
     lib.gsr_rigidity_forward.restype = C.c_int
@@ -520,6 +532,27 @@ def activate_backward(unnorm_rotations, opacities, scales, d_rot, d_op, d_sc):
         _check(lib.gsr_activate_backward(P, _ptr(unnorm_rotations), _ptr(opacities), _ptr(scales), _ptr(d_rot), _ptr(d_op), _ptr(d_sc),
                                          _ptr(d_u), _ptr(d_l), _ptr(d_s), _stream(dev)), "gsr_activate_backward")
     return d_u, d_l, d_s
+
+
+def adam_step(entries):
+    """One launch for the Adam update of several tensors.  ``entries``: (param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+    step) with contiguous fp32 HIP tensors and ``step`` >= 1 (the count AFTER this update, as torch keeps it)."""
+    lib = load_library()
+    if not entries:
+        return
+    dev = entries[0][0].device
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        for lo in range(0, len(entries), ADAM_MAX_TENSORS):
+            chunk = entries[lo:lo + ADAM_MAX_TENSORS]
+            arr = (GsrAdamTensor * len(chunk))()
+            for a_, (p, g, m, v, lr, b1, b2, eps, step) in zip(arr, chunk):
+                a_.param, a_.grad, a_.exp_avg, a_.exp_avg_sq, a_.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                a_.lr, a_.beta1, a_.beta2, a_.eps = lr, b1, b2, eps
+                a_.bias_correction1 = 1.0 - b1 ** step
+                a_.bias_correction2_sqrt = (1.0 - b2 ** step) ** 0.5
+                a_.one_minus_beta1, a_.one_minus_beta2 = 1.0 - b1, 1.0 - b2
+            _check(lib.gsr_adam_step(len(chunk), arr, st), "gsr_adam_step")
 
 
 def farthest_point_sampling(pos: torch.Tensor, npoints: int, start_idx: int = 0) -> torch.Tensor:

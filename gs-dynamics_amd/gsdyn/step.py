@@ -46,6 +46,9 @@ def initialize_optimizer(params, scene_radius: float):
     lrs = {"means3D": 0.00016 * scene_radius, "rgb_colors": 0.0, "seg_colors": 0.0, "unnorm_rotations": 0.001,
            "logit_opacities": 0.05, "log_scales": 0.001, "cam_m": 1e-4, "cam_c": 1e-4}
     groups = [{"params": [v], "name": k, "lr": lrs[k]} for k, v in params.items()]
+    if all(v.is_cuda for v in params.values()):      # same update, all groups in one kernel launch (gsdyn/optim.py)
+        from .optim import FusedAdam
+        return FusedAdam(groups, lr=0.0, eps=1e-15)
     return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
 

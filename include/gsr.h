@@ -192,6 +192,19 @@ int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float*
                           const float* d_rotations, const float* d_opacities, const float* d_scales, float* d_unnorm_rotations,
                           float* d_logit_opacities, float* d_log_scales, void* stream);
 
+/* ---- optimiser step of the tracking loop: torch.optim.Adam's default update (no weight decay, no amsgrad, not maximising) for up
+ * to GSR_ADAM_MAX_TENSORS parameter tensors in ONE launch.  The reference builds Adam with one parameter group per tensor
+ * (/root/reference/src/tracking/train_utils.py:152-164: per-group lr, eps 1e-15).  bias_correction1 = 1 - beta1^step and
+ * bias_correction2_sqrt = sqrt(1 - beta2^step) are formed by the caller from its step counter.  All pointers: device, fp32, n elements. */
+#define GSR_ADAM_MAX_TENSORS 16
+typedef struct gsr_adam_tensor {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+  int64_t n;
+  float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;
+  float one_minus_beta1, one_minus_beta2;   /* formed in double by the caller, as torch does (1 - float(0.999) is off by 1e-5) */
+} gsr_adam_tensor;
+int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* stream);
+
 /* ---- rollout plumbing (callers: gsdyn/dynamics.py)
  * gsr_fps: farthest point sampling of pos[N,3] -> out_idx[npoints] (int64), first pick start_idx, every further pick the
  *   point with the largest squared distance to the picked set (first maximum on ties).  Stands in for

@@ -951,6 +951,39 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
     assert len(_SHARED_NAMES) == 5 and aux["means2D_grad"].shape == (4, P, 3)
 
 
+def test_fused_adam_equals_torch_adam(dev):
+    """gsdyn.optim.FusedAdam (all parameter groups in one gsr_adam_step launch) against torch.optim.Adam with the reference's
+    group layout (per-group lr, eps 1e-15, one group with lr 0, one parameter without a gradient): parameters and both moment
+    buffers after several steps; state layout interchangeable (state_dict round trip into torch's Adam)."""
+    from gsdyn.optim import FusedAdam
+    g = torch.Generator(device="cpu").manual_seed(12)
+    shapes = dict(means3D=(5003, 3), rot=(5003, 4), op=(5003, 1), frozen=(5003, 3), cam=(50, 3), nograd=(77, 3))
+    lrs = dict(means3D=6.4e-4, rot=1e-3, op=0.05, frozen=0.0, cam=1e-4, nograd=0.01)
+    init = {k: torch.randn(sh, generator=g).to(dev) for k, sh in shapes.items()}
+    grads = [{k: torch.randn(sh, generator=g).to(dev) * (10.0 ** (i - 2)) for k, sh in shapes.items()} for i in range(5)]
+
+    def run(cls):
+        ps = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+        opt = cls([{"params": [v], "name": k, "lr": lrs[k]} for k, v in ps.items()], lr=0.0, eps=1e-15)
+        for gr in grads:
+            for k, v in ps.items():
+                v.grad = None if k == "nograd" else gr[k].clone()
+            opt.step()
+        return ps, opt
+    pa, oa = run(torch.optim.Adam)
+    pb, ob = run(FusedAdam)
+    for k in shapes:
+        assert (pa[k] - pb[k]).abs().max().item() <= 2e-6 * max(1.0, pa[k].abs().max().item()), k
+        if k != "nograd":
+            sa, sb = oa.state[pa[k]], ob.state[pb[k]]
+            assert float(sa["step"]) == float(sb["step"]) == 5.0
+            for name in ("exp_avg", "exp_avg_sq"):
+                assert (sa[name] - sb[name]).abs().max().item() <= 2e-6 * sa[name].abs().max().item() + 1e-30, (k, name)
+    assert torch.equal(pb["nograd"], init["nograd"]) and len(ob.state[pb["nograd"]]) == 0
+    assert torch.equal(pb["frozen"], init["frozen"])             # lr 0: moments move, the parameter does not
+    oa.load_state_dict(ob.state_dict())                            # same state layout
+
+
 def test_views_loss_more_images_than_one_library_call(dev):
     """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
     from gsdyn import losses as L
