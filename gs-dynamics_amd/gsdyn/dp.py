@@ -72,13 +72,15 @@ class ViewShardedStep:
     """One optimiser step over a set of views, sharded over the ranks of ``group``."""
 
     def __init__(self, params, optimizer: Optional[torch.optim.Optimizer], weights: LossWeights = LossWeights(),
-                 group=None, batched: Optional[bool] = None, density_control: Optional[dict] = None):
+                 group=None, batched: Optional[bool] = None, density_control: Optional[dict] = None,
+                 density_stats: Optional[bool] = None):
         """``density_control``: dict(remove_thresh, remove_thresh_5k, scale_scene_radius) switches on the reference's
         adaptive density control for first-timestep calls that pass ``iteration`` (``variables`` then needs
         ``scene_radius``); every rank runs it on the all-reduced statistics with the same random seed, so replicas
         stay identical."""
         self.params, self.optimizer, self.weights, self.group = params, optimizer, weights, group
         self.density_control = density_control
+        self.density_stats = density_stats     # None: keep the densification statistics in the first timestep only (their only reader)
         if batched is None:   # the multi-view entry point exists in the HIP package (not in the CPU test double)
             import diff_gaussian_rasterization as dgr
             batched = hasattr(dgr, "rasterize_gaussians_views")
@@ -98,8 +100,13 @@ class ViewShardedStep:
         P = self.params["means3D"].shape[0]
         dev = self.params["means3D"].device
         self.bucket.zero()
-        stat = torch.zeros((2, P), dtype=torch.float32, device=dev)   # [grad-norm * seen, seen]
-        rad = torch.zeros((P,), dtype=torch.float32, device=dev)
+        # Densification statistics (screen-space gradient norms, seen counts, radii): read only by the density control, i.e.
+        # in the first timestep (/root/reference/src/tracking/train_gs.py:31-37) -- the ~15 small kernels and the two extra
+        # collectives they cost are skipped at t > 0.
+        track = bool(is_initial_timestep) if self.density_stats is None else bool(self.density_stats)
+        untouched = None if track else (variables.get("max_2D_radius"), variables.get("seen"))
+        stat = torch.zeros((2, P), dtype=torch.float32, device=dev) if track else None   # [grad-norm * seen, seen]
+        rad = torch.zeros((P,), dtype=torch.float32, device=dev) if track else None
         total = torch.zeros((), dtype=torch.float32, device=dev)
         if self.batched and mine:
             # all cameras of the shard, colour + segmentation renders, in ONE rasterizer call
@@ -112,35 +119,44 @@ class ViewShardedStep:
                                                       frozen_colours=self.frozen_colours)
                 loss.backward()
             total += loss.detach()
-            with torch.no_grad():
-                seen_v = aux["radii"] > 0                                    # [V,P]
-                g2 = aux["means2D_grad"] if direct else aux["means2D"].grad
-                if g2 is not None:
-                    stat[0] += (torch.norm(g2[0::2, :, :2], dim=-1) * seen_v).sum(0)
-                stat[1] += seen_v.sum(0)
-                rad = torch.maximum(rad, variables["max_2D_radius"])
+            if track:
+                with torch.no_grad():
+                    seen_v = aux["radii"] > 0                                    # [V,P]
+                    g2 = aux["means2D_grad"] if direct else aux["means2D"].grad
+                    if g2 is not None:
+                        stat[0] += (torch.norm(g2[0::2, :, :2], dim=-1) * seen_v).sum(0)
+                    stat[1] += seen_v.sum(0)
+                    rad = torch.maximum(rad, variables["max_2D_radius"])
             mine = []
         for data in mine:
             loss, variables = get_loss(self.params, data, variables, is_initial_timestep, self.weights)
             loss.backward()
             total += loss.detach()
-            with torch.no_grad():
-                seen = variables["seen"]
-                g2 = variables["means2D"].grad
-                if g2 is not None:
-                    stat[0] += torch.norm(g2[:, :2], dim=-1) * seen
-                stat[1] += seen
-                rad = torch.maximum(rad, variables["max_2D_radius"])
+            if track:
+                with torch.no_grad():
+                    seen = variables["seen"]
+                    g2 = variables["means2D"].grad
+                    if g2 is not None:
+                        stat[0] += torch.norm(g2[:, :2], dim=-1) * seen
+                    stat[1] += seen
+                    rad = torch.maximum(rad, variables["max_2D_radius"])
         self.bucket.all_reduce(self.group)
-        if self.world > 1:
-            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group)
-        with torch.no_grad():
-            if "means2D_gradient_accum" in variables:
-                variables["means2D_gradient_accum"] += stat[0]
-                variables["denom"] += stat[1]
-            variables["max_2D_radius"] = rad
-            variables["seen"] = stat[1] > 0
+        if track:
+            if self.world > 1:
+                dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group)
+            with torch.no_grad():
+                if "means2D_gradient_accum" in variables:
+                    variables["means2D_gradient_accum"] += stat[0]
+                    variables["denom"] += stat[1]
+                variables["max_2D_radius"] = rad
+                variables["seen"] = stat[1] > 0
+        else:   # the per-rank values get_loss left behind would differ between replicas: put the shared ones back
+            for k, v in zip(("max_2D_radius", "seen"), untouched):
+                if v is not None:
+                    variables[k] = v
+                else:
+                    variables.pop(k, None)
         if self.density_control is not None and is_initial_timestep and iteration is not None and self.optimizer is not None:
             # between backward and the optimiser step, as in /root/reference/src/tracking/train_gs.py:31-37
             from .densify import densify

@@ -148,6 +148,15 @@ def _view_colours(params, variables, V: int, frozen: bool):
     return hit[1]
 
 
+def _radius_bookkeeping(variables, rad):
+    """``max_2D_radius`` / ``seen`` of /root/reference/src/tracking/train_utils.py:243-245 for the colour renders ``rad`` [V,P].
+    Their only reader is the density control, which runs in the first timestep only (train_gs.py:31-37), so the direct step
+    (``loss_and_grads_views``) skips these five small kernels at t > 0; ``get_loss`` / ``get_loss_views`` keep the reference's behaviour."""
+    m2r = variables["max_2D_radius"]
+    variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))
+    variables["seen"] = (rad > 0).any(0)
+
+
 def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights, frozen_colours: bool = False):
     """``get_loss`` for several cameras at once, equal to the SUM of the per-camera ``get_loss`` values, with ONE
     rasterizer call: the colour and the segmentation render of every camera (2 V renders) share the Gaussians'
@@ -179,9 +188,7 @@ def get_loss_views(params, datas, variables, is_initial_timestep: bool, w: LossW
         shared, _ = _shared_terms(params, rendervar, variables, weights, scale=float(V))   # every per-camera get_loss adds them once
         total = total + shared
     rad = radii[0::2]                                                             # colour renders
-    m2r = variables["max_2D_radius"]
-    variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))
-    variables["seen"] = (rad > 0).any(0)
+    _radius_bookkeeping(variables, rad)
     variables["means2D"] = m2
     return total, variables, dict(means2D=m2, radii=rad)
 
@@ -246,9 +253,8 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
         if params[k].requires_grad:
             _acc_grad(params[k], g)
     rad = radii[0::2]
-    m2r = variables["max_2D_radius"]
-    variables["max_2D_radius"] = torch.maximum(m2r, rad.max(0).values.to(m2r.dtype))
-    variables["seen"] = (rad > 0).any(0)
+    if is_initial_timestep:
+        _radius_bookkeeping(variables, rad)
     return total, variables, dict(means2D_grad=d2, radii=rad)
 
 

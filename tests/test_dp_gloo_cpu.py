@@ -73,7 +73,7 @@ def _worker(rank, world, port, out_dir):
     from gsdyn.dp import ViewShardedStep, shard_views
     params, views, rig = _make_problem()
     opt = initialize_optimizer(params, scene_radius=4.0)
-    stepper = ViewShardedStep(params, opt, LossWeights())
+    stepper = ViewShardedStep(params, opt, LossWeights(), density_stats=True)   # exercise the statistics collectives at t > 0 too
     assert shard_views(V, rank, world) == list(range(rank, V, world))
     variables = _variables(rig)
     before = {k: p.detach().clone() for k, p in params.items()}
@@ -107,7 +107,7 @@ def test_view_sharded_step_world2(tmp_path):
     from gsdyn.dp import ViewShardedStep
     params, views, rig = _make_problem()
     opt = initialize_optimizer(params, scene_radius=4.0)
-    stepper = ViewShardedStep(params, opt, LossWeights())
+    stepper = ViewShardedStep(params, opt, LossWeights(), density_stats=True)
     variables = _variables(rig)
     total, variables = stepper(views, variables, is_initial_timestep=False)
     flat = stepper.bucket.pack().numpy()    # a single rank never packs by itself

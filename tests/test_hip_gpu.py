@@ -890,7 +890,8 @@ def test_direct_step_equals_autograd_step(dev, initial):
     for k in ga:
         assert (ga[k] - gb[k]).abs().max().item() <= 1e-6 * ga[k].abs().max().item() + 1e-20, k
     assert (m2a - aux_b["means2D_grad"]).abs().max().item() <= 1e-6 * m2a.abs().max().item() + 1e-20
-    assert torch.equal(var_a["max_2D_radius"], var_b["max_2D_radius"]) and torch.equal(var_a["seen"], var_b["seen"])
+    if initial:   # the direct step keeps the densification bookkeeping for the first timestep only (its only reader)
+        assert torch.equal(var_a["max_2D_radius"], var_b["max_2D_radius"]) and torch.equal(var_a["seen"], var_b["seen"])
     # a second call accumulates
     loss_and_grads_views(params, views, fresh_variables(), initial, w)
     assert (params["means3D"].grad - 2 * ga["means3D"]).abs().max().item() <= 1e-5 * ga["means3D"].abs().max().item()
