@@ -222,6 +222,11 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
     if not m3.is_cuda or 2 * V > _hip.MAX_BATCH:
         raise RuntimeError("loss_and_grads_views: needs a HIP device and at most %d cameras per call" % (_hip.MAX_BATCH // 2))
     rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
+    shared = terms = work = w5 = None
+    if not is_initial_timestep:   # enqueued FIRST: the GPU works through it while the host prepares the rasterizer call
+        shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
+        w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
+        terms, work = _hip.shared_terms_forward(m3, rot, shared, w5)
     cams = [d["cam"] for d in datas for _ in (0, 1)]
     colours = _view_colours(params, variables, V, True)
     ims, radii, _depth, states = _hip.rasterize_forward_batch(cams, m3, op, colours, None, sc, rot, None, prepare_backward=True)
@@ -235,11 +240,7 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
     one = _ONES.get(dev)
     if one is None:
         one = _ONES[dev] = torch.ones((1,), dtype=torch.float32, device=dev)
-    shared = None
-    if not is_initial_timestep:
-        shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
-        w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
-        terms, work = _hip.shared_terms_forward(m3, rot, shared, w5)
+    if shared is not None:
         total = total + terms[5]
     # ---- backward, in reverse
     d_ims, d_cm, d_cc = _hip.views_loss_backward(lstate, ims, cam_m, cam_c, one, 0.8, 0.2)
