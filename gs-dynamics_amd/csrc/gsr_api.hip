@@ -73,7 +73,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
-  o.shares_lists = 0; o.fused_alias = 0;
+  o.shares_lists = 0; o.fused_alias = 0; o.D_dev = nullptr;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
   o.offsets = g.offsets;
@@ -163,6 +163,15 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
   }
   if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
     return rc;
+  if (!num_rendered_host) {   // capacity mode: the counts stay on the device (emit_entries adds the block sums up itself)
+    if (!gsr_host_block_scan(P))
+      for (int v = 0; v < V; ++v) {
+        GeomState g;
+        gsr_carve_geom(geom_states[v], P, &g);
+        if (int rc = gsr_launch_scan_exclusive(sums + (size_t)v * nblk, g.block_offsets, nblk, g.counters, st)) return rc;
+      }
+    return 0;
+  }
   uint32_t* host = pinned_sums();
   if (!host) { gsr_set_error("gsr forward: pinned host allocation failed"); return -1; }
   if (gsr_host_block_scan(P)) {
@@ -201,7 +210,8 @@ int check_geometry_of(int V, const int32_t* geometry_of) {
 }
 int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
            void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
-           const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st) {
+           const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st,
+           uint32_t* counts_dev = nullptr) {   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
@@ -237,8 +247,11 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     }
     bt.v[v].fused_alias = (uint32_t)fused[v];
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
+    if (counts_dev && owner == v) bt.v[v].D_dev = g.offsets + P;
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
+  if (counts_dev)
+    if (int rc = gsr_launch_gather_counts(bt, P, counts_dev, st)) return rc;
   return gsr_launch_render_fwd(rt, st);
 }
 }  // namespace
@@ -374,6 +387,34 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   if (!fits) return 1;
   return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
                 b.queue, geometry_of, (hipStream_t)stream);
+}
+
+int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                               const float* rotations, const float* opacities, const float* colors_precomp,
+                               const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                               void* const* geom_states, int32_t* const* radii, void* const* binning_states,
+                               const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
+                               const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                               uint32_t* counts_dev, void* stream) {
+  if (int rc = check_batch("gsr_forward_batch_capacity", V, s, batch_state)) return rc;
+  if (int rc = check_geometry_of(V, geometry_of)) return rc;
+  if (!geom_states || !radii || !binning_states || !capacity_entries || !image_states || !out_color || !out_depth || !counts_dev) {
+    gsr_set_error("gsr_forward_batch_capacity: NULL argument");
+    return -2;
+  }
+  if (P <= 0) { gsr_set_error("gsr_forward_batch_capacity: P must be positive (use gsr_forward_batch)"); return -2; }
+  for (int v = 0; v < V; ++v) {
+    const bool owner = !geometry_of || geometry_of[v] == v;
+    if (capacity_entries[v] == 0 || (owner && !binning_states[v])) { gsr_set_error("gsr_forward_batch_capacity: view %d has no capacity / binning state", v); return -2; }
+    if (!owner && capacity_entries[v] != capacity_entries[geometry_of[v]]) { gsr_set_error("gsr_forward_batch_capacity: view %d must have its owner's capacity", v); return -2; }
+  }
+  BatchState b;
+  gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
+                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream))
+    return rc;
+  return stage2(V, s, P, capacity_entries, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
+                b.queue, geometry_of, (hipStream_t)stream, counts_dev);
 }
 
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
@@ -545,6 +586,15 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
   return gsr_launch_shared_terms_bwd(P, n_fg, K, n_bg, means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight,
                                      neighbor_dist, prev_inv_rot_fg, prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total,
                                      rev_ptr, rev_edge, scratch, d_means3D, d_rotations, flags, (hipStream_t)stream);
+}
+
+int gsr_radius_bookkeeping(int32_t V, int32_t view_step, int32_t P, const int32_t* radii, float* max_2D_radius, uint8_t* seen,
+                           void* stream) {
+  if (V < 0 || view_step <= 0 || P < 0 || (V > 0 && P > 0 && (!radii || !max_2D_radius || !seen))) {
+    gsr_set_error("gsr_radius_bookkeeping: bad argument");
+    return -2;
+  }
+  return gsr_launch_radius_bookkeeping(V, view_step, P, radii, max_2D_radius, seen, (hipStream_t)stream);
 }
 
 int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* stream) {

@@ -80,6 +80,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exclusive_kernel(const uint
   }
 }
 
+// Entry count and radix block count of a view: from the table (the host knows D), or -- capacity mode, no host round trip --
+// from the device word emit_entries wrote, clamped to the capacity the buffers were sized for (an overflowing view renders a
+// truncated list without touching memory it does not own; the host learns the true count later and repeats the call).
+__device__ __forceinline__ uint32_t bin_entries(const GsrBinView& vw) { return vw.D_dev ? min(vw.D_dev[0], vw.D) : vw.D; }
+__device__ __forceinline__ uint32_t bin_blocks(const GsrBinView& vw, uint32_t D) {
+  return vw.D_dev ? (D == 0 ? 1u : (D + GSR_RADIX_EPB - 1) / GSR_RADIX_EPB) : vw.nblocks;
+}
+
 // ------------------------------------------------------------------ emit (duplicateWithKeys)
 // Block b owns Gaussians [256b, 256b+256).  Its first entry offset comes from the scan of the preprocess
 // block sums; the per-Gaussian offsets inside the block are scanned here in LDS and written out once
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
   if (g0 + tid == P - 1) offsets[P] = excl + mine;
   __syncthreads();
   if (vw.shares_lists) return;   // the lists come from the view with the same camera: only offsets were needed here
-  const uint32_t begin = soff[0], end = soff[GSR_BLOCK];
+  const uint32_t begin = soff[0];
+  const uint32_t end = vw.D_dev ? min(soff[GSR_BLOCK], vw.D) : soff[GSR_BLOCK];   // capacity mode: never past the buffers
   for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
     int lo = 0, hi = GSR_BLOCK;  // invariant: soff[lo] <= e < soff[hi]
 #pragma unroll
@@ -170,9 +179,10 @@ __device__ __forceinline__ uint64_t match_peers(uint32_t digit, bool valid, int 
 // Per-block digit histogram, block-major: block_hist[block * nbins + bin] (a coalesced row per block).
 __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(GsrBinViews tab, int cur, int shift, int bits) {
   const GsrBinView& vw = tab.v[blockIdx.y];
-  if (blockIdx.x >= vw.nblocks || vw.D == 0) return;   // grid.x is the maximum over the views
+  if (vw.D == 0) return;
+  const uint32_t D = bin_entries(vw);
+  if (D == 0 || blockIdx.x >= bin_blocks(vw, D)) return;   // grid.x is the maximum over the views (or their capacities)
   const uint32_t* __restrict__ tkey = vw.tkey[cur];
-  const uint32_t D = vw.D;
   uint32_t* __restrict__ block_hist = vw.block_hist;
   __shared__ uint32_t hist[256];
   const int tid = threadIdx.x;
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(1024) void radix_colscan_kernel(GsrBinViews tab, in
   __shared__ uint32_t carry_s;
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (vw.D == 0) return;
-  const uint32_t nb = 1u << bits, bin = blockIdx.x, nblocks = vw.nblocks;
+  const uint32_t Dv = bin_entries(vw);
+  if (Dv == 0) return;
+  const uint32_t nb = 1u << bits, bin = blockIdx.x, nblocks = bin_blocks(vw, Dv);
   uint32_t* __restrict__ hist = vw.block_hist;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) carry_s = 0;
@@ -230,12 +242,13 @@ __global__ __launch_bounds__(1024) void radix_colscan_kernel(GsrBinViews tab, in
 // order, 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
 __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits, int prescanned) {
   const GsrBinView& vw = tab.v[blockIdx.y];
-  if (blockIdx.x >= vw.nblocks || vw.D == 0) return;
+  if (vw.D == 0) return;
+  const uint32_t D = bin_entries(vw), nblocks = bin_blocks(vw, D);
+  if (D == 0 || blockIdx.x >= nblocks) return;
   const uint32_t* __restrict__ tkey_in = vw.tkey[cur];
   const uint64_t* __restrict__ dg_in = vw.dg[cur];
   uint32_t* __restrict__ tkey_out = vw.tkey[cur ^ 1];
   uint64_t* __restrict__ dg_out = vw.dg[cur ^ 1];
-  const uint32_t D = vw.D, nblocks = vw.nblocks;
   const uint32_t* __restrict__ block_hist = vw.block_hist;
   __shared__ uint32_t wcount[4][256];
   __shared__ uint32_t s_tot[4][256];   // per-wave partial: total count of each bin over all blocks
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab,
   const GsrBinView& vw = tab.v[blockIdx.y];
   const uint32_t* __restrict__ tkey = vw.tkey[cur];
   uint2* __restrict__ ranges = vw.ranges;
-  const uint32_t D = vw.D;
+  const uint32_t D = bin_entries(vw);
   uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   if (i >= D) return;
   uint32_t t = tkey[i];
@@ -796,6 +809,19 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st) {
   { GSR_PROF("tile_order", st);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+namespace {
+__global__ void gather_counts_kernel(GsrBinViews tab, int P, uint32_t* __restrict__ out) {
+  const int v = threadIdx.x;
+  if (v < tab.V) out[v] = tab.v[v].offsets[P];
+}
+}  // namespace
+
+int gsr_launch_gather_counts(const GsrBinViews& tab, int P, uint32_t* counts_dev, hipStream_t st) {
+  hipLaunchKernelGGL(gather_counts_kernel, dim3(1), dim3(64), 0, st, tab, P, counts_dev);
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

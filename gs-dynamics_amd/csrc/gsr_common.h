@@ -159,7 +159,8 @@ struct GsrBinView {            // emit .. tile_sort
   uint32_t* offsets;
   uint32_t* tkey[2]; uint64_t* dg[2]; uint32_t* point_list; uint32_t* block_hist;
   uint2* ranges;
-  uint32_t D, nblocks;
+  uint32_t D, nblocks;     // entries and radix blocks of the view -- or, with D_dev set, the CAPACITY the buffers were sized for
+  const uint32_t* D_dev;   // != nullptr: the entry count lives on the device (offsets[P], written by emit_entries): no host round trip
   uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
   uint32_t fused_alias;    // 1: additionally blended INSIDE its owner's tile pass (GsrRenderView::partner): no tickets for its busy tiles
 };
@@ -197,7 +198,8 @@ int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, cons
                           const float* shs, const float* cov3D_precomp, hipStream_t st);
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
 int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
-int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);   // uses only V, T, order, queue, v[].ranges, v[].fused_alias
+int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);
+int gsr_launch_gather_counts(const GsrBinViews& tab, int P, uint32_t* counts_dev, hipStream_t st);   // counts_dev[v] = offsets_v[P]   // uses only V, T, order, queue, v[].ranges, v[].fused_alias
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
@@ -255,6 +257,7 @@ int gsr_launch_activate_fwd(int P, const float* unnorm, const float* logit, cons
 int gsr_launch_activate_bwd(int P, const float* unnorm, const float* op, const float* sc, const float* d_rot, const float* d_op,
                             const float* d_sc, float* d_unnorm, float* d_logit, float* d_logs, hipStream_t st);
 int gsr_shared_terms_point_blocks(int nfg, int nbg);
+int gsr_launch_radius_bookkeeping(int V, int step, int P, const int32_t* radii, float* max_2d, uint8_t* seen, hipStream_t st);
 int gsr_launch_adam_step(int n_tensors, const gsr_adam_tensor* t, hipStream_t st);
 int gsr_launch_shared_terms_fwd(int nfg, int K, int nbg, const float* means3D, const float* rot, const int64_t* fg_idx,
                                 const int64_t* bg_idx, const int64_t* nbr, const float* nw, const float* nd, const float* prev_inv,

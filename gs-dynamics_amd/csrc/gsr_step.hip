@@ -184,6 +184,18 @@ __global__ __launch_bounds__(ST_BLOCK) void adam_step_kernel(AdamTab tab) {
   }
 }
 
+// max_2D_radius[i] = max(max_2D_radius[i], max_v radii[v][i]);  seen[i] = any_v radii[v][i] > 0   over the rows v = 0, step, 2 step, ...
+// of a [V,P] int32 array (the colour renders of a step): the bookkeeping of /root/reference/src/tracking/train_utils.py:243-245.
+__global__ __launch_bounds__(ST_BLOCK) void radius_bookkeeping_kernel(int V, int step, int P, const int32_t* __restrict__ radii,
+                                                                      float* __restrict__ max_2d, uint8_t* __restrict__ seen) {
+  const int i = blockIdx.x * ST_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  int m = 0;
+  for (int v = 0; v < V; v += step) m = max(m, radii[(size_t)v * P + i]);
+  max_2d[i] = fmaxf(max_2d[i], (float)m);
+  seen[i] = m > 0 ? 1 : 0;
+}
+
 inline int blocks_for(int n) { return (n + ST_BLOCK - 1) / ST_BLOCK; }
 
 }  // namespace
@@ -274,6 +286,14 @@ int gsr_launch_adam_step(int n_tensors, const gsr_adam_tensor* t, hipStream_t st
   if (blocks == 0) return 0;
   { GSR_PROF("adam_step", st);
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(ST_BLOCK), 0, st, tab); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_radius_bookkeeping(int V, int step, int P, const int32_t* radii, float* max_2d, uint8_t* seen, hipStream_t st) {
+  if (P <= 0 || V <= 0) return 0;
+  { GSR_PROF("radius_bookkeeping", st);
+    hipLaunchKernelGGL(radius_bookkeeping_kernel, dim3(blocks_for(P)), dim3(ST_BLOCK), 0, st, V, step, P, radii, max_2d, seen); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -61,12 +61,13 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
+           "gsr_forward_batch_capacity",
            "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
-           "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step")
+           "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping")
 
 
 def load_library():
@@ -106,6 +107,9 @@ def load_library():
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, C.POINTER(i32), PV, PV]
                                        + [vp, PV, vp, PV, vp, vp, vp, vp, vp])
+    lib.gsr_forward_batch_capacity.restype = C.c_int
+    lib.gsr_forward_batch_capacity.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(u32), PV, vp,
+                                               C.POINTER(i32), PV, PV, vp, vp])
     lib.gsr_image_loss_blocks.restype = i32
     lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
     lib.gsr_image_loss_forward.restype = C.c_int
@@ -132,6 +136,8 @@ def load_library():
     lib.gsr_activate_forward.argtypes = [i32] + [vp] * 7
     lib.gsr_activate_backward.restype = C.c_int
     lib.gsr_activate_backward.argtypes = [i32] + [vp] * 10
+    lib.gsr_radius_bookkeeping.restype = C.c_int
+    lib.gsr_radius_bookkeeping.argtypes = [i32, i32, i32, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [i32, C.POINTER(GsrAdamTensor), vp]
     lib.gsr_rigidity_blocks.restype = i32
@@ -167,8 +173,49 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_pinned_stream = None    # (device index, handle) while a caller holds the stream fixed over several library calls
+
+
 def _stream(dev: torch.device):
+    p = _pinned_stream
+    if p is not None and p[0] == dev.index:
+        return p[1]
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class hold_stream:
+    """``with hold_stream(dev):`` -- look the current stream up once for a sequence of library calls on it (the lookup costs
+    ~5 us per call through torch; the direct tracking step makes ten calls).  Do not change streams inside the block."""
+
+    def __init__(self, dev: torch.device):
+        self.dev = dev
+
+    def __enter__(self):
+        global _pinned_stream
+        self.prev = _pinned_stream
+        _pinned_stream = (self.dev.index, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        return self
+
+    def __exit__(self, *exc):
+        global _pinned_stream
+        _pinned_stream = self.prev
+        return False
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(dev: torch.device):
+    """``torch.cuda.device(dev)`` only when dev is not already the current device (the context manager costs ~8 us)."""
+    return _NULL if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
 _settings_cache = {}   # id(tensor) -> (weakref, version, contiguous fp32 copy on the render device)
@@ -197,7 +244,8 @@ def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Ten
 
 class RasterState:
     """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
-    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch", "geometry_of")
+    __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch", "geometry_of",
+                 "pending")
 
 
 def _make_settings(rs, dev, sh_coeffs: int):
@@ -228,7 +276,7 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
     P = int(means3D.shape[0])
     H, W = int(rs.image_height), int(rs.image_width)
     M = 0 if shs is None else int(shs.shape[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         s, keep = _make_settings(rs, dev, M)
         u8 = dict(dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -259,7 +307,7 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
     P, D = state.P, state.num_rendered
     M = 0 if shs is None else int(shs.shape[1])
     f32 = dict(dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = grad_color.to(**f32).contiguous()
         d_means3D = torch.empty((P, 3), **f32)
         d_means2D = torch.empty((P, 3), **f32)
@@ -279,6 +327,9 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
 
 
 MAX_BATCH = 16           # GSR_MAX_BATCH of include/gsr.h: views per library call
+_counts_slots = {}       # (device, V) -> (pinned int32[V], event) of the capacity-mode forward; one call in flight per slot
+_entries_capacity = {}   # (device, P, H, W) -> list entries per view the capacity-mode forward sizes its buffers for
+_ENTRIES_SLACK = 1.5
 _binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
 _scratch_capacity = {}   # same key -> bytes per view of backward scratch
 _BINNING_SLACK = 1.25
@@ -305,7 +356,7 @@ def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False
 
 
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                            prepare_backward: bool = False):
+                            prepare_backward: bool = False, no_host_sync: bool = False):
     """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V])."""
     lib = load_library()
     _require_device(means3D)
@@ -316,7 +367,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
     if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
         raise ValueError("rasterize_forward_batch: all views must share the image size")
     M = 0 if shs is None else int(shs.shape[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         sarr = (GsrSettings * V)()
         keeps = []
         for v, rs in enumerate(settings_list):
@@ -345,6 +396,46 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             geo.append(first.setdefault(k, v))
         geometry_of = (C.c_int32 * V)(*geo) if any(g != v for v, g in enumerate(geo)) else None
         owner = [geometry_of is None or geo[v] == v for v in range(V)]
+        cap_e = _entries_capacity.get(key, 0) if (no_host_sync and shs is None and P > 0) else 0
+        if cap_e:
+            # Capacity mode (gsr_forward_batch_capacity): no host wait inside the forward.  Buffers are sized for cap_e entries per
+            # view; the true counts come back through a pinned copy that `forward_counts_ok` inspects later.  The caller must not
+            # let anything of this call escape before that check (gsdyn.step.loss_and_grads_views repeats the call on overflow).
+            bbytes = int(lib.gsr_binning_bytes(cap_e, H, W))
+            binnings = [torch.empty((bbytes,), **u8) if owner[v] else None for v in range(V)]
+            pre = None
+            if prepare_backward:
+                pre = _alloc_backward(dev, V, P, [int(lib.gsr_backward_scratch_bytes(P, cap_e))] * V, cov3D_precomp is None,
+                                      colors_precomp is not None and colors_precomp.dim() == 3)
+            color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
+            per_view_col = colors_precomp is not None and colors_precomp.dim() == 3
+            if per_view_col and colors_precomp.shape[0] != V:
+                raise ValueError("rasterize_forward_batch: per-view colours must be [V,P,3]")
+            col_views = _ptr_array([colors_precomp[v] for v in range(V)]) if per_view_col else None
+            counts_dev = torch.empty((V,), dtype=torch.int32, device=dev)
+            capv = (C.c_uint32 * V)(*([cap_e] * V))
+            _check(lib.gsr_forward_batch_capacity(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                                  _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
+                                                  _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
+                                                  capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
+                                                  _ptr_array(depth_v), _ptr(counts_dev), st), "gsr_forward_batch_capacity")
+            slot = _counts_slots.get((dev.index, V))
+            if slot is None:      # pinned staging + event, allocated once (hipHostMalloc costs tens of microseconds)
+                slot = _counts_slots[(dev.index, V)] = (torch.empty((V,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            counts_host, ev = slot
+            counts_host.copy_(counts_dev, non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            states = []
+            for v in range(V):
+                state = RasterState()
+                state.settings, state.keep, state.P, state.num_rendered = sarr[v], keeps[v], P, int(cap_e)   # capacities fix the layouts
+                state.geom, state.binning, state.image, state.H, state.W = geoms[v], binnings[v], images[v], H, W
+                state.pre = pre if v == 0 else None
+                state.batch = batch if v == 0 else None
+                state.geometry_of = geometry_of if v == 0 else None
+                state.pending = (ev, counts_host, counts_dev, int(cap_e), key) if v == 0 else None
+                states.append(state)
+            return color, radii, depth, states
         binnings = [torch.empty((cap,), **u8) if (cap and owner[v]) else None for v in range(V)]
         caps = (C.c_size_t * V)(*([cap] * V))
         pre = None
@@ -369,6 +460,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
                                                 _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), st),
                    "gsr_forward_render_batch")
+        _entries_capacity[key] = max(int(max(Ds[v] for v in range(V)) * _ENTRIES_SLACK), 1024)
         if rc == 1 or need * 2 < cap:
             _binning_capacity[key] = int(need * _BINNING_SLACK)
             _scratch_capacity[key] = int(max(lib.gsr_backward_scratch_bytes(P, Ds[v]) for v in range(V)) * _BINNING_SLACK)
@@ -382,8 +474,23 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         state.pre = pre if v == 0 else None
         state.batch = batch if v == 0 else None
         state.geometry_of = geometry_of if v == 0 else None
+        state.pending = None
         states.append(state)
     return color, radii, depth, states
+
+
+def forward_counts_ok(states) -> bool:
+    """After a capacity-mode forward: wait for its entry counts (long since on the host when the caller did anything in
+    between), remember them for the next call's capacity, and tell whether every view fitted.  True for a synchronous forward."""
+    pending = states[0].pending
+    if pending is None:
+        return True
+    ev, counts_host, _counts_dev, cap_e, key = pending
+    ev.synchronize()
+    top = int(counts_host.max())
+    _entries_capacity[key] = max(int(top * _ENTRIES_SLACK), 1024)
+    states[0].pending = None
+    return top <= cap_e
 
 
 def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
@@ -400,7 +507,7 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
                 for v in range(V)]
         sm = lambda k: None if outs[0][k] is None else torch.stack([o[k] for o in outs]).sum(0)  # noqa: E731
         return sm(0), torch.stack([o[1] for o in outs]), None, sm(3), sm(4), sm(5), sm(6), sm(7)
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = grad_color.to(**f32).contiguous()
         sarr = (GsrSettings * V)()
         Ds = (C.c_uint32 * V)()
@@ -437,7 +544,7 @@ def rigidity_forward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_off
     _require_device(means3D)
     dev = means3D.device
     nfg, K = int(nbr.shape[0]), int(nbr.shape[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         nb = int(lib.gsr_rigidity_blocks(nfg))
         part = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)
         if nb == 0:
@@ -452,7 +559,7 @@ def rigidity_backward(means3D, rotations, fg_idx, nbr, nw, nd, prev_inv, prev_of
     lib = load_library()
     dev = means3D.device
     nfg, K = int(nbr.shape[0]), int(nbr.shape[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         scratch = torch.empty((7 * (nfg + nfg * K),), dtype=torch.float32, device=dev)
         d_m = torch.zeros_like(means3D)
         d_r = torch.zeros_like(rotations)
@@ -477,7 +584,7 @@ def shared_terms_forward(means3D, rotations, v, weights5):
     nfg, K = (int(d) for d in v["neighbor_indices"].shape)
     nbg = int(v["bg_idx"].shape[0])
     w5 = (C.c_float * 5)(*[float(x) for x in weights5])
-    with torch.cuda.device(dev):
+    with _on(dev):
         n = max(int(lib.gsr_shared_terms_partials(nfg, nbg)), int(lib.gsr_shared_terms_scratch(nfg, K)), 1)
         work = torch.empty((n,), dtype=torch.float32, device=dev)
         terms = torch.empty((6,), dtype=torch.float32, device=dev)
@@ -494,7 +601,7 @@ def shared_terms_backward(means3D, rotations, v, weights5, grad_total, accumulat
     nfg, K = (int(d) for d in v["neighbor_indices"].shape)
     nbg = int(v["bg_idx"].shape[0])
     w5 = (C.c_float * 5)(*[float(x) for x in weights5])
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
         need = max(int(lib.gsr_shared_terms_scratch(nfg, K)), 1)
         flags = 1 if accumulate_into is not None else 0
@@ -514,7 +621,7 @@ def activate_forward(unnorm_rotations, logit_opacities, log_scales):
     _require_device(unnorm_rotations)
     dev = unnorm_rotations.device
     P = int(unnorm_rotations.shape[0])
-    with torch.cuda.device(dev):
+    with _on(dev):
         rot, op, sc = torch.empty_like(unnorm_rotations), torch.empty_like(logit_opacities), torch.empty_like(log_scales)
         _check(lib.gsr_activate_forward(P, _ptr(unnorm_rotations), _ptr(logit_opacities), _ptr(log_scales), _ptr(rot), _ptr(op), _ptr(sc),
                                         _stream(dev)), "gsr_activate_forward")
@@ -525,13 +632,25 @@ def activate_backward(unnorm_rotations, opacities, scales, d_rot, d_op, d_sc):
     lib = load_library()
     dev = unnorm_rotations.device
     P = int(unnorm_rotations.shape[0])
-    with torch.cuda.device(dev):
+    with _on(dev):
         d_u, d_l, d_s = torch.empty_like(unnorm_rotations), torch.empty_like(opacities), torch.empty_like(scales)
         c = lambda t: None if t is None else t.contiguous()   # noqa: E731
         d_rot, d_op, d_sc = c(d_rot), c(d_op), c(d_sc)
         _check(lib.gsr_activate_backward(P, _ptr(unnorm_rotations), _ptr(opacities), _ptr(scales), _ptr(d_rot), _ptr(d_op), _ptr(d_sc),
                                          _ptr(d_u), _ptr(d_l), _ptr(d_s), _stream(dev)), "gsr_activate_backward")
     return d_u, d_l, d_s
+
+
+def radius_bookkeeping(radii, view_step, max_2D_radius):
+    """In-place max_2D_radius update and the ``seen`` mask (bool [P]) from the rows 0, view_step, ... of radii[V,P] (int32)."""
+    lib = load_library()
+    dev = radii.device
+    V, P = (int(d) for d in radii.shape)
+    with _on(dev):
+        seen = torch.empty((P,), dtype=torch.bool, device=dev)
+        _check(lib.gsr_radius_bookkeeping(V, int(view_step), P, _ptr(radii), _ptr(max_2D_radius), _ptr(seen), _stream(dev)),
+               "gsr_radius_bookkeeping")
+    return seen
 
 
 def adam_step(entries):
@@ -541,7 +660,7 @@ def adam_step(entries):
     if not entries:
         return
     dev = entries[0][0].device
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = _stream(dev)
         for lo in range(0, len(entries), ADAM_MAX_TENSORS):
             chunk = entries[lo:lo + ADAM_MAX_TENSORS]
@@ -576,7 +695,7 @@ def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat)
     P, nb = int(xyz.shape[0]), int(bones.shape[0])
     f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
     bones, rotations, translations, bone_quats = f(bones), f(rotations).reshape(nb, 9), f(translations), f(bone_quats)
-    with torch.cuda.device(dev):
+    with _on(dev):
         out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None
         _check(lib.gsr_lbs(P, nb, _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
@@ -589,7 +708,7 @@ def mark_visible(positions, viewmatrix) -> torch.Tensor:
     _require_device(positions)
     dev = positions.device
     P = int(positions.shape[0])
-    with torch.cuda.device(dev):
+    with _on(dev):
         pos = positions.to(dtype=torch.float32).contiguous()
         vm = _dev_f32(viewmatrix, dev, 16, "viewmatrix")
         present = torch.zeros((P,), dtype=torch.uint8, device=dev)
@@ -628,7 +747,7 @@ def debug_views(state: RasterState):
 def selftest(device=None) -> int:
     lib = load_library()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    with torch.cuda.device(dev):
+    with _on(dev):
         return int(lib.gsr_selftest(_stream(dev)))
 
 
@@ -656,7 +775,7 @@ def image_loss_forward(window11, pred, target):
     N = int(pred.shape[0]) if batched else 1
     Cc, H, W = (int(d) for d in pred.shape[-3:])
     win = (C.c_float * 11)(*[float(v) for v in window11])
-    with torch.cuda.device(dev):
+    with _on(dev):
         nb = int(lib.gsr_image_loss_blocks(N * Cc, H, W))
         f32 = dict(dtype=torch.float32, device=dev)
         fA, fC, fE = (torch.empty(tuple(pred.shape), **f32) for _ in range(3))
@@ -665,6 +784,17 @@ def image_loss_forward(window11, pred, target):
                                           _ptr(part[1]), _stream(dev)), "gsr_image_loss_forward")
     sums = part.view(2, N, nb // N).sum(2)          # block partials are channel-major: contiguous per image
     return (sums[0], sums[1], fA, fC, fE) if batched else (sums[0, 0], sums[1, 0], fA, fC, fE)
+
+
+_win_cache = {}
+
+
+def _window(window11):
+    key = tuple(window11)
+    w = _win_cache.get(key)
+    if w is None:
+        w = _win_cache[key] = (C.c_float * 11)(*[float(v) for v in window11])
+    return w
 
 
 def _loss_table(targets, cam_rows, weights, channels):
@@ -691,9 +821,9 @@ def views_loss_forward(window11, renders, targets, cam_rows, weights, cam_m, cam
     for t in targets:
         if tuple(t.shape) != (Cc, H, W) or t.device != dev:
             raise RuntimeError("views_loss_forward: every target must be [C,H,W] on the renders' device")
-    win = (C.c_float * 11)(*[float(v) for v in window11])
+    win = _window(window11)
     tab = _loss_table(targets, cam_rows, weights, Cc)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nb = int(lib.gsr_views_loss_blocks(n, Cc, H, W))
         f32 = dict(dtype=torch.float32, device=dev)
         maps = torch.empty((3,) + tuple(renders.shape), **f32)
@@ -711,7 +841,7 @@ def views_loss_backward(state, renders, cam_m, cam_c, grad_total, w_l1, w_ssim, 
     win, tab, _targets, maps, part = state
     dev = renders.device
     _n, _Cc, H, W = (int(d) for d in renders.shape)
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = grad_total.to(dtype=torch.float32, device=dev).reshape(1)
         d_renders = torch.empty_like(renders)
         d_m = d_c = None
@@ -732,7 +862,7 @@ def image_loss_backward(window11, pred, target, fA, fC, fE, grad_loss, w_l1, w_s
     N = int(pred.shape[0]) if pred.dim() == 4 else 1
     Cc, H, W = (int(d) for d in pred.shape[-3:])
     win = (C.c_float * 11)(*[float(v) for v in window11])
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = grad_loss.to(dtype=torch.float32, device=dev).reshape(N).contiguous()
         d_pred = torch.empty_like(pred)
         _check(lib.gsr_image_loss_backward(win, N * Cc, H, W, _ptr(pred), _ptr(target), _ptr(fA), _ptr(fC), _ptr(fE), _ptr(g), Cc,

@@ -95,10 +95,16 @@ def calc_ssim(img1, img2, window_size: int = 11, size_average: bool = True):
 
 
 # ---------------------------------------------------------------------------------------------------- fused image term
+_WIN1D = {}
+
+
 def _window_1d(size: int = 11, sigma: float = 1.5):
     """The reference's normalised 1-D Gaussian (float32), /root/reference/src/tracking/external.py:54-69."""
-    g = torch.tensor([math.exp(-(i - size // 2) ** 2 / (2 * sigma ** 2)) for i in range(size)])
-    return (g / g.sum()).tolist()
+    w = _WIN1D.get((size, sigma))
+    if w is None:
+        g = torch.tensor([math.exp(-(i - size // 2) ** 2 / (2 * sigma ** 2)) for i in range(size)])
+        w = _WIN1D[(size, sigma)] = tuple((g / g.sum()).tolist())
+    return w
 
 
 class _FusedImageLoss(torch.autograd.Function):

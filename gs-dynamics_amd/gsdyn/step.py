@@ -206,7 +206,7 @@ def _acc_grad(p, g):
 
 
 @torch.no_grad()
-def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights):
+def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights, _no_host_sync: bool = True):
     """``get_loss_views(..., frozen_colours=True)`` followed by ``loss.backward()``, as a straight sequence of library calls
     (activations, rasterizer, image terms, shared terms and their backward passes in reverse) without the autograd engine:
     same kernels, same values, about a third of the host time -- which is what bounds the reference's own loop shape, one camera
@@ -221,41 +221,53 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
     dev = m3.device
     if not m3.is_cuda or 2 * V > _hip.MAX_BATCH:
         raise RuntimeError("loss_and_grads_views: needs a HIP device and at most %d cameras per call" % (_hip.MAX_BATCH // 2))
-    rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
-    shared = terms = work = w5 = None
-    if not is_initial_timestep:   # enqueued FIRST: the GPU works through it while the host prepares the rasterizer call
-        shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
-        w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
-        terms, work = _hip.shared_terms_forward(m3, rot, shared, w5)
-    cams = [d["cam"] for d in datas for _ in (0, 1)]
-    colours = _view_colours(params, variables, V, True)
-    ims, radii, _depth, states = _hip.rasterize_forward_batch(cams, m3, op, colours, None, sc, rot, None, prepare_backward=True)
-    ids = [int(d["id"]) for d in datas]
-    targets = [t for d in datas for t in (d["im"], d["seg"])]
-    rows = [r for i in ids for r in (i, -1)]
-    win = _window_1d()
-    cam_m, cam_c = params["cam_m"], params["cam_c"]
-    losses, lstate = _hip.views_loss_forward(win, ims, targets, rows, [w.im, w.seg] * V, cam_m, cam_c, 0.8, 0.2)
-    total = losses[-1]
-    one = _ONES.get(dev)
-    if one is None:
-        one = _ONES[dev] = torch.ones((1,), dtype=torch.float32, device=dev)
-    if shared is not None:
-        total = total + terms[5]
-    # ---- backward, in reverse
-    d_ims, d_cm, d_cc = _hip.views_loss_backward(lstate, ims, cam_m, cam_c, one, 0.8, 0.2)
-    d3, d2, _dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, d_ims, m3, radii, colours, None, sc, rot, None,
-                                                                              want_color_grad=False)
-    if shared is not None:
-        _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot), work=work)
-    d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
-    for k, g in (("means3D", d3), ("unnorm_rotations", d_un), ("logit_opacities", d_lo), ("log_scales", d_ls), ("cam_m", d_cm),
-                 ("cam_c", d_cc)):
-        if params[k].requires_grad:
-            _acc_grad(params[k], g)
+    with _hip.hold_stream(dev):        # one stream lookup for the ten library calls below
+        rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
+        shared = terms = work = w5 = None
+        if not is_initial_timestep:   # enqueued FIRST: the GPU works through it while the host prepares the rasterizer call
+            shared = {k: (variables[k] if variables[k].is_contiguous() else variables[k].contiguous()) for k in _SHARED_KEYS}
+            w5 = [float(V) * x for x in (w.rigid, w.rot, w.iso, w.floor, w.bg)]     # every per-camera get_loss adds them once
+            terms, work = _hip.shared_terms_forward(m3, rot, shared, w5)
+        cams = [d["cam"] for d in datas for _ in (0, 1)]
+        colours = _view_colours(params, variables, V, True)
+        # no host wait inside the forward when the capacity of the previous step is known: the entry counts are checked below, before
+        # anything is differentiated (the images never leave this function, so a forward that overflowed its buffers is simply redone)
+        ims, radii, _depth, states = _hip.rasterize_forward_batch(cams, m3, op, colours, None, sc, rot, None, prepare_backward=True,
+                                                                  no_host_sync=_no_host_sync)
+        ids = [int(d["id"]) for d in datas]
+        targets = [t for d in datas for t in (d["im"], d["seg"])]
+        rows = [r for i in ids for r in (i, -1)]
+        win = _window_1d()
+        cam_m, cam_c = params["cam_m"], params["cam_c"]
+        losses, lstate = _hip.views_loss_forward(win, ims, targets, rows, [w.im, w.seg] * V, cam_m, cam_c, 0.8, 0.2)
+        total = losses[-1]
+        one = _ONES.get(dev)
+        if one is None:
+            one = _ONES[dev] = torch.ones((1,), dtype=torch.float32, device=dev)
+        if shared is not None:
+            total = total + terms[5]
+        # ---- backward, in reverse
+        d_ims, d_cm, d_cc = _hip.views_loss_backward(lstate, ims, cam_m, cam_c, one, 0.8, 0.2)
+        # the image terms do not depend on the list sizes; the rasterizer's backward does (its scratch is sized by the capacity):
+        # look at the counts now -- the GPU still has the image-term kernels queued, so the host wait hides behind them
+        if not _hip.forward_counts_ok(states):     # more entries than the buffers were sized for (the scene grew by > 50 % in one step)
+            return loss_and_grads_views(params, datas, variables, is_initial_timestep, w, _no_host_sync=False)
+        d3, d2, _dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, d_ims, m3, radii, colours, None, sc, rot, None,
+                                                                                  want_color_grad=False)
+        if shared is not None:
+            _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot), work=work)
+        d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
+        for k, g in (("means3D", d3), ("unnorm_rotations", d_un), ("logit_opacities", d_lo), ("log_scales", d_ls), ("cam_m", d_cm),
+                     ("cam_c", d_cc)):
+            if params[k].requires_grad:
+                _acc_grad(params[k], g)
     rad = radii[0::2]
     if is_initial_timestep:
-        _radius_bookkeeping(variables, rad)
+        m2r = variables["max_2D_radius"]
+        if m2r.dtype == torch.float32 and m2r.is_contiguous() and radii.is_contiguous():
+            variables["seen"] = _hip.radius_bookkeeping(radii, 2, m2r)      # one kernel; max_2D_radius updated in place
+        else:
+            _radius_bookkeeping(variables, rad)
     return total, variables, dict(means2D_grad=d2, radii=rad)
 
 

@@ -132,6 +132,20 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
 /* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): ONE blend-backward launch
  * over the combined tile queue, then ONE per-Gaussian kernel that loops over the views and writes the
  * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */
+/* Capacity mode of gsr_forward_batch: NO host synchronisation.  The caller sizes every binning buffer for `capacity_entries[v]`
+ * list entries (gsr_binning_bytes(capacity_entries[v], H, W); a view with geometry_of[v] != v repeats its owner's capacity) and
+ * keeps passing those capacities as `num_rendered` to gsr_backward_batch (they fix the buffer layouts; scratch:
+ * gsr_backward_scratch_bytes(P, capacity)).  The true counts are written to counts_dev[V] (device) at the end of the call;
+ * a view whose count exceeds its capacity was rendered from a TRUNCATED list: the caller must read counts_dev before using
+ * anything of that call and repeat it with enough room (gsdyn/step.py: loss_and_grads_views does, its images never leave
+ * the library).  The kernels read the counts on the device (the word emit_entries leaves behind the offsets). */
+int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                               const float* rotations, const float* opacities, const float* colors_precomp,
+                               const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                               void* const* geom_states, int32_t* const* radii, void* const* binning_states,
+                               const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
+                               const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                               uint32_t* counts_dev, void* stream);
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
@@ -191,6 +205,12 @@ int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* 
 int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float* opacities, const float* scales,
                           const float* d_rotations, const float* d_opacities, const float* d_scales, float* d_unnorm_rotations,
                           float* d_logit_opacities, float* d_log_scales, void* stream);
+
+/* ---- densification bookkeeping of a step (/root/reference/src/tracking/train_utils.py:243-245), for rows 0, view_step, 2 view_step, ...
+ * of radii[V,P] (view_step = 2: the colour renders of a colour + segmentation batch):
+ *   max_2D_radius[i] = max(max_2D_radius[i], max_v radii[v][i]);   seen[i] = any_v radii[v][i] > 0   (one byte per Gaussian) */
+int gsr_radius_bookkeeping(int32_t V, int32_t view_step, int32_t P, const int32_t* radii, float* max_2D_radius, uint8_t* seen,
+                           void* stream);
 
 /* ---- optimiser step of the tracking loop: torch.optim.Adam's default update (no weight decay, no amsgrad, not maximising) for up
  * to GSR_ADAM_MAX_TENSORS parameter tensors in ONE launch.  The reference builds Adam with one parameter group per tensor

@@ -986,6 +986,61 @@ def test_fused_adam_equals_torch_adam(dev):
     oa.load_state_dict(ob.state_dict())                            # same state layout
 
 
+def test_direct_step_without_host_sync_and_its_overflow_path(dev):
+    """The direct step renders in capacity mode (gsr_forward_batch_capacity: buffers sized from the previous call, entry counts
+    read on the device, no host wait in the forward).  (1) Steady state: same loss and gradients as the synchronous autograd
+    step, bit for bit in the rasterizer's integers (radii) and within rounding in the floats.  (2) The scene grows by more than
+    the slack between two calls: the forward overflows its buffers, the step notices before differentiating and repeats itself
+    synchronously -- still the right answer."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import LossWeights, get_loss_views, loss_and_grads_views, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    P, W, H = 5000, 176, 144                       # a shape no other test uses: its capacity cache starts empty
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04)
+    cams = synth_ring_cameras(2, W, H, device=dev)
+    im_gt, seg_gt = synth_targets(W, H, device=dev)
+    w = LossWeights()
+    views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in (0, 1)]
+    key = (dev.index, P, H, W)
+    _hip._entries_capacity.pop(key, None)
+
+    def both():
+        for p_ in params.values():
+            p_.grad = None
+        la, _, aux_a = get_loss_views(params, views, init_variables(P, dev), True, w, frozen_colours=True)
+        la.backward()
+        ga = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+        for p_ in params.values():
+            p_.grad = None
+        lb, _, aux_b = loss_and_grads_views(params, views, init_variables(P, dev), True, w)
+        gb = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+        assert abs(float(la.detach()) - float(lb)) <= 1e-6 * abs(float(lb))
+        assert torch.equal(aux_a["radii"], aux_b["radii"])
+        for k in ga:
+            assert (ga[k] - gb[k]).abs().max().item() <= 1e-6 * ga[k].abs().max().item() + 1e-20, k
+    both()                                          # first call: no capacity yet -> synchronous; leaves one behind
+    cap1 = _hip._entries_capacity[key]
+    calls = []
+    orig = _hip.rasterize_forward_batch
+
+    def spy(*a_, **k_):
+        out = orig(*a_, **k_)
+        calls.append((bool(k_.get("no_host_sync")), out[3][0].pending is not None))
+        return out
+    _hip.rasterize_forward_batch = spy
+    try:
+        both()                                      # steady state: the direct step runs in capacity mode
+        assert (True, True) in calls
+        with torch.no_grad():
+            params["log_scales"].add_(0.9)          # every Gaussian 2.5x larger: far more list entries than the capacity
+        calls.clear()
+        both()
+        assert (True, True) in calls and (False, False) in calls     # overflowed, then repeated synchronously
+    finally:
+        _hip.rasterize_forward_batch = orig
+    assert _hip._entries_capacity[key] > cap1
+
+
 def test_views_loss_more_images_than_one_library_call(dev):
     """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
     from gsdyn import losses as L
