@@ -782,7 +782,8 @@ def test_fused_image_loss_matches_torch_formula(dev, H, W):
     rng = np.random.default_rng(H * 1000 + W)
     x = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=dev, requires_grad=True)
     y = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=dev)
-    ref = 0.8 * L.l1_loss_v1(x, y) + 0.2 * (1.0 - L.calc_ssim(x, y))
+    xd = x.double()                # fp64 reference: no timing-dependent MIOpen solver choice in the comparison
+    ref = 0.8 * L.l1_loss_v1(xd, y.double()) + 0.2 * (1.0 - L.calc_ssim(xd, y.double()))
     (gref,) = torch.autograd.grad(ref * 3.0, x)
     x2 = x.detach().clone().requires_grad_(True)
     got = L.image_loss(x2, y)
@@ -831,7 +832,8 @@ def test_views_loss_matches_torch_formula(dev, H, W):
         per = []
         for i in range(n):
             pred = r[i] if rows[i] < 0 else torch.exp(m[rows[i]])[:, None, None] * r[i] + c[rows[i]][:, None, None]
-            per.append(0.8 * L.l1_loss_v1(pred, targets[i]) + 0.2 * (1.0 - L.calc_ssim(pred, targets[i])))
+            pd, td = pred.double(), targets[i].double()          # fp64: see test_fused_image_loss_matches_torch_formula
+            per.append((0.8 * L.l1_loss_v1(pd, td) + 0.2 * (1.0 - L.calc_ssim(pd, td))).float())
         return sum(w * l for w, l in zip(weights, per)), torch.stack(per)
 
     r1 = renders.clone().requires_grad_(True)
@@ -938,10 +940,13 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
         rv = params2rendervar(params)
         im, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**rv)
         im = torch.exp(params["cam_m"][d["id"]])[:, None, None] * im + params["cam_c"][d["id"]][:, None, None]
-        l_im = 0.8 * L.l1_loss_v1(im, d["im"]) + 0.2 * (1.0 - L.calc_ssim(im, d["im"]))
+        # image terms in fp64: no MIOpen solver choice (it is timing-dependent, and some fp32 solvers are not accurate to 1e-4)
+        imd, segt = im.double(), d["im"].double()
+        l_im = (0.8 * L.l1_loss_v1(imd, segt) + 0.2 * (1.0 - L.calc_ssim(imd, segt))).float()
         sv = params2rendervar(params, colors_key="seg_colors")
         seg, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**sv)
-        l_seg = 0.8 * L.l1_loss_v1(seg, d["seg"]) + 0.2 * (1.0 - L.calc_ssim(seg, d["seg"]))
+        segd, segg = seg.double(), d["seg"].double()
+        l_seg = (0.8 * L.l1_loss_v1(segd, segg) + 0.2 * (1.0 - L.calc_ssim(segd, segg))).float()
         shared, _ = _shared_terms(params, rv, torch_vars, weights)
         loss = w.im * l_im + w.seg * l_seg + shared
         loss.backward()
