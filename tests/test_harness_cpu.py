@@ -155,3 +155,36 @@ def test_synth_scene_is_deterministic_and_shaped():
     assert len(cams) == 4 and abs(cams[0].tanfovx - 0.5) < 1e-9 and abs(cams[0].tanfovy - 60 / 160) < 1e-9
     im, seg = synth_targets(80, 60, device="cpu")
     assert im.shape == (3, 60, 80) and seg.shape == (3, 60, 80) and torch.all(seg[0] + seg[2] == 1)
+
+
+def test_fused_pieces_have_host_fallbacks_or_fail_loudly():
+    """CPU tensors: FusedAdam steps through torch's own Adam, views_image_loss / activate evaluate the reference's torch formulas,
+    and the direct step -- which has no meaning without the library -- refuses to run."""
+    import numpy as np
+    import pytest
+    import torch
+    from gsdyn import LossWeights, loss_and_grads_views, synth_scene_params
+    from gsdyn import losses as L
+    from gsdyn.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(7, 3, generator=g))
+    b = torch.nn.Parameter(a.detach().clone())
+    oa, ob = torch.optim.Adam([{"params": [a], "lr": 0.01}], lr=0.0, eps=1e-15), FusedAdam([{"params": [b], "lr": 0.01}], lr=0.0, eps=1e-15)
+    for _ in range(3):
+        gr = torch.randn(7, 3, generator=g)
+        a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    assert torch.equal(a, b)
+    r = torch.rand(2, 3, 20, 24, generator=g, requires_grad=True)
+    t = [torch.rand(3, 20, 24, generator=g) for _ in range(2)]
+    m, c = torch.zeros(4, 3, requires_grad=True), torch.zeros(4, 3, requires_grad=True)
+    total, per = L.views_image_loss(r, t, [2, -1], [50.0, 200.0], m, c)
+    want = 50.0 * L.image_loss(torch.exp(m[2])[:, None, None] * r[0] + c[2][:, None, None], t[0]) + 200.0 * L.image_loss(r[1], t[1])
+    np.testing.assert_allclose(float(total), float(want), rtol=1e-6)
+    assert per.shape == (2,)
+    u = torch.randn(5, 4, generator=g)
+    rot, op, sc = L.activate(u, torch.zeros(5, 1), torch.zeros(5, 3))
+    assert torch.allclose(rot.norm(dim=1), torch.ones(5)) and torch.all(op == 0.5) and torch.all(sc == 1.0)
+    params = synth_scene_params(10, device="cpu")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        loss_and_grads_views(params, [], {}, True, LossWeights())
