@@ -180,7 +180,7 @@ def test_fused_pieces_have_host_fallbacks_or_fail_loudly():
     m, c = torch.zeros(4, 3, requires_grad=True), torch.zeros(4, 3, requires_grad=True)
     total, per = L.views_image_loss(r, t, [2, -1], [50.0, 200.0], m, c)
     want = 50.0 * L.image_loss(torch.exp(m[2])[:, None, None] * r[0] + c[2][:, None, None], t[0]) + 200.0 * L.image_loss(r[1], t[1])
-    np.testing.assert_allclose(float(total), float(want), rtol=1e-6)
+    np.testing.assert_allclose(float(total.detach()), float(want.detach()), rtol=1e-6)
     assert per.shape == (2,)
     u = torch.randn(5, 4, generator=g)
     rot, op, sc = L.activate(u, torch.zeros(5, 1), torch.zeros(5, 3))
