@@ -8,7 +8,7 @@ from gsdyn import LossWeights, get_loss_views, loss_and_grads_views, synth_ring_
 from gsdyn.dp import init_variables
 from gsdyn.step import make_rigidity_variables
 dev = torch.device("cuda:0")
-P, W, H = 500_000, 1920, 1080
+P, W, H = int(os.environ.get("BIG_P", "500000")), 1920, 1080
 torch.manual_seed(0)
 params = synth_scene_params(P, device=dev)
 cams = synth_ring_cameras(4, W, H, device=dev)
