@@ -231,7 +231,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     gsr_carve_image(image_states[owner], cam.H, cam.W, &im_owner);
     gsr_carve_binning(binning_states[owner], num_rendered[owner], &bs);
     if (v == 0) {
-      bt.V = V; bt.T = cam.T; bt.gx = cam.gx;
+      bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = counts_dev; bt.P = P;
       bt.order = order ? order : im.tile_order;
       bt.queue = queue ? queue : im.queue;
       render_header(rt, V, cam, bt.order, bt.queue);
@@ -250,8 +250,6 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     if (counts_dev && owner == v) bt.v[v].D_dev = g.offsets + P;
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
-  if (counts_dev)
-    if (int rc = gsr_launch_gather_counts(bt, P, counts_dev, st)) return rc;
   return gsr_launch_render_fwd(rt, st);
 }
 }  // namespace
@@ -466,7 +464,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
   uint32_t* __restrict__ queue = tab.queue;
   if (tid < 256) cnt[tid] = 0;
   if (tid < 8) queue[tid] = 0;
+  if (tab.counts_out && tid < tab.V) tab.counts_out[tid] = tab.v[tid].offsets[tab.P];   // capacity mode: the counts for the host
   __syncthreads();
   // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before
   // any is used (one memory latency per chunk instead of one per item); the view index is uniform, so the table
@@ -809,19 +810,6 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st) {
   { GSR_PROF("tile_order", st);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
-  GSR_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-namespace {
-__global__ void gather_counts_kernel(GsrBinViews tab, int P, uint32_t* __restrict__ out) {
-  const int v = threadIdx.x;
-  if (v < tab.V) out[v] = tab.v[v].offsets[P];
-}
-}  // namespace
-
-int gsr_launch_gather_counts(const GsrBinViews& tab, int P, uint32_t* counts_dev, hipStream_t st) {
-  hipLaunchKernelGGL(gather_counts_kernel, dim3(1), dim3(64), 0, st, tab, P, counts_dev);
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -164,7 +164,11 @@ struct GsrBinView {            // emit .. tile_sort
   uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
   uint32_t fused_alias;    // 1: additionally blended INSIDE its owner's tile pass (GsrRenderView::partner): no tickets for its busy tiles
 };
-struct GsrBinViews { int V, T, gx; uint4* order; uint32_t* queue; GsrBinView v[GSR_MAX_BATCH]; };
+struct GsrBinViews {
+  int V, T, gx; uint4* order; uint32_t* queue;
+  uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
+  GsrBinView v[GSR_MAX_BATCH];
+};
 struct GsrRenderView {         // blend forward / backward
   const uint32_t* point_list; const float4* rec; const float* bg;
   float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;

@@ -281,7 +281,7 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
         u8 = dict(dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)       # preprocess writes every element
         geom = torch.empty((lib.gsr_geom_bytes(P),), **u8)
         image = torch.empty((lib.gsr_image_bytes(H, W),), **u8)
         D = C.c_uint32(0)
@@ -377,7 +377,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         u8 = dict(dtype=torch.uint8, device=dev)
         color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((V, P), dtype=torch.int32, device=dev)
+        radii = torch.empty((V, P), dtype=torch.int32, device=dev)     # preprocess writes every element
         geoms = [torch.empty((lib.gsr_geom_bytes(P),), **u8) for _ in range(V)]
         images = [torch.empty((lib.gsr_image_bytes(H, W),), **u8) for _ in range(V)]
         batch = torch.empty((lib.gsr_batch_state_bytes(V, P, H, W),), **u8)
