@@ -89,6 +89,7 @@ def main():
 
     from diff_gaussian_rasterization import GaussianRasterizer, _hip
     from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    from gsdyn.step import params2rendervar_fused
     from gsdyn.dp import GradBucket
 
     params = synth_scene_params(P_GAUSS, seed=0, device=dev)
@@ -127,7 +128,7 @@ def main():
         nonlocal streams
         (bucket if args.with_activations else leaf_bucket).zero()
         if not args.per_view_calls:
-            rv = params2rendervar(params) if args.with_activations else rv_leaf
+            rv = params2rendervar_fused(params) if args.with_activations else rv_leaf   # one fused kernel each way (gsr_step.hip)
             im, radii, depth = rasterize_gaussians_views(
                 cams, rv["means3D"], m2_views, rv["opacities"], colors_precomp=rv["colors_precomp"], scales=rv["scales"],
                 rotations=rv["rotations"])
