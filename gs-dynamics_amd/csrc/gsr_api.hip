@@ -662,6 +662,12 @@ static int views_loss_check(const char* who, const gsr_loss_views* v, int32_t H,
   return 0;
 }
 
+int gsr_target_moments(const float* window11_host, int32_t channels, int32_t H, int32_t W, const float* target, float* moments,
+                       void* stream) {
+  if (!window11_host || !target || !moments || channels <= 0 || channels > 4 || H <= 0 || W <= 0) { gsr_set_error("gsr_target_moments: bad argument"); return -2; }
+  return gsr_launch_target_moments(window11_host, channels, H, W, target, moments, (hipStream_t)stream);
+}
+
 int gsr_views_loss_forward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
                            const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
                            float* partials, float* losses, void* stream) {

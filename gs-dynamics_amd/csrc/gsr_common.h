@@ -240,6 +240,7 @@ int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, cons
                               const float* fC, const float* fE, const float* grad_loss, int cpi, float w_l1, float w_ssim, float* dx,
                               hipStream_t st);
 int gsr_loss_blocks_per_channel(int H, int W);
+int gsr_launch_target_moments(const float* win11_host, int channels, int H, int W, const float* target, float* moments, hipStream_t st);
 int gsr_launch_views_loss_fwd(const float* win11_host, const gsr_loss_views* v, int H, int W, const float* renders,
                               const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
                               float* partials, float* losses, hipStream_t st);

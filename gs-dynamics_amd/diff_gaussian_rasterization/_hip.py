@@ -40,7 +40,8 @@ LOSS_MAX_IMAGES = 32
 
 class GsrLossViews(C.Structure):
     _fields_ = [("n_images", C.c_int32), ("channels", C.c_int32), ("cam_row", C.c_int32 * LOSS_MAX_IMAGES),
-                ("weight", C.c_float * LOSS_MAX_IMAGES), ("target", C.c_void_p * LOSS_MAX_IMAGES)]
+                ("weight", C.c_float * LOSS_MAX_IMAGES), ("target", C.c_void_p * LOSS_MAX_IMAGES),
+                ("target_moments", C.c_void_p * LOSS_MAX_IMAGES)]
 
 
 ADAM_MAX_TENSORS = 16
@@ -65,7 +66,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_backward_batch", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
-           "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward",
+           "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping")
 
@@ -116,6 +117,8 @@ def load_library():
     lib.gsr_image_loss_forward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 7 + [vp]
     lib.gsr_image_loss_backward.restype = C.c_int
     lib.gsr_image_loss_backward.argtypes = [C.POINTER(C.c_float), i32, i32, i32] + [vp] * 6 + [i32, C.c_float, C.c_float, vp, vp]
+    lib.gsr_target_moments.restype = C.c_int
+    lib.gsr_target_moments.argtypes = [C.POINTER(C.c_float), i32, i32, i32, vp, vp, vp]
     lib.gsr_views_loss_blocks.restype = i32
     lib.gsr_views_loss_blocks.argtypes = [i32] * 4
     lib.gsr_views_loss_forward.restype = C.c_int
@@ -797,11 +800,37 @@ def _window(window11):
     return w
 
 
-def _loss_table(targets, cam_rows, weights, channels):
+_target_moments = {}     # (data_ptr, version, shape) -> [2,C,H,W] blur(y), blur(y*y); a target seen ONCE is only noted (None)
+_TARGET_MOMENTS_MAX = 64
+
+
+def _moments_of(win, t):
+    """Cached window moments of a target image, or None the first time a target is seen (a target that changes every step
+    would pay for a kernel it never profits from)."""
+    key = (t.data_ptr(), t._version, tuple(t.shape))
+    if key not in _target_moments:
+        if len(_target_moments) >= _TARGET_MOMENTS_MAX:
+            _target_moments.clear()
+        _target_moments[key] = None
+        return None
+    m = _target_moments[key]
+    if m is None:
+        lib = load_library()
+        Cc, H, W = (int(d) for d in t.shape)
+        m = torch.empty((2, Cc, H, W), dtype=torch.float32, device=t.device)
+        _check(lib.gsr_target_moments(win, Cc, H, W, _ptr(t), _ptr(m), _stream(t.device)), "gsr_target_moments")
+        _target_moments[key] = (m, t)            # the target is kept alive with its moments: the key holds its address
+    else:
+        m = m[0]
+    return m
+
+
+def _loss_table(targets, cam_rows, weights, channels, moments=None):
     tab = GsrLossViews()
     tab.n_images, tab.channels = len(targets), channels
     for i, (t, r, w) in enumerate(zip(targets, cam_rows, weights)):
         tab.cam_row[i], tab.weight[i], tab.target[i] = int(r), float(w), t.data_ptr()
+        tab.target_moments[i] = moments[i].data_ptr() if moments is not None else None
     return tab
 
 
@@ -822,7 +851,10 @@ def views_loss_forward(window11, renders, targets, cam_rows, weights, cam_m, cam
         if tuple(t.shape) != (Cc, H, W) or t.device != dev:
             raise RuntimeError("views_loss_forward: every target must be [C,H,W] on the renders' device")
     win = _window(window11)
-    tab = _loss_table(targets, cam_rows, weights, Cc)
+    with _on(dev):
+        moms = [_moments_of(win, t) for t in targets]
+    moms = moms if all(m is not None for m in moms) else None
+    tab = _loss_table(targets, cam_rows, weights, Cc, moms)
     with _on(dev):
         nb = int(lib.gsr_views_loss_blocks(n, Cc, H, W))
         f32 = dict(dtype=torch.float32, device=dev)
@@ -832,7 +864,7 @@ def views_loss_forward(window11, renders, targets, cam_rows, weights, cam_m, cam
         _check(lib.gsr_views_loss_forward(win, C.byref(tab), H, W, _ptr(renders), _ptr(cam_m), _ptr(cam_c), float(w_l1), float(w_ssim),
                                           _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]), _ptr(part), _ptr(losses), _stream(dev)),
                "gsr_views_loss_forward")
-    return losses, (win, tab, targets, maps, part)
+    return losses, (win, tab, (targets, moms), maps, part)
 
 
 def views_loss_backward(state, renders, cam_m, cam_c, grad_total, w_l1, w_ssim, want_cam_grads=True):

@@ -269,8 +269,14 @@ typedef struct gsr_loss_views {
   int32_t cam_row[GSR_LOSS_MAX_IMAGES];
   float weight[GSR_LOSS_MAX_IMAGES];
   const float* target[GSR_LOSS_MAX_IMAGES];    /* DEVICE [channels,H,W] each */
+  const float* target_moments[GSR_LOSS_MAX_IMAGES];  /* optional (all or none): gsr_target_moments of target[i], [2,channels,H,W]:
+                                                        a target that stays fixed over many steps has its two blurred maps computed
+                                                        once; the forward then runs 3 instead of 5 window passes, same bits */
 } gsr_loss_views;
 int32_t gsr_views_loss_blocks(int32_t n_images, int32_t channels, int32_t H, int32_t W);
+/* moments[2,channels,H,W] = window blur of target and of target^2 (zero padding), for gsr_loss_views::target_moments */
+int gsr_target_moments(const float* window11_host, int32_t channels, int32_t H, int32_t W, const float* target, float* moments,
+                       void* stream);
 int gsr_views_loss_forward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
                            const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
                            float* partials, float* losses, void* stream);

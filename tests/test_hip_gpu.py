@@ -1046,6 +1046,47 @@ def test_direct_step_without_host_sync_and_its_overflow_path(dev):
     assert _hip._entries_capacity[key] > cap1
 
 
+def test_views_loss_with_cached_target_moments_is_bit_identical(dev):
+    """A target seen for the second time has blur(y), blur(y*y) computed once (gsr_target_moments) and the forward runs its 3-moment
+    build from then on: same bits as the 5-moment build, for the losses and for every gradient; an in-place change of a target
+    invalidates its entry."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import losses as L
+    rng = np.random.default_rng(21)
+    n, H, W = 4, 131, 97
+    mk = lambda *sh: torch.tensor(rng.uniform(0, 1, sh).astype(np.float32), device=dev)   # noqa: E731
+    renders, targets = mk(n, 3, H, W), [mk(3, H, W) for _ in range(n)]
+    rows, weights = [1, -1, 0, -1], [50.0, 200.0, 50.0, 200.0]
+    cam_m, cam_c = (mk(3, 3) * 0.2).requires_grad_(True), (mk(3, 3) * 0.1).requires_grad_(True)
+    _hip._target_moments.clear()
+    seen = []
+    orig = _hip._loss_table
+
+    def spy(*a_, **k_):
+        seen.append(a_[4] is not None if len(a_) > 4 else k_.get("moments") is not None)
+        return orig(*a_, **k_)
+    _hip._loss_table = spy
+    try:
+        outs = []
+        for it in range(3):
+            r = renders.clone().requires_grad_(True)
+            total, per = L.views_image_loss(r, targets, rows, weights, cam_m, cam_c)
+            g = torch.autograd.grad(total, (r, cam_m, cam_c))
+            outs.append((total.detach().clone(), per.clone(), [x.clone() for x in g]))
+        assert seen == [False, True, True]
+        for it in (1, 2):
+            assert torch.equal(outs[0][0], outs[it][0]) and torch.equal(outs[0][1], outs[it][1])
+            assert all(torch.equal(x, y) for x, y in zip(outs[0][2], outs[it][2]))
+        targets[2].mul_(0.5)                        # new version of one target: its cached maps no longer apply
+        seen.clear()
+        r = renders.clone().requires_grad_(True)
+        t1, _ = L.views_image_loss(r, targets, rows, weights, cam_m, cam_c)
+        t2, _ = L.views_image_loss(r, targets, rows, weights, cam_m, cam_c)
+        assert seen == [False, True] and torch.equal(t1, t2) and not torch.equal(t1, outs[0][0])
+    finally:
+        _hip._loss_table = orig
+
+
 def test_views_loss_more_images_than_one_library_call(dev):
     """40 images (> GSR_LOSS_MAX_IMAGES = 32): the Python entry point splits the call; total and gradients equal the per-image sums."""
     from gsdyn import losses as L
