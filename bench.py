@@ -30,7 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-P_GAUSS, W, H, VIEWS_PER_RANK = 100_000, 800, 800, 4
+P_GAUSS, W, H, VIEWS_PER_RANK = 100_000, 800, 800, 4   # VIEWS_PER_RANK: --views overrides
 HBM_PEAK = 8.0e12       # B/s, MI355X spec (MI355X_MICROARCH.md)
 VALU_PEAK = 78.6e12     # fp32 lane-instructions/s (157.3 TFLOP/s / 2)
 
@@ -59,7 +59,10 @@ def main():
                     help="one GaussianRasterizer call per view (reference call pattern) instead of the batched multi-view call")
     ap.add_argument("--with-activations", action="store_true",
                     help="include params2rendervar (normalize/sigmoid/exp) and its backward in the timed step")
+    ap.add_argument("--views", type=int, default=4, help="views per rank")
     args = ap.parse_args()
+    global VIEWS_PER_RANK
+    VIEWS_PER_RANK = args.views
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -298,7 +298,7 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
     state = RasterState()
     state.settings, state.keep, state.P, state.num_rendered = s, keep, P, int(D.value)
     state.geom, state.binning, state.image, state.H, state.W = geom, binning, image, H, W
-    state.pre = state.batch = state.geometry_of = None
+    state.pre = state.batch = state.geometry_of = state.pending = None
     return color, radii, depth, state
 
 
@@ -330,7 +330,9 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
 
 
 MAX_BATCH = 16           # GSR_MAX_BATCH of include/gsr.h: views per library call
-_counts_slots = {}       # (device, V) -> (pinned int32[V], event) of the capacity-mode forward; one call in flight per slot
+_counts_slots = {}       # (device, V) -> list of [pinned int32[V], event, in_flight] of the capacity-mode forward (a small ring:
+                         # a slot is taken by one call and handed back by forward_counts_ok, so two calls never share counts)
+_COUNTS_RING = 8
 _entries_capacity = {}   # (device, P, H, W) -> list entries per view the capacity-mode forward sizes its buffers for
 _ENTRIES_SLACK = 1.5
 _binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
@@ -370,6 +372,13 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
     if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
         raise ValueError("rasterize_forward_batch: all views must share the image size")
     M = 0 if shs is None else int(shs.shape[1])
+    if shs is not None:
+        # SH colours depend on the camera position, and the multi-view backward kernel covers precomputed colours only: every
+        # view takes the single-view entry points, so that each state owns the tile order / queue / binning that
+        # gsr_backward reads (the batch state of a multi-view call keeps them in one shared table instead).
+        outs = [rasterize_forward(rs, means3D, opacities, None, shs, scales, rotations, cov3D_precomp) for rs in settings_list]
+        return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.stack([o[2] for o in outs]),
+                [o[3] for o in outs])
     with _on(dev):
         sarr = (GsrSettings * V)()
         keeps = []
@@ -422,10 +431,16 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                                                   _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
                                                   capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
                                                   _ptr_array(depth_v), _ptr(counts_dev), st), "gsr_forward_batch_capacity")
-            slot = _counts_slots.get((dev.index, V))
-            if slot is None:      # pinned staging + event, allocated once (hipHostMalloc costs tens of microseconds)
-                slot = _counts_slots[(dev.index, V)] = (torch.empty((V,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-            counts_host, ev = slot
+            ring = _counts_slots.setdefault((dev.index, V), [])
+            slot = next((sl for sl in ring if not sl[2]), None)
+            if slot is None:      # pinned staging + event, allocated once per ring entry (hipHostMalloc costs tens of microseconds)
+                if len(ring) >= _COUNTS_RING:
+                    raise RuntimeError(f"rasterize_forward_batch(no_host_sync=True): {_COUNTS_RING} capacity-mode forwards are in flight "
+                                       "without forward_counts_ok(); check each call's counts before issuing more")
+                slot = [torch.empty((V,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), False]
+                ring.append(slot)
+            slot[2] = True
+            counts_host, ev = slot[0], slot[1]
             counts_host.copy_(counts_dev, non_blocking=True)
             ev.record(torch.cuda.current_stream(dev))
             states = []
@@ -436,7 +451,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                 state.pre = pre if v == 0 else None
                 state.batch = batch if v == 0 else None
                 state.geometry_of = geometry_of if v == 0 else None
-                state.pending = (ev, counts_host, counts_dev, int(cap_e), key) if v == 0 else None
+                state.pending = (ev, counts_host, counts_dev, int(cap_e), key, slot) if v == 0 else None
                 states.append(state)
             return color, radii, depth, states
         binnings = [torch.empty((cap,), **u8) if (cap and owner[v]) else None for v in range(V)]
@@ -488,9 +503,10 @@ def forward_counts_ok(states) -> bool:
     pending = states[0].pending
     if pending is None:
         return True
-    ev, counts_host, _counts_dev, cap_e, key = pending
+    ev, counts_host, _counts_dev, cap_e, key, slot = pending
     ev.synchronize()
     top = int(counts_host.max())
+    slot[2] = False          # the ring entry may serve the next call
     _entries_capacity[key] = max(int(top * _ENTRIES_SLACK), 1024)
     states[0].pending = None
     return top <= cap_e
@@ -800,29 +816,41 @@ def _window(window11):
     return w
 
 
-_target_moments = {}     # (data_ptr, version, shape) -> [2,C,H,W] blur(y), blur(y*y); a target seen ONCE is only noted (None)
-_TARGET_MOMENTS_MAX = 64
+_target_moments = {}     # id(target as the caller passed it) -> [weakref, version, fp32 contiguous image, moments | None, bytes]
+_TARGET_CACHE_BYTES = 1 << 30   # converted targets + moments kept alive at most (cleared when exceeded)
+
+
+def _target_entry(t):
+    """Cache record of a target image, keyed on the tensor object the CALLER holds (id + version, weakref-checked): the
+    reference's loader hands over ``permute(2, 0, 1) / 255`` views, whose contiguous copy would otherwise be a fresh temporary
+    (and a fresh address) every step.  Returns [ref, version, contiguous fp32 image, moments or None, bytes]."""
+    e = _target_moments.get(id(t))
+    if e is not None and e[0]() is t and e[1] == t._version:
+        return e
+    conv = t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+    nbytes = 0 if conv is t else conv.numel() * 4
+    if sum(x[4] for x in _target_moments.values()) + nbytes > _TARGET_CACHE_BYTES:
+        _target_moments.clear()
+    for k in [k for k, x in _target_moments.items() if x[0]() is None]:   # dead targets: drop their images
+        del _target_moments[k]
+    e = _target_moments[id(t)] = [weakref.ref(t), t._version, conv, None, nbytes]
+    return e
 
 
 def _moments_of(win, t):
-    """Cached window moments of a target image, or None the first time a target is seen (a target that changes every step
-    would pay for a kernel it never profits from)."""
-    key = (t.data_ptr(), t._version, tuple(t.shape))
-    if key not in _target_moments:
-        if len(_target_moments) >= _TARGET_MOMENTS_MAX:
-            _target_moments.clear()
-        _target_moments[key] = None
-        return None
-    m = _target_moments[key]
-    if m is None:
+    """Window moments blur(y), blur(y*y) of a target, computed the SECOND time the same target (object and version) is seen
+    (a target that changes every step would pay for a kernel it never profits from).  Returns (image, moments or None)."""
+    known = id(t) in _target_moments and _target_moments[id(t)][0]() is t and _target_moments[id(t)][1] == t._version
+    e = _target_entry(t)
+    if known and e[3] is None:
         lib = load_library()
-        Cc, H, W = (int(d) for d in t.shape)
-        m = torch.empty((2, Cc, H, W), dtype=torch.float32, device=t.device)
-        _check(lib.gsr_target_moments(win, Cc, H, W, _ptr(t), _ptr(m), _stream(t.device)), "gsr_target_moments")
-        _target_moments[key] = (m, t)            # the target is kept alive with its moments: the key holds its address
-    else:
-        m = m[0]
-    return m
+        img = e[2]
+        Cc, H, W = (int(d) for d in img.shape)
+        m = torch.empty((2, Cc, H, W), dtype=torch.float32, device=img.device)
+        _check(lib.gsr_target_moments(win, Cc, H, W, _ptr(img), _ptr(m), _stream(img.device)), "gsr_target_moments")
+        e[3] = m
+        e[4] += m.numel() * 4
+    return e[2], e[3]
 
 
 def _loss_table(targets, cam_rows, weights, channels, moments=None):
@@ -846,13 +874,20 @@ def views_loss_forward(window11, renders, targets, cam_rows, weights, cam_m, cam
         raise RuntimeError(f"views_loss_forward: 1..{LOSS_MAX_IMAGES} images with one target / camera row / weight each")
     if not renders.is_contiguous() or renders.dtype != torch.float32:
         raise RuntimeError("views_loss_forward: renders must be a contiguous float32 batch")
-    targets = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t in targets]
     for t in targets:
         if tuple(t.shape) != (Cc, H, W) or t.device != dev:
             raise RuntimeError("views_loss_forward: every target must be [C,H,W] on the renders' device")
+    n_rows = 0 if cam_m is None else int(cam_m.shape[0])
+    for r in cam_rows:     # the kernel indexes cam_m / cam_c with these rows: an id past the table would read foreign memory
+        if int(r) >= n_rows or (int(r) >= 0 and (cam_m is None or cam_c is None)):
+            raise RuntimeError(f"views_loss_forward: camera row {int(r)} outside cam_m / cam_c with {n_rows} rows")
+    if cam_m is not None and (cam_c is None or tuple(cam_c.shape) != tuple(cam_m.shape)):
+        raise RuntimeError("views_loss_forward: cam_m and cam_c must have the same shape")
     win = _window(window11)
     with _on(dev):
-        moms = [_moments_of(win, t) for t in targets]
+        pairs = [_moments_of(win, t) for t in targets]
+    targets = [p[0] for p in pairs]
+    moms = [p[1] for p in pairs]
     moms = moms if all(m is not None for m in moms) else None
     tab = _loss_table(targets, cam_rows, weights, Cc, moms)
     with _on(dev):

@@ -15,23 +15,23 @@ import torch
 class FusedAdam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
+        loss = None
+        if closure is not None:        # first: the gradients gathered below are the ones the closure produces
+            with torch.enable_grad():
+                loss = closure()
         entries = []
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad") or group.get("maximize") or group.get("capturable") \
                     or group.get("differentiable"):
-                return super().step(closure)
+                return self._fallback(loss)
             beta1, beta2 = group["betas"]
             for p in group["params"]:
                 g = p.grad
                 if g is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or g.is_sparse or not p.is_contiguous():
-                    return super().step(closure)
+                    return self._fallback(loss)
                 entries.append((group, p, g if g.is_contiguous() else g.contiguous(), float(beta1), float(beta2)))
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
         from diff_gaussian_rasterization import _hip
         packed = []
         for group, p, g, beta1, beta2 in entries:
@@ -46,4 +46,13 @@ class FusedAdam(torch.optim.Adam):
                 state["exp_avg"], state["exp_avg_sq"] = m, v = m.contiguous(), v.contiguous()
             packed.append((p, g, m, v, float(group["lr"]), beta1, beta2, float(group["eps"]), float(state["step"])))
         _hip.adam_step(packed)
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that caches keyed on
+        # (data_ptr, _version) -- the per-view colour stack of gsdyn.step, converted settings tensors -- see the update
+        for p, *_ in packed:
+            torch.autograd.graph.increment_version(p)
+        return loss
+
+    def _fallback(self, loss):
+        """torch's own step for what the kernel does not cover (the closure, if any, has already run)."""
+        super().step()
         return loss

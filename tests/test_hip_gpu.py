@@ -21,6 +21,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def _margin(tag, err, scale):
+    """Relative error, printed with GSR_TEST_VERBOSE=1 (tools/test_margins.sh collects them from a GPU run)."""
+    r = err / max(scale, 1e-300)
+    if os.environ.get("GSR_TEST_VERBOSE"):
+        print(f"margin {tag}: {r:.2e}")
+    return r
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
@@ -39,8 +47,8 @@ def _settings(cam: OracleCamera, dev, sh_degree=None):
 
 def _run_hip(cam, g, dev, dL=None, want_state=False):
     from diff_gaussian_rasterization import GaussianRasterizer, _hip
-    t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
-    means2D = torch.zeros((g["means3D"].shape[0], 3), device=dev, requires_grad=True)
+    t = {k: torch.tensor(v, device=dev, requires_grad=dL is not None) for k, v in g.items()}
+    means2D = torch.zeros((g["means3D"].shape[0], 3), device=dev, requires_grad=dL is not None)
     rs = _settings(cam, dev)
     state = {}
     if want_state:
@@ -143,14 +151,21 @@ def _check_lists(views, H, W, o_point_list, o_ranges, o_n_contrib, ok, o_means2D
 
 
 
-def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min_ok=0.995):
-    """Forward + backward of the HIP path vs oracle O2 on the same inputs.
+AMBIGUOUS_PIXEL_BOUND = 4e-3     # one flipped alpha >= 1/255 decision moves a pixel by at most (1/255) * T * colour
+
+
+def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min_ok=0.995, backward=True):
+    """Forward + backward of the HIP path vs oracle O2 on the same inputs (``backward=False``: forward only, under the
+    caller's no-grad inputs -- the forward-only configs).
 
     Pixels where the oracle saw a threshold decision (alpha >= 1/255, T >= 1e-4) within 1e-5 relative of
     flipping are 'ambiguous': two correct fp32 implementations may legitimately decide differently there,
     and one flipped pair changes a pixel by up to ~4e-3 * colour.  They are excluded from the image
     comparison, and the upstream gradient is zeroed on them (for both sides) so they cannot leak into
-    the per-Gaussian gradient comparison through the 1/(1-alpha) amplification."""
+    the per-Gaussian gradient comparison through the 1/(1-alpha) amplification.  At least 98 % of the pixels must take
+    part in the tight comparison, and the excluded ones are still compared, at the bound a single flipped pair allows
+    (4e-3 x the colour / depth scale), so they are not a blind spot of the image comparison."""
+    assert min_ok >= 0.98, "a comparison that drops more than 2 % of the pixels proves little"
     H, W = cam.image_height, cam.image_width
     o2 = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g.get("colors_precomp"), shs=g.get("shs"),
                      scales=g.get("scales"), rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"),
@@ -159,7 +174,7 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
     assert ok.mean() > min_ok, "too many threshold-ambiguous pixels for a meaningful comparison"
     dL = np.random.default_rng(seed).uniform(-1, 1, (3, H, W)).astype(np.float32)
     dL[:, ~ok] = 0.0
-    color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
+    color, radii, depth, grads, views = _run_hip(cam, g, dev, dL=dL if backward else None, want_state=True)
     assert np.array_equal(radii, o2.radii), "radii differ"
     if check_lists:
         _check_lists(views, H, W, o2.point_list, o2.ranges, o2.n_contrib, ok, o2.means2D, o2.conic_opacity,
@@ -167,6 +182,14 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         assert mixed_err(views["final_T"].cpu().numpy()[ok], o2.final_T[ok]) < TOL
     assert mixed_err(color[:, ok], o2.color[:, ok]) < TOL, "colour"
     assert mixed_err(depth[:, ok], o2.depth[:, ok]) < TOL, "depth"
+    if (~ok).any():     # threshold-ambiguous pixels: within what one flipped decision can move them
+        cs = max(1.0, float(np.abs(o2.color).max()))
+        assert np.abs(color[:, ~ok] - o2.color[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * cs, "colour on ambiguous pixels"
+        assert np.abs(depth[:, ~ok] - o2.depth[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * max(1.0, float(o2.depth.max())), "depth on ambiguous pixels"
+    rg = views["ranges"].cpu().numpy().astype(np.int64)
+    o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max())        # longest per-tile list the HIP path sorted
+    if not backward:
+        return o2
     gr = o2.backward(dL)
     worst = {}
     for k, v in grads.items():
@@ -175,8 +198,6 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         assert e < TOL, f"grad {k}: rel err {e:.3e}"
     if os.environ.get("GSR_TEST_VERBOSE"):
         print("parity margins:", {k: f"{e:.2e}" for k, e in worst.items()}, "colour", f"{mixed_err(color[:, ok], o2.color[:, ok]):.2e}")
-    rg = views["ranges"].cpu().numpy().astype(np.int64)
-    o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max())        # longest per-tile list the HIP path sorted
     return o2
 
 
@@ -201,6 +222,86 @@ def test_committed_goldens(dev, golden_dir):
         assert mixed_err(depth[:, ok], z[f"{n}/depth"][:, ok]) < TOL, n
         for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"):
             assert rel_err(grads[k], z[f"{n}/grad_{k}"]) < TOL, (n, k)
+
+
+def test_committed_multi_view_goldens(dev, golden_dir):
+    """raster_cases_views.npz through ``rasterize_gaussians_views`` (one library call per case): a 3-camera case with shared
+    colours, and a case where each camera is rendered with two colour sets (the colour + segmentation pattern of get_loss:
+    views of one camera share their tile lists and are blended in one tile pass).  Per-view images / radii / depth / means2D
+    gradients / colour gradients and the view-summed gradients of the other inputs against the oracle's."""
+    from diff_gaussian_rasterization import rasterize_gaussians_views
+    z = np.load(os.path.join(golden_dir, "raster_cases_views.npz"))
+    t = lambda a, **k: torch.tensor(np.asarray(a, np.float32), device=dev, **k)  # noqa: E731
+    for n in [str(x) for x in z["names"]]:
+        vc, vcol = z[f"{n}/view_cam"], z[f"{n}/view_colour"]
+        V = len(vc)
+        by_cam = {}
+        settings = []
+        for vi in range(V):          # views with the same ring index get the SAME settings tensors (that is how the library
+            v = z[f"{n}/cam"][vi]    # recognises a shared camera), with their own background
+            if vc[vi] not in by_cam:
+                cam = OracleCamera(int(v[0]), int(v[1]), float(v[2]), float(v[3]), v[4:7].astype(np.float32), 1.0,
+                                   v[7:23].astype(np.float32), v[23:39].astype(np.float32), 0, v[39:42].astype(np.float32))
+                by_cam[vc[vi]] = _settings(cam, dev)
+            settings.append(by_cam[vc[vi]])
+        inp = {k: t(z[f"{n}/in_{k}"], requires_grad=True) for k in ("means3D", "scales", "rotations", "opacities")}
+        cols = z[f"{n}/in_colours"]
+        per_view_col = cols.shape[0] > 1
+        colours = t(cols[vcol] if per_view_col else cols[0], requires_grad=True)
+        P = inp["means3D"].shape[0]
+        m2 = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        im, radii, depth = rasterize_gaussians_views(settings, inp["means3D"], m2, inp["opacities"], colors_precomp=colours,
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+        im.backward(gradient=t(z[f"{n}/dL_dcolor"]))
+        torch.cuda.synchronize()
+        ok = ~z[f"{n}/ambiguous"]
+        for vi in range(V):
+            assert np.array_equal(radii[vi].cpu().numpy(), z[f"{n}/radii"][vi]), (n, vi)
+            assert mixed_err(im[vi].detach().cpu().numpy()[:, ok[vi]], z[f"{n}/color"][vi][:, ok[vi]]) < TOL, (n, vi)
+            assert mixed_err(depth[vi].detach().cpu().numpy()[:, ok[vi]], z[f"{n}/depth"][vi][:, ok[vi]]) < TOL, (n, vi)
+            assert rel_err(m2.grad[vi].cpu().numpy(), z[f"{n}/grad_means2D"][vi]) < TOL, (n, vi)
+        gc = colours.grad.cpu().numpy()
+        want_c = z[f"{n}/grad_colours_per_view"]
+        assert rel_err(gc, want_c if per_view_col else want_c.sum(0)) < TOL, n
+        for k in ("means3D", "opacities", "scales", "rotations"):
+            assert rel_err(inp[k].grad.cpu().numpy(), z[f"{n}/grad_sum_{k}"]) < TOL, (n, k)
+
+
+def test_sh_colours_through_the_multi_view_call(dev):
+    """``rasterize_gaussians_views(shs=...)``: forward and backward equal per-view ``GaussianRasterizer`` calls (which are
+    oracle-checked above), including a camera that appears twice.  (the batched forward used to hand the
+    single-view backward states whose tile order and queue lived in the shared batch state.)"""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    P, W, H = 600, 112, 80
+    g = random_gaussians(P, seed=71, scale_lo=0.03, scale_hi=0.25, sh_M=16)
+    cams = [ring_camera(W, H, v=i, sh_degree=2, bg=(0.2, 0.3, 0.1)) for i in (0, 1)]
+    s0, s1 = _settings(cams[0], dev), _settings(cams[1], dev)
+    settings = [s0, s1, s0]          # the third view repeats the first camera
+    dL = torch.tensor(np.random.default_rng(9).uniform(-1, 1, (3, 3, H, W)).astype(np.float32), device=dev)
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+
+    def leaves():
+        return {k: torch.tensor(g[k], device=dev, requires_grad=True) for k in names}
+    a = leaves()
+    ims, m2g = [], []
+    for vi, rs in enumerate(settings):
+        m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+        im, radii, depth = GaussianRasterizer(raster_settings=rs)(means3D=a["means3D"], means2D=m2, opacities=a["opacities"],
+                                                                 shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+        im.backward(gradient=dL[vi])
+        ims.append(im.detach()); m2g.append(m2.grad)
+    b = leaves()
+    m2v = torch.zeros((3, P, 3), device=dev, requires_grad=True)
+    imb, radb, depb = rasterize_gaussians_views(settings, b["means3D"], m2v, b["opacities"], shs=b["shs"], scales=b["scales"],
+                                                rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    torch.cuda.synchronize()
+    assert torch.equal(imb.detach(), torch.stack(ims))
+    assert torch.equal(m2v.grad, torch.stack(m2g))
+    for k in names:
+        ga, gb = a[k].grad, b[k].grad
+        assert gb is not None and torch.isfinite(gb).all(), k
+        assert (ga - gb).abs().max().item() <= 2e-6 * ga.abs().max().item(), k     # same per-view values, summed in another order
 
 
 @pytest.mark.parametrize("P,W,H,seed", [(1, 16, 16, 1), (37, 33, 17, 2), (700, 130, 94, 3), (5000, 256, 192, 4)])
@@ -249,10 +350,11 @@ def test_huge_tile_lists_take_the_global_sort_path(dev, monkeypatch, rcap, P):
     """More than 2 x RCAP entries per tile: the per-tile sort leaves LDS and runs its network in global memory
     (RCAP = radix capacity of the tile_sort build, pinned here; the library picks it from the average list length)."""
     monkeypatch.setenv("GSR_TILE_SORT_RCAP", rcap)
-    g = random_gaussians(P, seed=33, scale_lo=0.5, scale_hi=0.9, spread=0.5)
-    g["opacities"][:] = 0.02  # nearly transparent: nothing terminates early, every entry matters
-    # thousands of faint Gaussians x every pixel: a few % of pixels graze the 1/255 threshold within 1e-5 (excluded)
-    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6, min_ok=0.85)
+    # Gaussians far wider than the image (sigma 45-80 pixels over 32): alpha = 0.017 .. 0.02 at every pixel, nowhere near the
+    # 1/255 threshold, so (almost) no pixel is threshold-ambiguous although thousands of entries cover each one
+    g = random_gaussians(P, seed=33, scale_lo=5.0, scale_hi=9.0, spread=0.5)
+    g["opacities"][:] = 0.02
+    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6, min_ok=0.98)
     assert o2.hip_max_list > 2 * int(rcap)
 
 
@@ -263,9 +365,9 @@ def test_tile_sort_paths(dev, monkeypatch, P, rcap):
     keys per lane), <= RCAP LDS radix sort, <= 2 RCAP LDS network (beyond: test_huge_tile_lists...), for both builds of
     the kernel (RCAP 2048 / 4096)."""
     monkeypatch.setenv("GSR_TILE_SORT_RCAP", rcap)
-    g = random_gaussians(P, seed=40 + P, scale_lo=0.5, scale_hi=0.9, spread=0.5)
+    g = random_gaussians(P, seed=40 + P, scale_lo=5.0, scale_hi=9.0, spread=0.5)   # wider than the image: see the test above
     g["opacities"][:] = 0.03
-    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=8, min_ok=0.9)
+    o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=8, min_ok=0.98)
     n = o2.hip_max_list
     lo, hi = {50: (1, 64), 100: (65, 128), 200: (129, 256), 400: (257, 512), 1500: (513, 2048), 3000: (2049, 4096)}[P]
     assert lo <= n <= hi, n
@@ -349,9 +451,14 @@ def full_scene(dev):
     return params, cams, params2rendervar
 
 
-def test_full_size_matches_oracle_one_view(dev, full_scene):
-    """BASELINE config 3 sizes (100k Gaussians, 800x800), view 0, against the (threaded) oracle."""
+@pytest.mark.parametrize("P,backward", [(100_000, True), (50_000, False)])
+def test_full_size_matches_oracle_one_view(dev, full_scene, P, backward):
+    """BASELINE configs[2] (100k Gaussians, 800x800, forward + backward) and configs[1] (50k Gaussians, one 800x800 view,
+    forward only, no autograd graph), view 0, against the (threaded) oracle."""
     params, cams, p2r = full_scene
+    if P != 100_000:
+        from gsdyn import synth_scene_params
+        params = synth_scene_params(P, device=dev)
     with torch.no_grad():
         rv = {k: v.detach().cpu().numpy() for k, v in p2r(params).items()}
     cam = cams[0]
@@ -360,7 +467,7 @@ def test_full_size_matches_oracle_one_view(dev, full_scene):
                         cam.campos.cpu().numpy())
     g = dict(means3D=rv["means3D"], scales=rv["scales"], rotations=rv["rotations"], opacities=rv["opacities"],
              colors_precomp=rv["colors_precomp"])
-    o2 = _check_against_oracle(ocam, g, dev, seed=11, nthreads=os.cpu_count() or 8)
+    o2 = _check_against_oracle(ocam, g, dev, seed=11, nthreads=os.cpu_count() or 8, backward=backward)
     print("num_rendered", o2.num_rendered, "ambiguous px", int(o2.ambiguous.sum()))
 
 
@@ -933,8 +1040,14 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
 
     for p_ in params.values():
         p_.grad = None
-    torch_vars = {k: v for k, v in rig.items() if k not in ("rev_ptr", "rev_edge")}     # no reverse adjacency -> torch formulas
+    # no reverse adjacency -> torch formulas; evaluated in fp64 on double copies of the parameters, like the image terms: the
+    # literal side then carries fp32 rounding only where the rasterizer itself computes (the thing under test on both sides)
+    torch_vars = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in rig.items()
+                  if k not in ("rev_ptr", "rev_edge")}
     weights = dict(rigid=w.rigid, rot=w.rot, iso=w.iso, floor=w.floor, bg=w.bg)
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in params.items()}
+    shared64, _ = _shared_terms(p64, params2rendervar(p64), torch_vars, weights)
+    (float(len(views)) * shared64).backward()            # the reference adds the shared terms once per rendered camera
     total = 0.0
     for d in views:
         rv = params2rendervar(params)
@@ -947,14 +1060,14 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
         seg, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**sv)
         segd, segg = seg.double(), d["seg"].double()
         l_seg = (0.8 * L.l1_loss_v1(segd, segg) + 0.2 * (1.0 - L.calc_ssim(segd, segg))).float()
-        shared, _ = _shared_terms(params, rv, torch_vars, weights)
-        loss = w.im * l_im + w.seg * l_seg + shared
+        loss = w.im * l_im + w.seg * l_seg
         loss.backward()
-        total += float(loss.detach())
+        total += float(loss.detach()) + float(shared64.detach())
     assert abs(float(loss_f) - total) <= 2e-5 * abs(total), (float(loss_f), total)
     for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "cam_m", "cam_c"):
-        want, got = params[k].grad, g_f[k]
-        assert (got - want).abs().max().item() <= 3e-4 * want.abs().max().item(), (k, (got - want).abs().max().item(), want.abs().max().item())
+        want = params[k].grad.double() + (p64[k].grad if p64[k].grad is not None else 0.0)
+        got = g_f[k].double()
+        assert _margin(f"direct_step/{k}", (got - want).abs().max().item(), want.abs().max().item()) <= TOL, k
     assert len(_SHARED_NAMES) == 5 and aux["means2D_grad"].shape == (4, P, 3)
 
 
@@ -1125,14 +1238,28 @@ def test_get_loss_views_equals_sum_of_get_loss(dev):
     w = LossWeights()
     ids = [2, 0, 2]
     views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in ids]
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar
+    from gsdyn import losses as L
     for p_ in params.values():
         p_.grad = None
-    total = 0.0
-    for d in views:
-        loss, _ = get_loss(params, d, init_variables(P, dev), True, w)
+    total, total32 = 0.0, 0.0
+    for d in views:       # the literal per-camera step (train_utils.py:174-195) with the image terms evaluated in fp64 on the renders
+        im, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**params2rendervar(params))
+        im = torch.exp(params["cam_m"][d["id"]])[:, None, None] * im + params["cam_c"][d["id"]][:, None, None]
+        seg, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**params2rendervar(params, colors_key="seg_colors"))
+        l_im = 0.8 * L.l1_loss_v1(im.double(), d["im"].double()) + 0.2 * (1.0 - L.calc_ssim(im.double(), d["im"].double()))
+        l_seg = 0.8 * L.l1_loss_v1(seg.double(), d["seg"].double()) + 0.2 * (1.0 - L.calc_ssim(seg.double(), d["seg"].double()))
+        loss = w.im * l_im + w.seg * l_seg
         loss.backward()
         total += float(loss.detach())
     ref = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+    for p_ in params.values():
+        p_.grad = None
+    for d in views:       # ... and gsdyn.get_loss (fp32 torch loss ops) agrees on the value
+        loss, _ = get_loss(params, d, init_variables(P, dev), True, w)
+        total32 += float(loss.detach())
+    assert abs(total32 - total) <= 2e-5 * abs(total)
     for p_ in params.values():
         p_.grad = None
     loss, _, _ = get_loss_views(params, views, init_variables(P, dev), True, w)
@@ -1142,7 +1269,7 @@ def test_get_loss_views_equals_sum_of_get_loss(dev):
     for k, g in ref.items():
         got = params[k].grad
         assert got is not None, k
-        assert (got - g).abs().max().item() <= 2e-4 * g.abs().max().item() + 1e-12, k
+        assert _margin(f"get_loss_views/{k}", (got - g).abs().max().item(), g.abs().max().item() + 1e-30) <= TOL, k
 
 
 def test_fused_image_loss_matches_reference_golden(dev, golden_dir):
@@ -1154,7 +1281,8 @@ def test_fused_image_loss_matches_reference_golden(dev, golden_dir):
     got = L.image_loss(x, y, 0.0, 1.0)           # = 1 - SSIM
     np.testing.assert_allclose(1.0 - got.item(), float(ref["ssim"]), rtol=2e-5)
     got.backward()
-    np.testing.assert_allclose(-x.grad.cpu().numpy(), ref["ssim_grad"], rtol=2e-4, atol=2e-8)
+    gx = -x.grad.cpu().numpy()
+    assert _margin("ssim_golden/grad", np.abs(gx - ref["ssim_grad"]).max(), np.abs(ref["ssim_grad"]).max()) <= TOL
     comb = L.image_loss(x.detach(), y)
     np.testing.assert_allclose(comb.item(), float(ref["im_term"]), rtol=2e-5)
 
@@ -1286,7 +1414,7 @@ def test_fused_rigidity_terms_match_torch_autograd(dev):
         assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item()) + 1e-9
     for got, want, name in ((m1.grad, m2.grad, "means3D"), (r1.grad, r2.grad, "rotations")):
         err = (got.double() - want).abs().max().item()
-        assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
+        assert _margin(f"rigidity/{name}", err, want.abs().max().item()) <= TOL, (name, err, want.abs().max().item())
     assert torch.all(m1.grad[~is_fg] == 0) and torch.all(r1.grad[~is_fg] == 0)
 
 
@@ -1318,7 +1446,7 @@ def test_fused_shared_terms_match_torch(dev):
     assert float(ref_each[3]) > 0
     for got, want, name in ((m1.grad, m2.grad, "means3D"), (r1.grad, r2.grad, "rotations")):
         err = (got.double() - want).abs().max().item()
-        assert err <= 2e-4 * want.abs().max().item(), (name, err, want.abs().max().item())
+        assert _margin(f"shared_terms/{name}", err, want.abs().max().item()) <= TOL, (name, err, want.abs().max().item())
     # deterministic
     m3, r3 = means.clone().requires_grad_(True), rots.clone().requires_grad_(True)
     total3, _ = _shared_terms(params, dict(means3D=m3, rotations=r3), variables, weights, scale=3.0)

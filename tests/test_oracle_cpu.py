@@ -41,6 +41,36 @@ def test_o2_reproduces_committed_goldens(golden_dir):
             assert rel_err(gr[k], z[f"{n}/grad_{k}"]) < 1e-5, (n, k)
 
 
+def test_o2_reproduces_committed_multi_view_goldens(golden_dir):
+    """raster_cases_views.npz (tests/golden/gen_raster_view_goldens.py): per-view outputs, per-view screen-space and colour
+    gradients, and the sum over views of the remaining input gradients -- what the batched entry point must return."""
+    z = np.load(os.path.join(golden_dir, "raster_cases_views.npz"))
+    for n in [str(x) for x in z["names"]]:
+        g = {k: z[f"{n}/in_{k}"] for k in ("means3D", "scales", "rotations", "opacities")}
+        cols = z[f"{n}/in_colours"]
+        sums = {k: 0.0 for k in ("means3D", "opacities", "scales", "rotations")}
+        for vi in range(len(z[f"{n}/view_cam"])):
+            o2 = TiledOracle(_cam_from_vec(z[f"{n}/cam"][vi]), g["means3D"], g["opacities"],
+                             colors_precomp=cols[z[f"{n}/view_colour"][vi]], scales=g["scales"], rotations=g["rotations"])
+            assert np.array_equal(o2.radii, z[f"{n}/radii"][vi])
+            np.testing.assert_allclose(o2.color, z[f"{n}/color"][vi], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(o2.depth, z[f"{n}/depth"][vi], rtol=0, atol=1e-5)
+            gr = o2.backward(z[f"{n}/dL_dcolor"][vi])
+            assert rel_err(gr["means2D"], z[f"{n}/grad_means2D"][vi]) < 1e-5
+            assert rel_err(gr["colors_precomp"], z[f"{n}/grad_colours_per_view"][vi]) < 1e-5
+            for k in sums:
+                sums[k] = sums[k] + gr[k].astype(np.float64)
+        for k in sums:
+            assert rel_err(sums[k], z[f"{n}/grad_sum_{k}"]) < 1e-5, (n, k)
+        same_cam = z[f"{n}/view_cam"]
+        if n.startswith("pairs"):          # views of one camera share geometry: identical radii / depth, different colours
+            for a in range(len(same_cam)):
+                for b in range(a + 1, len(same_cam)):
+                    if same_cam[a] == same_cam[b]:
+                        assert np.array_equal(z[f"{n}/radii"][a], z[f"{n}/radii"][b])
+                        assert np.array_equal(z[f"{n}/depth"][a], z[f"{n}/depth"][b])
+
+
 def _o1(cam, g, sh_degree=0, dL=None):
     t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in g.items()}
     color, radii, depth, m2 = dense_rasterize(
