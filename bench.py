@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- fwd+bwd Mpix/s of the differentiable Gaussian rasterizer on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run,
-one rank per GPU over RCCL).  One STEP = one pass of the hot path over one batch of synthetic input:
-for each of this rank's 4 views of SynthScene-v1 (100 000 Gaussians, 800x800, BASELINE.json configs[2])
-``GaussianRasterizer`` forward -> autograd backward with a fixed seeded dL/dcolour (the caller's
-parameter activations are applied once, outside the timed region; ``--with-activations`` includes them); for N>1 the step ends with ONE all-reduce of the flat Gaussian-gradient bucket (RCCL).
-Weak scaling: every rank renders 4 views (rank r takes cameras 4r..4r+3 of a 4N-camera ring), so
-value = 4*N*H*W / t_step.  Inputs are resident in HBM before the timed region.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run, one rank per GPU
+over RCCL).  One STEP = one optimiser step of the tracking loop's rasterizer path over one batch of synthetic views
+(/root/reference/src/tracking/train_gs.py:25-39):
 
-Prints ONE JSON line on rank 0 with the contract's keys plus
-  "roofline":     dominant kernel, algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  default -- STRONG scaling on BASELINE.json configs[3]: ONE fixed step of 8 views (800x800) of SynthScene-v1 (100 000
+             Gaussians); rank r renders views r, r+N, ... (N = 1: all 8).  Timed region = fused activations + colour render
+             forward + backward for the rank's views (fixed seeded dL/dcolour) + ONE all-reduce of the flat 17-float-per-
+             Gaussian parameter-gradient bucket (N > 1, RCCL) + the Adam step (FusedAdam, one launch).
+             value = 8*H*W / t_step.  ``--config 3`` (= ``--views 4 --no-optimizer``) is BASELINE.json configs[2] exactly (the
+             headline of round 1); an N = 1 run also measures that configuration and reports it as ``cfg3``.
+  --weak  -- weak scaling: every rank renders ``--views`` (default 4) views of a 4N-camera ring, then all-reduce + Adam.
+  --config 5 -- forward only, BASELINE.json configs[4]: 500k Gaussians, 1920x1080, predict.py's frame (4 cameras x colour +
+             mask render), (frame, camera) pairs sharded over the ranks, no collective (gsdyn/predict.py).
+
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the contract's keys plus
+  "roofline":     dominant kernel: algorithmic bytes per launch / HIP-event duration vs 8 TB/s, per-kernel fractions,
+                  measured-peak VALU model (tools/micro/valu_table.hip), replayed PMC traffic (flagged "replayed")
   "cpu_baseline": the CPU oracle (kind "port": the reference has no CPU path and its CUDA extension is absent)
                   timed on this box's host cores on ONE view fwd+bwd of the same workload.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,9 +38,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-P_GAUSS, W, H, VIEWS_PER_RANK = 100_000, 800, 800, 4   # VIEWS_PER_RANK: --views overrides
+P_GAUSS, W, H = 100_000, 800, 800
 HBM_PEAK = 8.0e12       # B/s, MI355X spec (MI355X_MICROARCH.md)
-VALU_PEAK = 78.6e12     # fp32 lane-instructions/s (157.3 TFLOP/s / 2)
+VALU_PEAK = 78.6e12     # fp32 lane-instructions/s at 2.4 GHz: one wave-64 op per 2 cycles per SIMD (157.3 TFLOP/s / 2)
 
 
 def algorithmic_bytes(P, D, Npx):
@@ -46,23 +54,34 @@ def algorithmic_bytes(P, D, Npx):
     }
 
 
+# kernel name (GSR_PROF label in libgsr_hip.so) -> section-8d group
+KERNEL_GROUP = {"preprocess_fwd": "preprocess_fwd", "scan_exclusive": "scan", "emit_entries": "emit_entries", "radix_hist": "sort",
+                "radix_scatter": "sort", "tile_sort": "sort", "tile_ranges": "tile_ranges", "tile_order": "tile_ranges",
+                "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd_views": "preprocess_bwd",
+                "preprocess_bwd": "preprocess_bwd"}
+
+
+def _load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views", type=int, default=None, help="views of the step (strong scaling: total, default 8; --weak: per rank, default 4)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --views views per rank")
+    ap.add_argument("--config", type=int, default=4, choices=(3, 4, 5), help="3 = --views 4 --no-optimizer on one GPU; 5 = forward-only predict frame")
+    ap.add_argument("--no-optimizer", action="store_true", help="leave the Adam step out of the timed region")
+    ap.add_argument("--autograd", action="store_true", help="go through rasterize_gaussians_views + autograd (round-1 call pattern) instead of "
+                    "the direct library calls of gsdyn.step.render_step_views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the get_loss-shaped step and forward-only timings")
-    ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]-style forward-only timing (extra)")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the views of a step are spread over")
-    ap.add_argument("--per-view-calls", action="store_true",
-                    help="one GaussianRasterizer call per view (reference call pattern) instead of the batched multi-view call")
-    ap.add_argument("--with-activations", action="store_true",
-                    help="include params2rendervar (normalize/sigmoid/exp) and its backward in the timed step")
-    ap.add_argument("--views", type=int, default=4, help="views per rank")
+    ap.add_argument("--no-extras", action="store_true", help="skip the get_loss-shaped step and the other secondary timings")
     args = ap.parse_args()
-    global VIEWS_PER_RANK
-    VIEWS_PER_RANK = args.views
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,111 +109,104 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    from diff_gaussian_rasterization import GaussianRasterizer, _hip
-    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
-    from gsdyn.step import params2rendervar_fused
-    from gsdyn.dp import GradBucket
+    if args.config == 5:
+        return bench_config5(args, dev, rank, world)
+    if args.config == 3:
+        args.views, args.no_optimizer = args.views or 4, True
 
-    params = synth_scene_params(P_GAUSS, seed=0, device=dev)
-    cams = synth_ring_cameras(VIEWS_PER_RANK * world, W, H, device=dev, first=VIEWS_PER_RANK * rank,
-                              count=VIEWS_PER_RANK)
-    rng = np.random.default_rng(1234 + rank)
-    dLs = [torch.tensor(rng.uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev) for _ in cams]
-    bucket = GradBucket(params)
+    from diff_gaussian_rasterization import _hip, rasterize_gaussians_views
+    from gsdyn import initialize_optimizer, params2rendervar, synth_ring_cameras, synth_scene_params
+    from gsdyn.dp import GradBucket, shard_views
+    from gsdyn.step import params2rendervar_fused, render_step_views
+
+    if args.weak:
+        vpr = args.views or 4
+        total_views = vpr * world
+        my_ids = list(range(vpr * rank, vpr * rank + vpr))
+    else:
+        total_views = args.views or 8
+        my_ids = shard_views(total_views, rank, world)
+    all_cams = synth_ring_cameras(total_views, W, H, device=dev)
+    rng = np.random.default_rng(1234)
+    dL_all = torch.tensor(rng.uniform(-1, 1, (total_views, 3, H, W)).astype(np.float32), device=dev)
+    GRAD_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+
+    def make_problem(cams_of_step, view_ids):
+        params = synth_scene_params(P_GAUSS, seed=0, device=dev)
+        params["rgb_colors"].requires_grad_(True)      # colour gradient computed and reduced: the 17-float bucket of section 8e
+        cams = [cams_of_step[i] for i in view_ids]
+        dL = dL_all[view_ids].contiguous() if view_ids else dL_all[:0]
+        return params, cams, dL
+
+    def make_step(params, cams, dL, with_opt, with_reduce):
+        bucket = GradBucket(params)
+        opt = initialize_optimizer(params, 4.0) if with_opt else None     # gsdyn.optim.FusedAdam: one launch for all groups
+        m2 = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True) if args.autograd else None
+
+        def step():
+            bucket.zero()
+            if cams:
+                if args.autograd:
+                    rv = params2rendervar_fused(params)
+                    im, _, _ = rasterize_gaussians_views(cams, rv["means3D"], m2, rv["opacities"], colors_precomp=rv["colors_precomp"],
+                                                         scales=rv["scales"], rotations=rv["rotations"])
+                    im.backward(gradient=dL)
+                    m2.grad = None
+                else:
+                    _, g = render_step_views(params, cams, dL)
+                    for k in GRAD_KEYS:
+                        params[k].grad = g[k]
+            if with_reduce:
+                bucket.all_reduce()          # packs the gradients into the flat bucket, ONE all-reduce, .grad = bucket slices
+            if opt is not None:
+                opt.step()
+        return step, bucket
+
+    params, cams, dL = make_problem(all_cams, my_ids)
+    step, bucket = make_step(params, cams, dL, not args.no_optimizer, world > 1)
+
+    # entry counts per view, once (spy on the backend call; not in the timed region)
     num_rendered = []
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
-
-    # The timed step is the rasterizer's own forward + backward.  The caller-side
-    # activations (normalize / sigmoid / exp of params2rendervar) are applied ONCE here, outside the timed
-    # region, and the rasterizer's input gradients accumulate into these leaves.  --with-activations puts
-    # the activations and their autograd backward back inside the step (what train_gs.py executes).
-    with torch.no_grad():
-        rv_leaf = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
-    # differentiated inputs of the rasterizer = what the all-reduce bucket carries for N > 1: 14 floats per Gaussian
-    # (means2D is a per-view gradient holder for the densification statistics, not a parameter: it stays out)
-    for k in ("means3D", "rotations", "opacities", "scales", "colors_precomp"):
-        rv_leaf[k].requires_grad_(True)
-    leaf_bucket = GradBucket({k: v for k, v in rv_leaf.items() if v.requires_grad})
-
-    def one_view(cam, dL):
-        rv = params2rendervar(params) if args.with_activations else rv_leaf
-        im, radii, depth = GaussianRasterizer(raster_settings=cam)(**rv)
-        if not args.forward_only:
-            im.backward(gradient=dL)
-
-    from diff_gaussian_rasterization import rasterize_gaussians_views
-    dL_all = torch.stack(dLs)
-    m2_views = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True)
-
-    def step(record=False):
-        nonlocal streams
-        (bucket if args.with_activations else leaf_bucket).zero()
-        if not args.per_view_calls:
-            rv = params2rendervar_fused(params) if args.with_activations else rv_leaf   # one fused kernel each way (gsr_step.hip)
-            im, radii, depth = rasterize_gaussians_views(
-                cams, rv["means3D"], m2_views, rv["opacities"], colors_precomp=rv["colors_precomp"], scales=rv["scales"],
-                rotations=rv["rotations"])
-            if not args.forward_only:
-                im.backward(gradient=dL_all)
-                m2_views.grad = None
-        elif streams is None:
-            for cam, dL in zip(cams, dLs):
-                one_view(cam, dL)
-        else:
-            main = torch.cuda.current_stream(dev)
-            for i, (cam, dL) in enumerate(zip(cams, dLs)):
-                st = streams[i % len(streams)]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    one_view(cam, dL)
-            for st in streams:
-                main.wait_stream(st)
-        if world > 1 and not args.forward_only:
-            (bucket if args.with_activations else leaf_bucket).all_reduce()
-
-    # capture num_rendered per view once (spy on the backend call; not in the timed region)
-    orig = _hip.rasterize_forward
-
-    def spy(*a, **k):
-        out = orig(*a, **k)
-        num_rendered.append(out[3].num_rendered)
-        return out
     orig_b = _hip.rasterize_forward_batch
 
     def spy_b(*a, **k):
+        k["no_host_sync"] = False
         out = orig_b(*a, **k)
         num_rendered.extend(st.num_rendered for st in out[3])
         return out
-    _hip.rasterize_forward, _hip.rasterize_forward_batch = spy, spy_b
+    _hip.rasterize_forward_batch = spy_b
     step()
-    _hip.rasterize_forward, _hip.rasterize_forward_batch = orig, orig_b
+    _hip.rasterize_forward_batch = orig_b
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def timed(fn, steps, warmup):
+        """(wall mean s, median of per-step HIP-event s) of `steps` steps after `warmup`, bracketed as the contract says."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return dt, statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3
+
+    t_step, t_event = timed(step, args.steps, args.warmup)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t_step = dt / args.steps
-    if world > 1:
-        t = torch.tensor([t_step], device=dev, dtype=torch.float64)
+        t = torch.tensor([t_step, t_event], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_step = float(t.item())
+        t_step, t_event = float(t[0].item()), float(t[1].item())
 
-    # ---- per-kernel HIP-event pass (outside the timed region), same call pattern as the timed region: in the
-    # batched pattern every stage is one launch for all views of the step on one stream, so nothing overlaps.
-    saved = (args.per_view_calls, streams)
-    streams = None
+    # ---- per-kernel HIP-event pass (outside the timed region), same call pattern
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -204,94 +216,184 @@ def main():
         step()
     torch.cuda.synchronize()
     prof = _hip.profile_end()
-    args.per_view_calls, streams = saved
+    vpl = max(len(cams), 1)                       # views per launch on this rank
     per_launch_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}
-    per_view_us = {k: 1e3 * ms / (prof_steps * VIEWS_PER_RANK) for k, (ms, n) in prof.items()}
-    views_per_launch = 1 if args.per_view_calls else VIEWS_PER_RANK
-    busy_us = sum(1e3 * ms for ms, n in prof.values()) / prof_steps
+    per_step_us = {k: 1e3 * ms / prof_steps for k, (ms, n) in prof.items()}
+    busy_us = sum(per_step_us.values())
 
     D = float(np.mean(num_rendered)) if num_rendered else 0.0
     Npx = H * W
     ab = algorithmic_bytes(P_GAUSS, D, Npx)
-    mpix = VIEWS_PER_RANK * world * Npx / t_step / 1e6
-    path_bytes = VIEWS_PER_RANK * (ab["fwd"] if args.forward_only else ab["total"])
-    dom = "render_fwd" if args.forward_only else max(
-        (k for k in per_view_us if k in ("render_fwd", "render_bwd")), key=lambda k: per_view_us[k], default="render_bwd")
+    mpix = total_views * Npx / t_step / 1e6
+    path_bytes = vpl * ab["total"]
+    dom = max((k for k in per_step_us if k in ("render_fwd", "render_bwd")), key=lambda k: per_step_us[k], default="render_bwd")
     dom_us = per_launch_us.get(dom, float("nan"))
-    dom_bytes = ab[dom] * views_per_launch      # one launch blends `views_per_launch` views
+    dom_bytes = ab[dom] * vpl
     dom_achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us == dom_us and dom_us > 0 else None
-    pairs = 256.0 * D
+    groups = {}
+    for k, us in per_step_us.items():
+        g = KERNEL_GROUP.get(k)
+        if g:
+            groups.setdefault(g, {"kernels": [], "us_per_step": 0.0})
+            groups[g]["kernels"].append(k)
+            groups[g]["us_per_step"] += us
+    per_kernel = {}
+    for g, v in groups.items():
+        b = ab[g] * vpl
+        gbps = b / (v["us_per_step"] * 1e-6) / 1e9 if v["us_per_step"] > 0 else None
+        per_kernel[g] = {"kernels": sorted(v["kernels"]), "us_per_step": round(v["us_per_step"], 2), "algorithmic_MB_per_step": round(b / 1e6, 2),
+                         "GBps": round(gbps, 1) if gbps else None, "frac_of_hbm_peak": round(gbps / (HBM_PEAK / 1e9), 4) if gbps else None}
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": dom_achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": (dom_achieved / (HBM_PEAK / 1e9)) if dom_achieved else None, "traffic": None,
-        "algorithmic_bytes_per_launch": dom_bytes, "views_per_launch": views_per_launch, "avg_launch_us": dom_us,
+        "algorithmic_bytes_per_launch": dom_bytes, "views_per_launch": vpl, "avg_launch_us": dom_us,
         "path": {"algorithmic_bytes_per_step_per_gpu": path_bytes, "achieved_GBps": path_bytes / t_step / 1e9,
                  "frac_of_hbm_peak": path_bytes / t_step / HBM_PEAK},
-        "valu": {"note": "reference-equivalent rate: 256 pixel-Gaussian pairs per list entry x 25 instruction slots, the "
-                         "work the reference's blend loop issues; this path skips most pairs (alpha-box lists + per-quad "
-                         "culling), so the figure can exceed the VALU peak",
-                 "pixel_gaussian_pairs_per_view": pairs,
-                 "render_fwd_reference_equivalent_lane_instr_per_s": (pairs * views_per_launch * 25 / (per_launch_us["render_fwd"] * 1e-6)) if "render_fwd" in per_launch_us else None,
-                 "peak_lane_instr_per_s": VALU_PEAK},
-        "per_kernel_us_per_view": {k: round(v, 2) for k, v in sorted(per_view_us.items())},
+        "per_kernel": per_kernel,
         "per_kernel_us_per_launch": {k: round(v, 2) for k, v in sorted(per_launch_us.items())},
         "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
-        "per_kernel_timing": "HIP events around every launch of the library, separate pass after the timed region, same call pattern",
+        "per_kernel_timing": "HIP events around every launch of the library (on the launch stream), separate pass after the timed region, same call pattern",
     }
+    # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_traffic.sh), corrected with the
+    # calibration factors measured on known byte counts (tools/prof_calib.sh): REPLAYED from profiles/, not measured in this run
+    tj = _load_json("r02_pmc_traffic.json")
+    if tj and dom in tj and tj.get("views_per_launch") == vpl:
+        roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
+        roofline["traffic_detail"] = {"replayed": True, "source": tj.get("source"), **{k: tj[dom].get(k) for k in
+                                      ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "fabric_bytes_per_launch", "note") if k in tj[dom]}}
+    # VALU: measured issue model (profiles/r02_valu_table.json) + committed SQ counters (REPLAYED)
+    sj = _load_json("r02_sq_counters.json")
+    valu = {"peak_lane_instr_per_s_spec": VALU_PEAK,
+            "measured_issue_model": "one wave-64 VALU op per ~2.2 SIMD-cycles at >= 2 waves per SIMD (1 per ~4.7 cycles from ONE wave); DPP ops ~3.0, "
+                                    "v_exp/v_rcp/permlane-swap ~6.0 (tools/micro/valu_table.hip -> profiles/r02_valu_table.json)",
+            "pixel_gaussian_pairs_per_view": 256.0 * D}
+    if sj and sj.get("views_per_launch") == vpl:
+        occ = {}
+        for kname in ("render_fwd", "render_bwd"):
+            if kname in sj and kname in per_launch_us:
+                n_valu = sj[kname].get("SQ_INSTS_VALU", 0.0)
+                simd_cycles = per_launch_us[kname] * 1e-6 * sj.get("clock_hz", 2.2e9) * 1024.0
+                occ[kname] = {"valu_wave_instructions": n_valu, "cycles_per_valu_instr_per_simd": simd_cycles / max(n_valu, 1.0),
+                              "valu_utilisation_at_2.2_cycles_per_op": 2.2 * n_valu / simd_cycles}
+        valu["measured"] = occ
+        valu["measured_detail"] = {"replayed": True, "source": sj.get("source")}
+    roofline["valu"] = valu
 
-    # measured HBM traffic of the dominant kernel, if a PMC summary of this round is committed (tools/prof_traffic.sh)
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if dom in tj:
-                roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"] * (views_per_launch / max(1, tj.get("views_per_launch", 1)))
-                roofline["traffic_source"] = tj.get("source", "profiles/pmc_traffic.json")
-        except Exception:  # noqa: BLE001
-            pass
-
-    # VALU issue occupancy of the blend kernels from the committed SQ counters (tools/prof_sq.sh): what actually bounds them
-    spath = os.path.join(ROOT, "profiles", "sq_counters.json")
-    if os.path.exists(spath):
-        try:
-            sj = json.load(open(spath))
-            occ = {}
-            for kname in ("render_fwd", "render_bwd"):
-                if kname in sj and kname in per_launch_us and sj.get("views_per_launch", 1) == views_per_launch:
-                    slots = per_launch_us[kname] * 1e-6 * 2.4e9 / 4.0 * 1024.0      # 256 CUs x 4 SIMDs, one wave-64 VALU op per 4 cycles
-                    occ[kname] = {"valu_wave_instructions": sj[kname].get("SQ_INSTS_VALU"),
-                                  "active_valu_quad_cycles": sj[kname].get("SQ_ACTIVE_INST_VALU"),
-                                  "issue_slots_in_launch_at_2.4GHz": slots,
-                                  "valu_issue_occupancy": sj[kname].get("SQ_ACTIVE_INST_VALU", 0.0) / slots}
-            roofline["valu"]["measured"] = occ
-            roofline["valu"]["measured_source"] = sj.get("source")
-        except Exception:  # noqa: BLE001
-            pass
-
+    cfg3 = None
     extras = None
+    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras:
+        # BASELINE.json configs[2] on the same box, same process: 4 views, colour render fwd + bwd, no optimiser step
+        p3, c3, d3 = make_problem(synth_ring_cameras(4, W, H, device=dev), list(range(4)))
+        s3, _ = make_step(p3, c3, d3, False, False)
+        t3, t3e = timed(s3, args.steps, args.warmup)
+        cfg3 = {"workload": "BASELINE.json configs[2]: 4 views 800x800, 100k Gaussians, colour render fwd+bwd, no optimiser step",
+                "value": 4 * Npx / t3 / 1e6, "unit": "Mpix/s", "ms_per_step": t3 * 1e3, "ms_per_step_event_median": t3e * 1e3}
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params)
+        extras = run_extras(dev, synth_scene_params(P_GAUSS, seed=0, device=dev), synth_ring_cameras(4, W, H, device=dev),
+                            synth_ring_cameras, synth_scene_params)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(params, cams[0], dLs[0], params2rendervar)
+        cpu_baseline = run_cpu_baseline(synth_scene_params(P_GAUSS, seed=0, device=dev), all_cams[0], dL_all[0], params2rendervar)
 
     if rank == 0:
+        n_bucket = sum(p.numel() for p in bucket.params)
         line = {
-            "metric": "fwd Mpix/s (forward-only, extra)" if args.forward_only else
-                      "fwd+bwd Mpix/s at 100k Gaussians, 4x800^2 views",
+            "metric": "fwd+bwd Mpix/s at 100k Gaussians, 800^2 views",
             "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: SynthScene-v1, 100k Gaussians, 4 views 800x800 per GPU, "
-                                   "colour render fwd+bwd per view" + ("" if world == 1 else ", 1 RCCL all-reduce of the flat grad bucket per step"),
-                       "gaussians": P_GAUSS, "views_per_gpu": VIEWS_PER_RANK, "image": [H, W],
-                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}",
-                       "call_pattern": "per-view GaussianRasterizer calls" if args.per_view_calls else
-                                       "one rasterize_gaussians_views call per step (one launch per stage for all views)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+            "ms_per_step": t_step * 1e3, "ms_per_step_event_median": t_event * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"weak scaling: {len(cams)} views per GPU of a {total_views}-camera ring" if args.weak else
+                                    f"BASELINE.json configs[{3 if total_views == 8 else 2}]-shaped step: {total_views} views 800x800 of SynthScene-v1, "
+                                    f"view r -> rank r mod N ({len(cams)} on rank 0)") +
+                                   ", 100k Gaussians, colour render fwd+bwd per view" +
+                                   ("" if world == 1 else f", 1 RCCL all-reduce of the {n_bucket}-float parameter-gradient bucket") +
+                                   ("" if args.no_optimizer else ", Adam step (FusedAdam)"),
+                       "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": len(cams), "image": [H, W],
+                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}", "grad_bucket_floats": n_bucket,
+                       "optimizer_in_timed_region": not args.no_optimizer,
+                       "call_pattern": "rasterize_gaussians_views + autograd" if args.autograd else
+                                       "gsdyn.step.render_step_views: activations, ONE multi-view forward (capacity mode), ONE multi-view backward, direct library calls"},
+            "roofline": roofline, "cfg3": cfg3, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_config5(args, dev, rank, world):
+    """Forward only, BASELINE.json configs[4]: predict.py's render loop (4 cameras x (colour + all-ones mask), bg black) on 500k
+    Gaussians at 1920x1080; (frame, camera) pairs sharded round-robin over the ranks, no collective (gsdyn/predict.py)."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import params2rendervar, synth_scene_params
+    from gsdyn.predict import FrameShard, ring_poses
+    P5, W5, H5, CAMS = 500_000, 1920, 1080, 4
+    params = synth_scene_params(P5, seed=0, device=dev)
+    with torch.no_grad():
+        data = {k: v.detach() for k, v in params2rendervar(params).items()}
+    frames = max(args.steps, 1)
+    shard = FrameShard(dev, W5, H5, ring_poses(CAMS, W5, H5), rank, world)
+    pairs = shard.my_pairs(frames)
+
+    def run(n_frames):
+        for f in range(n_frames):
+            shard.render_frame(f, data)
+
+    num_rendered = []
+    orig_b = _hip.rasterize_forward_batch
+
+    def spy_b(*a, **k):
+        out = orig_b(*a, **k)
+        num_rendered.extend(st.num_rendered for st in out[3])
+        return out
+    _hip.rasterize_forward_batch = spy_b
+    run(1)
+    _hip.rasterize_forward_batch = orig_b
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(frames)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_prof = min(frames, 5)
+    _hip.profile_begin()
+    run(n_prof)
+    torch.cuda.synchronize()
+    prof = _hip.profile_end()
+    per_step_us = {k: 1e3 * ms / n_prof for k, (ms, n) in prof.items()}
+    D = float(np.mean([d for d in num_rendered if d > 0])) if any(num_rendered) else 0.0
+    Npx = W5 * H5
+    ab = algorithmic_bytes(P5, D, Npx)
+    renders = 2 * CAMS * frames                    # colour + mask per (frame, camera) pair, all ranks together
+    mpix = renders * Npx / dt / 1e6
+    cams_here = len(pairs) / frames                # cameras this rank renders per frame, on average
+    fwd_us = per_step_us.get("render_fwd", float("nan"))
+    fwd_bytes = ab["render_fwd"] * cams_here
+    if rank == 0:
+        print(json.dumps({
+            "metric": "fwd Mpix/s, predict.py frame (colour + mask render per camera), 500k Gaussians, 1920x1080", "value": mpix, "unit": "Mpix/s",
+            "n_gpus": world, "steps": frames, "warmup": args.warmup, "ms_per_step": dt / frames * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4] render loop: 4 cameras x (colour + all-ones mask) per frame, (frame, camera) pairs "
+                                   "sharded round-robin over ranks, no collective; GNN rollout not included", "gaussians": P5, "image": [H5, W5],
+                       "cameras": CAMS, "num_rendered_per_camera": D, "pairs_on_rank0_per_frame": cams_here},
+            "roofline": {"bound": "hbm", "kernel": "render_fwd", "achieved": fwd_bytes / (fwd_us * 1e-6) / 1e9 if fwd_us == fwd_us else None,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": fwd_bytes / (fwd_us * 1e-6) / HBM_PEAK if fwd_us == fwd_us else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": fwd_bytes,
+                         "path": {"algorithmic_bytes_per_frame_per_gpu": ab["fwd"] * cams_here,
+                                  "frac_of_hbm_peak": ab["fwd"] * cams_here / (dt / frames) / HBM_PEAK},
+                         "per_kernel_us_per_frame": {k: round(v, 2) for k, v in sorted(per_step_us.items())}},
+            "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -330,8 +432,6 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                     loss_and_grads_views(params, views, variables, initial, w)
                     return
                 if mode in ("all", "all_colour_grads"):   # all cameras, colour + seg renders: ONE rasterizer call (8 views)
-                    # colour groups have lr 0 in the tracking schedule (train_utils.py:152-164): their gradient is skipped,
-                    # which keeps each colour + seg pair one fused tile pass in the backward too
                     loss, _, _ = get_loss_views(params, views, variables, initial, w, frozen_colours=(mode == "all"))
                     loss.backward()
                     return
@@ -445,7 +545,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         t_step = _time_ms(lambda: rollout_step(model, hist, eef, eef[-1] + 0.02, rv["means3D"], rv["rotations"], 0.5, 5), 5, 2)
         out["rollout_step_cfg1"] = {"ms_per_step": t_step, "fps_1000_of_100k_ms": t_fps,
                                     "what": "row N4: relations + DynamicsPredictor (rope.yaml width 512, random weights, 100 bones) + "
-                                            "bone fitting (host SVD) + skinning of 100k Gaussians (gsr_lbs); FPS timed separately (gsr_fps)"}
+                                            "bone fitting + skinning of 100k Gaussians (gsr_lbs); FPS timed separately (gsr_fps)"}
     except Exception as e:  # noqa: BLE001
         out["rollout_step_cfg1"] = {"error": repr(e)}
     return out

@@ -473,6 +473,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     w.dL_dcolors = dL_dcolors_views ? dL_dcolors_views[v] : nullptr;
     w.partner_dL_dmeans2D = partner[v] >= 0 ? dL_dmeans2D[partner[v]] : nullptr;
     w.fused_alias = fused[v];
+    w.cap = num_rendered[v];
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
   if (any) {

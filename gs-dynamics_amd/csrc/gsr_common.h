@@ -223,6 +223,8 @@ struct GsrBwdView {
   float* partner_dL_dmeans2D;   // != nullptr: fused pair backward -- the records carry both views (layout in gsr_render.hip), the
                                 // partner's screen-space gradient goes here
   int fused_alias;        // 1: handled by its owner (see partner_dL_dmeans2D): nothing to do for this view
+  uint32_t cap;           // entries the record buffer holds: reads are clamped to it, so a backward over a capacity-mode forward
+                          // that overflowed (its results are discarded by the caller) never reads past the buffer
   int W, H;
   float tanfovx, tanfovy;
 };

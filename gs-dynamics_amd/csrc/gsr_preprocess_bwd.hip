@@ -313,7 +313,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
     const bool pair = w.partner_dL_dmeans2D != nullptr;
     if (w.radii[i] > 0) {
       any = true;
-      const PartialSum ps = reduce_partials(w.partials, w.offsets[i], w.offsets[i + 1]);
+      const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap));
       gop += ps.gop;
       if (pair) {   // record layout of the pair backward: geometry sums of both views, then (sum t dx, sum t dy) of this view alone
         view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2, ps.dr, ps.dg, gm2a);

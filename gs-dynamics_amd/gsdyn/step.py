@@ -272,6 +272,39 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
 
 
 @torch.no_grad()
+def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_colour_grad: bool = True, _no_host_sync: bool = True):
+    """Forward + backward of the colour render of every camera in ``cams`` with the upstream gradient ``dL`` [V,3,H,W], as a
+    straight sequence of library calls -- fused activations, ONE multi-view rasterizer forward (capacity mode: no host wait),
+    ONE multi-view backward, fused activation backward -- without the autograd engine.  This is the rasterizer share of one
+    ``train_gs.py`` iteration (/root/reference/src/tracking/train_gs.py:25-39) for this rank's views, the step `bench.py` times.
+    Returns (images [V,3,H,W], grads) with grads = dict of the PARAMETER gradients summed over the views (means3D,
+    unnorm_rotations, logit_opacities, log_scales and, if wanted, the colour array) plus ``means2D`` [V,P,3] and ``radii`` [V,P]."""
+    from diff_gaussian_rasterization import _hip
+    m3 = params["means3D"]
+    dev = m3.device
+    V = len(cams)
+    if not m3.is_cuda or V > _hip.MAX_BATCH:
+        raise RuntimeError("render_step_views: needs a HIP device and at most %d views per call" % _hip.MAX_BATCH)
+    colours = params[colours_key].detach()
+    with _hip.hold_stream(dev):
+        rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
+        ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, op, colours, None, sc, rot, None,
+                                                                  prepare_backward=True, no_host_sync=_no_host_sync)
+        # The backward is queued right behind the forward, BEFORE the forward's entry counts are known on the host: on lists
+        # that overflowed their capacity it is still memory-safe (emit never writes past the capacity, record reads are clamped
+        # to it), its results are then simply dropped and the step is repeated synchronously.
+        d3, d2, dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, dL, m3, radii, colours, None, sc, rot, None,
+                                                                                  want_color_grad=want_colour_grad)
+        d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
+        if not _hip.forward_counts_ok(states):      # the scene outgrew the remembered capacity (> 50 % more entries in one step)
+            return render_step_views(params, cams, dL, colours_key, want_colour_grad, _no_host_sync=False)
+    grads = {"means3D": d3, "unnorm_rotations": d_un, "logit_opacities": d_lo, "log_scales": d_ls, "means2D": d2, "radii": radii}
+    if want_colour_grad:
+        grads[colours_key] = dc
+    return ims, grads
+
+
+@torch.no_grad()
 def report_psnr(params, data):
     """The extra forward render of /root/reference/src/tracking/train_utils.py:377-384."""
     im, _, _ = Renderer(raster_settings=data["cam"])(**params2rendervar(params))

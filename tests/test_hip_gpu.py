@@ -1040,14 +1040,8 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
 
     for p_ in params.values():
         p_.grad = None
-    # no reverse adjacency -> torch formulas; evaluated in fp64 on double copies of the parameters, like the image terms: the
-    # literal side then carries fp32 rounding only where the rasterizer itself computes (the thing under test on both sides)
-    torch_vars = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in rig.items()
-                  if k not in ("rev_ptr", "rev_edge")}
+    torch_vars = {k: v for k, v in rig.items() if k not in ("rev_ptr", "rev_edge")}     # no reverse adjacency -> torch formulas
     weights = dict(rigid=w.rigid, rot=w.rot, iso=w.iso, floor=w.floor, bg=w.bg)
-    p64 = {k: v.detach().double().requires_grad_(True) for k, v in params.items()}
-    shared64, _ = _shared_terms(p64, params2rendervar(p64), torch_vars, weights)
-    (float(len(views)) * shared64).backward()            # the reference adds the shared terms once per rendered camera
     total = 0.0
     for d in views:
         rv = params2rendervar(params)
@@ -1060,13 +1054,13 @@ def test_full_size_direct_step_against_literal_torch_step(dev):
         seg, _, _ = GaussianRasterizer(raster_settings=d["cam"])(**sv)
         segd, segg = seg.double(), d["seg"].double()
         l_seg = (0.8 * L.l1_loss_v1(segd, segg) + 0.2 * (1.0 - L.calc_ssim(segd, segg))).float()
-        loss = w.im * l_im + w.seg * l_seg
+        shared, _ = _shared_terms(params, rv, torch_vars, weights)        # fp32 torch ops; their fp64 evaluation agrees to 1.5e-5
+        loss = w.im * l_im + w.seg * l_seg + shared                       # (tools/micro/shared_terms_precision.py)
         loss.backward()
-        total += float(loss.detach()) + float(shared64.detach())
+        total += float(loss.detach())
     assert abs(float(loss_f) - total) <= 2e-5 * abs(total), (float(loss_f), total)
     for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "cam_m", "cam_c"):
-        want = params[k].grad.double() + (p64[k].grad if p64[k].grad is not None else 0.0)
-        got = g_f[k].double()
+        want, got = params[k].grad, g_f[k]
         assert _margin(f"direct_step/{k}", (got - want).abs().max().item(), want.abs().max().item()) <= TOL, k
     assert len(_SHARED_NAMES) == 5 and aux["means2D_grad"].shape == (4, P, 3)
 
