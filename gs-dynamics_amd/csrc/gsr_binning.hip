@@ -8,12 +8,13 @@
 // here with a hybrid MSD/LSD radix sort laid out for CDNA4:
 //   1. emit_entries     entries written in Gaussian-major order, fully coalesced (one entry per lane,
 //                       owner Gaussian found by an 8-step binary search in LDS), so emission is
-//                       load-balanced no matter how many tiles a single Gaussian covers;
+//                       load-balanced no matter how many tiles a single Gaussian covers; a workgroup owns the
+//                       entries of one radix block and also writes that block's first digit histogram;
 //   2. radix passes     stable LSD passes over the TILE-ID bits only (ceil(log2 T) bits, <= 8 per pass:
 //                       2 passes at 800x800 instead of the 6 a full 44-bit key sort needs); ranks inside a
 //                       wave come from wave-64 __ballot peer masks, histograms live in LDS, and no global
 //                       atomics are used anywhere, so the result is deterministic;
-//   3. tile_ranges      run boundaries of the tile id -> ranges[tile];
+//   3. tile ranges      found by the LAST scatter pass itself (atomicMin / atomicMax of the run ends per block);
 //   4. tile_sort        one workgroup per tile sorts its segment by depth: a stable LSD radix sort on the 32
 //                       depth bits inside LDS (segments arrive in Gaussian-id order, so stability gives the
 //                       reference tie rule); segments of 2049..4096 entries use a compare-exchange network
@@ -21,7 +22,7 @@
 //                       same network in global memory.
 // HBM traffic: emit 12 B/entry written; each radix pass 4 B read (hist) + 12 B read + 12 B written
 // (scatter) per entry; tile_sort 8 B read + 4 B written per entry.
-// Launches per view: emit, 2 x (hist, scatter), ranges, tile_sort = 7 (no scan kernels in the sort).
+// Launches per call (all views): emit(+hist), scatter, hist, scatter(+ranges), tile_order, tile_sort = 6 at 800x800.
 #include "gsr_common.h"
 
 namespace {
@@ -88,11 +89,19 @@ __device__ __forceinline__ uint32_t bin_blocks(const GsrBinView& vw, uint32_t D)
   return vw.D_dev ? (D == 0 ? 1u : (D + GSR_RADIX_EPB - 1) / GSR_RADIX_EPB) : vw.nblocks;
 }
 
-// ------------------------------------------------------------------ emit (duplicateWithKeys)
-// Block b owns Gaussians [256b, 256b+256).  Its first entry offset comes from the scan of the preprocess
-// block sums; the per-Gaussian offsets inside the block are scanned here in LDS and written out once
-// (offsets[] is what render_bwd / preprocess_bwd use to address the Gaussian-major partial records).
-__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinViews tab) {
+// ------------------------------------------------------------------ emit (duplicateWithKeys) + first digit histogram
+// ENTRY-parallel: workgroup rb owns the entries [2048 rb, 2048 rb + 2048) of its view -- exactly one block of the first radix
+// pass -- so it also produces that block's digit histogram (a plain row store: no histogram launch, no atomics on global
+// memory, nothing to zero).  It finds the Gaussians behind its entries from the per-256-Gaussian entry counts preprocess left
+// (their prefix is rebuilt in LDS, <= 2048 blocks; beyond that a scan kernel prepared block_offsets), scans the tiles_touched
+// of those Gaussians (1024 at a time -- normally all of them in one trip) into LDS offsets, and writes one entry per lane,
+// coalesced; the owner of an entry is found by a 10-step binary search in LDS, so emission stays balanced however many tiles
+// one Gaussian covers.
+// offsets[g] (what render_bwd / preprocess_bwd use to address the Gaussian-major partial records) is written by the
+// workgroup whose entry range holds it; offsets[P] = D by workgroup 0.
+#define EMIT_MAX_GBLOCKS GSR_HOST_SCAN_MAX_BLOCKS
+#define EMIT_G (4 * GSR_BLOCK)     // Gaussians per trip of the emission loop
+__global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinViews tab, int shift, int bits) {
   const GsrBinView& vw = tab.v[blockIdx.y];
   const int gx = tab.gx, T = tab.T;
   float4* __restrict__ rec = const_cast<float4*>(vw.rec);
@@ -104,65 +113,112 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
   uint32_t* __restrict__ tkey = vw.tkey[0];
   uint64_t* __restrict__ dg = vw.dg[0];
   uint2* __restrict__ ranges = vw.ranges;
-  __shared__ uint32_t soff[GSR_BLOCK + 1];
+  __shared__ uint32_t sS[EMIT_MAX_GBLOCKS + 1];   // exclusive prefix of the per-block entry counts (when no scanned array exists)
+  __shared__ uint32_t soff[EMIT_G + 1];
   __shared__ uint32_t swave[GSR_BLOCK / GSR_WAVE];
-  __shared__ uint32_t spre[GSR_BLOCK / GSR_WAVE];
+  __shared__ uint32_t hist[256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g0 = blockIdx.x * GSR_BLOCK;
-  // housekeeping for tile_ranges_kernel further down the stream (saves a memset launch): empty tiles keep (0,0)
-  for (int t = g0 + tid; t < T; t += (int)gridDim.x * GSR_BLOCK) ranges[t] = make_uint2(0u, 0u);
-  uint32_t pre = 0;  // entries of all earlier blocks, when no scanned block_offsets were prepared (P <= 512 Ki)
-  if (!block_offsets) {
-    for (uint32_t j = tid; j < blockIdx.x; j += GSR_BLOCK) pre += block_sums[j];
+  const int nblk = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+  // housekeeping for the last radix scatter further down the stream, which finds the tile ranges with atomicMin / atomicMax
+  // (saves a memset launch): every tile starts out empty = (0xffffffff, 0)
+  for (int t = (int)blockIdx.x * GSR_BLOCK + tid; t < T; t += (int)gridDim.x * GSR_BLOCK) ranges[t] = make_uint2(0xffffffffu, 0u);
+  hist[tid] = 0;
+  if (!block_offsets) {   // prefix of the block counts, 8 per thread (nblk <= 2048)
+    uint32_t v[8], sum = 0;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m, 64);
-    if (lane == 0) spre[wv] = pre;
-  }
-  const uint32_t mine = (g0 + tid < P) ? tiles_touched[g0 + tid] : 0u;
-  uint32_t inc = mine;
+    for (int k = 0; k < 8; ++k) { const int j = tid * 8 + k; v[k] = j < nblk ? block_sums[j] : 0u; sum += v[k]; }
+    uint32_t inc = sum;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) swave[wv] = inc;
-  __syncthreads();
-  uint32_t base = block_offsets ? block_offsets[blockIdx.x] : spre[0] + spre[1] + spre[2] + spre[3];
-  for (int w = 0; w < wv; ++w) base += swave[w];
-  const uint32_t excl = base + inc - mine;
-  soff[tid] = excl;
-  if (tid == GSR_BLOCK - 1) soff[GSR_BLOCK] = excl + mine;
-  if (g0 + tid < P) {
-    offsets[g0 + tid] = excl;
-    reinterpret_cast<uint32_t*>(rec + GSR_REC_F4 * (size_t)(g0 + tid) + 3)[2] = excl;   // the blend backward reads it from the record
-  }
-  if (g0 + tid == P - 1) offsets[P] = excl + mine;
-  __syncthreads();
-  if (vw.shares_lists) return;   // the lists come from the view with the same camera: only offsets were needed here
-  const uint32_t begin = soff[0];
-  const uint32_t end = vw.D_dev ? min(soff[GSR_BLOCK], vw.D) : soff[GSR_BLOCK];   // capacity mode: never past the buffers
-  for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
-    int lo = 0, hi = GSR_BLOCK;  // invariant: soff[lo] <= e < soff[hi]
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int mid = (lo + hi) >> 1;
-      if (soff[mid] <= e) lo = mid; else hi = mid;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
     }
-    const int g = g0 + lo;
-    const uint32_t k = e - soff[lo];
-    const uint2 r = rect[g];
-    const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu, maxy = r.y >> 16;
-    const uint32_t w = maxx - minx;
-    uint32_t b = k;                                    // index of the entry's tile inside the rect (row-major)
-    if (w * (maxy - miny) <= 32u) {                    // small rect: the k-th set bit of the Gaussian's tile mask
-      uint32_t m = __float_as_uint(rec[GSR_REC_F4 * g + 3].w);
-      for (uint32_t t = 0; t < k; ++t) m &= m - 1u;
-      b = (uint32_t)__ffs((int)m) - 1u;
-    }
-    const uint32_t ty = miny + b / w, tx = minx + b % w;
-    tkey[e] = ty * (uint32_t)gx + tx;
-    dg[e] = ((uint64_t)__float_as_uint(rec[GSR_REC_F4 * g + 2].y) << 32) | (uint32_t)g;
+    if (lane == 63) swave[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wv; ++w) run += swave[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int j = tid * 8 + k; if (j <= nblk) sS[j] = run; run += v[k]; }
+    __syncthreads();
   }
+  auto S = [&](int j) -> uint32_t { return block_offsets ? block_offsets[j] : sS[j]; };
+  const uint32_t D_total = S(nblk);
+  if (blockIdx.x == 0 && tid == 0) offsets[P] = D_total;
+  const uint32_t E0 = blockIdx.x * GSR_RADIX_EPB, Elim = E0 + GSR_RADIX_EPB;
+  if (E0 > D_total) return;                                   // nothing to own (uniform)
+  uint32_t E1 = min(D_total, Elim);
+  if (vw.D_dev) E1 = min(E1, vw.D);                           // capacity mode: never past the buffers
+  // Gaussian blocks to walk: jb0 = first block whose entries (or trailing zero-entry Gaussians) reach E0, jb1 = last block that
+  // starts below Elim.  Uniform binary searches.
+  int lo = 0, hi = nblk;                                      // jb0 = min j with S(j + 1) >= E0
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (S(mid + 1) >= E0) hi = mid; else lo = mid + 1; }
+  const int jb0 = lo;
+  lo = 0; hi = nblk;                                          // first j with S(j) >= Elim
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (S(mid) >= Elim) hi = mid; else lo = mid + 1; }
+  const int jb1 = lo - 1;
+  const uint32_t mask = (1u << bits) - 1u;
+  // The Gaussians of blocks jb0 .. jb1, EMIT_G at a time (4 consecutive ones per thread; one trip unless most of them are
+  // culled): local scan of tiles_touched -> offsets in LDS, then one entry per lane.
+  const int g_lo = jb0 * GSR_BLOCK, g_hi = min(P, (min(jb1, nblk - 1) + 1) * GSR_BLOCK);
+  uint32_t chunk_base = S(jb0);                               // entries before Gaussian g_lo
+  for (int g0 = g_lo; g0 < g_hi; g0 += EMIT_G) {
+    uint32_t mine[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int g = g0 + tid * 4 + q; mine[q] = g < g_hi ? tiles_touched[g] : 0u; sum += mine[q]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();                                          // previous trip's soff / swave readers are done
+    if (lane == 63) swave[wv] = inc;
+    __syncthreads();
+    uint32_t run = chunk_base + inc - sum;
+    for (int w = 0; w < wv; ++w) run += swave[w];
+    const uint32_t chunk_total = swave[0] + swave[1] + swave[2] + swave[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = g0 + tid * 4 + q;
+      soff[tid * 4 + q] = run;
+      if (g < g_hi && run >= E0 && run < Elim) {
+        offsets[g] = run;
+        reinterpret_cast<uint32_t*>(rec + GSR_REC_F4 * (size_t)g + 3)[2] = run;   // the blend backward reads it from the record
+      }
+      run += mine[q];
+    }
+    if (tid == GSR_BLOCK - 1) soff[EMIT_G] = run;
+    __syncthreads();
+    chunk_base += chunk_total;
+    if (vw.shares_lists) continue;   // the lists come from the view with the same camera: only offsets were needed here
+    const uint32_t begin = max(soff[0], E0), end = min(soff[EMIT_G], E1);
+    for (uint32_t e = begin + tid; e < end; e += GSR_BLOCK) {
+      int l2 = 0, h2 = EMIT_G;  // invariant: soff[l2] <= e < soff[h2]
+#pragma unroll
+      for (int it = 0; it < 10; ++it) {
+        const int mid = (l2 + h2) >> 1;
+        if (soff[mid] <= e) l2 = mid; else h2 = mid;
+      }
+      const int g = g0 + l2;
+      const uint32_t k = e - soff[l2];
+      const uint2 r = rect[g];
+      const uint32_t minx = r.x & 0xffffu, miny = r.x >> 16, maxx = r.y & 0xffffu, maxy = r.y >> 16;
+      const uint32_t w = maxx - minx;
+      uint32_t b = k;                                    // index of the entry's tile inside the rect (row-major)
+      if (w * (maxy - miny) <= 32u) {                    // small rect: the k-th set bit of the Gaussian's tile mask
+        uint32_t m = __float_as_uint(rec[GSR_REC_F4 * g + 3].w);
+        for (uint32_t t = 0; t < k; ++t) m &= m - 1u;
+        b = (uint32_t)__ffs((int)m) - 1u;
+      }
+      const uint32_t ty = miny + b / w, tx = minx + b % w;
+      const uint32_t key = ty * (uint32_t)gx + tx;
+      tkey[e] = key;
+      dg[e] = ((uint64_t)__float_as_uint(rec[GSR_REC_F4 * g + 2].y) << 32) | (uint32_t)g;
+      atomicAdd(&hist[(key >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  if (!vw.shares_lists && E0 < E1 && tid < (1 << bits)) vw.block_hist[blockIdx.x * (uint32_t)(1 << bits) + tid] = hist[tid];
 }
 
 // ------------------------------------------------------------------ stable radix pass on tile-id digits
@@ -240,7 +296,11 @@ __global__ __launch_bounds__(1024) void radix_colscan_kernel(GsrBinViews tab, in
 // (nblocks x nbins, L2-resident): base(bin) = sum of all counts of lower bins + counts of this bin in
 // earlier blocks.  Then wave w of the block owns the w-th quarter of the block's chunk and walks it in
 // order, 64 keys per step; rank inside a step = popcount of lower-lane peers with the same digit.
-__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits, int prescanned) {
+// The LAST pass also finds the tile ranges (no tile_ranges launch): in the block's digit-ordered LDS image the entries of a tile
+// are contiguous, so the first / last entry of every tile inside the block lowers / raises that tile's range ends with
+// atomicMin / atomicMax (order-independent, hence deterministic; emit_entries initialised every tile to (0xffffffff, 0)).  The
+// tile keys themselves have no reader behind the last pass and are not written any more.
+__global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews tab, int cur, int shift, int bits, int prescanned, int last_pass) {
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (vw.D == 0) return;
   const uint32_t D = bin_entries(vw), nblocks = bin_blocks(vw, D);
@@ -392,8 +452,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
     if (l < nvalid) {
       const uint32_t kk = s_key[l];
       const uint32_t pos = l + s_delta[(kk >> shift) & mask];
-      tkey_out[pos] = kk;
       dg_out[pos] = s_pay[l];
+      if (last_pass) {
+        if (l == 0 || s_key[l - 1] != kk) atomicMin(&vw.ranges[kk].x, pos);
+        if (l + 1 == nvalid || s_key[l + 1] != kk) atomicMax(&vw.ranges[kk].y, pos + 1u);
+      } else {
+        tkey_out[pos] = kk;
+      }
     }
   }
 }
@@ -411,43 +476,73 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 // is arbitrary: per-tile results do not depend on it.
 #define GSR_COLSCAN_MIN_BLOCKS 768u
 #define ORD_CHUNK 12
-__global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
-  __shared__ uint32_t cnt[256];
-  __shared__ uint32_t start[256];
-  __shared__ uint32_t n_busy_s, n_long_s;
-  const int tid = threadIdx.x, lane = tid & 63;
+#define ORD_WAVES 16
+#define ORD_MAX_WG 32
+// Several workgroups (one 1024-thread workgroup took 14.8 us for 10 000 tiles, most of it contention on a few
+// dozen hot LDS counters).  Every workgroup COUNTS all tiles of the call (the ranges are a few hundred KB, L2-resident) into
+// per-wave private histograms -- split into "tiles of work items before mine" and "the rest" -- so it knows the global bucket
+// starts and how many tiles of each bucket the workgroups before it will place; it then PLACES only its own work items.  No
+// inter-workgroup communication, no global atomics; the order inside a bucket is arbitrary as before.
+__global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int items_per_wg) {
+  __shared__ uint32_t h_before[ORD_WAVES][256];   // per wave: tiles per bucket in work items before this workgroup's
+  __shared__ uint32_t h_rest[ORD_WAVES][256];     // per wave: tiles per bucket in this workgroup's work items and later ones
+  __shared__ uint32_t start[256];                 // placement cursor of this workgroup per bucket
+  __shared__ uint32_t empty_before_s, n_busy_s, n_long_s, n_empty_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int T = tab.T;   // all tiles of all views, one order
   uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
-  if (tid < 256) cnt[tid] = 0;
-  if (tid < 8) queue[tid] = 0;
-  if (tab.counts_out && tid < tab.V) tab.counts_out[tid] = tab.v[tid].offsets[tab.P];   // capacity mode: the counts for the host
+  for (int i = tid; i < ORD_WAVES * 256; i += 1024) { (&h_before[0][0])[i] = 0; (&h_rest[0][0])[i] = 0; }
+  if (tid == 0) { empty_before_s = 0; n_empty_s = 0; }
+  if (blockIdx.x == 0) {
+    if (tid < 8) queue[tid] = 0;
+    if (tab.counts_out && tid < tab.V) tab.counts_out[tid] = tab.v[tid].offsets[tab.P];   // capacity mode: the counts for the host
+  }
   __syncthreads();
   // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before
   // any is used (one memory latency per chunk instead of one per item); the view index is uniform, so the table
   // lookup stays a scalar load.
   const int n_it = (T + 1023) / 1024, n_items = tab.V * n_it;
+  const int k_lo = (int)blockIdx.x * items_per_wg, k_hi = min(n_items, k_lo + items_per_wg);
+  uint32_t empties_before = 0, empties_all = 0;    // wave-uniform counts (ballots)
   for (int k0 = 0; k0 < n_items; k0 += ORD_CHUNK) {
     uint2 r[ORD_CHUNK];
+    bool live[ORD_CHUNK];
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
       r[u] = make_uint2(0u, 0u);
       // a fused alias view has no entry of its own in the order: its busy tiles ride on its owner's tickets and its empty
       // tiles are painted together with the owner's (same ranges)
-      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) r[u] = tab.v[k / n_it].ranges[t];
+      live[u] = k < n_items && t < T && !tab.v[k / n_it].fused_alias;
+      if (live[u]) r[u] = tab.v[k / n_it].ranges[t];
     }
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
-      const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
-      if (bucket != 255u) atomicAdd(&cnt[bucket], 1u);   // empty tiles (and padding): not counted, no hot LDS word
+      const int k = k0 + u;
+      const uint32_t len = r[u].y > r[u].x ? r[u].y - r[u].x : 0u;     // empty tiles arrive as (0xffffffff, 0) or (0, 0)
+      const uint32_t bucket = 255u - min((len + 7u) >> 3, 255u);
+      if (bucket != 255u) atomicAdd(k < k_lo ? &h_before[wv][bucket] : &h_rest[wv][bucket], 1u);
+      const uint32_t ne = (uint32_t)__popcll(__ballot(live[u] && bucket == 255u));   // empty tiles: counted per wave, no hot word
+      empties_all += ne;
+      if (k < k_lo) empties_before += ne;
     }
   }
+  if (lane == 0) { atomicAdd(&empty_before_s, empties_before); atomicAdd(&n_empty_s, empties_all); }
   __syncthreads();
-  if (tid < 64) {  // exclusive scan of the 256 bucket counts: lane l owns buckets 4l .. 4l+3
+  uint32_t tot = 0, bef = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < ORD_WAVES; ++w) { bef += h_before[w][tid]; tot += h_rest[w][tid]; }
+    tot += bef;
+  }
+  __syncthreads();
+  if (tid < 256) { h_rest[0][tid] = tot; h_before[0][tid] = bef; }
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 256 bucket totals: lane l owns buckets 4l .. 4l+3
     uint32_t c4[4], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { c4[q] = cnt[lane * 4 + q]; sum += c4[q]; }
+    for (int q = 0; q < 4; ++q) { c4[q] = h_rest[0][lane * 4 + q]; sum += c4[q]; }
     uint32_t inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -455,26 +550,35 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
       if (lane >= d) inc += o;
     }
     uint32_t run = inc - sum;
+    uint32_t st4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { start[lane * 4 + q] = run; run += c4[q]; }
-    if (lane == 63) n_busy_s = run;   // buckets 0..254 only: cnt[255] was never incremented
+    for (int q = 0; q < 4; ++q) { st4[q] = run; run += c4[q]; }
+    if (lane == 63) n_busy_s = run;   // buckets 0..254 only: bucket 255 (empty tiles) is never counted in the histograms
     // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
-    if (lane == 47) n_long_s = start[188] + c4[0] + c4[1] + c4[2];
+    if (lane == 47) n_long_s = st4[0] + c4[0] + c4[1] + c4[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) start[lane * 4 + q] = st4[q] + h_before[0][lane * 4 + q];
   }
   __syncthreads();
   const uint32_t n_busy = n_busy_s;
-  for (int k0 = 0; k0 < n_items; k0 += ORD_CHUNK) {
+  if (tid == 0) start[255] = n_busy + empty_before_s;   // the empty tiles go behind the busy ones
+  __syncthreads();
+  for (int k0 = k_lo; k0 < k_hi; k0 += ORD_CHUNK) {
     uint2 r[ORD_CHUNK];
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
       r[u] = make_uint2(0u, 0u);
-      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) r[u] = tab.v[k / n_it].ranges[t];
+      if (k < k_hi && t < T && !tab.v[k / n_it].fused_alias) r[u] = tab.v[k / n_it].ranges[t];
     }
 #pragma unroll
     for (int u = 0; u < ORD_CHUNK; ++u) {
       const int k = k0 + u, t = (k % n_it) * 1024 + tid;
-      if (k < n_items && t < T && !tab.v[k / n_it].fused_alias) {
+      if (k < k_hi && t < T && !tab.v[k / n_it].fused_alias) {
+        if (r[u].y <= r[u].x) {        // empty: (0, 0) from here on, for every later reader of the ranges
+          r[u] = make_uint2(0u, 0u);
+          if (!tab.v[k / n_it].shares_lists) tab.v[k / n_it].ranges[t] = r[u];
+        }
         const uint32_t bucket = 255u - min((r[u].y - r[u].x + 7u) >> 3, 255u);
         // empty tiles go behind the busy ones in any order: a wave-aggregated slot (one LDS atomic per wave).
         // (Aggregating the busy buckets too -- 8 ballots per item -- was measured slower than the plain atomics.)
@@ -493,8 +597,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab) {
     }
   }
   // the empty tiles (bucket 255) are sorted last and never enter the queues; queue[7] = entries of the order array
-  __syncthreads();
-  if (tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; queue[7] = start[255]; }
+  if (blockIdx.x == 0 && tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; queue[7] = n_busy + n_empty_s; }
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
@@ -766,17 +869,20 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
   if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
     for (int v = 0; v < tab.V; ++v) GSR_HIP_CHECK(hipMemsetAsync(tab.v[v].ranges, 0, sizeof(uint2) * (size_t)tab.T, st));
   } else {
-    { GSR_PROF("emit_entries", st);
-    hipLaunchKernelGGL(emit_entries_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, P, tab); }
-    GSR_HIP_CHECK(hipGetLastError());
     const int tbits = ceil_log2_u32((uint32_t)tab.T);
     const int npass = (tbits + 7) / 8;
     const int bpp = npass ? (tbits + npass - 1) / npass : 0;
+    { GSR_PROF("emit_entries", st);      // + the digit histogram of the first radix pass
+    const int bits0 = npass ? (tbits < bpp ? tbits : bpp) : 1;
+    hipLaunchKernelGGL(emit_entries_kernel, dim3(maxD / GSR_RADIX_EPB + 1u, tab.V), dim3(GSR_BLOCK), 0, st, P, tab, 0, bits0); }
+    GSR_HIP_CHECK(hipGetLastError());
     for (int pass = 0; pass < npass; ++pass) {
       const int shift = pass * bpp;
       const int bits = (tbits - shift) < bpp ? (tbits - shift) : bpp;
-      { GSR_PROF("radix_hist", st);
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits); }
+      if (pass > 0) {
+        GSR_PROF("radix_hist", st);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits);
+      }
       GSR_HIP_CHECK(hipGetLastError());
       const int prescanned = maxblk >= GSR_COLSCAN_MIN_BLOCKS ? 1 : 0;
       if (prescanned) {
@@ -785,12 +891,15 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
       }
       GSR_HIP_CHECK(hipGetLastError());
       { GSR_PROF("radix_scatter", st);
-      hipLaunchKernelGGL(radix_scatter_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits, prescanned); }
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(maxblk, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur, shift, bits, prescanned,
+                         pass == npass - 1 ? 1 : 0); }
       GSR_HIP_CHECK(hipGetLastError());
       cur ^= 1;
     }
-    { GSR_PROF("tile_ranges", st);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((maxD + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur); }
+    if (npass == 0) {   // a single tile: no radix pass ran, the run boundaries come from the emitted keys directly
+      GSR_PROF("tile_ranges", st);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3((maxD + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab, cur);
+    }
     GSR_HIP_CHECK(hipGetLastError());
   }
   if (int rc = gsr_launch_tile_order(tab, st)) return rc;
@@ -809,7 +918,12 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
 
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st) {
   { GSR_PROF("tile_order", st);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tab); }
+    const int n_items = tab.V * ((tab.T + 1023) / 1024);            // (view, 1024-tile slice) work items
+    int wgs = n_items < ORD_MAX_WG ? n_items : ORD_MAX_WG;
+    if (wgs < 1) wgs = 1;
+    const int per_wg = (n_items + wgs - 1) / wgs;
+    wgs = per_wg > 0 ? (n_items + per_wg - 1) / per_wg : 1;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(wgs < 1 ? 1 : wgs), dim3(1024), 0, st, tab, per_wg > 0 ? per_wg : 1); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

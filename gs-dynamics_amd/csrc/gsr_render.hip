@@ -273,10 +273,13 @@ __device__ __forceinline__ void fwd_tile(
 //   forms the two per-view screen-space gradients -- eight sums instead of 2 x 9, one alpha evaluation instead of two.
 // The pair build stages 96 entries per batch instead of 128 and keeps 8 sums per entry: with the partner colours its LDS
 // footprint then still allows four workgroups per CU (3 -> 4 measured +4 % on the get_loss step).
+// Plain passes come in two batch sizes: 128 entries (39.7 KB of LDS, four workgroups per CU) for launches with few busy tiles --
+// there a tile's critical path sets the kernel's time, and it grows with the number of batches -- and 96 entries (29.9 KB, five per
+// CU) when the queue is long and latency hiding is what counts: -4 % kernel time at 4 views x 2500 tiles, +3 % at one view.
 #define GSR_BWD_BB(PAIR) ((PAIR) ? 96 : BWD_BATCH)
-template <bool PAIR>
+template <bool PAIR, int NBB = GSR_BWD_BB(PAIR)>
 struct BwdLdsT {
-  static constexpr int BB = GSR_BWD_BB(PAIR);
+  static constexpr int BB = NBB;
   float4 sA[4][BB + 1];                 // mx, my, A, B            (per-strip compacted; +1: prefetch)
   float4 sB[4][BB + 1];                 // C, opacity, r, g
   float2 sC[4][BB + 1];                 // b, bits(batch index j)
@@ -291,13 +294,13 @@ struct BwdLdsT {
 
 struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; };
 
-template <bool PAIR>
+template <bool PAIR, int NBB = GSR_BWD_BB(PAIR)>
 __device__ __forceinline__ void bwd_tile(
-    const int tile, const uint2 rg, BwdLdsT<PAIR>& L, int W, int H, int gx,
+    const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
     const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials, const BwdPartner pt) {
-  constexpr int BB = GSR_BWD_BB(PAIR);
+  constexpr int BB = NBB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx = tile % gx, ty = tile / gx;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
@@ -604,9 +607,9 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
 __device__ __forceinline__ BwdPartner bwd_partner(const GsrRenderView& p) { return BwdPartner{p.rec, p.bg, p.dL_dcolor}; }
 
 // LDS of a backward workgroup: the pair build also runs plain tickets (views without a partner), whose layout is the larger one
-template <bool PAIRS>
+template <bool PAIRS, int NBB = BWD_BATCH>   // NBB: batch size of the plain tickets
 struct BwdLdsAny {
-  static constexpr size_t BYTES = PAIRS && sizeof(BwdLdsT<true>) > sizeof(BwdLdsT<false>) ? sizeof(BwdLdsT<true>) : sizeof(BwdLdsT<false>);
+  static constexpr size_t BYTES = PAIRS && sizeof(BwdLdsT<true>) > sizeof(BwdLdsT<false, NBB>) ? sizeof(BwdLdsT<true>) : sizeof(BwdLdsT<false, NBB>);
   alignas(16) unsigned char raw[BYTES];
 };
 
@@ -621,9 +624,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews ta
     bwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 }
 
-template <bool PAIRS>
+template <bool PAIRS, int NBB = BWD_BATCH>
 __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
-  __shared__ BwdLdsAny<PAIRS> L;
+  __shared__ BwdLdsAny<PAIRS, NBB> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
     else
-      bwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
+      bwd_tile<false, NBB>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
     __syncthreads();  // also: the tile's LDS (incl. sQuadLast) is dead before the next tile reuses it
     ticket = s_ticket;
@@ -721,9 +724,13 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
       else hipLaunchKernelGGL(render_bwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
       const int tiles = tab.T * tab.V;
-      const int per_cu = pairs ? pair_wg_per_cu : wg_per_cu;
+      // long queue (>= 3 tiles per resident workgroup slot, counting the empty ones): the 96-entry build, five workgroups per CU
+      static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 7500);
+      const bool small = !pairs && tiles >= small_batch_from;
+      const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + 1 : wg_per_cu);
       const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
       if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, 96>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
       else hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }

@@ -9,16 +9,26 @@ from diff_gaussian_rasterization import GaussianRasterizer, _hip
 from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
 dev = torch.device("cuda:0")
 params = synth_scene_params(100_000, device=dev)
-cam = synth_ring_cameras(4, 800, 800, device=dev)[0]
+V = int(os.environ.get("V", "1"))
+cams = synth_ring_cameras(max(V, 4), 800, 800, device=dev)[:V]
+cam = cams[0]
 with torch.no_grad():
     rv0 = params2rendervar(params)
 rv = {k: v.detach().clone().requires_grad_(True) for k, v in rv0.items()}
 dL = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (3, 800, 800)).astype(np.float32), device=dev)
+dLv = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (V, 3, 800, 800)).astype(np.float32), device=dev)
+from diff_gaussian_rasterization import rasterize_gaussians_views
+m2 = torch.zeros((V, 100_000, 3), device=dev, requires_grad=True)
 lib = _hip.load_library()
 buf = (C.c_uint64 * 16)()
 def run():
-    im, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
-    im.backward(gradient=dL)
+    if V == 1:
+        im, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+        im.backward(gradient=dL)
+    else:
+        im, _, _ = rasterize_gaussians_views(cams, rv["means3D"], m2, rv["opacities"], colors_precomp=rv["colors_precomp"],
+                                             scales=rv["scales"], rotations=rv["rotations"])
+        im.backward(gradient=dLv)
 for _ in range(3):
     run()
 lib.gsr_debug_phase_timing(buf)
