@@ -609,6 +609,13 @@ int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* strea
   return gsr_launch_adam_step(n_tensors, tensors, (hipStream_t)stream);
 }
 
+size_t gsr_fps_scratch_bytes(int32_t N, int32_t npoints) { return gsr_fps_scratch_size(N, npoints); }
+
+int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_related, float* rotations, int32_t* code, void* stream) {
+  if (n_bones < 0 || (n_bones > 0 && (!moments || !n_related || !rotations || !code))) { gsr_set_error("gsr_fit_rotations: bad argument"); return -2; }
+  return gsr_launch_fit_rotations(n_bones, moments, n_related, rotations, (int*)code, (hipStream_t)stream);
+}
+
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }
   if (npoints > N || (N > 0 && (start_idx < 0 || start_idx >= N))) { gsr_set_error("gsr_fps: npoints / start_idx out of range"); return -2; }

@@ -4,6 +4,7 @@
 //   gsr_lbs : moving every Gaussian with the bones -- inverse-distance weights, blended rigid transforms and blended
 //             quaternions in ONE pass (the reference loops over bones in Python and materialises [P, n_bones, 3],
 //             /root/reference/src/render/utils.py:207-239).
+#include <stdlib.h>
 #include "gsr_common.h"
 
 namespace {
@@ -53,6 +54,81 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos
   }
 }
 
+// ---------------------------------------------------------------- farthest point sampling, several workgroups
+// The single-workgroup kernel above streams the whole cloud from memory once per pick (20 us per pick at 100 k points).  Here every
+// workgroup keeps a slice of the cloud AND its running minimum distances in LDS (2048 points = 32 KB), so a pick costs one pass
+// over LDS plus ONE device-wide exchange without atomics: each workgroup publishes its best candidate as one 64-bit word (key =
+// distance bits << 32 | ~index: the maximum key is the largest distance and, on ties, the smallest index -- the same "first
+// maximum" as the single-workgroup kernel) with a write-through store into ITS slot of the pick's row, then wave 0 of every
+// workgroup sweeps the row with L1-bypassing loads until all slots are filled (a key is never 0, so the data is its own flag)
+// and reduces it.  One row PER PICK (zeroed by the launcher): nothing is ever reset or reused.  All workgroups must be resident
+// together: at most 256 of them (one per CU), i.e. N <= 524 288; larger clouds take the single-workgroup kernel.
+#define FPS_SLICE 2048
+__global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __restrict__ pos, int N, int npoints, int start,
+                                                             unsigned long long* __restrict__ cand, long long* __restrict__ out) {
+  __shared__ float sx[FPS_SLICE], sy[FPS_SLICE], sz[FPS_SLICE], sm[FPS_SLICE];
+  __shared__ unsigned long long s_key[GSR_BLOCK / GSR_WAVE];
+  __shared__ int s_cur;
+  __shared__ float s_c[3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int base = (int)blockIdx.x * FPS_SLICE, n = min(FPS_SLICE, N - base);
+  for (int i = tid; i < n; i += GSR_BLOCK) {
+    sx[i] = pos[3 * (base + i)]; sy[i] = pos[3 * (base + i) + 1]; sz[i] = pos[3 * (base + i) + 2];
+    sm[i] = __builtin_inff();
+  }
+  int cur = start;
+  for (int k = 0; k < npoints; ++k) {
+    if (blockIdx.x == 0 && tid == 0) out[k] = cur;
+    __syncthreads();                                     // previous trip's readers of s_c / s_key are done
+    if (tid < 3) s_c[tid] = pos[3 * cur + tid];          // three lanes, one cache line
+    __syncthreads();
+    const float cx = s_c[0], cy = s_c[1], cz = s_c[2];
+    float best = -1.0f;
+    int besti = 0x7fffffff;
+    for (int i = tid; i < n; i += GSR_BLOCK) {
+      const float dx = sx[i] - cx, dy = sy[i] - cy, dz = sz[i] - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const float m = fminf(sm[i], d);
+      sm[i] = m;
+      if (m > best) { best = m; besti = base + i; }     // increasing i: keeps the first maximum of this thread
+    }
+    // distances are >= 0, so their bit patterns order like the values; ~index makes the smaller index the larger key
+    unsigned long long key = best < 0.0f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)(~(uint32_t)besti));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = (unsigned long long)__shfl_xor((long long)key, off, 64);
+      key = o > key ? o : key;
+    }
+    if (lane == 0) s_key[wv] = key;
+    __syncthreads();
+    if (wv == 0) {
+      unsigned long long* row = cand + (size_t)k * gridDim.x;
+      if (lane == 0) {
+        unsigned long long kk = s_key[0];
+        for (int w = 1; w < GSR_BLOCK / GSR_WAVE; ++w) kk = s_key[w] > kk ? s_key[w] : kk;
+        __hip_atomic_store(&row[blockIdx.x], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned long long win = 0ull;
+      for (int g0 = 0; g0 < (int)gridDim.x; g0 += 64) {     // sweep the row, 64 slots at a time, until every slot is filled
+        const bool mine = g0 + lane < (int)gridDim.x;
+        unsigned long long v;
+        do {
+          v = mine ? __hip_atomic_load(&row[g0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
+        } while (__ballot(v == 0ull) != 0ull);
+        if (mine) win = v > win ? v : win;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = (unsigned long long)__shfl_xor((long long)win, off, 64);
+        win = o > win ? o : win;
+      }
+      if (lane == 0) s_cur = (int)(~(uint32_t)win);
+    }
+    __syncthreads();
+    cur = s_cur;
+  }
+}
+
 // ---------------------------------------------------------------- linear blend skinning of the Gaussians
 #define LBS_CHUNK 256   // bones staged per LDS round
 __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const float* __restrict__ bones,
@@ -97,10 +173,93 @@ __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const flo
   }
 }
 
+// ---------------------------------------------------------------- per-bone rotation fit (batched 3x3 problems)
+// One thread per bone: singular value decomposition of the 3x3 moment matrix F by one-sided Jacobi rotations in fp64 (accurate
+// small singular values, so the rank test of the reference -- S > S.max * 3 eps_fp32, /root/reference/src/render/utils.py:160-170
+// -- takes the same decisions as LAPACK's), then the reference's decision tree (utils.py:147-205):
+//   no related bone, or F = 0            -> identity                                                   code 0
+//   rank 1                               -> NOT decided here: the reference turns the x axis onto U[:, 0], whose SIGN is a
+//                                           convention of the SVD backend; the caller resolves these bones with the same
+//                                           LAPACK driver the reference runs                           code 1
+//   rank 3 with det F < 0                -> identity (the reference indexes S[3, 3], fails, and falls back)   code 0
+//   rank 2, or rank 3 with det F > 0     -> u1 v1^T + u2 v2^T + (u1 x u2)(v1 x v2)^T: for a full-rank F with positive determinant
+//                                           this IS U V^T; for rank 2 it is the reference's U S V^T after its det = -1 repair
+//                                           (both null vectors completed right-handed), independent of sign conventions   code 2
+__global__ __launch_bounds__(64) void fit_rotations_kernel(int nb, const float* __restrict__ F, const float* __restrict__ n_adj,
+                                                           float* __restrict__ R, int* __restrict__ code) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nb) return;
+  double A[3][3], V[3][3];
+  bool zero = true;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { A[i][j] = (double)F[9 * b + 3 * i + j]; V[i][j] = i == j ? 1.0 : 0.0; zero = zero && A[i][j] == 0.0; }
+  auto identity = [&](int c) { for (int i = 0; i < 9; ++i) R[9 * b + i] = (i % 4 == 0) ? 1.0f : 0.0f; code[b] = c; };
+  if (n_adj[b] <= 0.0f || zero) { identity(0); return; }
+  for (int sweep = 0; sweep < 40; ++sweep) {            // A V0 = U S: rotate column pairs until they are orthogonal
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0.0, be = 0.0, ga = 0.0;
+        for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+        if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+        off = fmax(off, fabs(ga) / sqrt(al * be));
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sg[3];
+  for (int j = 0; j < 3; ++j) sg[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  int o0 = 0, o1 = 1, o2 = 2;                          // descending order of the singular values
+  if (sg[o0] < sg[o1]) { const int t = o0; o0 = o1; o1 = t; }
+  if (sg[o1] < sg[o2]) { const int t = o1; o1 = o2; o2 = t; }
+  if (sg[o0] < sg[o1]) { const int t = o0; o0 = o1; o1 = t; }
+  const double thr = sg[o0] * 3.0 * 1.1920928955078125e-07;
+  const int rank = (sg[o0] > thr) + (sg[o1] > thr) + (sg[o2] > thr);
+  if (rank == 1) { identity(1); return; }
+  if (rank == 0) { identity(0); return; }
+  double u1[3], u2[3], v1[3], v2[3];
+  for (int i = 0; i < 3; ++i) { u1[i] = A[i][o0] / sg[o0]; u2[i] = A[i][o1] / sg[o1]; v1[i] = V[i][o0]; v2[i] = V[i][o1]; }
+  const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+  const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+  if (rank == 3) {   // sign of det F = handedness of (u1, u2, u_o2) times handedness of (v1, v2, v_o2)
+    double du = 0.0, dv = 0.0;
+    for (int i = 0; i < 3; ++i) { du += u3[i] * A[i][o2]; dv += v3[i] * V[i][o2]; }
+    if (du * dv < 0.0) { identity(0); return; }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[9 * b + 3 * i + j] = (float)(u1[i] * v1[j] + u2[i] * v2[j] + u3[i] * v3[j]);
+  code[b] = 2;
+}
+
 }  // namespace
+
+static int fps_workgroups(int N) { return (N + FPS_SLICE - 1) / FPS_SLICE; }
+size_t gsr_fps_scratch_size(int N, int npoints) {   // N floats of running minima (single-workgroup path) + one row of candidate words per pick
+  const int wgs = fps_workgroups(N);
+  const size_t rows = (wgs > 1 && wgs <= 256) ? (size_t)(npoints > 0 ? npoints : 1) * wgs * 8 : 0;
+  return gsr_align((size_t)(N > 0 ? N : 1) * 4) + gsr_align(rows);
+}
 
 int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st) {
   if (N <= 0 || npoints <= 0) return 0;
+  static const bool single = [] { const char* e = getenv("GSR_FPS_SINGLE_WG"); return e && *e && atoi(e) != 0; }();
+  const int wgs = fps_workgroups(N);
+  if (!single && wgs > 1 && wgs <= 256) {
+    unsigned long long* cand = (unsigned long long*)((char*)mind + gsr_align((size_t)N * 4));
+    GSR_HIP_CHECK(hipMemsetAsync(cand, 0, (size_t)npoints * wgs * 8, st));
+    { GSR_PROF("fps", st);
+      hipLaunchKernelGGL(fps_multi_kernel, dim3(wgs), dim3(GSR_BLOCK), 0, st, pos, N, npoints, start, cand, out); }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   { GSR_PROF("fps", st);
     hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(1024), 0, st, pos, N, npoints, start, mind, out); }
   GSR_HIP_CHECK(hipGetLastError());
@@ -113,6 +272,14 @@ int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const floa
   { GSR_PROF("lbs", st);
     hipLaunchKernelGGL(lbs_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, nb, bones, R, t, bq, xyz, quat,
                        out_xyz, out_quat); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_fit_rotations(int nb, const float* F, const float* n_adj, float* R, int* code, hipStream_t st) {
+  if (nb <= 0) return 0;
+  { GSR_PROF("fit_rotations", st);
+    hipLaunchKernelGGL(fit_rotations_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, F, n_adj, R, code); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -64,7 +64,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_forward_batch_capacity",
            "gsr_backward_batch", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_lbs",
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
@@ -151,6 +151,10 @@ def load_library():
     lib.gsr_rigidity_backward.argtypes = [i32, i32] + [vp] * 14 + [vp]
     lib.gsr_fps.restype = C.c_int
     lib.gsr_fps.argtypes = [i32, vp, i32, i32, vp, vp, vp]
+    lib.gsr_fps_scratch_bytes.restype = sz
+    lib.gsr_fps_scratch_bytes.argtypes = [i32, i32]
+    lib.gsr_fit_rotations.restype = C.c_int
+    lib.gsr_fit_rotations.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
     lib.gsr_lbs.argtypes = [i32, i32] + [vp] * 8 + [vp]
     lib.gsr_mark_visible.restype = C.c_int
@@ -699,10 +703,25 @@ def farthest_point_sampling(pos: torch.Tensor, npoints: int, start_idx: int = 0)
     _require_device(pos)
     N = int(pos.shape[0])
     with torch.cuda.device(pos.device):
-        scratch = torch.empty((max(N, 1),), dtype=torch.float32, device=pos.device)
+        scratch = torch.empty((int(lib.gsr_fps_scratch_bytes(N, int(npoints))),), dtype=torch.uint8, device=pos.device)
         out = torch.empty((npoints,), dtype=torch.int64, device=pos.device)
         _check(lib.gsr_fps(N, _ptr(pos), int(npoints), int(start_idx), _ptr(scratch), _ptr(out), _stream(pos.device)), "gsr_fps")
     return out
+
+
+def fit_rotations(moments: torch.Tensor, n_related: torch.Tensor):
+    """moments [nb,3,3] fp32, n_related [nb] (any dtype) on a HIP device -> (rotations [nb,3,3], code [nb] int32), see gsr_fit_rotations."""
+    lib = load_library()
+    _require_device(moments)
+    dev = moments.device
+    nb = int(moments.shape[0])
+    with _on(dev):
+        F = moments.to(torch.float32).contiguous()
+        n = n_related.to(torch.float32).contiguous()
+        R = torch.empty((nb, 3, 3), dtype=torch.float32, device=dev)
+        code = torch.empty((nb,), dtype=torch.int32, device=dev)
+        _check(lib.gsr_fit_rotations(nb, _ptr(F), _ptr(n), _ptr(R), _ptr(code), _stream(dev)), "gsr_fit_rotations")
+    return R, code
 
 
 def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat):

@@ -266,14 +266,28 @@ def fit_bone_rotations(bones: torch.Tensor, motions: torch.Tensor, relations: to
       0 neighbours -> identity;  rank 1 -> the rotation taking the x axis onto the dominant left singular vector;
       otherwise the Kabsch rotation U S V^T, with the reference's quirks kept: for a full-rank F with negative determinant
       its index error falls back to the identity, and a result with det = -1 is repaired by flipping S[rank, rank].
-    The 3x3 problems are solved on the host in one batched SVD (see the module docstring); the per-bone decision tree is
-    evaluated for all bones at once with numpy masks (a Python loop of torch CPU ops over 100 bones cost 20 ms per step --
-    ``_fit_bone_rotations_loop`` keeps that literal form for the tests)."""
+    On a HIP device all bones are fitted by ONE kernel (``gsr_fit_rotations``: fp64 one-sided Jacobi SVD per bone + the decision
+    tree); only rank-1 bones -- where the reference's answer hangs on the sign convention of its SVD backend -- come back
+    flagged and are resolved on the host with the same LAPACK driver (a handful of 3x3 problems at most; normally none).  CPU
+    tensors take the host path for every bone (one batched SVD, the per-bone decision tree evaluated with numpy masks;
+    ``_fit_bone_rotations_loop`` keeps the reference's literal one-bone-at-a-time form for the tests)."""
     F_dev, n_adj_dev = _bone_moment_matrices(bones, motions, relations)
     nb = bones.shape[0]
-    packed = torch.cat([F_dev.reshape(nb, 9), n_adj_dev.to(torch.float32)[:, None]], 1).cpu()      # one D2H copy
-    F_t = packed[:, :9].reshape(nb, 3, 3).contiguous()
-    n_adj = packed[:, 9].numpy()
+    if bones.is_cuda:
+        from diff_gaussian_rasterization import _hip
+        R_dev, code = _hip.fit_rotations(F_dev, n_adj_dev)
+        flagged = (code == 1).nonzero().squeeze(1)              # the one host round trip of the step: nb small integers
+        if flagged.numel():
+            sub = torch.cat([F_dev[flagged].reshape(-1, 9), n_adj_dev[flagged].to(torch.float32)[:, None]], 1).cpu()
+            R_dev[flagged] = torch.from_numpy(_fit_rotations_host(sub[:, :9].reshape(-1, 3, 3).contiguous(), sub[:, 9].numpy())).to(bones.device)
+        return R_dev
+    packed = torch.cat([F_dev.reshape(nb, 9), n_adj_dev.to(torch.float32)[:, None]], 1).cpu()
+    return torch.from_numpy(_fit_rotations_host(packed[:, :9].reshape(nb, 3, 3).contiguous(), packed[:, 9].numpy())).to(bones.device)
+
+
+def _fit_rotations_host(F_t: torch.Tensor, n_adj: np.ndarray) -> np.ndarray:
+    """Host evaluation of the decision tree for CPU moment matrices F_t [nb,3,3] (fp32) -> rotations [nb,3,3] (numpy)."""
+    nb = F_t.shape[0]
     U_t, S_t, Vh_t = torch.linalg.svd(F_t)               # same LAPACK driver as the literal form
     F, U, S, Vh = F_t.numpy(), U_t.numpy(), S_t.numpy(), Vh_t.numpy()
     eps = np.finfo(np.float32).eps
@@ -314,7 +328,7 @@ def fit_bone_rotations(bones: torch.Tensor, motions: torch.Tensor, relations: to
             Sg[np.arange(idx.size)[again], rr[again], rr[again]] *= -1.0
             Ri[again] = U[idx][again] @ Sg[again] @ Vh[idx][again]
         R[idx] = Ri.astype(np.float32)
-    return torch.from_numpy(R).to(bones.device)
+    return R
 
 
 def _fit_bone_rotations_loop(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor) -> torch.Tensor:
@@ -412,3 +426,104 @@ def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_h
     rel = relations_to_matrix(recv, send, nobj + 1)[:nobj, :nobj]
     xyz_new, quat_new, _ = interpolate_motions(bones, pred[0] - bones, rel, all_xyz, quat=all_quat)
     return pred[0], xyz_new, quat_new, (recv, send)
+
+
+# ------------------------------------------------------------------------------------------ the whole rollout (predict.py's scene data)
+def downsample_vertices(xyz: torch.Tensor, max_nobj: int, radius: float, start_idx: int = 0):
+    """Bones for the graph (/root/reference/src/render/dynamics_module.py:44-51): ``max_nobj`` farthest points, thinned until every
+    one of them lies within ``radius`` of a kept one.  Returns (points [M,3], indices into ``xyz`` [M]).  (The reference draws the
+    thinning's first index at random; here it is ``start_idx``.)"""
+    idx1 = farthest_point_sampler(xyz[None], max_nobj, start_idx=0)[0]
+    _, idx2 = fps_radius(xyz[idx1], radius, start_idx=start_idx)
+    idx = idx1[idx2.to(idx1.device)]
+    return xyz[idx], idx
+
+
+@torch.no_grad()
+def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_steps: int, inlier_idx_all, *, max_nobj: int,
+            fps_radius_value: float, adj_thresh: float, topk: int, connect_all: bool, dist_thresh: float, n_fps_all: int = 1000,
+            thin_start_idx: int = 0, storage_device=None):
+    """The autoregressive loop of /root/reference/src/render/dynamics_module.py:53-172.  1000 (``n_fps_all``) farthest points of the
+    inlier Gaussians carry the particle history; per step the bones are re-sampled from them, the GNN predicts the bones' next
+    positions from the last ``n_his`` states and the end-effector motion, and all Gaussians follow the bones
+    (``interpolate_motions``).  A step whose end-effector target moved less than ``dist_thresh`` repeats the previous frame.
+    Everything stays on the device of ``xyz_0`` (the reference shuttles every frame to the CPU); ``storage_device`` moves the
+    per-frame arrays elsewhere if wanted.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
+    eef [S,1,3])."""
+    dev = xyz_0.device
+    store = dev if storage_device is None else torch.device(storage_device)
+    n_his = int(model.model_config["n_his"])
+    inl = torch.as_tensor(inlier_idx_all, device=dev, dtype=torch.long)
+    all_pos = xyz_0
+    fps_all_idx = farthest_point_sampler(xyz_0[inl][None], n_fps_all, start_idx=0)[0]
+    fps_all_pos = all_pos[inl][fps_all_idx]
+    hist = fps_all_pos[None].repeat(n_his, 1, 1)
+    eef_hist = eef_xyz[0][None].repeat(n_his, 1, 1)
+    eef_pos = eef_xyz[0]
+    p0, _ = downsample_vertices(fps_all_pos, max_nobj, fps_radius_value, thin_start_idx)
+    rep = lambda t: t.to(store)[None].repeat(n_steps, *([1] * t.dim()))  # noqa: E731
+    quat, xyz, rgb, opa = rep(quat_0), rep(xyz_0), rep(rgb_0), rep(opa_0)
+    xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
+    eef = rep(eef_xyz[0])
+    xyz_bones[0, :p0.shape[0]] = p0.to(store)
+    for i in range(1, n_steps):
+        if float(torch.norm(eef_xyz[i] - eef_pos)) < dist_thresh:
+            for a in (quat, xyz, rgb, opa, xyz_bones, eef):
+                a[i] = a[i - 1]
+            continue
+        eef_next = eef_xyz[i]
+        bones, fps_idx = downsample_vertices(fps_all_pos, max_nobj, fps_radius_value, thin_start_idx)
+        pred, all_pos, all_rot, _ = rollout_step(model, hist[:, fps_idx], eef_hist, eef_next, all_pos, quat[i - 1].to(dev),
+                                                 adj_thresh, topk, connect_all)
+        eef_hist = torch.cat([eef_hist[1:], eef_next[None]], 0)
+        eef_pos = eef_next
+        fps_all_pos = all_pos[inl][fps_all_idx]
+        hist = torch.cat([hist[1:], fps_all_pos[None]], 0)
+        quat[i], xyz[i], rgb[i], opa[i] = all_rot.to(store), all_pos.to(store), rgb[i - 1], opa[i - 1]
+        xyz_bones[i, :bones.shape[0]] = pred.to(store)
+        eef[i] = eef_pos.to(store)
+    return xyz, rgb, quat, opa, xyz_bones, eef
+
+
+def smooth_frames(xyz, rgb, quat, opa, xyz_bones, eef):
+    """Linear interpolation across the frames the rollout repeated (/root/reference/src/render/dynamics_module.py:223-236): between
+    two consecutive frames in which the Gaussians actually moved, every array is lerped; quaternions are re-normalised.  In place."""
+    moved = (xyz - torch.cat([xyz[0:1], xyz[:-1]], 0)).norm(dim=-1).sum(-1).nonzero().squeeze(1)
+    cps = torch.cat([torch.zeros(1, dtype=moved.dtype, device=moved.device), moved]).tolist()
+    for a, b in zip(cps[:-1], cps[1:]):
+        if b - a < 2:
+            continue
+        w = torch.linspace(0, 1, b - a + 1, device=xyz.device)
+        for arr in (xyz, rgb, quat, opa, xyz_bones, eef):
+            ww = w.to(arr.device)[(slice(None),) + (None,) * (arr.dim() - 1)]
+            arr[a:b] = torch.lerp(arr[a][None], arr[b][None], ww)[:-1]
+    quat[:] = torch.nn.functional.normalize(quat, dim=-1)
+    return xyz, rgb, quat, opa, xyz_bones, eef
+
+
+def pack_scene_data(xyz, rgb, quat, opa, scales, xyz_bones, eef):
+    """Per-frame render inputs and keypoints, as ``collect_scene_data`` hands them to the renderer (dynamics_module.py:239-257)."""
+    scene, vis = [], []
+    for t in range(xyz.shape[0]):
+        scene.append({"means3D": xyz[t], "colors_precomp": rgb[t], "rotations": quat[t], "opacities": opa[t], "scales": scales,
+                      "means2D": torch.zeros_like(xyz[t])})
+        vis.append({"kp": xyz_bones[t].cpu().numpy(), "tool_kp": eef[t].cpu().numpy()})
+    return scene, vis
+
+
+def remove_statistical_outliers(xyz: torch.Tensor, nb_neighbors: int = 50, std_ratio0: float = 2.0, step: float = 0.5):
+    """The outlier loop of ``collect_scene_data`` (dynamics_module.py:195-207): repeat Open3D's statistical outlier removal with a
+    growing ``std_ratio`` until a pass removes nothing; returns the surviving indices.  Open3D is an absent third-party library:
+    its filter is restated from its documentation (mean distance to the ``nb_neighbors`` nearest points, the query included; a
+    point stays if that mean is below cloud mean + std_ratio x sample standard deviation) and is NOT pinned by a golden."""
+    keep = torch.arange(xyz.shape[0], device=xyz.device)
+    it = 0
+    while True:
+        pts = xyz[keep]
+        k = min(nb_neighbors, pts.shape[0])
+        md = torch.cat([torch.topk(torch.cdist(pts[s:s + 4096], pts), k, dim=1, largest=False)[0].mean(1) for s in range(0, pts.shape[0], 4096)])
+        ok = md < md.mean() + (std_ratio0 + step * it) * md.std()
+        if bool(ok.all()):
+            return keep
+        keep = keep[ok]
+        it += 1

@@ -228,10 +228,19 @@ int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* strea
 /* ---- rollout plumbing (callers: gsdyn/dynamics.py)
  * gsr_fps: farthest point sampling of pos[N,3] -> out_idx[npoints] (int64), first pick start_idx, every further pick the
  *   point with the largest squared distance to the picked set (first maximum on ties).  Stands in for
- *   dgl.geometry.farthest_point_sampler (/root/reference/src/render/dynamics_module.py:46,65).  scratch: N floats.
+ *   dgl.geometry.farthest_point_sampler (/root/reference/src/render/dynamics_module.py:46,65).  scratch: gsr_fps_scratch_bytes(N,
+ *   npoints) bytes (256-byte aligned).  Clouds of 2049 .. 524 288 points are sampled by up to 256 co-resident workgroups that keep
+ *   their slice in LDS and meet once per pick (same picks as the single-workgroup path, bit for bit).
  * gsr_lbs: moves P Gaussians with n_bones bones (/root/reference/src/render/utils.py:207-239): weights 1/max(|x - bone|, 1e-4)
  *   normalised over the bones; out_xyz = sum_b w_b (R_b (x - bone_b) + t_b + bone_b); out_quat = normalise(sum_b w_b q_b) * quat
  *   (quaternions w,x,y,z; rotations row-major 3x3; quat / out_quat may be NULL). */
+size_t gsr_fps_scratch_bytes(int32_t N, int32_t npoints);
+/* gsr_fit_rotations: one rotation per bone from its 3x3 moment matrix F_i = sum_j (new_j - new_i)(old_j - old_i)^T (row-major, fp32)
+ *   and the number of related bones, with the decision tree of /root/reference/src/render/utils.py:147-205 (batched on the device:
+ *   fp64 one-sided Jacobi SVD per bone).  code[i]: 0 = identity by rule (no related bone, F = 0, or full rank with det F < 0),
+ *   2 = Kabsch rotation written, 1 = rank-1 bone LEFT AS IDENTITY for the caller: the reference's answer there depends on the sign
+ *   convention of its SVD backend (the caller resolves those few bones with that backend). */
+int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_related, float* rotations, int32_t* code, void* stream);
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream);
 int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
             const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);

@@ -175,3 +175,45 @@ def test_fit_bone_rotations_vectorised_equals_literal_form():
         assert a.shape == b.shape == (nb, 3, 3)
         assert float((a - b).abs().max()) <= 1e-6, trial
         assert torch.equal(a[0], torch.eye(3))
+
+
+def test_rollout_matches_reference_loop(golden_dir):
+    """``gsdyn.dynamics.rollout`` + ``smooth_frames`` against the reference's ``DynamicsModule.rollout`` and the smoothing block of
+    ``collect_scene_data``, captured by importing the reference (tests/golden/gen_rollout_goldens.py): seven steps, two of which
+    move the end effector by less than ``dist_thresh`` (repeated frames), history shift, per-step bone re-sampling."""
+    from gsdyn.dynamics import DynamicsPredictor, pack_scene_data, rollout, smooth_frames
+    z = np.load(os.path.join(golden_dir, "rollout_host.npz"))
+    cfg = dict(nf_particle=32, nf_relation=32, nf_effect=32, attr_dim=2, state_dim=0, action_dim=3, pstep=3, rel_attr_dim=2,
+               rel_group_dim=1, rel_distance_dim=3, n_his=3)
+    torch.manual_seed(0)
+    model = DynamicsPredictor(cfg).eval()
+    t = lambda k: torch.tensor(z[k])  # noqa: E731
+    max_nobj, fps_r, adj, topk, call, dth = z["cfg"]
+    S = z["xyz"].shape[0]
+    out = rollout(model, t("xyz_0"), t("rgb_0"), t("quat_0"), t("opa_0"), t("eef_xyz"), S, z["inlier"], max_nobj=int(max_nobj),
+                  fps_radius_value=float(fps_r), adj_thresh=float(adj), topk=int(topk), connect_all=bool(call), dist_thresh=float(dth))
+    xyz, rgb, quat, opa, bones, eef = out
+    assert torch.equal(xyz[2], xyz[1]) and torch.equal(xyz[5], xyz[4])          # the two skipped steps repeat their predecessor
+    # fp32 rounding of a different operation order (gather / scatter-add message passing, batched rotation fit) compounds over
+    # the autoregressive steps: 1e-7 after one step, 7e-6 after five
+    np.testing.assert_allclose(xyz.numpy(), z["xyz"], atol=2e-5)
+    np.testing.assert_allclose(quat.numpy(), z["quat"], atol=5e-5)
+    np.testing.assert_allclose(bones.numpy(), z["bones"], atol=2e-6)
+    np.testing.assert_allclose(eef.numpy(), z["eef"], atol=0)
+    assert torch.equal(rgb[-1], t("rgb_0")) and torch.equal(opa[-1], t("opa_0"))
+    xs, rs, qs, os_, bs, es = smooth_frames(*(a.clone() for a in out))
+    np.testing.assert_allclose(xs.numpy(), z["smooth_xyz"], atol=2e-5)
+    np.testing.assert_allclose(qs.numpy(), z["smooth_quat"], atol=5e-5)
+    np.testing.assert_allclose(bs.numpy(), z["smooth_bones"], atol=2e-6)
+    np.testing.assert_allclose(es.numpy(), z["smooth_eef"], atol=1e-7)
+    scene, vis = pack_scene_data(xs, rs, qs, os_, torch.full((xs.shape[1], 3), 0.01), bs, es)
+    assert len(scene) == S and set(scene[0]) == {"means3D", "colors_precomp", "rotations", "opacities", "scales", "means2D"}
+    assert vis[3]["kp"].shape == (int(max_nobj), 3) and vis[3]["tool_kp"].shape == (1, 3)
+
+
+def test_statistical_outlier_loop_drops_far_points():
+    from gsdyn.dynamics import remove_statistical_outliers
+    g = torch.Generator().manual_seed(1)
+    pts = torch.cat([0.05 * torch.randn(400, 3, generator=g), torch.tensor([[3.0, 0, 0], [0, -4.0, 0], [2.0, 2.0, 2.0]])])
+    keep = remove_statistical_outliers(pts, nb_neighbors=20)
+    assert keep.max() < 400 and keep.numel() >= 380

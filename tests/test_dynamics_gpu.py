@@ -97,3 +97,52 @@ def test_rollout_step_feeds_the_rasterizer(dev, golden_dir):
                                                                colors_precomp=rv["colors_precomp"], scales=rv["scales"],
                                                                rotations=torch.nn.functional.normalize(quat_new, dim=-1))
     assert im.shape == (3, 120, 160) and torch.isfinite(im).all() and int((radii > 0).sum()) > 0
+
+
+def test_fps_single_and_multi_workgroup_paths_agree(dev):
+    """The multi-workgroup sampler (slices in LDS, one atomicMax exchange per pick) takes the same picks as the single-workgroup
+    kernel, ties included (duplicated points force equal distances): run in subprocesses, one per path."""
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gsdyn.dynamics import farthest_point_sampler\n"
+            "g = torch.Generator().manual_seed(5); p = torch.rand(30000, 3, generator=g); p = torch.cat([p, p[:5000]])\n"
+            "print(farthest_point_sampler(p[None].cuda(), 700, start_idx=3)[0].cpu().tolist())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "gs-dynamics_amd"))
+    outs = []
+    for single in ("0", "1"):
+        env = dict(os.environ, GSR_FPS_SINGLE_WG=single)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(eval(outs[0])) == 700
+
+
+def test_device_rotation_fit_matches_the_literal_decision_tree(dev):
+    """gsr_fit_rotations (fp64 one-sided Jacobi per bone + decision tree, rank-1 bones resolved by the host's LAPACK) against the
+    literal per-bone form of the reference's control flow: generic bones, bones with one neighbour (rank 1), coplanar
+    neighbourhoods (rank 2), reflected motions (det F < 0: the reference's identity fallback) and isolated bones."""
+    from gsdyn.dynamics import _fit_bone_rotations_loop, fit_bone_rotations
+    g = torch.Generator().manual_seed(11)
+    nb = 160
+    bones = torch.rand(nb, 3, generator=g)
+    bones[40:80, 2] = 0.5                                   # a coplanar patch: rank-2 moment matrices
+    ang = 0.3
+    Rz = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=torch.float32)
+    new = (bones - 0.5) @ Rz.T + 0.5 + 0.002 * torch.randn(nb, 3, generator=g)
+    new[80:100] = (bones[80:100] - 0.5) * torch.tensor([1.0, 1.0, -1.0]) + 0.5     # mirrored: det F < 0
+    new[40:80, 2] = 0.5 + 0.1 * (bones[40:80, 0] - 0.5)    # the patch stays planar (tilted)
+    motions = new - bones
+    rel = (torch.cdist(bones, bones) < 0.22).long()
+    rel[120:140] = 0
+    for i in range(120, 130):                               # exactly one neighbour: rank 1
+        rel[i, (i + 7) % nb] = 1
+    rel[130:140] = 0                                        # isolated bones
+    rel[40:80, :40] = 0; rel[40:80, 80:] = 0                # the patch only sees itself  # noqa: E702
+    want = _fit_bone_rotations_loop(bones, motions, rel)
+    got = fit_bone_rotations(bones.to(dev), motions.to(dev), rel.to(dev)).cpu()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().amax(dim=(1, 2))
+    assert float(err.max()) < 2e-5, (int(err.argmax()), float(err.max()))
+    det = torch.linalg.det(got.double())
+    assert float((det - 1).abs().max()) < 1e-4
+    assert torch.equal(got[130:140], torch.eye(3).expand(10, 3, 3))
