@@ -15,7 +15,36 @@ struct ProfRec { const char* name; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
-GsrProfScope::GsrProfScope(const char* name, hipStream_t s) : slot(-1), st(s) {
+// ---- roctx ranges (tracing): every exported compute entry point and every kernel launch site opens a range
+// named after itself, so a rocprofv3 --marker-trace timeline reads gsr_forward_batch > preprocess_fwd, emit_entries, ...  The marker
+// library is looked up at first use (librocprofiler-sdk-roctx, else libroctx64) and is optional: without it the ranges are no-ops.
+// GSR_ROCTX=0 switches them off.
+#include <dlfcn.h>
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+bool roctx_ready() {
+  static const bool ok = [] {
+    const char* e = getenv("GSR_ROCTX");
+    if (e && *e && atoi(e) == 0) return false;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+      g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+      if (g_roctx_push && g_roctx_pop) return true;
+    }
+    return false;
+  }();
+  return ok;
+}
+}  // namespace
+GsrRange::GsrRange(const char* name) : on(roctx_ready()) { if (on) g_roctx_push(name); }
+GsrRange::~GsrRange() { if (on) g_roctx_pop(); }
+
+GsrProfScope::GsrProfScope(const char* name, hipStream_t s) : slot(-1), st(s), range(name) {
   if (!g_prof_on) return;
   ProfRec r; r.name = name;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -259,6 +288,7 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
                            const float* rotations, const float* opacities, const float* colors_precomp,
                            const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
                            uint32_t* num_rendered_host, void* stream) {
+  GsrRange _range("gsr_forward_preprocess");
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
   if (num_rendered_host) *num_rendered_host = 0;
@@ -276,6 +306,7 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
 
 int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state,
                        void* binning_state, void* image_state, float* out_color, float* out_depth, void* stream) {
+  GsrRange _range("gsr_forward_render");
   if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
   void* geom = const_cast<void*>(geom_state);
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
@@ -288,6 +319,7 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
                  const void* binning_state, const void* image_state, const float* dL_dcolor, void* scratch,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dsh, void* stream) {
+  GsrRange _range("gsr_backward");
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -332,6 +364,7 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                  const float* const* colors_views, const float* shs, const float* cov3D_precomp,
                                  void* const* geom_states,
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream) {
+  GsrRange _range("gsr_forward_preprocess_batch");
   if (int rc = check_batch("gsr_forward_preprocess_batch", V, s, batch_state)) return rc;
   if (!geom_states || !radii || !num_rendered_host) { gsr_set_error("gsr_forward_preprocess_batch: NULL argument"); return -2; }
   for (int v = 0; v < V; ++v) num_rendered_host[v] = 0;
@@ -346,6 +379,7 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
                              void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
                              void* stream) {
+  GsrRange _range("gsr_forward_render_batch");
   if (int rc = check_batch("gsr_forward_render_batch", V, s, batch_state)) return rc;
   if (!num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
     gsr_set_error("gsr_forward_render_batch: NULL argument");
@@ -364,6 +398,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
                       void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
                       uint32_t* num_rendered_host, void* stream) {
+  GsrRange _range("gsr_forward_batch");
   if (int rc = check_batch("gsr_forward_batch", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!geom_states || !radii || !num_rendered_host || !image_states || !out_color || !out_depth) {
@@ -394,6 +429,7 @@ int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, cons
                                const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
                                const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
                                uint32_t* counts_dev, void* stream) {
+  GsrRange _range("gsr_forward_batch_capacity");
   if (int rc = check_batch("gsr_forward_batch_capacity", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!geom_states || !radii || !binning_states || !capacity_entries || !image_states || !out_color || !out_depth || !counts_dev) {
@@ -423,6 +459,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        float* const* dL_dmeans2D,
                        float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* stream) {
+  GsrRange _range("gsr_backward_batch");
   if (int rc = check_batch("gsr_backward_batch", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
@@ -497,6 +534,7 @@ int32_t gsr_rigidity_blocks(int32_t n_fg) { return gsr_rigidity_fwd_blocks(n_fg)
 int gsr_rigidity_forward(int32_t n_fg, int32_t K, const float* means3D, const float* rotations, const int64_t* fg_idx,
                          const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
                          const float* prev_inv_rot_fg, const float* prev_offset, float* block_partials, void* stream) {
+  GsrRange _range("gsr_rigidity_forward");
   if (n_fg < 0 || K <= 0 || (n_fg > 0 && (!means3D || !rotations || !fg_idx || !neighbor_indices || !neighbor_weight || !neighbor_dist ||
                                           !prev_inv_rot_fg || !prev_offset || !block_partials))) {
     gsr_set_error("gsr_rigidity_forward: bad argument");
@@ -510,6 +548,7 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
                           const int64_t* neighbor_indices, const float* neighbor_weight, const float* neighbor_dist,
                           const float* prev_inv_rot_fg, const float* prev_offset, const float* grad3, const int32_t* rev_ptr,
                           const int32_t* rev_edge, float* scratch, float* d_means3D, float* d_rotations, void* stream) {
+  GsrRange _range("gsr_rigidity_backward");
   if (n_fg < 0 || K <= 0 || (n_fg > 0 && (!means3D || !rotations || !fg_idx || !neighbor_indices || !neighbor_weight || !neighbor_dist ||
                                           !prev_inv_rot_fg || !prev_offset || !grad3 || !rev_ptr || !rev_edge || !scratch || !d_means3D ||
                                           !d_rotations))) {
@@ -524,6 +563,7 @@ int gsr_rigidity_backward(int32_t n_fg, int32_t K, const float* means3D, const f
 
 int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* logit_opacities, const float* log_scales,
                          float* rotations, float* opacities, float* scales, void* stream) {
+  GsrRange _range("gsr_activate_forward");
   if (P < 0 || (P > 0 && (!unnorm_rotations || !logit_opacities || !log_scales || !rotations || !opacities || !scales))) {
     gsr_set_error("gsr_activate_forward: bad argument");
     return -2;
@@ -534,6 +574,7 @@ int gsr_activate_forward(int32_t P, const float* unnorm_rotations, const float* 
 int gsr_activate_backward(int32_t P, const float* unnorm_rotations, const float* opacities, const float* scales,
                           const float* d_rotations, const float* d_opacities, const float* d_scales, float* d_unnorm_rotations,
                           float* d_logit_opacities, float* d_log_scales, void* stream) {
+  GsrRange _range("gsr_activate_backward");
   if (P < 0 || (P > 0 && (!unnorm_rotations || !opacities || !scales || !d_unnorm_rotations || !d_logit_opacities || !d_log_scales))) {
     gsr_set_error("gsr_activate_backward: bad argument");
     return -2;
@@ -563,6 +604,7 @@ int gsr_shared_terms_forward(int32_t n_fg, int32_t K, int32_t n_bg, const float*
                              const float* neighbor_dist, const float* prev_inv_rot_fg, const float* prev_offset,
                              const float* init_bg_pts, const float* init_bg_rot, const float* weights5_host, float* partials,
                              float* terms6, void* stream) {
+  GsrRange _range("gsr_shared_terms_forward");
   const void* ptrs[] = {means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
                         prev_offset, init_bg_pts, init_bg_rot, weights5_host, partials, terms6};
   if (int e = shared_terms_check("gsr_shared_terms_forward", n_fg, K, n_bg, ptrs, 14)) return e;
@@ -577,6 +619,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
                               const float* prev_offset, const float* init_bg_pts, const float* init_bg_rot,
                               const float* weights5_host, const float* grad_total, const int32_t* rev_ptr, const int32_t* rev_edge,
                               float* scratch, float* d_means3D, float* d_rotations, int32_t flags, void* stream) {
+  GsrRange _range("gsr_shared_terms_backward");
   const void* ptrs[] = {means3D, rotations, fg_idx, bg_idx, neighbor_indices, neighbor_weight, neighbor_dist, prev_inv_rot_fg,
                         prev_offset, init_bg_pts, init_bg_rot, weights5_host, grad_total, rev_ptr, rev_edge, scratch, d_means3D,
                         d_rotations};
@@ -589,6 +632,7 @@ int gsr_shared_terms_backward(int32_t P, int32_t n_fg, int32_t K, int32_t n_bg, 
 
 int gsr_radius_bookkeeping(int32_t V, int32_t view_step, int32_t P, const int32_t* radii, float* max_2D_radius, uint8_t* seen,
                            void* stream) {
+  GsrRange _range("gsr_radius_bookkeeping");
   if (V < 0 || view_step <= 0 || P < 0 || (V > 0 && P > 0 && (!radii || !max_2D_radius || !seen))) {
     gsr_set_error("gsr_radius_bookkeeping: bad argument");
     return -2;
@@ -597,6 +641,7 @@ int gsr_radius_bookkeeping(int32_t V, int32_t view_step, int32_t P, const int32_
 }
 
 int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* stream) {
+  GsrRange _range("gsr_adam_step");
   if (n_tensors < 0 || n_tensors > GSR_ADAM_MAX_TENSORS || (n_tensors > 0 && !tensors)) {
     gsr_set_error("gsr_adam_step: 0..%d tensors per call", GSR_ADAM_MAX_TENSORS);
     return -2;
@@ -612,11 +657,13 @@ int gsr_adam_step(int32_t n_tensors, const gsr_adam_tensor* tensors, void* strea
 size_t gsr_fps_scratch_bytes(int32_t N, int32_t npoints) { return gsr_fps_scratch_size(N, npoints); }
 
 int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_related, float* rotations, int32_t* code, void* stream) {
+  GsrRange _range("gsr_fit_rotations");
   if (n_bones < 0 || (n_bones > 0 && (!moments || !n_related || !rotations || !code))) { gsr_set_error("gsr_fit_rotations: bad argument"); return -2; }
   return gsr_launch_fit_rotations(n_bones, moments, n_related, rotations, (int*)code, (hipStream_t)stream);
 }
 
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
+  GsrRange _range("gsr_fps");
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }
   if (npoints > N || (N > 0 && (start_idx < 0 || start_idx >= N))) { gsr_set_error("gsr_fps: npoints / start_idx out of range"); return -2; }
   return gsr_launch_fps(N, pos, npoints, start_idx, scratch, (long long*)out_idx, (hipStream_t)stream);
@@ -624,6 +671,7 @@ int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, flo
 
 int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
             const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream) {
+  GsrRange _range("gsr_lbs");
   if (P < 0 || n_bones <= 0 || !bones || !rotations || !translations || !bone_quats || (P > 0 && (!xyz || !out_xyz))) {
     gsr_set_error("gsr_lbs: bad argument");
     return -2;
@@ -635,6 +683,7 @@ int32_t gsr_image_loss_blocks(int32_t C, int32_t H, int32_t W) { return C * gsr_
 
 int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred, const float* target,
                            float* fA, float* fC, float* fE, float* block_l1, float* block_ssim, void* stream) {
+  GsrRange _range("gsr_image_loss_forward");
   if (!window11_host || !pred || !target || !fA || !fC || !fE || !block_l1 || !block_ssim || C <= 0 || H <= 0 || W <= 0) {
     gsr_set_error("gsr_image_loss_forward: bad argument");
     return -2;
@@ -645,6 +694,7 @@ int gsr_image_loss_forward(const float* window11_host, int32_t C, int32_t H, int
 int gsr_image_loss_backward(const float* window11_host, int32_t C, int32_t H, int32_t W, const float* pred,
                             const float* target, const float* fA, const float* fC, const float* fE, const float* grad_loss,
                             int32_t channels_per_image, float w_l1, float w_ssim, float* d_pred, void* stream) {
+  GsrRange _range("gsr_image_loss_backward");
   if (!window11_host || !pred || !target || !fA || !fC || !fE || !grad_loss || !d_pred || C <= 0 || H <= 0 || W <= 0) {
     gsr_set_error("gsr_image_loss_backward: bad argument");
     return -2;
@@ -672,6 +722,7 @@ static int views_loss_check(const char* who, const gsr_loss_views* v, int32_t H,
 
 int gsr_target_moments(const float* window11_host, int32_t channels, int32_t H, int32_t W, const float* target, float* moments,
                        void* stream) {
+  GsrRange _range("gsr_target_moments");
   if (!window11_host || !target || !moments || channels <= 0 || channels > 4 || H <= 0 || W <= 0) { gsr_set_error("gsr_target_moments: bad argument"); return -2; }
   return gsr_launch_target_moments(window11_host, channels, H, W, target, moments, (hipStream_t)stream);
 }
@@ -679,6 +730,7 @@ int gsr_target_moments(const float* window11_host, int32_t channels, int32_t H, 
 int gsr_views_loss_forward(const float* window11_host, const gsr_loss_views* views, int32_t H, int32_t W, const float* renders,
                            const float* cam_m, const float* cam_c, float w_l1, float w_ssim, float* fA, float* fC, float* fE,
                            float* partials, float* losses, void* stream) {
+  GsrRange _range("gsr_views_loss_forward");
   if (int e = views_loss_check("gsr_views_loss_forward", views, H, W, cam_m, cam_c)) return e;
   if (!window11_host || !renders || !fA || !fC || !fE || !partials || !losses) { gsr_set_error("gsr_views_loss_forward: NULL argument"); return -2; }
   return gsr_launch_views_loss_fwd(window11_host, views, H, W, renders, cam_m, cam_c, w_l1, w_ssim, fA, fC, fE, partials, losses,
@@ -689,6 +741,7 @@ int gsr_views_loss_backward(const float* window11_host, const gsr_loss_views* vi
                             const float* cam_m, const float* cam_c, int32_t n_cams, const float* fA, const float* fC,
                             const float* fE, const float* grad_total, float w_l1, float w_ssim, float* d_renders, float* partials,
                             float* d_cam_m, float* d_cam_c, void* stream) {
+  GsrRange _range("gsr_views_loss_backward");
   if (int e = views_loss_check("gsr_views_loss_backward", views, H, W, cam_m, cam_c)) return e;
   if (!window11_host || !renders || !fA || !fC || !fE || !grad_total || !d_renders || !partials) { gsr_set_error("gsr_views_loss_backward: NULL argument"); return -2; }
   for (int i = 0; i < views->n_images; ++i)
@@ -698,6 +751,7 @@ int gsr_views_loss_backward(const float* window11_host, const gsr_loss_views* vi
 }
 
 int gsr_mark_visible(const float* viewmatrix, int32_t P, const float* means3D, uint8_t* present, void* stream) {
+  GsrRange _range("gsr_mark_visible");
   if (P <= 0) return 0;
   if (!viewmatrix || !means3D || !present) { gsr_set_error("gsr_mark_visible: NULL argument"); return -2; }
   return gsr_launch_mark_visible(viewmatrix, P, means3D, present, (hipStream_t)stream);

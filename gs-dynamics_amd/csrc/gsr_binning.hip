@@ -25,7 +25,8 @@
 // Launches per call (all views): emit(+hist), scatter, hist, scatter(+ranges), tile_order, tile_sort = 6 at 800x800.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_binning::<kernel>, not "(anonymous namespace)"
+namespace gsr_binning {
 
 // ------------------------------------------------------------------ exclusive scan, single workgroup
 // out[i] = sum_{j<i} in[j], out[n] = total.  1024 threads x 8 items per round, carry between rounds.
@@ -846,7 +847,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
   }
 }
 
-}  // namespace
+}  // namespace gsr_binning
+using namespace gsr_binning;
 
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st) {
   { GSR_PROF("scan", st);

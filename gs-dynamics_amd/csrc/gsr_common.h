@@ -123,11 +123,17 @@ void gsr_set_error(const char* fmt, ...);
 // When profiling is enabled (gsr_profile_begin) every launch site brackets its kernel with two events
 // recorded on the launch stream; gsr_profile_end turns them into per-kernel totals.  Off by default:
 // no events are created or recorded in normal operation.
+struct GsrRange {          // roctx range (no-op when the marker library is absent or GSR_ROCTX=0), see gsr_api.hip
+  explicit GsrRange(const char* name);
+  ~GsrRange();
+  bool on;
+};
 struct GsrProfScope {
   GsrProfScope(const char* name, hipStream_t st);
   ~GsrProfScope();
   int slot;
   hipStream_t st;
+  GsrRange range;        // every launch site is a range named like its kernel
 };
 #define GSR_PROF_CAT2(a, b) a##b
 #define GSR_PROF_CAT(a, b) GSR_PROF_CAT2(a, b)

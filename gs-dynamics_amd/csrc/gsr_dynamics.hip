@@ -7,7 +7,8 @@
 #include <stdlib.h>
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_dynamics::<kernel>, not "(anonymous namespace)"
+namespace gsr_dynamics {
 
 // ---------------------------------------------------------------- farthest point sampling
 // One workgroup of 1024 threads walks the cloud once per pick: min-distance update + arg-max (first maximum on ties).
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(64) void fit_rotations_kernel(int nb, const float* 
   code[b] = 2;
 }
 
-}  // namespace
+}  // namespace gsr_dynamics
+using namespace gsr_dynamics;
 
 static int fps_workgroups(int N) { return (N + FPS_SLICE - 1) / FPS_SLICE; }
 size_t gsr_fps_scratch_size(int N, int npoints) {   // N floats of running minima (single-workgroup path) + one row of candidate words per pick

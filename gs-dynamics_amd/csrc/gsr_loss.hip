@@ -20,7 +20,8 @@
 // (or the caller) add up in a fixed order: no atomics, deterministic.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_loss::<kernel>, not "(anonymous namespace)"
+namespace gsr_loss {
 
 #define TW 32               // output tile width
 #define TH 54               // output tile height
@@ -389,7 +390,8 @@ LossTab make_tab(const gsr_loss_views* v) {
 
 inline dim3 loss_grid(int C, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, C); }
 
-}  // namespace
+}  // namespace gsr_loss
+using namespace gsr_loss;
 
 int gsr_loss_blocks_per_channel(int H, int W) { return ((W + TW - 1) / TW) * ((H + TH - 1) / TH); }
 

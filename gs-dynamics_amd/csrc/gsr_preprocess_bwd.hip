@@ -11,7 +11,8 @@
 // HBM per Gaussian: reads 36*tiles + 12 + 12 + 16 + 8 + 4 + 4, writes 12+12+12+4+12+16+24 = 92 B.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_preprocess_bwd::<kernel>, not "(anonymous namespace)"
+namespace gsr_preprocess_bwd {
 
 __constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
                              -1.0925484305920792f, 0.5462742152960396f};
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
   }
 }
 
-}  // namespace
+}  // namespace gsr_preprocess_bwd
+using namespace gsr_preprocess_bwd;
 
 int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, const float* scales,
                               const float* rotations, const float* colors_precomp, const float* shs,

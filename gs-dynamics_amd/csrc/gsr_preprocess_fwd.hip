@@ -10,7 +10,8 @@
 // The 4x4 matrices are read through uniform (scalar) loads: they never occupy VGPRs.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_preprocess_fwd::<kernel>, not "(anonymous namespace)"
+namespace gsr_preprocess_fwd {
 
 __constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
                              -1.0925484305920792f, 0.5462742152960396f};
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
   present[i] = z > GSR_NEAR_Z ? 1 : 0;
 }
 
-}  // namespace
+}  // namespace gsr_preprocess_fwd
+using namespace gsr_preprocess_fwd;
 
 int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,

@@ -48,7 +48,8 @@ __device__ unsigned long long g_bwd_timing[16];
 #define GSR_TFLUSH_B() do {} while (0)
 #endif
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_render::<kernel>, not "(anonymous namespace)"
+namespace gsr_render {
 
 #define GSR_QW 8   // pixel region of one wave inside the 16x16 tile: 8x8 quad (2 x 2 quads per tile)
 #define GSR_QH 8
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
   }
 }
 
-}  // namespace
+}  // namespace gsr_render
+using namespace gsr_render;
 
 // Debug: copy out and clear the forward phase timers (zeros in a normal build).
 int gsr_debug_fwd_timing(unsigned long long* out16) {

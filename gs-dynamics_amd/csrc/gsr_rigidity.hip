@@ -18,7 +18,8 @@
 // input -- deterministic, no float atomics.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_rigidity::<kernel>, not "(anonymous namespace)"
+namespace gsr_rigidity {
 
 struct Quat { float w, x, y, z; };
 
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(RG_BLOCK) void rigidity_bwd_gather_kernel(
   d_rot[4 * gj + 0] = o[3]; d_rot[4 * gj + 1] = o[4]; d_rot[4 * gj + 2] = o[5]; d_rot[4 * gj + 3] = o[6];
 }
 
-}  // namespace
+}  // namespace gsr_rigidity
+using namespace gsr_rigidity;
 
 int gsr_rigidity_fwd_blocks(int nfg) { return nfg > 0 ? (nfg + RG_PTS - 1) / RG_PTS : 0; }
 

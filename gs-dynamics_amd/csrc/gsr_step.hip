@@ -11,7 +11,8 @@
 // No float atomics anywhere: block partials + fixed-order finishing sums.
 #include "gsr_common.h"
 
-namespace {
+// kernels live in a NAMED namespace: profilers and traces show gsr_step::<kernel>, not "(anonymous namespace)"
+namespace gsr_step {
 
 #define ST_BLOCK 256
 
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(ST_BLOCK) void radius_bookkeeping_kernel(int V, int
 
 inline int blocks_for(int n) { return (n + ST_BLOCK - 1) / ST_BLOCK; }
 
-}  // namespace
+}  // namespace gsr_step
+using namespace gsr_step;
 
 int gsr_launch_activate_fwd(int P, const float* unnorm, const float* logit, const float* logs, float* rot, float* op, float* sc,
                             hipStream_t st) {

@@ -1,0 +1,153 @@
+// gsr_torch.cpp -- the thin torch C++ layer over the C-ABI of libgsr_hip.so (include/gsr.h): the three entry points the upstream
+// extension's Python wrapper binds -- rasterize_gaussians, rasterize_gaussians_backward, mark_visible (upstream is
+// installed per /root/reference/README.md:28-32) -- with upstream's argument order and result tuples.  This layer owns ALLOCATION
+// (torch's caching allocator) and the current-stream lookup; every byte of compute stays behind the C-ABI.  One native call per
+// forward and one per backward: the unchanged-caller path (`GaussianRasterizer(raster_settings=cam)(**rendervar)` per render,
+// /root/reference/src/tracking/train_utils.py:178,192) no longer pays ~20 ctypes calls and their Python glue.
+//
+// Built in-tree by __graft_entry__.build() (torch.utils.cpp_extension, host compiler only: there is no device code here) as
+// gs-dynamics_amd/diff_gaussian_rasterization/_C.so, linked against ../csrc/libgsr_hip.so through an $ORIGIN rpath.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include <string>
+#include <tuple>
+
+#include "../../include/gsr.h"
+
+namespace {
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", gsr_last_error());
+}
+
+const float* fptr(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+
+torch::Tensor f32c(const torch::Tensor& t, const c10::Device& dev) {   // contiguous fp32 on the render device (no copy when already so)
+  if (t.numel() == 0) return t;
+  if (t.device() == dev && t.scalar_type() == torch::kFloat32 && t.is_contiguous()) return t;
+  return t.to(dev, torch::kFloat32).contiguous();
+}
+
+struct Settings {
+  gsr_settings s;
+  torch::Tensor bg, view, proj, campos;   // keep-alives of the converted settings tensors
+};
+
+Settings make_settings(const torch::Tensor& bg, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const torch::Tensor& campos,
+                       double tanfovx, double tanfovy, int64_t H, int64_t W, double scale_modifier, int64_t degree, int64_t M, bool prefiltered,
+                       const c10::Device& dev) {
+  Settings o;
+  o.bg = f32c(bg, dev); o.view = f32c(viewmatrix, dev); o.proj = f32c(projmatrix, dev); o.campos = f32c(campos, dev);
+  TORCH_CHECK(o.bg.numel() >= 3 && o.view.numel() >= 16 && o.proj.numel() >= 16 && o.campos.numel() >= 3,
+              "raster settings: bg / campos must hold 3 floats, viewmatrix / projmatrix 16");
+  o.s.image_height = (int32_t)H; o.s.image_width = (int32_t)W;
+  o.s.tanfovx = (float)tanfovx; o.s.tanfovy = (float)tanfovy; o.s.scale_modifier = (float)scale_modifier;
+  o.s.sh_degree = (int32_t)degree; o.s.sh_coeffs = (int32_t)M; o.s.prefiltered = prefiltered ? 1 : 0;
+  o.s.bg = o.bg.data_ptr<float>(); o.s.viewmatrix = o.view.data_ptr<float>(); o.s.projmatrix = o.proj.data_ptr<float>();
+  o.s.campos = o.campos.data_ptr<float>();
+  return o;
+}
+
+// upstream: RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+//           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered)
+//           -> (num_rendered, out_color, out_depth, radii, geomBuffer, binningBuffer, imgBuffer)        [the w-depth fork's tuple]
+std::tuple<int64_t, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
+                    const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
+                    const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
+                    int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered) {
+  TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+  TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build) runs on a HIP device only; there is no CPU fallback");
+  const c10::Device dev = means3D.device();
+  c10::hip::HIPGuard guard(dev.index());
+  const int64_t P = means3D.size(0), H = image_height, W = image_width;
+  const int64_t M = sh.numel() ? sh.size(1) : 0;
+  auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
+  auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+  if (P == 0) {   // zero-filled outputs without launching anything
+    return std::make_tuple((int64_t)0, torch::zeros({3, H, W}, f32), torch::zeros({1, H, W}, f32),
+                           torch::zeros({0}, f32.dtype(torch::kInt32)), torch::empty({0}, u8), torch::empty({0}, u8), torch::empty({0}, u8));
+  }
+  const torch::Tensor m3 = f32c(means3D, dev), col = f32c(colors, dev), op = f32c(opacity, dev), sc = f32c(scales, dev),
+                      rot = f32c(rotations, dev), cov = f32c(cov3D_precomp, dev), shs = f32c(sh, dev);
+  Settings st = make_settings(background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree, M, prefiltered, dev);
+  torch::Tensor color = torch::empty({3, H, W}, f32), depth = torch::empty({1, H, W}, f32);
+  torch::Tensor radii = torch::empty({P}, f32.dtype(torch::kInt32));
+  torch::Tensor geom = torch::empty({(int64_t)gsr_geom_bytes((int32_t)P)}, u8);
+  torch::Tensor image = torch::empty({(int64_t)gsr_image_bytes((int32_t)H, (int32_t)W)}, u8);
+  void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+  uint32_t D = 0;
+  check(gsr_forward_preprocess(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
+                               radii.data_ptr<int32_t>(), &D, stream), "gsr_forward_preprocess");
+  torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
+  check(gsr_forward_render(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
+                           depth.data_ptr<float>(), stream), "gsr_forward_render");
+  return std::make_tuple((int64_t)D, color, depth, radii, geom, binning, image);
+}
+
+// upstream: RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+//           projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer)
+//           -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+// (image height / width travel in upstream's dL_dout_color shape: here too)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii, const torch::Tensor& colors,
+                             const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
+                             const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy,
+                             const torch::Tensor& dL_dout_color, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos,
+                             const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer) {
+  const c10::Device dev = means3D.device();
+  c10::hip::HIPGuard guard(dev.index());
+  const int64_t P = means3D.size(0);
+  const int64_t M = sh.numel() ? sh.size(1) : 0;
+  TORCH_CHECK(dL_dout_color.dim() == 3 && dL_dout_color.size(0) == 3, "dL_dout_color must be [3, H, W]");
+  const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+  auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
+  torch::Tensor d_means3D = torch::empty({P, 3}, f32), d_means2D = torch::empty({P, 3}, f32), d_opacity = torch::empty({P, 1}, f32);
+  torch::Tensor d_colors = M ? torch::empty({0}, f32) : torch::empty({P, 3}, f32);
+  torch::Tensor d_cov = torch::empty({P, 6}, f32);
+  torch::Tensor d_sh = M ? torch::empty({P, M, 3}, f32) : torch::empty({0}, f32);
+  const bool has_sr = scales.numel() > 0;
+  torch::Tensor d_scales = has_sr ? torch::empty({P, 3}, f32) : torch::empty({0}, f32);
+  torch::Tensor d_rot = has_sr ? torch::empty({P, 4}, f32) : torch::empty({0}, f32);
+  if (P == 0) return std::make_tuple(d_means2D, d_colors, d_opacity, d_means3D, d_cov, d_sh, d_scales, d_rot);
+  const torch::Tensor m3 = f32c(means3D, dev), col = f32c(colors, dev), sc = f32c(scales, dev), rot = f32c(rotations, dev),
+                      cov = f32c(cov3D_precomp, dev), shs = f32c(sh, dev), g = f32c(dL_dout_color, dev);
+  Settings st = make_settings(background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree, M, false, dev);
+  torch::Tensor scratch = torch::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)P, (uint32_t)R)},
+                                       torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+  void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+  auto optr = [](torch::Tensor& t) -> float* { return t.numel() ? t.data_ptr<float>() : nullptr; };
+  check(gsr_backward(&st.s, (int32_t)P, (uint32_t)R, fptr(m3), fptr(sc), fptr(rot), fptr(col), fptr(shs), fptr(cov), radii.data_ptr<int32_t>(),
+                     geomBuffer.data_ptr(), R ? binningBuffer.data_ptr() : nullptr, imageBuffer.data_ptr(), g.data_ptr<float>(),
+                     R ? scratch.data_ptr() : nullptr, d_means3D.data_ptr<float>(), d_means2D.data_ptr<float>(), optr(d_colors),
+                     d_opacity.data_ptr<float>(), optr(d_scales), optr(d_rot), d_cov.data_ptr<float>(), optr(d_sh), stream),
+        "gsr_backward");
+  return std::make_tuple(d_means2D, d_colors, d_opacity, d_means3D, d_cov, d_sh, d_scales, d_rot);
+}
+
+// upstream: markVisible(means3D, viewmatrix, projmatrix) -> bool[P]
+torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix) {
+  (void)projmatrix;   // the test is the near-plane cull in view space, as upstream's
+  TORCH_CHECK(means3D.is_cuda(), "mark_visible: HIP device tensors only");
+  const c10::Device dev = means3D.device();
+  c10::hip::HIPGuard guard(dev.index());
+  const int64_t P = means3D.size(0);
+  torch::Tensor present = torch::zeros({P}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+  if (P == 0) return present.to(torch::kBool);
+  const torch::Tensor m3 = f32c(means3D, dev), vm = f32c(viewmatrix, dev);
+  void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+  check(gsr_mark_visible(vm.data_ptr<float>(), (int32_t)P, m3.data_ptr<float>(), present.data_ptr<uint8_t>(), stream), "gsr_mark_visible");
+  return present.to(torch::kBool);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "MI355X rasterizer: torch layer over libgsr_hip.so (rasterize_gaussians / rasterize_gaussians_backward / mark_visible)";
+  m.def("rasterize_gaussians", &rasterize_gaussians);
+  m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
+  m.def("mark_visible", &mark_visible);
+  m.def("abi_version", []() { return gsr_version(); });
+}

@@ -17,7 +17,29 @@ from typing import NamedTuple, Optional
 import torch
 from torch import nn
 
+import os
+
 from . import _hip
+
+# The torch C++ layer (csrc/gsr_torch.cpp -> _C.so, built by __graft_entry__.build()): upstream's three entry points, one native call
+# per forward / backward.  Absent (not built) or switched off (GSR_NO_TORCH_EXT=1, or GSR_HIP_LIB pointing at another library
+# build, which _C is not linked against): the ctypes binding in _hip.py does the same work call by call.
+_C = None
+if os.environ.get("GSR_NO_TORCH_EXT") != "1" and "GSR_HIP_LIB" not in os.environ:
+    try:
+        import importlib
+        _C = importlib.import_module(__name__ + "._C")
+    except ImportError:
+        _C = None
+_CTYPES_FORWARD, _CTYPES_BACKWARD = _hip.rasterize_forward, _hip.rasterize_backward
+
+
+def _native():
+    """The torch C++ layer, unless a test double / spy has replaced the ctypes entry points (then those must be the ones called)."""
+    if _C is not None and _hip.rasterize_forward is _CTYPES_FORWARD and _hip.rasterize_backward is _CTYPES_BACKWARD:
+        return _C
+    return None
+
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_views"]
 
@@ -67,6 +89,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         if m3.dim() != 2 or m3.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         ctx.empty = False
+        native = _native() if m3.is_cuda else None
+        if native is not None:
+            rs = raster_settings
+            e = m3.new_empty(0)
+            t = lambda x: e if (x is None or x.numel() == 0) else x   # noqa: E731
+            col_, sh_, sc_, rot_, cov_ = t(colors_precomp), t(sh), t(scales), t(rotations), t(cov3Ds_precomp)
+            D, color, depth, radii, geom, binning, image = native.rasterize_gaussians(
+                rs.bg, m3, col_, opacities, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
+                float(rs.tanfovy), int(rs.image_height), int(rs.image_width), sh_, int(rs.sh_degree), rs.campos, bool(rs.prefiltered))
+            ctx.native, ctx.rs, ctx.num_rendered = native, rs, int(D)
+            ctx.has = (sh_.numel() > 0, col_.numel() > 0, sc_.numel() > 0, cov_.numel() > 0)
+            ctx.save_for_backward(m3, radii, col_, sh_, sc_, rot_, cov_, geom, binning, image)
+            ctx.mark_non_differentiable(radii)
+            return color, radii, depth
+        ctx.native = None
         sh_, col_, op_ = _prep(sh), _prep(colors_precomp), _prep(opacities)
         sc_, rot_, cov_ = _prep(scales), _prep(rotations), _prep(cov3Ds_precomp)
         color, radii, depth, state = _hip.rasterize_forward(raster_settings, m3, op_, col_, sh_, sc_, rot_, cov_)
@@ -83,6 +120,17 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, grad_radii, grad_depth):  # grad_radii / grad_depth: accepted, ignored
         if ctx.empty:
             return (None,) * 9
+        if ctx.native is not None:
+            m3, radii, col_, sh_, sc_, rot_, cov_, geom, binning, image = ctx.saved_tensors
+            has_sh, has_col, has_sc, has_cov = ctx.has
+            rs = ctx.rs
+            if grad_color is None:
+                grad_color = torch.zeros((3, int(rs.image_height), int(rs.image_width)), device=m3.device)
+            d2, dc, do, d3, dcov, dsh, ds, dr = ctx.native.rasterize_gaussians_backward(
+                rs.bg, m3, radii, col_, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
+                float(rs.tanfovy), grad_color, sh_, int(rs.sh_degree), rs.campos, geom, ctx.num_rendered, binning, image)
+            return (d3, d2, dsh if has_sh else None, dc if has_col else None, do, ds if has_sc else None, dr if has_sc else None,
+                    dcov if has_cov else None, None)
         m3, radii, col_, sh_, sc_, rot_, cov_ = ctx.saved_tensors
         has_sh, has_col, has_sc, has_cov = ctx.has
         if grad_color is None:
@@ -181,6 +229,8 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
+            if _C is not None and positions.is_cuda:
+                return _C.mark_visible(positions, self.raster_settings.viewmatrix, self.raster_settings.projmatrix)
             return _hip.mark_visible(positions, self.raster_settings.viewmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,

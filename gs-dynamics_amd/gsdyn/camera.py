@@ -44,9 +44,11 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100, bg=(0, 0, 0), device=None) ->
 
 
 def Rt_to_w2c(R, t):
-    """4x4 world-to-camera from rotation + translation (/root/reference/src/real_world/gs/trainer.py:15-18)."""
-    w2c = np.concatenate([np.concatenate([R, t.reshape(3, 1)], axis=1), np.array([[0, 0, 0, 1]])], axis=0)
-    return w2c
+    """4x4 world-to-camera from a camera POSE (rotation + translation of the camera in the world): the pose matrix [R t; 0 1] is
+    assembled and INVERTED (/root/reference/src/real_world/gs/trainer.py:15-18)."""
+    c2w = np.concatenate([np.concatenate([np.asarray(R, np.float64), np.asarray(t, np.float64).reshape(3, 1)], axis=1),
+                          np.array([[0.0, 0.0, 0.0, 1.0]])], axis=0)
+    return np.linalg.inv(c2w)
 
 
 def look_at_w2c(center, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)) -> np.ndarray:

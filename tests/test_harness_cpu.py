@@ -188,3 +188,16 @@ def test_fused_pieces_have_host_fallbacks_or_fail_loudly():
     params = synth_scene_params(10, device="cpu")
     with pytest.raises(RuntimeError, match="HIP device"):
         loss_and_grads_views(params, [], {}, True, LossWeights())
+
+
+def test_rt_to_w2c_inverts_the_camera_pose(golden_dir):
+    """``Rt_to_w2c`` (/root/reference/src/real_world/gs/trainer.py:15-18) on the demo cameras: [R t; 0 1] is the camera's pose, the
+    result is its inverse -- so the camera centre recovered from the world-to-camera matrix is t itself."""
+    from gsdyn import Rt_to_w2c
+    z = np.load(os.path.join(golden_dir, "demo_scene.npz"))
+    for R, t in zip(z["R_list"], z["t_list"]):
+        w2c = Rt_to_w2c(R, t)
+        pose = np.eye(4)
+        pose[:3, :3], pose[:3, 3] = R, t
+        np.testing.assert_allclose(w2c @ pose, np.eye(4), atol=1e-12)
+        np.testing.assert_allclose(np.linalg.inv(w2c)[:3, 3], t, atol=1e-12)
