@@ -625,6 +625,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews ta
     bwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 }
 
+#ifdef GSR_TRACE_TICKETS
+// Debug build (tools/ticket_trace.py): per backward ticket {start, end (s_memrealtime, 100 MHz), workgroup, list length}
+#define GSR_TRACE_MAX 65536
+__device__ uint4 g_ticket_trace[GSR_TRACE_MAX];
+#endif
 template <bool PAIRS, int NBB = BWD_BATCH>
 __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLdsAny<PAIRS, NBB> L;
@@ -636,12 +641,19 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
   // of bwd_tile issues global loads right at tile start, and they would queue behind the in-flight atomic.)
   uint32_t ticket = blockIdx.x;
   while (ticket < n_busy) {
+#ifdef GSR_TRACE_TICKETS
+    const unsigned long long tr0 = wall_clock64();
+#endif
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
     else
       bwd_tile<false, NBB>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
+#ifdef GSR_TRACE_TICKETS
+    if (threadIdx.x == 0 && ticket < GSR_TRACE_MAX)
+      g_ticket_trace[ticket] = make_uint4((uint32_t)tr0, (uint32_t)wall_clock64(), blockIdx.x, ord.z - ord.y);
+#endif
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[1], 1u);
     __syncthreads();  // also: the tile's LDS (incl. sQuadLast) is dead before the next tile reuses it
     ticket = s_ticket;
@@ -677,6 +689,14 @@ int gsr_debug_fwd_timing(unsigned long long* out16) {
   return 1;
 #endif
 }
+
+#ifdef GSR_TRACE_TICKETS
+extern "C" int gsr_debug_ticket_trace(uint32_t* out4, int n) {   // debug builds only: not part of include/gsr.h
+  GSR_HIP_CHECK(hipDeviceSynchronize());
+  GSR_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ticket_trace), sizeof(uint4) * (size_t)(n < GSR_TRACE_MAX ? n : GSR_TRACE_MAX)));
+  return 0;
+}
+#endif
 
 static bool env_flag(const char* name) {
   const char* v = getenv(name);
