@@ -358,7 +358,9 @@ __device__ __forceinline__ float gsr_swz_xor4(float x) {  // ds_swizzle bit mode
 __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float v2, float v3, float v4, float v5,
                                                       float v6, float v7, float v8) {
   const int lane = gsr_lane();
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  const bool b0 = lane & 1, b1 = lane & 2;
+#ifdef GSR_SUM_CNDMASK   // every level as two selects + one exchange-add (34 VALU issues): kept for A/B builds
+  const bool b2 = lane & 4, b3 = lane & 8;
   // xor 1 (quad_perm [1,0,3,2]): 9 -> 5
   const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
   const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
@@ -374,23 +376,60 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
   const float p8 = q8 + gsr_swz_xor4(q8);
   // xor 8 (row_ror:8): 2 -> 1   (lanes with bit 3 clear: v_(lane&7); bit 3 set: v8)
   float z = (b3 ? p8 : p07) + gsr_dpp_get<0x128>(b3 ? p07 : p8);
+#else
+  // A level of the packed butterfly keeps "x_self + x_partner" of value a in the lanes whose selector bit is clear and of value
+  // b in the others.  Where the selector is a DPP write-mask group -- lane bits 2 and 3 are the four-lane "banks" of a 16-lane
+  // row -- the select folds into the add: one DPP add per half with bank_mask, two issues per pair instead of two v_cndmask +
+  // one DPP add.  So the WIDE level (9 -> 5, four pairs) runs on bit 2 (row_shl:4 into banks 0/2, row_shr:4 into banks 1/3) and
+  // the last in-row level on bit 3 (row_ror:8); bits 0 and 1 (no write mask inside a quad) take the two narrow levels with
+  // selects.  24 VALU issues instead of 34, the same final layout.  The masked adds are inline asm (the compiler has no pattern
+  // for them and its hazard recogniser does not look inside): the leading s_nop covers a VALU write of a source just before
+  // the block (2 wait states) or an EXEC write (5); inside, no source was written by the two preceding instructions.
+  float r01, r23, r45, r67;   // bit 2 clear: totals over xor 4 of v0 / v1 / v2 / v3, set: of v4 / v5 / v6 / v7
+  asm("s_nop 4\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67)
+      : "v"(v0), "v"(v4), "v"(v1), "v"(v5), "v"(v2), "v"(v6), "v"(v3), "v"(v7));
+  const float r8 = v8 + gsr_swz_xor4(v8);
+  // xor 1 (quad_perm [1,0,3,2]): 5 -> 3   (bit 0 picks v1 / v5 over v0 / v4, v3 / v7 over v2 / v6)
+  const float q03 = (b0 ? r23 : r01) + gsr_dpp_get<0xB1>(b0 ? r01 : r23);
+  const float q47 = (b0 ? r67 : r45) + gsr_dpp_get<0xB1>(b0 ? r45 : r67);
+  const float q8 = r8 + gsr_dpp_get<0xB1>(r8);
+  // xor 2 (quad_perm [2,3,0,1]): 3 -> 2   (lane & 7 now indexes v0..v7)
+  const float p07 = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
+  const float p8 = q8 + gsr_dpp_get<0x4E>(q8);
+  // xor 8 (row_ror:8): 2 -> 1   (lanes with bit 3 clear: v_(lane & 7); bit 3 set: v8)
+  float z;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+      : "=&v"(z) : "v"(p07), "v"(p8));
+#endif
   // rows: the packed layout differs per lane, so the row levels must be lane-wise exchanges (row_bcast would
-  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  (An LDS-free variant -- xor 4 as
-  // two bank-masked DPP row shifts, xor 16 / 32 as v_permlane16/32_swap on two copies -- passes the self-test but
-  // costs 4 more VALU issues per reduction and measured 3 % SLOWER: SQ counters put the blend backward at 99 % VALU
-  // issue occupancy, so the crossbar round trips are already hidden by the other waves and VALU slots are what count.)  Every lane ends up
+  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  (An LDS-free variant -- xor 16 / 32 as
+  // v_permlane16/32_swap on two copies -- passes the self-test but costs more VALU issues and measured SLOWER: the blend
+  // backward sits at the VALU issue limit, the crossbar round trips are hidden by the other waves.)  Every lane ends up
   // with the total of "its" value: lane & 15 in 0..7 -> v_(lane & 7), lane & 8 set -> v8.
   z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
   z += __shfl_xor(z, 32, 64);
   return z;
 }
 
-// Eight values (fused pair backward without colour gradients): 9 -> 4 -> 2 -> 1 registers, 27 instructions.
+// Eight values (fused pair backward without colour gradients): 8 -> 4 -> 2 -> 1 registers, 20 VALU issues (see above).
 // Result z (in every lane): lane with (lane & 7) = i holds the wave total of v_i.
 __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float v2, float v3, float v4, float v5,
                                                       float v6, float v7) {
   const int lane = gsr_lane();
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  const bool b0 = lane & 1, b1 = lane & 2;
+#ifdef GSR_SUM_CNDMASK
+  const bool b2 = lane & 4;
   const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
   const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
   const float r45 = (b0 ? v5 : v4) + gsr_dpp_get<0xB1>(b0 ? v4 : v5);
@@ -398,6 +437,23 @@ __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float 
   const float q03 = (b1 ? r23 : r01) + gsr_dpp_get<0x4E>(b1 ? r01 : r23);
   const float q47 = (b1 ? r67 : r45) + gsr_dpp_get<0x4E>(b1 ? r45 : r67);
   float z = (b2 ? q47 : q03) + gsr_swz_xor4(b2 ? q03 : q47);
+#else
+  float r01, r23, r45, r67;
+  asm("s_nop 4\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67)
+      : "v"(v0), "v"(v4), "v"(v1), "v"(v5), "v"(v2), "v"(v6), "v"(v3), "v"(v7));
+  const float q03 = (b0 ? r23 : r01) + gsr_dpp_get<0xB1>(b0 ? r01 : r23);
+  const float q47 = (b0 ? r67 : r45) + gsr_dpp_get<0xB1>(b0 ? r45 : r67);
+  float z = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
+#endif
   z += gsr_dpp_get<0x128>(z);                                                        // xor 8 (row_ror:8)
   z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));       // xor 16
   z += __shfl_xor(z, 32, 64);
