@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--autograd", action="store_true", help="go through rasterize_gaussians_views + autograd (round-1 call pattern) instead of "
                     "the direct library calls of gsdyn.step.render_step_views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen-colours", action="store_true",
+                    help="rgb_colors.requires_grad = False as in the reference's training (train_utils.py:133): no colour gradient is computed. "
+                         "The default keeps ALL gradients (the metric's 'all backward gradients'); an N = 1 run reports this variant as "
+                         "``frozen_colours``")
     ap.add_argument("--no-extras", action="store_true", help="skip the get_loss-shaped step and the other secondary timings")
     args = ap.parse_args()
 
@@ -138,7 +142,9 @@ def main():
         dL = dL_all[view_ids].contiguous() if view_ids else dL_all[:0]
         return params, cams, dL
 
-    def make_step(params, cams, dL, with_opt, with_reduce):
+    def make_step(params, cams, dL, with_opt, with_reduce, frozen_colours=False):
+        if frozen_colours:   # the reference's own setting: rgb_colors never gets a gradient (train_utils.py:133) and has lr 0 (:155)
+            params["rgb_colors"].requires_grad_(False)
         bucket = GradBucket(params)
         opt = initialize_optimizer(params, 4.0) if with_opt else None     # gsdyn.optim.FusedAdam: one launch for all groups
         m2 = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True) if args.autograd else None
@@ -153,9 +159,9 @@ def main():
                     im.backward(gradient=dL)
                     m2.grad = None
                 else:
-                    _, g = render_step_views(params, cams, dL)
+                    _, g = render_step_views(params, cams, dL, want_colour_grad=not frozen_colours)
                     for k in GRAD_KEYS:
-                        params[k].grad = g[k]
+                        params[k].grad = g.get(k)
             if with_reduce:
                 bucket.all_reduce()          # packs the gradients into the flat bucket, ONE all-reduce, .grad = bucket slices
             if opt is not None:
@@ -163,7 +169,7 @@ def main():
         return step, bucket
 
     params, cams, dL = make_problem(all_cams, my_ids)
-    step, bucket = make_step(params, cams, dL, not args.no_optimizer, world > 1)
+    step, bucket = make_step(params, cams, dL, not args.no_optimizer, world > 1, args.frozen_colours)
 
     # entry counts per view, once (spy on the backend call; not in the timed region)
     num_rendered = []
@@ -288,6 +294,15 @@ def main():
         t3, t3e = timed(s3, args.steps, args.warmup)
         cfg3 = {"workload": "BASELINE.json configs[2]: 4 views 800x800, 100k Gaussians, colour render fwd+bwd, no optimiser step",
                 "value": 4 * Npx / t3 / 1e6, "unit": "Mpix/s", "ms_per_step": t3 * 1e3, "ms_per_step_event_median": t3e * 1e3}
+    frozen = None
+    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras and not args.frozen_colours and not args.autograd:
+        # the same step as the headline with rgb_colors frozen, as the reference trains (no dL/dcolour: six sums per list entry)
+        pf, cf, df = make_problem(all_cams, my_ids)
+        sf, _ = make_step(pf, cf, df, not args.no_optimizer, False, True)
+        tf, tfe = timed(sf, args.steps, args.warmup)
+        frozen = {"workload": "the headline step with rgb_colors.requires_grad = False (/root/reference/src/tracking/train_utils.py:133,155): "
+                              "every gradient the reference's optimiser uses, no dL/dcolour",
+                  "value": len(cams) * Npx / tf / 1e6, "unit": "Mpix/s", "ms_per_step": tf * 1e3, "ms_per_step_event_median": tfe * 1e3}
     if rank == 0 and world == 1 and not args.no_extras:
         extras = run_extras(dev, synth_scene_params(P_GAUSS, seed=0, device=dev), synth_ring_cameras(4, W, H, device=dev),
                             synth_ring_cameras, synth_scene_params)
@@ -306,7 +321,7 @@ def main():
             "config": {"workload": (f"weak scaling: {len(cams)} views per GPU of a {total_views}-camera ring" if args.weak else
                                     f"BASELINE.json configs[{3 if total_views == 8 else 2}]-shaped step: {total_views} views 800x800 of SynthScene-v1, "
                                     f"view r -> rank r mod N ({len(cams)} on rank 0)") +
-                                   ", 100k Gaussians, colour render fwd+bwd per view" +
+                                   ", 100k Gaussians, colour render fwd+bwd per view" + (" (rgb_colors frozen: no colour gradient)" if args.frozen_colours else "") +
                                    ("" if world == 1 else f", 1 RCCL all-reduce of the {n_bucket}-float parameter-gradient bucket") +
                                    ("" if args.no_optimizer else ", Adam step (FusedAdam)"),
                        "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": len(cams), "image": [H, W],
@@ -314,7 +329,7 @@ def main():
                        "optimizer_in_timed_region": not args.no_optimizer,
                        "call_pattern": "rasterize_gaussians_views + autograd" if args.autograd else
                                        "gsdyn.step.render_step_views: activations, ONE multi-view forward (capacity mode), ONE multi-view backward, direct library calls"},
-            "roofline": roofline, "cfg3": cfg3, "cpu_baseline": cpu_baseline, "extras": extras,
+            "roofline": roofline, "cfg3": cfg3, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:

@@ -129,7 +129,7 @@ void pair_up(int V, const int32_t* geometry_of, const uint32_t* num_rendered, in
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
-  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue;
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0;
 }
 
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).
@@ -337,6 +337,7 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
   if (num_rendered > 0) {
     GsrRenderViews rt;
     render_header(rt, 1, cam, im.tile_order, im.queue);
+    rt.no_colour_grad = (!shs && !dL_dcolors) ? 1 : 0;   // precomputed colours and no gradient wanted for them
     fill_render_view(rt.v[0], cam, g, bs, im, nullptr, nullptr, dL_dcolor, partials);
     if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
   }
@@ -497,7 +498,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     gsr_carve_image(image_states[owner], cam.H, cam.W, &im_owner);
     gsr_carve_binning(binning_states[owner], num_rendered[owner], &bs);
     if (num_rendered[v] > 0 && (!binning_states[owner] || !scratch[v])) { gsr_set_error("gsr_backward_batch: NULL binning/scratch"); return -2; }
-    if (v == 0) render_header(rt, V, cam, b.order, b.queue);
+    if (v == 0) { render_header(rt, V, cam, b.order, b.queue); rt.no_colour_grad = (!dL_dcolors && !dL_dcolors_views) ? 1 : 0; }
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
@@ -832,6 +833,15 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   // eight-value form of the fused pair backward: lane & 7 = i holds the total of value i
   const float z8 = gsr_wave_sum8_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v);
   okz = okz && __ballot(z8 != (float)((l & 7) + 1) * b) == 0ull;
+  // six-value form (no colour gradient): gsr_sum6_slot names the value a lane holds
+  const float z6 = gsr_wave_sum6_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v);
+  const int s6 = gsr_sum6_slot(l);
+  okz = okz && __ballot(s6 >= 0 && z6 != (float)(s6 + 1) * b) == 0ull;
+  {  // every value 0..5 has a lane in the last row (the lanes that write the totals to LDS)
+    uint32_t have = 0;
+    for (int q = 48; q < 64; ++q) if (gsr_sum6_slot(q) >= 0) have |= 1u << gsr_sum6_slot(q);
+    okz = okz && have == 0x3fu;
+  }
   // the blend backward runs unused lanes with alpha = 0 and relies on 1 / (1 - 0) being exactly 1 (v_rcp_f32)
   const float alpha0 = fminf(0.99f, 0.7f * (v * 0.0f));
   okz = okz && __ballot(__builtin_amdgcn_rcpf(1.0f - alpha0) != 1.0f) == 0ull;

@@ -183,7 +183,11 @@ struct GsrRenderView {         // blend forward / backward
   int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
   int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
 };
-struct GsrRenderViews { int V, W, H, gx, T; const uint4* order; uint32_t* queue; GsrRenderView v[GSR_MAX_BATCH]; };
+struct GsrRenderViews {
+  int V, W, H, gx, T; const uint4* order; uint32_t* queue;
+  int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
+  GsrRenderView v[GSR_MAX_BATCH];
+};
 
 // Batch state (V > 1): the structures shared by the views of one call.
 struct BatchState {
@@ -460,6 +464,39 @@ __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float 
   return z;
 }
 
+// Six values (plain backward when no colour gradient is wanted -- rgb_colors is frozen throughout the reference's training,
+// /root/reference/src/tracking/train_utils.py:133,155): 6 -> 3 -> 2 -> 1 registers, 15 VALU issues.
+// Result z: of the lanes with bit 1 clear, an even lane holds v_(2 * bit 3 + bit 2), an odd lane with bit 3 clear v_(4 + bit 2)
+// (gsr_sum6_slot gives a lane's value index, -1 for the lanes that hold a duplicate).
+__device__ __forceinline__ int gsr_sum6_slot(int lane) {
+  if (lane & 2) return -1;
+  if (!(lane & 1)) return 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
+  return (lane & 8) ? -1 : 4 + ((lane >> 2) & 1);
+}
+__device__ __forceinline__ float gsr_wave_sum6_packed(float v0, float v1, float v2, float v3, float v4, float v5) {
+  const bool b0 = gsr_lane() & 1;
+  float r01, r23, r45, q03, q45;
+  asm("s_nop 4\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"      // bit 2 (xor 4): 6 -> 3
+      "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(r01), "=&v"(r23), "=&v"(r45)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5));
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"      // bit 3 (xor 8): 3 -> 2
+      "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"      // (inside the block: r45 comes from the asm above)
+      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
+      : "=&v"(q03), "=&v"(q45) : "v"(r01), "v"(r23), "v"(r45));
+  float z = (b0 ? q45 : q03) + gsr_dpp_get<0xB1>(b0 ? q03 : q45);               // bit 0 (xor 1): 2 -> 1
+  z += gsr_dpp_get<0x4E>(z);                                                     // xor 2
+  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));   // xor 16
+  z += __shfl_xor(z, 32, 64);
+  return z;
+}
+
 // exp(x) for x <= 0: v_exp_f32 on x * log2(e) -- two VALU issues.  Relative error ~ |x| * 6e-8 + 1 ulp (|x| <= 5.6 wherever
 // alpha >= 1/255).  A compensated form (exact product error folded back in, ~1-2 ulp, 7 issues) was used until the parity
 // margins were measured for both: gradient errors against the oracle are 1e-7 .. 4e-6 of the tensor maximum with either
@@ -470,6 +507,16 @@ struct GsrF3 { float x, y, z; };   // 12 bytes, 4-byte aligned: one global_load/
 __device__ __forceinline__ void gsr_store_partial(float4* base, size_t e, float4 r0, float4 r1, float r2x) {
   GsrF3* p = reinterpret_cast<GsrF3*>(reinterpret_cast<float*>(base) + e * GSR_PARTIAL_FLOATS);
   p[0] = GsrF3{r0.x, r0.y, r0.z}; p[1] = GsrF3{r0.w, r1.x, r1.y}; p[2] = GsrF3{r1.z, r1.w, r2x};
+}
+// the geometry part alone (no colour gradient wanted): the record's first 24 bytes
+__device__ __forceinline__ void gsr_store_partial6(float4* base, size_t e, float4 r0, float r1x, float r1y) {
+  GsrF3* p = reinterpret_cast<GsrF3*>(reinterpret_cast<float*>(base) + e * GSR_PARTIAL_FLOATS);
+  p[0] = GsrF3{r0.x, r0.y, r0.z}; p[1] = GsrF3{r0.w, r1x, r1y};
+}
+__device__ __forceinline__ void gsr_load_partial6(const float4* base, size_t e, float4& r0, float& r1x, float& r1y) {
+  const GsrF3* p = reinterpret_cast<const GsrF3*>(reinterpret_cast<const float*>(base) + e * GSR_PARTIAL_FLOATS);
+  const GsrF3 a = p[0], b = p[1];
+  r0 = make_float4(a.x, a.y, a.z, b.x); r1x = b.y; r1y = b.z;
 }
 __device__ __forceinline__ void gsr_load_partial(const float4* base, size_t e, float4& r0, float4& r1, float& r2x) {
   const GsrF3* p = reinterpret_cast<const GsrF3*>(reinterpret_cast<const float*>(base) + e * GSR_PARTIAL_FLOATS);

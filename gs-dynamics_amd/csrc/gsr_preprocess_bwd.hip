@@ -96,9 +96,20 @@ __device__ void sh_backward(int deg, int M, const float* __restrict__ sh, float3
 struct PartialSum { float gmx, gmy, gA, gB, gC, gop, dr, dg, db; };
 
 // Sum of a Gaussian's entry records (one per touched tile, contiguous, ascending tile order).
-__device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__ partials, uint32_t e0, uint32_t e1) {
+// `col` = false: the blend backward wrote the six geometry sums only (24 of the 36 bytes; no colour gradient wanted).
+__device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__ partials, uint32_t e0, uint32_t e1, bool col = true) {
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2x = 0.f;
+  if (!col) {
+    for (uint32_t e = e0; e < e1; ++e) {
+      float4 q0;
+      float q1x, q1y;
+      gsr_load_partial6(partials, e, q0, q1x, q1y);
+      r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
+      r1.x += q1x; r1.y += q1y;
+    }
+    e0 = e1;
+  }
   for (uint32_t e = e0; e < e1; ++e) {
     float4 q0, q1;
     float q2x;
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     for (int k = 0; k < M * 3; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
   }
   if (alive) {
-    const PartialSum ps = reduce_partials(partials, offsets[i], offsets[i + 1]);
+    const PartialSum ps = reduce_partials(partials, offsets[i], offsets[i + 1], USE_SH || dL_dcolors != nullptr);
     gop = ps.gop;
     const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     if (USE_SH) {
@@ -314,7 +325,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
     const bool pair = w.partner_dL_dmeans2D != nullptr;
     if (w.radii[i] > 0) {
       any = true;
-      const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap));
+      const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap),
+                                            pair || w.dL_dcolors != nullptr || dL_dcolors != nullptr);
       gop += ps.gop;
       if (pair) {   // record layout of the pair backward: geometry sums of both views, then (sum t dx, sum t dy) of this view alone
         view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2, ps.dr, ps.dg, gm2a);

@@ -295,7 +295,26 @@ struct BwdLdsT {
 
 struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; };
 
-template <bool PAIR, int NBB = GSR_BWD_BB(PAIR)>
+// COL = false (plain passes only): the caller wants no colour gradient -- six sums per entry instead of nine (15 instead of 24
+// VALU issues of reduction, four multiplies less) and 24-byte records.
+// The no-colour reduction.  Measured on one box (8 views, render_bwd per launch): nine-value reduction with three zero inputs
+// 438 us, the six-value reduction (gsr_wave_sum6_packed, 9 VALU issues fewer) 510-525 us, the eight-value one with two zeros 541 us
+// -- against 448-465 us with colours.  The kernel is latency-bound, not issue-bound (SQ counters: one VALU issue per ~4 SIMD
+// cycles), and the shorter reductions are one serial chain of DPP adds with nothing to interleave; why that costs this much is
+// not understood.  GSR_NOCOL_SUM6 selects the six-value form for retests.
+#ifdef GSR_NOCOL_SUM6
+#define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum6_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5); \
+                           if (red6 >= 0) L.sRed[wv][j][red6] = z; }
+#else
+#define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum9_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5, 0.f, 0.f, 0.f); \
+                           if (lane >= 48 && lane <= 53) L.sRed[wv][j][lane - 48] = z; }
+#endif
+#ifdef GSR_NOCOL_FULL_RECORDS   // experiment: 36-byte stores although only 24 bytes carry data
+#define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial(p, e, r0, make_float4(a, b, 0.f, 0.f), 0.f)
+#else
+#define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial6(p, e, r0, a, b)
+#endif
+template <bool PAIR, int NBB = GSR_BWD_BB(PAIR), bool COL = true>
 __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -350,8 +369,11 @@ __device__ __forceinline__ void bwd_tile(
     const uint32_t e = __float_as_uint(sl.z) + gsr_tile_rank(__float_as_uint(sl.w), (maxx - minx) * (maxy - miny),
                                                             ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    gsr_store_partial(partials, e, z, z, 0.f);
+    if (PAIR || COL) gsr_store_partial(partials, e, z, z, 0.f);
+    else GSR_NOCOL_STORE6(partials, e, z, 0.f, 0.f);
   }
+  const int red6 = lane >= 48 ? gsr_sum6_slot(lane) : -1;   // !COL (GSR_NOCOL_SUM6): where this lane's total of the six-value reduction goes
+  (void)red6;
 
   // Software-pipelined staging (see fwd_tile): batch b+1 is fetched while batch b is processed.
   float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
@@ -464,6 +486,12 @@ __device__ __forceinline__ void bwd_tile(
           const float tx = t * dx, ty = t * dy;                                                               \
           const float z = gsr_wave_sum8_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5, tA * dx, tA * dy);      \
           if (lane >= 48 && lane <= 55) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                  \
+        } else if (!COL) {                                                                                    \
+          last_alpha = alpha;                                                                                 \
+          const float v5 = G * dL_dalpha;                                                                     \
+          const float t = eb.y * v5;                                                                          \
+          const float tx = t * dx, ty = t * dy;                                                               \
+          GSR_NOCOL_REDUCE                                                                                    \
         } else {                                                                                              \
         last_alpha = alpha;                                                                                   \
         const float w = alpha * T;                                                                            \
@@ -510,12 +538,14 @@ __device__ __forceinline__ void bwd_tile(
         if ((L.sActive[w][tid >> 6] >> (tid & 63)) & 1ull) {
           const float* q = L.sRed[w][tid];
           r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
-          r1.x += q[4]; r1.y += q[5]; r1.z += q[6]; r1.w += q[7];
-          if (!PAIR) r2.x += q[8];
+          r1.x += q[4]; r1.y += q[5];
+          if (PAIR || COL) { r1.z += q[6]; r1.w += q[7]; }
+          if (!PAIR && COL) r2.x += q[8];
         }
       }
       const uint32_t e = L.sSlot[tid];
-      gsr_store_partial(partials, e, r0, r1, r2.x);
+      if (PAIR || COL) gsr_store_partial(partials, e, r0, r1, r2.x);
+      else GSR_NOCOL_STORE6(partials, e, r0, r1.x, r1.y);
     }
     GSR_TP(6);
     __syncthreads();
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews ta
 #define GSR_TRACE_MAX 65536
 __device__ uint4 g_ticket_trace[GSR_TRACE_MAX];
 #endif
-template <bool PAIRS, int NBB = BWD_BATCH>
+template <bool PAIRS, int NBB = BWD_BATCH, bool COL = true>
 __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLdsAny<PAIRS, NBB> L;
   __shared__ uint32_t s_ticket;
@@ -649,7 +679,7 @@ __global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persis
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
     else
-      bwd_tile<false, NBB>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
+      bwd_tile<false, NBB, COL>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 #ifdef GSR_TRACE_TICKETS
     if (threadIdx.x == 0 && ticket < GSR_TRACE_MAX)
       g_ticket_trace[ticket] = make_uint4((uint32_t)tr0, (uint32_t)wall_clock64(), blockIdx.x, ord.z - ord.y);
@@ -751,9 +781,12 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
       const bool small = !pairs && tiles >= small_batch_from;
       const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + 1 : wg_per_cu);
       const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+      const bool col = !tab.no_colour_grad;
       if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, 96>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (small && col) hipLaunchKernelGGL((render_bwd_persistent<false, 96>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, 96, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (col) hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL((render_bwd_persistent<false, BWD_BATCH, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());

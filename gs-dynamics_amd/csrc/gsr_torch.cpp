@@ -96,7 +96,8 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
                              const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy,
                              const torch::Tensor& dL_dout_color, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos,
-                             const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer) {
+                             const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                             bool want_color_grad) {   // extension over upstream (default true): false = colours_precomp needs no gradient
   const c10::Device dev = means3D.device();
   c10::hip::HIPGuard guard(dev.index());
   const int64_t P = means3D.size(0);
@@ -105,7 +106,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
   const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
   auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
   torch::Tensor d_means3D = torch::empty({P, 3}, f32), d_means2D = torch::empty({P, 3}, f32), d_opacity = torch::empty({P, 1}, f32);
-  torch::Tensor d_colors = M ? torch::empty({0}, f32) : torch::empty({P, 3}, f32);
+  torch::Tensor d_colors = (M || !want_color_grad) ? torch::empty({0}, f32) : torch::empty({P, 3}, f32);
   torch::Tensor d_cov = torch::empty({P, 6}, f32);
   torch::Tensor d_sh = M ? torch::empty({P, M, 3}, f32) : torch::empty({0}, f32);
   const bool has_sr = scales.numel() > 0;
@@ -147,7 +148,14 @@ torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& vi
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "MI355X rasterizer: torch layer over libgsr_hip.so (rasterize_gaussians / rasterize_gaussians_backward / mark_visible)";
   m.def("rasterize_gaussians", &rasterize_gaussians);
-  m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
+  {
+    namespace py = pybind11;
+    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),
+          py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
+          py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"),
+          py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
+          py::arg("want_color_grad") = true);
+  }
   m.def("mark_visible", &mark_visible);
   m.def("abi_version", []() { return gsr_version(); });
 }

@@ -128,8 +128,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_color = torch.zeros((3, int(rs.image_height), int(rs.image_width)), device=m3.device)
             d2, dc, do, d3, dcov, dsh, ds, dr = ctx.native.rasterize_gaussians_backward(
                 rs.bg, m3, radii, col_, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
-                float(rs.tanfovy), grad_color, sh_, int(rs.sh_degree), rs.campos, geom, ctx.num_rendered, binning, image)
-            return (d3, d2, dsh if has_sh else None, dc if has_col else None, do, ds if has_sc else None, dr if has_sc else None,
+                float(rs.tanfovy), grad_color, sh_, int(rs.sh_degree), rs.campos, geom, ctx.num_rendered, binning, image,
+                bool(has_col and ctx.needs_input_grad[3]))   # frozen colours (the reference's training): the six-sum backward
+            return (d3, d2, dsh if has_sh else None, dc if (has_col and ctx.needs_input_grad[3]) else None, do, ds if has_sc else None, dr if has_sc else None,
                     dcov if has_cov else None, None)
         m3, radii, col_, sh_, sc_, rot_, cov_ = ctx.saved_tensors
         has_sh, has_col, has_sc, has_cov = ctx.has
@@ -137,7 +138,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_color = torch.zeros((3, ctx.state.H, ctx.state.W), device=m3.device)
         d_means3D, d_means2D, d_colors, d_opacity, d_scales, d_rot, d_cov, d_sh = _hip.rasterize_backward(
             ctx.state, grad_color, m3, radii, col_ if has_col else None, sh_ if has_sh else None,
-            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None)
+            sc_ if has_sc else None, rot_ if has_sc else None, cov_ if has_cov else None,
+            want_color_grad=bool(has_col and ctx.needs_input_grad[3]))
         return (d_means3D, d_means2D, d_sh if has_sh else None, d_colors if has_col else None, d_opacity,
                 d_scales if has_sc else None, d_rot if has_sc else None, d_cov if has_cov else None, None)
 

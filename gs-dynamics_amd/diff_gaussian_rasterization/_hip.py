@@ -307,8 +307,10 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
 
 
 def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_precomp, shs, scales, rotations,
-                       cov3D_precomp):
-    """K7..K9.  Returns (dmeans3D, dmeans2D, dcolors, dopacity[P,1], dscales, drotations, dcov3D, dsh)."""
+                       cov3D_precomp, want_color_grad: bool = True):
+    """K7..K9.  Returns (dmeans3D, dmeans2D, dcolors, dopacity[P,1], dscales, drotations, dcov3D, dsh).
+    ``want_color_grad=False`` (precomputed colours that need no gradient): dcolors is None and the blend backward keeps six sums
+    per list entry instead of nine."""
     lib = load_library()
     dev = means3D.device
     P, D = state.P, state.num_rendered
@@ -318,7 +320,7 @@ def rasterize_backward(state: RasterState, grad_color, means3D, radii, colors_pr
         g = grad_color.to(**f32).contiguous()
         d_means3D = torch.empty((P, 3), **f32)
         d_means2D = torch.empty((P, 3), **f32)
-        d_colors = torch.empty((P, 3), **f32) if shs is None else None
+        d_colors = torch.empty((P, 3), **f32) if (shs is None and want_color_grad) else None
         d_opacity = torch.empty((P, 1), **f32)
         d_scales = torch.empty((P, 3), **f32) if cov3D_precomp is None else None
         d_rot = torch.empty((P, 4), **f32) if cov3D_precomp is None else None

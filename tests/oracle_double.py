@@ -28,10 +28,11 @@ def rasterize_forward(rs, means3D, opacities, colors_precomp, shs, scales, rotat
             torch.tensor(o2.depth, device=dev), st)
 
 
-def rasterize_backward(state, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp):
+def rasterize_backward(state, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
+                       want_color_grad=True):
     g = state.o2.backward(_np(grad_color).astype(np.float32))
     t = lambda a: None if a is None else torch.tensor(a, device=means3D.device)  # noqa: E731
-    return (t(g["means3D"]), t(g["means2D"]), t(g["colors_precomp"]), t(g["opacities"]), t(g["scales"]),
+    return (t(g["means3D"]), t(g["means2D"]), t(g["colors_precomp"]) if want_color_grad else None, t(g["opacities"]), t(g["scales"]),
             t(g["rotations"]), t(g["cov3D_precomp"]), t(g["shs"]))
 
 

@@ -1644,3 +1644,55 @@ def test_end_to_end_fit_on_the_demo_assets(dev, golden_dir):
     assert last < first
     assert all(a > b + 1.0 for a, b in zip(after, before)), (before, after)
     assert min(after) > 30.0, after      # measured: 22 dB before, 37 .. 44 dB after 400 iterations
+
+
+def test_frozen_colours_backward_equals_full_backward(dev):
+    """colors_precomp.requires_grad == False (rgb_colors in the reference's training, /root/reference/src/tracking/train_utils.py:133):
+    the blend backward keeps six sums per list entry instead of nine.  Every other gradient must equal the full backward's -- the
+    geometry sums are the same products, only their reduction tree differs (rounding level) -- through the drop-in module (torch
+    C++ layer), the ctypes path and the multi-view call."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    P, W, H, V = 30000, 400, 304, 3
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.06)
+    cams = synth_ring_cameras(V, W, H, device=dev)
+    dL = torch.tensor(np.random.default_rng(11).uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    names = ("means3D", "opacities", "scales", "rotations")
+
+    def one_view(frozen, env=None):
+        leaves = {k: rv[k].clone().requires_grad_(not (frozen and k == "colors_precomp")) for k in names + ("colors_precomp",)}
+        m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+        im, _, _ = GaussianRasterizer(raster_settings=cams[0])(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                                              colors_precomp=leaves["colors_precomp"], scales=leaves["scales"],
+                                                              rotations=leaves["rotations"])
+        im.backward(gradient=dL[0])
+        return leaves, m2
+
+    def views(frozen):
+        leaves = {k: rv[k].clone().requires_grad_(not (frozen and k == "colors_precomp")) for k in names + ("colors_precomp",)}
+        m2 = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        im, _, _ = rasterize_gaussians_views(cams, leaves["means3D"], m2, leaves["opacities"], colors_precomp=leaves["colors_precomp"],
+                                             scales=leaves["scales"], rotations=leaves["rotations"])
+        im.backward(gradient=dL)
+        return leaves, m2
+
+    import diff_gaussian_rasterization as dgr
+    for run in (one_view, views):
+        (a, m2a), (b, m2b) = run(False), run(True)
+        assert b["colors_precomp"].grad is None and a["colors_precomp"].grad is not None
+        for k in names:
+            scale = a[k].grad.abs().max().item()
+            assert (a[k].grad - b[k].grad).abs().max().item() <= 4e-6 * scale, (run.__name__, k)
+        assert (m2a.grad - m2b.grad).abs().max().item() <= 4e-6 * m2a.grad.abs().max().item(), run.__name__
+    # the ctypes path of the single-view module (what runs when the torch C++ layer is absent)
+    saved = dgr._C
+    try:
+        dgr._C = None
+        (a, m2a), (b, m2b) = one_view(False), one_view(True)
+    finally:
+        dgr._C = saved
+    assert b["colors_precomp"].grad is None
+    for k in names:
+        assert (a[k].grad - b[k].grad).abs().max().item() <= 4e-6 * a[k].grad.abs().max().item(), ("ctypes", k)

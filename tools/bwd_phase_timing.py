@@ -14,7 +14,8 @@ cams = synth_ring_cameras(max(V, 4), 800, 800, device=dev)[:V]
 cam = cams[0]
 with torch.no_grad():
     rv0 = params2rendervar(params)
-rv = {k: v.detach().clone().requires_grad_(True) for k, v in rv0.items()}
+FROZEN = os.environ.get("FROZEN", "0") == "1"   # colors_precomp without gradient: the six-sum backward
+rv = {k: v.detach().clone().requires_grad_(not (FROZEN and k == "colors_precomp")) for k, v in rv0.items()}
 dL = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (3, 800, 800)).astype(np.float32), device=dev)
 dLv = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (V, 3, 800, 800)).astype(np.float32), device=dev)
 from diff_gaussian_rasterization import rasterize_gaussians_views
