@@ -830,6 +830,8 @@ __global__ void st_wave_sum_kernel(const float* in, float* out_dpp, float* out_r
   const int l = threadIdx.x & 63;
   const float zexp = ((l & 8) == 0) ? (float)((l & 7) + 1) * b : 9.f * b;
   bool okz = __ballot(z != zexp) == 0ull;
+  const float zp = gsr_wave_sum9_packed<true>(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v, 9.f * v);   // row levels by lane swaps
+  okz = okz && __ballot(zp != zexp) == 0ull;
   // eight-value form of the fused pair backward: lane & 7 = i holds the total of value i
   const float z8 = gsr_wave_sum8_packed(v, 2.f * v, 3.f * v, 4.f * v, 5.f * v, 6.f * v, 7.f * v, 8.f * v);
   okz = okz && __ballot(z8 != (float)((l & 7) + 1) * b) == 0ull;

@@ -359,6 +359,26 @@ __device__ __forceinline__ float gsr_dpp_get(float x) {
 __device__ __forceinline__ float gsr_swz_xor4(float x) {  // ds_swizzle bit mode: src lane = lane ^ 4
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101F));
 }
+// The two row levels (xor 16, xor 32) of a packed reduction: every lane adds its partners in the other rows.
+// PERM = false: ds_swizzle + ds_bpermute -- two LDS-crossbar round trips, 2 VALU issues.  PERM = true: v_permlane16/32_swap on
+// two copies -- no LDS, 6 VALU issues.  Measured (same box): with five workgroups per CU and a long ticket queue the kernel is
+// short of issue slots and the crossbar form wins (render_bwd 452 vs 459 us, 8 views); with four per CU and about one tile per
+// workgroup (one or two views) the serial chain of a tile counts and the swap form wins (103 -> 96.5 us).
+template <bool PERM>
+__device__ __forceinline__ float gsr_rows_sum(float z) {
+  if (PERM) {
+    float a = z, b = z;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: rows {0,0,2,2} of z, b: rows {1,1,3,3}
+    z = a + b;
+    a = z; b = z;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: low half twice, b: high half twice
+    return a + b;
+  }
+  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
+  z += __shfl_xor(z, 32, 64);
+  return z;
+}
+template <bool PERM = false>
 __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float v2, float v3, float v4, float v5,
                                                       float v6, float v7, float v8) {
   const int lane = gsr_lane();
@@ -417,13 +437,9 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
       : "=&v"(z) : "v"(p07), "v"(p8));
 #endif
   // rows: the packed layout differs per lane, so the row levels must be lane-wise exchanges (row_bcast would
-  // broadcast a single lane): xor 16 via ds_swizzle, xor 32 via a bpermute shuffle.  (An LDS-free variant -- xor 16 / 32 as
-  // v_permlane16/32_swap on two copies -- passes the self-test but costs more VALU issues and measured SLOWER: the blend
-  // backward sits at the VALU issue limit, the crossbar round trips are hidden by the other waves.)  Every lane ends up
-  // with the total of "its" value: lane & 15 in 0..7 -> v_(lane & 7), lane & 8 set -> v8.
-  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));
-  z += __shfl_xor(z, 32, 64);
-  return z;
+  // broadcast a single lane), see gsr_rows_sum.  Every lane ends up with the total of "its" value: lane & 15 in 0..7 ->
+  // v_(lane & 7), lane & 8 set -> v8.
+  return gsr_rows_sum<PERM>(z);
 }
 
 // Eight values (fused pair backward without colour gradients): 8 -> 4 -> 2 -> 1 registers, 20 VALU issues (see above).
@@ -459,9 +475,7 @@ __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float 
   float z = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
 #endif
   z += gsr_dpp_get<0x128>(z);                                                        // xor 8 (row_ror:8)
-  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));       // xor 16
-  z += __shfl_xor(z, 32, 64);
-  return z;
+  return gsr_rows_sum<false>(z);                                                     // xor 16, xor 32
 }
 
 // Six values (plain backward when no colour gradient is wanted -- rgb_colors is frozen throughout the reference's training,
@@ -492,9 +506,7 @@ __device__ __forceinline__ float gsr_wave_sum6_packed(float v0, float v1, float 
       : "=&v"(q03), "=&v"(q45) : "v"(r01), "v"(r23), "v"(r45));
   float z = (b0 ? q45 : q03) + gsr_dpp_get<0xB1>(b0 ? q03 : q45);               // bit 0 (xor 1): 2 -> 1
   z += gsr_dpp_get<0x4E>(z);                                                     // xor 2
-  z += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(z), 0x401F));   // xor 16
-  z += __shfl_xor(z, 32, 64);
-  return z;
+  return gsr_rows_sum<false>(z);                                                 // xor 16, xor 32
 }
 
 // exp(x) for x <= 0: v_exp_f32 on x * log2(e) -- two VALU issues.  Relative error ~ |x| * 6e-8 + 1 ulp (|x| <= 5.6 wherever

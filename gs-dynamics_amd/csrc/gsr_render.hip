@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
   return m;
 }
 
+#ifndef GSR_INDEX_AHEAD
+#define GSR_INDEX_AHEAD 1
+#endif
 // Per-strip compacted entry lists of one staged batch (stable: list order is preserved).
 // PAIR: the tile pass also blends a partner view that shares this view's camera and differs only in its colours (the
 // segmentation render next to the colour render of get_loss, the mask render next to the colour render of predict.py):
@@ -145,8 +148,12 @@ __device__ __forceinline__ void fwd_tile(
   float2 nc = make_float2(0.f, 0.f);
   float3 np = make_float3(0.f, 0.f, 0.f);   // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
+  // The gather is two dependent trips (list entry -> record).  The list entry of batch b+2 is fetched while batch b is walked,
+  // so the record loads of batch b+1 issue without waiting for an index (GSR_INDEX_AHEAD=0: index and record in one go).
+  uint32_t g_ahead = 0;
   if (tid < FWD_BATCH && tid < n) {
     const uint32_t g = point_list[rg.x + tid];
+    if (GSR_INDEX_AHEAD && tid + FWD_BATCH < n) g_ahead = point_list[rg.x + tid + FWD_BATCH];
     { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
     if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
@@ -165,7 +172,8 @@ __device__ __forceinline__ void fwd_tile(
     {
       const int nidx = idx + FWD_BATCH;
       if (tid < FWD_BATCH && nidx < n) {
-        const uint32_t g = point_list[rg.x + nidx];
+        const uint32_t g = GSR_INDEX_AHEAD ? g_ahead : point_list[rg.x + nidx];
+        if (GSR_INDEX_AHEAD && nidx + FWD_BATCH < n) g_ahead = point_list[rg.x + nidx + FWD_BATCH];
         { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
         if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
@@ -306,7 +314,7 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
 #define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum6_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5); \
                            if (red6 >= 0) L.sRed[wv][j][red6] = z; }
 #else
-#define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum9_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5, 0.f, 0.f, 0.f); \
+#define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum9_packed<ROWS_PERM>(tx, ty, tx * dx, tx * dy, ty * dy, v5, 0.f, 0.f, 0.f); \
                            if (lane >= 48 && lane <= 53) L.sRed[wv][j][lane - 48] = z; }
 #endif
 #ifdef GSR_NOCOL_FULL_RECORDS   // experiment: 36-byte stores although only 24 bytes carry data
@@ -319,8 +327,9 @@ __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, float4* __restrict__ partials, const BwdPartner pt) {
+    float4* __restrict__ partials, const BwdPartner pt) {
   constexpr int BB = NBB;
+  constexpr bool ROWS_PERM = !PAIR && NBB == BWD_BATCH;   // the short-queue build: see gsr_rows_sum
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx = tile % gx, ty = tile / gx;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
@@ -359,18 +368,15 @@ __device__ __forceinline__ void bwd_tile(
   __syncthreads();
   const int ql0 = L.sQuadLast[0], ql1 = L.sQuadLast[1], ql2 = L.sQuadLast[2], ql3 = L.sQuadLast[3];
   const int max_last = max(max(ql0, ql1), max(ql2, ql3));  // entries [max_last, n) are used by no pixel of this tile
-
-  // entries nobody reached still own a slot in the Gaussian-major partial buffer: zero them
-  for (int k = max_last + tid; k < n; k += GSR_BLOCK) {
-    const uint32_t g = point_list[rg.x + k];
-    const float4 sl = rec[GSR_REC_F4 * g + 3];   // rect bits, offsets[g]
-    const uint32_t rx = __float_as_uint(sl.x), ry = __float_as_uint(sl.y);
-    const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu, maxy = ry >> 16;
-    const uint32_t e = __float_as_uint(sl.z) + gsr_tile_rank(__float_as_uint(sl.w), (maxx - minx) * (maxy - miny),
-                                                            ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PAIR || COL) gsr_store_partial(partials, e, z, z, 0.f);
-    else GSR_NOCOL_STORE6(partials, e, z, 0.f, 0.f);
+  // The list entries of the zero-fill (entries nobody reached still own a record in the Gaussian-major scratch) and of the
+  // first two batches are requested together, then their records: two dependent memory trips instead of four.
+  const int kz = max_last + tid;
+  uint32_t gz = 0;
+  if (kz < n) gz = point_list[rg.x + kz];
+  uint32_t ng = 0, ng_ahead = 0;                     // ng_ahead: list entry of batch b+2 (see fwd_tile)
+  if (tid < BB && tid < max_last) {
+    ng = point_list[rg.x + (max_last - 1 - tid)];
+    if (GSR_INDEX_AHEAD && tid + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (tid + BB))];
   }
   const int red6 = lane >= 48 ? gsr_sum6_slot(lane) : -1;   // !COL (GSR_NOCOL_SUM6): where this lane's total of the six-value reduction goes
   (void)red6;
@@ -381,13 +387,25 @@ __device__ __forceinline__ void bwd_tile(
   float4 nslot = na;   // record word 3: rect bits, offsets[g]
   float4 np = na;      // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
-  uint32_t ng = 0;
+  float4 slz = na;
+  if (kz < n) slz = rec[GSR_REC_F4 * gz + 3];   // rect bits, offsets[g]
   if (tid < BB && tid < max_last) {
-    ng = point_list[rg.x + (max_last - 1 - tid)];
     { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
     if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * ng + 1]; np = make_float4(q1.z, q1.w, pt.rec[GSR_REC_F4 * ng + 2].x, 0.f); }
+  }
+  // zero-fill of the unreached entries: the first 256 rode along with the loads above, the rest (rare) in a plain loop
+  for (int k = kz; k < n; k += GSR_BLOCK) {
+    float4 sl = slz;
+    if (k != kz) sl = rec[GSR_REC_F4 * point_list[rg.x + k] + 3];
+    const uint32_t rx = __float_as_uint(sl.x), ry = __float_as_uint(sl.y);
+    const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu, maxy = ry >> 16;
+    const uint32_t e = __float_as_uint(sl.z) + gsr_tile_rank(__float_as_uint(sl.w), (maxx - minx) * (maxy - miny),
+                                                            ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PAIR || COL) gsr_store_partial(partials, e, z, z, 0.f);
+    else GSR_NOCOL_STORE6(partials, e, z, 0.f, 0.f);
   }
   GSR_TP(0);
   for (int base = 0; base < max_last; base += BB) {
@@ -411,7 +429,8 @@ __device__ __forceinline__ void bwd_tile(
     {
       const int nj = base + BB + tid;
       if (tid < BB && nj < max_last) {
-        ng = point_list[rg.x + (max_last - 1 - nj)];
+        ng = GSR_INDEX_AHEAD ? ng_ahead : point_list[rg.x + (max_last - 1 - nj)];
+        if (GSR_INDEX_AHEAD && nj + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (nj + BB))];
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
@@ -457,7 +476,7 @@ __device__ __forceinline__ void bwd_tile(
       const float dx = ea.x - pxf, dy = ea.y - pyf;                                                           \
       const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);        \
       const float G0 = __builtin_amdgcn_exp2f(power);  /* power is in log2 units (pre-scaled conic) */        \
-      const bool hit = (pos < last) && power <= 0.0f && fminf(GSR_ALPHA_MAX, eb.y * G0) >= GSR_ALPHA_MIN;     \
+      const bool hit = (pos < last) && power <= 0.0f && eb.y * G0 >= GSR_ALPHA_MIN; /* = min(0.99, .) >= 1/255 */ \
       if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
         /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
            alpha = 0, 1/(1-alpha) = 1, T and the accumulated colour are unchanged (an alpha = 0 entry only flushes \
@@ -505,7 +524,7 @@ __device__ __forceinline__ void bwd_tile(
         const float v0 = tx, v1 = ty;                                                                         \
         const float v2 = tx * dx, v3 = tx * dy, v4 = ty * dy;                                                 \
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
-        const float z = gsr_wave_sum9_packed(v0, v1, v2, v3, v4, v5, v6, v7, v8);                             \
+        const float z = gsr_wave_sum9_packed<ROWS_PERM>(v0, v1, v2, v3, v4, v5, v6, v7, v8);                  \
         if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
         }                                                                                                     \
         if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));                           \
@@ -559,7 +578,7 @@ __device__ __forceinline__ void bwd_tile(
 // view}; the view's pointers come from the kernarg table (uniform index: scalar loads).
 #define GSR_FWD_PASS(vw) tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).out_color, (vw).out_depth
 #define GSR_BWD_PASS(vw) \
-  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).rect, (vw).offsets, (vw).partials
+  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials
 
 __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
   return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth};
