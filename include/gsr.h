@@ -81,6 +81,9 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
  *   dL_dmeans3D[P,3] dL_dmeans2D[P,3] (x,y = dL/d(NDC), z = 0) dL_dcolors[P,3] dL_dopacity[P]
  *   dL_dscales[P,3] dL_drotations[P,4] dL_dcov3D[P,6] dL_dsh[P,M,3]
  * Pointers for unused outputs (dL_dsh without shs; dL_dcolors with shs) may be NULL.
+ * dL_dcolors == NULL with colors_precomp means "no colour gradient wanted" (rgb_colors is frozen throughout the reference's
+ * training, /root/reference/src/tracking/train_utils.py:133,155): the blend backward then keeps six sums per list entry instead
+ * of nine.  Every other gradient is the same up to the rounding of a different reduction tree.
  * Incoming gradients for radii and depth do not exist in this ABI: they are ignored by contract
  * (no reference call site differentiates them, /root/reference/src/tracking/train_utils.py:178,192). */
 int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,
