@@ -462,6 +462,11 @@ __device__ __forceinline__ void bwd_tile(
     __syncthreads();
     GSR_TP(3);
     uint64_t active_lo = 0ull, active_hi = 0ull;
+#ifdef GSR_ACTIVE_BRANCHY
+#define GSR_MARK_ACTIVE(j) if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
+#else   // branch-free scalar form: the compiler turns the if/else above into two scalar branches per visit
+#define GSR_MARK_ACTIVE(j) { const uint64_t bit_ = 1ull << (j & 63); active_lo |= j < 64 ? bit_ : 0ull; active_hi |= j < 64 ? 0ull : bit_; }
+#endif
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
@@ -527,7 +532,7 @@ __device__ __forceinline__ void bwd_tile(
         const float z = gsr_wave_sum9_packed<ROWS_PERM>(v0, v1, v2, v3, v4, v5, v6, v7, v8);                  \
         if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
         }                                                                                                     \
-        if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));                           \
+        GSR_MARK_ACTIVE(j)                                                                                    \
       }                                                                                                       \
     }
     // two entries per trip on ping-pong registers (see fwd_tile): no copies to rotate the LDS prefetch
