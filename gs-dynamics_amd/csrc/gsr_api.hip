@@ -502,7 +502,7 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];

@@ -477,6 +477,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 // is arbitrary: per-tile results do not depend on it.
 #define GSR_COLSCAN_MIN_BLOCKS 768u
 #define ORD_CHUNK 12
+// tile_sort's wave path (one wave per tile, entries in registers, no barriers) takes lists up to tab.wave_cap entries; longer ones
+// get a workgroup each.  512 for ordinary scenes -- a lone wave sorting 800 entries is slower than a workgroup, and with only a few
+// such tiles it is the launch's tail (800^2 / 100 k, one view: tile_sort 17 -> 31 us with 1024) -- and 1024 when the lists are long
+// on average (1080p / 500 k: 735 entries per tile, tile_sort 589 -> 547 us per frame).
+// n > 512 <=> (n + 7) >> 3 >= 65 <=> bucket <= 190: the long tickets end where bucket 191 starts (the fourth bucket of lane 47);
+// n > 1024 <=> bucket <= 126: lane 31.
 #define ORD_WAVES 16
 #define ORD_MAX_WG 32
 // Several workgroups (one 1024-thread workgroup took 14.8 us for 10 000 tiles, most of it contention on a few
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
     for (int q = 0; q < 4; ++q) { st4[q] = run; run += c4[q]; }
     if (lane == 63) n_busy_s = run;   // buckets 0..254 only: bucket 255 (empty tiles) is never counted in the histograms
     // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
-    if (lane == 47) n_long_s = st4[0] + c4[0] + c4[1] + c4[2];
+    if (lane == (tab.wave_cap == 1024 ? 31 : 47)) n_long_s = st4[0] + c4[0] + c4[1] + c4[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) start[lane * 4 + q] = st4[q] + h_before[0][lane * 4 + q];
   }
@@ -670,7 +676,7 @@ __device__ __forceinline__ uint32_t gsr_lane_xor(uint32_t v) {   // value of lan
 template <int MASK, int NR>
 __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
   constexpr int L = MASK & 63, R = MASK >> 6;
-  constexpr int HB = MASK >= 256 ? 256 : MASK >= 128 ? 128 : MASK >= 64 ? 64 : MASK >= 32 ? 32 : MASK >= 16 ? 16 : MASK >= 8 ? 8 : MASK >= 4 ? 4 : MASK >= 2 ? 2 : 1;
+  constexpr int HB = MASK >= 512 ? 512 : MASK >= 256 ? 256 : MASK >= 128 ? 128 : MASK >= 64 ? 64 : MASK >= 32 ? 32 : MASK >= 16 ? 16 : MASK >= 8 ? 8 : MASK >= 4 ? 4 : MASK >= 2 ? 2 : 1;
   uint64_t y[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -688,6 +694,7 @@ __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
 template <int LK, int NR>
 __device__ __forceinline__ void wave_sort_stage(uint64_t (&x)[NR], int lane) {   // merge size k = 2^LK
   wave_sort_step<(1 << LK) - 1, NR>(x, lane);
+  if constexpr (LK >= 10) wave_sort_step<256, NR>(x, lane);
   if constexpr (LK >= 9) wave_sort_step<128, NR>(x, lane);
   if constexpr (LK >= 8) wave_sort_step<64, NR>(x, lane);
   if constexpr (LK >= 7) wave_sort_step<32, NR>(x, lane);
@@ -707,10 +714,10 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ seg,
   if constexpr (NR >= 2) wave_sort_stage<7, NR>(x, lane);
   if constexpr (NR >= 4) wave_sort_stage<8, NR>(x, lane);
   if constexpr (NR >= 8) wave_sort_stage<9, NR>(x, lane);
+  if constexpr (NR >= 16) wave_sort_stage<10, NR>(x, lane);
 #pragma unroll
   for (int r = 0; r < NR; ++r) { const uint32_t e = (uint32_t)(r * 64 + lane); if (e < n) out[e] = (uint32_t)x[r]; }
 }
-#define TS_WAVE_CAP 512
 
 // Stable LSD radix sort of one tile's entries inside LDS (n <= RCAP).  The segment arrives in
 // ascending Gaussian-id order (the global tile-digit passes are stable and emission was id-major), so a
@@ -806,7 +813,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     if (n <= 64) wave_sort_tile<1>(seg, out, n, tid & 63);
     else if (n <= 128) wave_sort_tile<2>(seg, out, n, tid & 63);
     else if (n <= 256) wave_sort_tile<4>(seg, out, n, tid & 63);
-    else wave_sort_tile<8>(seg, out, n, tid & 63);
+    else if (n <= 512) wave_sort_tile<8>(seg, out, n, tid & 63);
+    else wave_sort_tile<16>(seg, out, n, tid & 63);
     return;
   }
   const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
@@ -863,10 +871,14 @@ static int ceil_log2_u32(uint32_t n) {
   return b;
 }
 
-int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
-  if (tab.V <= 0 || tab.T <= 0) return 0;
+int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
+  if (tab_in.V <= 0 || tab_in.T <= 0) return 0;
+  GsrBinViews tab = tab_in;
   uint32_t maxD = 0, maxblk = 0;
   for (int v = 0; v < tab.V; ++v) { maxD = tab.v[v].D > maxD ? tab.v[v].D : maxD; maxblk = tab.v[v].nblocks > maxblk ? tab.v[v].nblocks : maxblk; }
+  const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
+  const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
+  tab.wave_cap = big ? 1024 : 512;
   int cur = 0;
   if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
     for (int v = 0; v < tab.V; ++v) GSR_HIP_CHECK(hipMemsetAsync(tab.v[v].ranges, 0, sizeof(uint2) * (size_t)tab.T, st));
@@ -907,8 +919,6 @@ int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st) {
   if (int rc = gsr_launch_tile_order(tab, st)) return rc;
   if (maxD > 0 && P > 0) {
     { GSR_PROF("tile_sort", st);
-    const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
-    const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);
     if (big)   // long lists on average: the big-LDS build
       hipLaunchKernelGGL(tile_sort_kernel<4096>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
     else

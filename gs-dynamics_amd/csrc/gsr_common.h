@@ -173,6 +173,7 @@ struct GsrBinView {            // emit .. tile_sort
 struct GsrBinViews {
   int V, T, gx; uint4* order; uint32_t* queue;
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
+  int wave_cap;                  // tile_sort: lists up to this length (512 / 1024) are sorted by one wave each (set by gsr_launch_binning)
   GsrBinView v[GSR_MAX_BATCH];
 };
 struct GsrRenderView {         // blend forward / backward
