@@ -317,11 +317,7 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
 #define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum9_packed<ROWS_PERM>(tx, ty, tx * dx, tx * dy, ty * dy, v5, 0.f, 0.f, 0.f); \
                            if (lane >= 48 && lane <= 53) L.sRed[wv][j][lane - 48] = z; }
 #endif
-#ifdef GSR_NOCOL_FULL_RECORDS   // experiment: 36-byte stores although only 24 bytes carry data
-#define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial(p, e, r0, make_float4(a, b, 0.f, 0.f), 0.f)
-#else
-#define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial6(p, e, r0, a, b)
-#endif
+#define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial6(p, e, r0, a, b)   // (36-byte stores instead: measured the same)
 template <bool PAIR, int NBB = GSR_BWD_BB(PAIR), bool COL = true>
 __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
@@ -462,11 +458,8 @@ __device__ __forceinline__ void bwd_tile(
     __syncthreads();
     GSR_TP(3);
     uint64_t active_lo = 0ull, active_hi = 0ull;
-#ifdef GSR_ACTIVE_BRANCHY
-#define GSR_MARK_ACTIVE(j) if (j < 64) active_lo |= (1ull << j); else active_hi |= (1ull << (j - 64));
-#else   // branch-free scalar form: the compiler turns the if/else above into two scalar branches per visit
+    // branch-free scalar form (an if / else on j < 64 becomes two scalar branches per visit: +0.5 % at 8 views, +1.5 % at one)
 #define GSR_MARK_ACTIVE(j) { const uint64_t bit_ = 1ull << (j & 63); active_lo |= j < 64 ? bit_ : 0ull; active_hi |= j < 64 ? 0ull : bit_; }
-#endif
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
