@@ -58,6 +58,9 @@ namespace gsr_render {
 #ifndef FWD_BATCH
 #define FWD_BATCH 128
 #define FWD_UNROLL 8     // entries per unrolled block of the forward blend loop
+#ifndef FWD_UNROLL_PAIR
+#define FWD_UNROLL_PAIR 3   // the pair build: six colour accumulators; 3 -> 90 VGPRs (five workgroups per CU need <= 96), 4 -> 98
+#endif
 #endif
 #ifndef BWD_BATCH
 #define BWD_BATCH 128
@@ -239,10 +242,11 @@ __device__ __forceinline__ void fwd_tile(
       // address computations and four scalar branches per trip: render_fwd 222 -> 201 us at 8 views, 58 -> 49 us at one view.  The
       // backward's visits branch on __ballot(hit), the loads cannot move across that, and there the hand-rotated prefetch is 3 %
       // faster than blocks.)
+      constexpr int UN = PAIR ? FWD_UNROLL_PAIR : FWD_UNROLL;
       int j = 0;
-      for (; j + FWD_UNROLL <= m; j += FWD_UNROLL) {
+      for (; j + UN <= m; j += UN) {
 #pragma unroll
-        for (int u = 0; u < FWD_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
           const float4 ea = wA[j + u], eb = wB[j + u], ec = wC[j + u];
           const float2 ed = PAIR ? wD[j + u] : make_float2(0.f, 0.f);
           GSR_FWD_ENTRY(ea, eb, ec, ed)
