@@ -164,7 +164,7 @@ int check_inputs(const char* who, const float* means3D, const float* opacities, 
 int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
-           uint32_t* num_rendered_host, hipStream_t st) {
+           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr) {
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -172,6 +172,17 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
   }
   GsrPreViews tab;
   tab.V = V;
+  tab.raw_rot = tab.raw_op = tab.raw_sc = nullptr;
+  tab.rot_out = tab.op_out = tab.sc_out = nullptr;
+  if (raw) {
+    if (!raw->unnorm_rotations || !raw->logit_opacities || !raw->log_scales || !raw->rotations_out || !raw->opacities_out || !raw->scales_out ||
+        raw->rotations_out != rotations || raw->opacities_out != opacities || raw->scales_out != scales || cov3D_precomp) {
+      gsr_set_error("gsr forward (raw parameters): NULL pointer, cov3D_precomp given, or rotations / opacities / scales are not the *_out buffers");
+      return -2;
+    }
+    tab.raw_rot = raw->unnorm_rotations; tab.raw_op = raw->logit_opacities; tab.raw_sc = raw->log_scales;
+    tab.rot_out = raw->rotations_out; tab.op_out = raw->opacities_out; tab.sc_out = raw->scales_out;
+  }
   GsrCam cam0;
   const uint32_t nblk = (uint32_t)((P + GSR_BLOCK - 1) / GSR_BLOCK);
   for (int v = 0; v < V; ++v) {
@@ -430,6 +441,18 @@ int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, cons
                                const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
                                const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
                                uint32_t* counts_dev, void* stream) {
+  return gsr_forward_batch_capacity_raw(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
+                                        geom_states, radii, binning_states, capacity_entries, image_states, batch_state, geometry_of,
+                                        out_color, out_depth, counts_dev, nullptr, stream);
+}
+
+int gsr_forward_batch_capacity_raw(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                   const float* rotations, const float* opacities, const float* colors_precomp,
+                                   const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                                   void* const* geom_states, int32_t* const* radii, void* const* binning_states,
+                                   const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
+                                   const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                                   uint32_t* counts_dev, const gsr_raw_params* raw, void* stream) {
   GsrRange _range("gsr_forward_batch_capacity");
   if (int rc = check_batch("gsr_forward_batch_capacity", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
@@ -446,7 +469,7 @@ int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, cons
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream))
+                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw))
     return rc;
   return stage2(V, s, P, capacity_entries, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
                 b.queue, geometry_of, (hipStream_t)stream, counts_dev);
@@ -460,12 +483,30 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
                        float* const* dL_dmeans2D,
                        float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity, float* dL_dscales,
                        float* dL_drotations, float* dL_dcov3D, void* stream) {
+  return gsr_backward_batch_raw(V, s, P, num_rendered, means3D, scales, rotations, colors_precomp, cov3D_precomp, radii, geom_states,
+                                binning_states, image_states, batch_state, geometry_of, dL_dcolor, scratch, dL_dmeans3D, dL_dmeans2D, dL_dcolors,
+                                dL_dcolors_views, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, nullptr, stream);
+}
+
+int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
+                       const float* scales, const float* rotations, const float* colors_precomp,
+                       const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
+                       void* const* binning_states, void* const* image_states, void* batch_state,
+                       const int32_t* geometry_of, const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
+                       float* const* dL_dmeans2D,
+                       float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D, const gsr_raw_params* raw, void* stream) {
   GsrRange _range("gsr_backward_batch");
   if (int rc = check_batch("gsr_backward_batch", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   if (!num_rendered || !radii || !geom_states || !binning_states || !image_states || !dL_dcolor || !scratch ||
-      !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !means3D) {
+      !dL_dmeans3D || !dL_dmeans2D || (!dL_dopacity && !raw) || !means3D) {
     gsr_set_error("gsr_backward_batch: NULL argument");
+    return -2;
+  }
+  if (raw && (!raw->unnorm_rotations || !raw->d_unnorm_rotations || !raw->d_logit_opacities || !raw->d_log_scales || !scales || !rotations ||
+              !raw->opacities_out || cov3D_precomp)) {
+    gsr_set_error("gsr_backward_batch (raw parameters): NULL pointer or cov3D_precomp given");
     return -2;
   }
   if (P <= 0) return 0;
@@ -474,6 +515,9 @@ int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   GsrBwdViews vw;
   vw.V = V;
+  vw.raw_rot = raw ? raw->unnorm_rotations : nullptr; vw.act_op = raw ? raw->opacities_out : nullptr; vw.act_sc = raw ? scales : nullptr;
+  vw.d_raw_rot = raw ? raw->d_unnorm_rotations : nullptr; vw.d_raw_op = raw ? raw->d_logit_opacities : nullptr;
+  vw.d_raw_sc = raw ? raw->d_log_scales : nullptr;
   GsrRenderViews rt;
   GsrBinViews bt;          // only for a tile_order rebuild (ranges + flags)
   bool any = false;

@@ -158,7 +158,13 @@ struct GsrPreView {            // preprocess
   float tanfovx, tanfovy;
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
 };
-struct GsrPreViews { int V; GsrPreView v[GSR_MAX_BATCH]; };
+struct GsrPreViews {
+  int V;
+  // raw-parameter mode (include/gsr.h: gsr_raw_params): activations applied inline, activated values written by the view-0 blocks
+  const float *raw_rot, *raw_op, *raw_sc;
+  float *rot_out, *op_out, *sc_out;
+  GsrPreView v[GSR_MAX_BATCH];
+};
 struct GsrBinView {            // emit .. tile_sort
   const float4* rec; const uint2* rect; const uint32_t* tiles_touched;
   const uint32_t* block_sums; const uint32_t* block_offsets;   // block_offsets == nullptr: emit adds up block_sums itself
@@ -241,6 +247,9 @@ struct GsrBwdView {
 };
 struct GsrBwdViews {
   int V;
+  // raw-parameter mode: chain through the activations applied at the end of the per-Gaussian kernel (all nullptr otherwise)
+  const float *raw_rot, *act_op, *act_sc;
+  float *d_raw_rot, *d_raw_op, *d_raw_sc;
   GsrBwdView v[GSR_MAX_BATCH];
 };
 int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_modifier, const float* means3D,
@@ -508,6 +517,28 @@ __device__ __forceinline__ float gsr_wave_sum6_packed(float v0, float v1, float 
   float z = (b0 ? q45 : q03) + gsr_dpp_get<0xB1>(b0 ? q03 : q45);               // bit 0 (xor 1): 2 -> 1
   z += gsr_dpp_get<0x4E>(z);                                                     // xor 2
   return gsr_rows_sum<false>(z);                                                 // xor 16, xor 32
+}
+
+// ---- parameter activations of the tracking step (/root/reference/src/tracking/helpers.py:36-45): rotation = normalize(unnorm),
+// opacity = sigmoid(logit), scale = exp(log_scale).  One definition for the stand-alone kernels (gsr_step.hip) and for the
+// preprocess kernels that apply them inline (raw-parameter mode); the sums are spelled with fmaf so that files compiled with and
+// without contraction produce the same bits.
+__device__ __forceinline__ float gsr_quat_norm(float4 q) { return sqrtf(fmaf(q.w, q.w, fmaf(q.z, q.z, fmaf(q.y, q.y, q.x * q.x)))); }
+__device__ __forceinline__ float4 gsr_act_rotation(float4 q) {
+  const float d = fmaxf(gsr_quat_norm(q), 1e-12f);   // torch.nn.functional.normalize: x / max(|x|, eps)
+  return make_float4(q.x / d, q.y / d, q.z / d, q.w / d);
+}
+__device__ __forceinline__ float gsr_act_opacity(float logit) { return 1.0f / (1.0f + expf(-logit)); }
+__device__ __forceinline__ float gsr_act_scale(float logs) { return expf(logs); }
+__device__ __forceinline__ float4 gsr_act_rotation_bwd(float4 q, float4 dr) {
+  const float n = gsr_quat_norm(q);
+  if (n > 1e-12f) {
+    const float inv = 1.0f / n;
+    const float rx = q.x * inv, ry = q.y * inv, rz = q.z * inv, rw = q.w * inv;
+    const float dot = fmaf(rw, dr.w, fmaf(rz, dr.z, fmaf(ry, dr.y, rx * dr.x)));
+    return make_float4((dr.x - rx * dot) * inv, (dr.y - ry * dot) * inv, (dr.z - rz * dot) * inv, (dr.w - rw * dot) * inv);
+  }
+  return make_float4(dr.x * 1e12f, dr.y * 1e12f, dr.z * 1e12f, dr.w * 1e12f);   // clamped denominator: a constant
 }
 
 // exp(x) for x <= 0: v_exp_f32 on x * log2(e) -- two VALU issues.  Relative error ~ |x| * 6e-8 + 1 ulp (|x| <= 5.6 wherever

@@ -349,7 +349,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
   if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
-  dL_dopacity[i] = gop;
+  if (vw.d_raw_rot) {   // raw-parameter mode: the chain through normalize / sigmoid / exp, here instead of in a launch of its own
+    reinterpret_cast<float4*>(vw.d_raw_rot)[i] =
+        gsr_act_rotation_bwd(reinterpret_cast<const float4*>(vw.raw_rot)[i], make_float4(gq[0], gq[1], gq[2], gq[3]));
+    const float o = vw.act_op[i];
+    vw.d_raw_op[i] = gop * o * (1.0f - o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vw.d_raw_sc[3 * (size_t)i + k] = gs[k] * vw.act_sc[3 * (size_t)i + k];
+  }
+  if (dL_dopacity) dL_dopacity[i] = gop;
   if (dL_dscales) { dL_dscales[3 * i] = gs[0]; dL_dscales[3 * i + 1] = gs[1]; dL_dscales[3 * i + 2] = gs[2]; }
   if (dL_drot) { dL_drot[4 * i] = gq[0]; dL_drot[4 * i + 1] = gq[1]; dL_drot[4 * i + 2] = gq[2]; dL_drot[4 * i + 3] = gq[3]; }
   if (dL_dcov3D) {

@@ -92,6 +92,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
 
   float3 p = make_float3(0.f, 0.f, 0.f);
   if (in_range) p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+  // raw-parameter mode: this Gaussian's activated rotation / scale / opacity are computed here (every view's block does, view 0's
+  // writes them out for the backward and for the caller)
+  float4 act_q = make_float4(1.f, 0.f, 0.f, 0.f);
+  float act_s[3] = {0.f, 0.f, 0.f}, act_o = 0.f;
+  const bool raw = tab.raw_rot != nullptr;
+  if (raw && in_range) {
+    act_q = gsr_act_rotation(reinterpret_cast<const float4*>(tab.raw_rot)[i]);
+    act_o = gsr_act_opacity(tab.raw_op[i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) act_s[k] = gsr_act_scale(tab.raw_sc[3 * (size_t)i + k]);
+    if (blockIdx.y == 0) {
+      reinterpret_cast<float4*>(tab.rot_out)[i] = act_q;
+      tab.op_out[i] = act_o;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tab.sc_out[3 * (size_t)i + k] = act_s[k];
+    }
+  }
   float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
   float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
   float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
@@ -107,11 +124,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
       c0 = cov3D_precomp[6 * i]; c1 = cov3D_precomp[6 * i + 1]; c2_ = cov3D_precomp[6 * i + 2];
       c3 = cov3D_precomp[6 * i + 3]; c4 = cov3D_precomp[6 * i + 4]; c5 = cov3D_precomp[6 * i + 5];
     } else {
-      float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+      float r, x, y, z;
+      if (raw) { r = act_q.x; x = act_q.y; y = act_q.z; z = act_q.w; }
+      else { r = rotations[4 * i]; x = rotations[4 * i + 1]; y = rotations[4 * i + 2]; z = rotations[4 * i + 3]; }
       float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
       float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
       float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
-      float s0 = mod * scales[3 * i], s1 = mod * scales[3 * i + 1], s2 = mod * scales[3 * i + 2];
+      float s0, s1, s2;
+      if (raw) { s0 = mod * act_s[0]; s1 = mod * act_s[1]; s2 = mod * act_s[2]; }
+      else { s0 = mod * scales[3 * i]; s1 = mod * scales[3 * i + 1]; s2 = mod * scales[3 * i + 2]; }
       float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
       float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
       float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
@@ -169,7 +190,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
         // sqrt(2 ln(255 o) * Sigma_xx), sqrt(.. * Sigma_yy).  The +0.02 on the log (2 % slack on alpha) and the
         // outward rounding make it safe against any fp32 difference with the per-pixel evaluation; pixels
         // outside the box would be skipped by the alpha test anyway, so using it cannot change a result.
-        const float tau2 = 2.0f * (__logf(255.0f * opacities[i]) + 0.02f);
+        const float opac = raw ? act_o : opacities[i];
+        const float tau2 = 2.0f * (__logf(255.0f * opac) + 0.02f);
         if (tau2 > 0.0f) {
           const float hx = sqrtf(tau2 * a) + 0.01f, hy = sqrtf(tau2 * cc) + 0.01f;
           const int xmin = max(-32768, min(32767, (int)floorf(px - hx)));
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
           }
         }
         a4 = make_float4(px, py, cA, cB);
-        b4 = make_float4(cC, opacities[i], rgb[0], rgb[1]);
+        b4 = make_float4(cC, opac, rgb[0], rgb[1]);
         c2 = make_float2(rgb[2], pvz);
       }
     }

@@ -27,14 +27,11 @@ __global__ __launch_bounds__(ST_BLOCK) void activate_fwd_kernel(int P, const flo
                                                                 float* __restrict__ op, float* __restrict__ sc) {
   const int i = blockIdx.x * ST_BLOCK + threadIdx.x;
   if (i >= P) return;
-  const float4 q = reinterpret_cast<const float4*>(unnorm)[i];
-  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  const float d = fmaxf(n, 1e-12f);                    // torch.nn.functional.normalize: x / max(|x|, eps)
-  reinterpret_cast<float4*>(rot)[i] = make_float4(q.x / d, q.y / d, q.z / d, q.w / d);
-  op[i] = 1.0f / (1.0f + expf(-logit[i]));
-  sc[3 * (size_t)i] = expf(logs[3 * (size_t)i]);
-  sc[3 * (size_t)i + 1] = expf(logs[3 * (size_t)i + 1]);
-  sc[3 * (size_t)i + 2] = expf(logs[3 * (size_t)i + 2]);
+  reinterpret_cast<float4*>(rot)[i] = gsr_act_rotation(reinterpret_cast<const float4*>(unnorm)[i]);
+  op[i] = gsr_act_opacity(logit[i]);
+  sc[3 * (size_t)i] = gsr_act_scale(logs[3 * (size_t)i]);
+  sc[3 * (size_t)i + 1] = gsr_act_scale(logs[3 * (size_t)i + 1]);
+  sc[3 * (size_t)i + 2] = gsr_act_scale(logs[3 * (size_t)i + 2]);
 }
 
 // any of the incoming gradients may be NULL (that output was not used): its parameter gradient is zero
@@ -46,19 +43,7 @@ __global__ __launch_bounds__(ST_BLOCK) void activate_bwd_kernel(int P, const flo
   const int i = blockIdx.x * ST_BLOCK + threadIdx.x;
   if (i >= P) return;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (d_rot) {
-    const float4 q = reinterpret_cast<const float4*>(unnorm)[i];
-    const float4 dr = reinterpret_cast<const float4*>(d_rot)[i];
-    const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    if (n > 1e-12f) {
-      const float inv = 1.0f / n;
-      const float rx = q.x * inv, ry = q.y * inv, rz = q.z * inv, rw = q.w * inv;
-      const float dot = rx * dr.x + ry * dr.y + rz * dr.z + rw * dr.w;
-      g = make_float4((dr.x - rx * dot) * inv, (dr.y - ry * dot) * inv, (dr.z - rz * dot) * inv, (dr.w - rw * dot) * inv);
-    } else {
-      g = make_float4(dr.x * 1e12f, dr.y * 1e12f, dr.z * 1e12f, dr.w * 1e12f);   // clamped denominator: a constant
-    }
-  }
+  if (d_rot) g = gsr_act_rotation_bwd(reinterpret_cast<const float4*>(unnorm)[i], reinterpret_cast<const float4*>(d_rot)[i]);
   reinterpret_cast<float4*>(d_unnorm)[i] = g;
   const float o = op[i];
   d_logit[i] = d_op ? d_op[i] * o * (1.0f - o) : 0.f;

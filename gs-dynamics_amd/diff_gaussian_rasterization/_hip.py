@@ -58,12 +58,18 @@ class GsrKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64)]
 
 
+class GsrRawParams(C.Structure):
+    """gsr_raw_params of include/gsr.h: the tracking step's parameters before their activations (fused into the per-Gaussian kernels)."""
+    _fields_ = [(n, C.c_void_p) for n in ("unnorm_rotations", "logit_opacities", "log_scales", "rotations_out", "opacities_out", "scales_out",
+                                          "d_unnorm_rotations", "d_logit_opacities", "d_log_scales")]
+
+
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
-           "gsr_forward_batch_capacity",
-           "gsr_backward_batch", "gsr_debug_phase_timing",
+           "gsr_forward_batch_capacity", "gsr_forward_batch_capacity_raw",
+           "gsr_backward_batch", "gsr_backward_batch_raw", "gsr_debug_phase_timing",
            "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
@@ -111,6 +117,10 @@ def load_library():
     lib.gsr_forward_batch_capacity.restype = C.c_int
     lib.gsr_forward_batch_capacity.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(u32), PV, vp,
                                                C.POINTER(i32), PV, PV, vp, vp])
+    lib.gsr_forward_batch_capacity_raw.restype = C.c_int
+    lib.gsr_forward_batch_capacity_raw.argtypes = lib.gsr_forward_batch_capacity.argtypes[:-1] + [C.POINTER(GsrRawParams), vp]
+    lib.gsr_backward_batch_raw.restype = C.c_int
+    lib.gsr_backward_batch_raw.argtypes = lib.gsr_backward_batch.argtypes[:-1] + [C.POINTER(GsrRawParams), vp]
     lib.gsr_image_loss_blocks.restype = i32
     lib.gsr_image_loss_blocks.argtypes = [i32, i32, i32]
     lib.gsr_image_loss_forward.restype = C.c_int
@@ -252,7 +262,11 @@ def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Ten
 class RasterState:
     """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
     __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch", "geometry_of",
-                 "pending")
+                 "pending", "act", "raw_fused")
+
+    def __init__(self):
+        self.act = None          # batch forward with raw=...: (rotations, opacities, scales) after their activations (view 0's state)
+        self.raw_fused = None    # (unnorm_rotations,) when the activations ran inside the forward: the backward applies their chain too
 
 
 def _make_settings(rs, dev, sh_coeffs: int):
@@ -367,10 +381,22 @@ def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False
 
 
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                            prepare_backward: bool = False, no_host_sync: bool = False):
-    """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V])."""
+                            prepare_backward: bool = False, no_host_sync: bool = False, raw=None):
+    """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V]).
+    ``raw = (unnorm_rotations, logit_opacities, log_scales)`` (then ``opacities`` / ``scales`` / ``rotations`` are None): the
+    activations are applied inside the preprocess kernel when the call runs in capacity mode (``states[0].raw_fused``), by
+    ``activate_forward`` otherwise; either way ``states[0].act = (rotations, opacities, scales)`` holds the activated tensors."""
     lib = load_library()
     _require_device(means3D)
+    act = None
+    if raw is not None:
+        if cov3D_precomp is not None or shs is not None:
+            raise ValueError("rasterize_forward_batch(raw=...): precomputed colours and scales / rotations only")
+        key_ = (means3D.device.index, int(means3D.shape[0]), int(settings_list[0].image_height), int(settings_list[0].image_width))
+        if not (no_host_sync and int(means3D.shape[0]) > 0 and _entries_capacity.get(key_, 0)):
+            act = activate_forward(*raw)               # no capacity yet (first call / overflow repeat): the stand-alone kernel
+            rotations, opacities, scales = act
+            raw = None
     dev = means3D.device
     V = len(settings_list)
     P = int(means3D.shape[0])
@@ -432,11 +458,19 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             col_views = _ptr_array([colors_precomp[v] for v in range(V)]) if per_view_col else None
             counts_dev = torch.empty((V,), dtype=torch.int32, device=dev)
             capv = (C.c_uint32 * V)(*([cap_e] * V))
-            _check(lib.gsr_forward_batch_capacity(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                                  _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
-                                                  _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
-                                                  capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
-                                                  _ptr_array(depth_v), _ptr(counts_dev), st), "gsr_forward_batch_capacity")
+            rawp = None
+            if raw is not None:     # activations inside the preprocess kernel: its view-0 blocks write the activated values here
+                f32_ = dict(dtype=torch.float32, device=dev)
+                rotations, opacities, scales = torch.empty((P, 4), **f32_), torch.empty((P, 1), **f32_), torch.empty((P, 3), **f32_)
+                act = (rotations, opacities, scales)
+                un_, lo_, ls_ = (t.contiguous() for t in raw)
+                rawp = GsrRawParams(_ptr(un_), _ptr(lo_), _ptr(ls_), _ptr(rotations), _ptr(opacities), _ptr(scales), None, None, None)
+            _check(lib.gsr_forward_batch_capacity_raw(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                                      _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
+                                                      _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
+                                                      capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
+                                                      _ptr_array(depth_v), _ptr(counts_dev), C.byref(rawp) if rawp is not None else None, st),
+                   "gsr_forward_batch_capacity")
             ring = _counts_slots.setdefault((dev.index, V), [])
             slot = next((sl for sl in ring if not sl[2]), None)
             if slot is None:      # pinned staging + event, allocated once per ring entry (hipHostMalloc costs tens of microseconds)
@@ -458,6 +492,8 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                 state.batch = batch if v == 0 else None
                 state.geometry_of = geometry_of if v == 0 else None
                 state.pending = (ev, counts_host, counts_dev, int(cap_e), key, slot) if v == 0 else None
+                state.act = act if v == 0 else None
+                state.raw_fused = (un_, ) if (v == 0 and rawp is not None) else None
                 states.append(state)
             return color, radii, depth, states
         binnings = [torch.empty((cap,), **u8) if (cap and owner[v]) else None for v in range(V)]
@@ -499,6 +535,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         state.batch = batch if v == 0 else None
         state.geometry_of = geometry_of if v == 0 else None
         state.pending = None
+        state.act = act if v == 0 else None
         states.append(state)
     return color, radii, depth, states
 
@@ -549,15 +586,22 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
 
         def per_view(t):
             return _ptr_array([t[v] for v in range(V)])
-        _check(lib.gsr_backward_batch(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations),
-                                      _ptr(None if per_view_col else colors_precomp),
-                                      _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
-                                      _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
-                                      _ptr(states[0].batch), states[0].geometry_of, per_view(g), _ptr_array(scratch), _ptr(d_means3D),
-                                      per_view(d_means2D),
-                                      _ptr(None if (per_view_col or not want_color_grad) else d_colors),
-                                      per_view(d_colors) if (per_view_col and want_color_grad) else None,
-                                      _ptr(d_opacity), _ptr(d_scales), _ptr(d_rot), _ptr(d_cov), _stream(dev)),
+        rawp, fused = None, states[0].raw_fused
+        if fused is not None:    # the chain through the activations runs inside the per-Gaussian kernel: d_rot / d_opacity / d_scales
+            #                      come back as the gradients of the UNACTIVATED parameters (same shapes)
+            rawp = GsrRawParams(_ptr(fused[0]), None, None, _ptr(rotations), _ptr(states[0].act[1]), _ptr(scales),
+                                _ptr(d_rot), _ptr(d_opacity), _ptr(d_scales))
+        _check(lib.gsr_backward_batch_raw(V, sarr, P, Ds, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                          _ptr(None if per_view_col else colors_precomp),
+                                          _ptr(cov3D_precomp), per_view(radii), _ptr_array([stt.geom for stt in states]),
+                                          _ptr_array([stt.binning for stt in states]), _ptr_array([stt.image for stt in states]),
+                                          _ptr(states[0].batch), states[0].geometry_of, per_view(g), _ptr_array(scratch), _ptr(d_means3D),
+                                          per_view(d_means2D),
+                                          _ptr(None if (per_view_col or not want_color_grad) else d_colors),
+                                          per_view(d_colors) if (per_view_col and want_color_grad) else None,
+                                          _ptr(None if fused is not None else d_opacity), _ptr(None if fused is not None else d_scales),
+                                          _ptr(None if fused is not None else d_rot), _ptr(d_cov),
+                                          C.byref(rawp) if rawp is not None else None, _stream(dev)),
                "gsr_backward_batch")
     # without a colour gradient, views that share a camera stay fused in the backward (one replay of the tile lists for both)
     return d_means3D, d_means2D, (d_colors if want_color_grad else None), d_opacity, d_scales, d_rot, d_cov, None

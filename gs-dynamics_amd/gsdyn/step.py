@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
@@ -287,15 +289,26 @@ def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_co
         raise RuntimeError("render_step_views: needs a HIP device and at most %d views per call" % _hip.MAX_BATCH)
     colours = params[colours_key].detach()
     with _hip.hold_stream(dev):
-        rot, op, sc = _hip.activate_forward(params["unnorm_rotations"], params["logit_opacities"], params["log_scales"])
-        ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, op, colours, None, sc, rot, None,
-                                                                  prepare_backward=True, no_host_sync=_no_host_sync)
+        # the activations (normalize / sigmoid / exp) ride inside the preprocess kernel once the call runs in capacity mode, and
+        # their chain inside the per-Gaussian backward kernel (gsr_raw_params): two launches per step fewer
+        raw = (params["unnorm_rotations"].detach(), params["logit_opacities"].detach(), params["log_scales"].detach())
+        if os.environ.get("GSR_NO_FUSED_ACTIVATIONS") == "1":     # A/B switch: the two stand-alone activation launches
+            rot, op, sc = _hip.activate_forward(*raw)
+            ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, op, colours, None, sc, rot, None,
+                                                                      prepare_backward=True, no_host_sync=_no_host_sync)
+        else:
+            ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, None, colours, None, None, None, None,
+                                                                      prepare_backward=True, no_host_sync=_no_host_sync, raw=raw)
+            rot, op, sc = states[0].act
         # The backward is queued right behind the forward, BEFORE the forward's entry counts are known on the host: on lists
         # that overflowed their capacity it is still memory-safe (emit never writes past the capacity, record reads are clamped
         # to it), its results are then simply dropped and the step is repeated synchronously.
         d3, d2, dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, dL, m3, radii, colours, None, sc, rot, None,
                                                                                   want_color_grad=want_colour_grad)
-        d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
+        if states[0].raw_fused is not None:
+            d_un, d_lo, d_ls = d_rot, d_op, d_sc      # already the gradients of the unactivated parameters
+        else:
+            d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
         if not _hip.forward_counts_ok(states):      # the scene outgrew the remembered capacity (> 50 % more entries in one step)
             return render_step_views(params, cams, dL, colours_key, want_colour_grad, _no_host_sync=False)
     grads = {"means3D": d3, "unnorm_rotations": d_un, "logit_opacities": d_lo, "log_scales": d_ls, "means2D": d2, "radii": radii}

@@ -149,6 +149,39 @@ int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, cons
                                const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
                                const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
                                uint32_t* counts_dev, void* stream);
+/* ---- raw-parameter mode (the tracking step, /root/reference/src/tracking/helpers.py:36-45): the caller holds unnormalised
+ * rotations, logit opacities and log scales; their activations (normalize / sigmoid / exp) and the chain back through them are
+ * applied INSIDE the per-Gaussian kernels of the forward and the backward instead of in two launches of their own.
+ * Forward: the activated values are also written to rotations_out / opacities_out / scales_out -- the SAME buffers must be passed
+ * as the call's `rotations` / `opacities` / `scales` arguments (and again to the backward).  Backward: the parameter gradients go
+ * to d_unnorm_rotations / d_logit_opacities / d_log_scales; dL_drotations / dL_dopacity / dL_dscales may then be NULL.
+ * Values are bit-identical to gsr_activate_forward / gsr_activate_backward. */
+typedef struct gsr_raw_params {
+  const float* unnorm_rotations;   /* [P,4] */
+  const float* logit_opacities;    /* [P]   */
+  const float* log_scales;         /* [P,3] */
+  float* rotations_out;            /* forward: [P,4] */
+  float* opacities_out;            /* forward: [P]   */
+  float* scales_out;               /* forward: [P,3] */
+  float* d_unnorm_rotations;       /* backward: [P,4] */
+  float* d_logit_opacities;        /* backward: [P]   */
+  float* d_log_scales;             /* backward: [P,3] */
+} gsr_raw_params;
+/* gsr_forward_batch_capacity / gsr_backward_batch with the activations fused (raw == NULL: exactly those functions). */
+int gsr_forward_batch_capacity_raw(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                   const float* rotations, const float* opacities, const float* colors_precomp,
+                                   const float* const* colors_views, const float* shs, const float* cov3D_precomp,
+                                   void* const* geom_states, int32_t* const* radii, void* const* binning_states,
+                                   const uint32_t* capacity_entries, void* const* image_states, void* batch_state,
+                                   const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
+                                   uint32_t* counts_dev, const gsr_raw_params* raw, void* stream);
+int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
+                           const float* scales, const float* rotations, const float* colors_precomp,
+                           const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,
+                           void* const* binning_states, void* const* image_states, void* batch_state,
+                           const int32_t* geometry_of, const float* const* dL_dcolor, void* const* scratch, float* dL_dmeans3D,
+                           float* const* dL_dmeans2D, float* dL_dcolors, float* const* dL_dcolors_views, float* dL_dopacity,
+                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D, const gsr_raw_params* raw, void* stream);
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
                        const float* scales, const float* rotations, const float* colors_precomp,
                        const float* cov3D_precomp, const int32_t* const* radii, void* const* geom_states,

@@ -1696,3 +1696,38 @@ def test_frozen_colours_backward_equals_full_backward(dev):
     assert b["colors_precomp"].grad is None
     for k in names:
         assert (a[k].grad - b[k].grad).abs().max().item() <= 4e-6 * a[k].grad.abs().max().item(), ("ctypes", k)
+
+
+def test_fused_activations_in_the_direct_step(dev):
+    """render_step_views: the first call has no capacity yet and runs the stand-alone activation kernels; later calls apply the
+    activations inside preprocess_fwd and their chain inside preprocess_bwd_views (gsr_raw_params).  One definition of the
+    arithmetic (gsr_common.h), so images and every parameter gradient are bit-identical between the two."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import synth_ring_cameras, synth_scene_params
+    from gsdyn.step import render_step_views
+    P, W, H, V = 25000, 336, 256, 3
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.06)
+    cams = synth_ring_cameras(V, W, H, device=dev)
+    dL = torch.tensor(np.random.default_rng(21).uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+    key = (dev.index, P, H, W)
+    _hip._entries_capacity.pop(key, None)
+    seen = []
+    orig = _hip.rasterize_backward_batch
+
+    def spy(states, *a, **k):
+        seen.append(states[0].raw_fused is not None)
+        return orig(states, *a, **k)
+    _hip.rasterize_backward_batch = spy
+    try:
+        im0, g0 = render_step_views(params, cams, dL)      # no capacity known: stand-alone activations
+        im1, g1 = render_step_views(params, cams, dL)      # capacity mode: fused
+        im2, g2 = render_step_views(params, cams, dL, want_colour_grad=False)
+    finally:
+        _hip.rasterize_backward_batch = orig
+    torch.cuda.synchronize()
+    assert seen[0] is False and seen[-2] is True and seen[-1] is True, seen
+    assert torch.equal(im0, im1) and torch.equal(im0, im2)
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors", "means2D"):
+        assert torch.equal(g0[k], g1[k]), k
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales"):     # frozen colours: another reduction tree
+        assert (g0[k] - g2[k]).abs().max().item() <= 4e-6 * g0[k].abs().max().item(), k
