@@ -684,10 +684,14 @@ __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
     if constexpr (L == 0) y[r] = src;
     else y[r] = ((uint64_t)gsr_lane_xor<L>((uint32_t)(src >> 32)) << 32) | gsr_lane_xor<L>((uint32_t)src);
   }
+  // The element with the lower index keeps the minimum: take the partner's key when it is smaller (lower) or larger (upper).  Keys
+  // are distinct -- only padding entries (~0) tie, and swapping equals changes nothing -- so "larger" is "not smaller" and one 64-bit
+  // compare XOR the (register-independent) upper-half predicate decides: half the VALU work of comparing both ways and selecting.
+  const bool upper_lane = HB < 64 ? ((lane & HB) != 0) : false;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const bool lower = HB < 64 ? ((lane & HB) == 0) : (((r * 64) & HB) == 0);
-    const bool take = lower ? (y[r] < x[r]) : (y[r] > x[r]);
+    const bool upper = HB < 64 ? upper_lane : (((r * 64) & HB) != 0);
+    const bool take = (y[r] < x[r]) != upper;
     x[r] = take ? y[r] : x[r];
   }
 }
