@@ -4,7 +4,7 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/gs-dynamics_amd/csrc; O=/tmp/gsr_variant_$1; mkdir -p $O
 make -C $C -j8 >/dev/null
-B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $2"
+B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $2"
 $B -c $C/gsr_binning.hip -o $O/gsr_binning.o &
 $B -fno-slp-vectorize -c $C/gsr_render.hip -o $O/gsr_render.o &
 $B -c $C/gsr_api.hip -o $O/gsr_api.o &
