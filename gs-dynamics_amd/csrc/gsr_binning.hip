@@ -140,6 +140,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void emit_entries_kernel(int P, GsrBinVi
     for (int w = 0; w < wv; ++w) run += swave[w];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int j = tid * 8 + k; if (j <= nblk) sS[j] = run; run += v[k]; }
+    if (tid == GSR_BLOCK - 1) sS[8 * GSR_BLOCK] = run;   // nblk == 2048 (P in 524033 .. 524288): the total sits one past the last thread's slots
     __syncthreads();
   }
   auto S = [&](int j) -> uint32_t { return block_offsets ? block_offsets[j] : sS[j]; };

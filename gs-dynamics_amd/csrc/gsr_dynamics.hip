@@ -254,7 +254,17 @@ int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind,
   if (N <= 0 || npoints <= 0) return 0;
   static const bool single = [] { const char* e = getenv("GSR_FPS_SINGLE_WG"); return e && *e && atoi(e) != 0; }();
   const int wgs = fps_workgroups(N);
-  if (!single && wgs > 1 && wgs <= 256) {
+  // fps_multi_kernel's workgroups wait for each other's candidates: every one of them must be RESIDENT, or the launch never ends.
+  // Bound the grid by what the device can hold at once (occupancy of this kernel x compute units, queried once per process);
+  // anything larger -- or a device shared with other streams, GSR_FPS_SINGLE_WG=1 -- takes the single-workgroup kernel.
+  static const int resident = [] {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_multi_kernel, GSR_BLOCK, 0) != hipSuccess) return 0;
+    return (per_cu > 0 ? 1 : 0) * prop.multiProcessorCount;   // ONE workgroup per CU counted: others may hold the rest
+  }();
+  if (!single && wgs > 1 && wgs <= 256 && wgs <= resident) {
     unsigned long long* cand = (unsigned long long*)((char*)mind + gsr_align((size_t)N * 4));
     GSR_HIP_CHECK(hipMemsetAsync(cand, 0, (size_t)npoints * wgs * 8, st));
     { GSR_PROF("fps", st);

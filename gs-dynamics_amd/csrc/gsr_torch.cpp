@@ -30,6 +30,18 @@ torch::Tensor f32c(const torch::Tensor& t, const c10::Device& dev) {   // contig
   return t.to(dev, torch::kFloat32).contiguous();
 }
 
+// element counts of the optional per-Gaussian inputs (an empty tensor = "not given"): a wrongly sized tensor would otherwise be read
+// out of bounds on the device
+void check_counts(const char* who, int64_t P, const torch::Tensor& colors, const torch::Tensor& opacity, const torch::Tensor& scales,
+                  const torch::Tensor& rotations, const torch::Tensor& cov3D, const torch::Tensor& sh) {
+  auto want = [&](const torch::Tensor& t, int64_t n, const char* name) {
+    TORCH_CHECK(t.numel() == 0 || t.numel() == n, who, ": ", name, " must hold ", n, " floats for ", P, " Gaussians, got ", t.numel());
+  };
+  want(colors, 3 * P, "colors_precomp"); want(scales, 3 * P, "scales"); want(rotations, 4 * P, "rotations"); want(cov3D, 6 * P, "cov3D_precomp");
+  TORCH_CHECK(opacity.numel() == P, who, ": opacities must hold ", P, " floats, got ", opacity.numel());
+  TORCH_CHECK(sh.numel() == 0 || (sh.dim() == 3 && sh.size(0) == P && sh.size(2) == 3), who, ": shs must be [P, M, 3]");
+}
+
 struct Settings {
   gsr_settings s;
   torch::Tensor bg, view, proj, campos;   // keep-alives of the converted settings tensors
@@ -70,6 +82,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     return std::make_tuple((int64_t)0, torch::zeros({3, H, W}, f32), torch::zeros({1, H, W}, f32),
                            torch::zeros({0}, f32.dtype(torch::kInt32)), torch::empty({0}, u8), torch::empty({0}, u8), torch::empty({0}, u8));
   }
+  check_counts("rasterize_gaussians", P, colors, opacity, scales, rotations, cov3D_precomp, sh);
   const torch::Tensor m3 = f32c(means3D, dev), col = f32c(colors, dev), op = f32c(opacity, dev), sc = f32c(scales, dev),
                       rot = f32c(rotations, dev), cov = f32c(cov3D_precomp, dev), shs = f32c(sh, dev);
   Settings st = make_settings(background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree, M, prefiltered, dev);
@@ -113,6 +126,17 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
   torch::Tensor d_scales = has_sr ? torch::empty({P, 3}, f32) : torch::empty({0}, f32);
   torch::Tensor d_rot = has_sr ? torch::empty({P, 4}, f32) : torch::empty({0}, f32);
   if (P == 0) return std::make_tuple(d_means2D, d_colors, d_opacity, d_means3D, d_cov, d_sh, d_scales, d_rot);
+  {
+    auto want = [&](const torch::Tensor& t, int64_t n, const char* name) {
+      TORCH_CHECK(t.numel() == 0 || t.numel() == n, "rasterize_gaussians_backward: ", name, " must hold ", n, " elements, got ", t.numel());
+    };
+    want(colors, 3 * P, "colors_precomp"); want(scales, 3 * P, "scales"); want(rotations, 4 * P, "rotations"); want(cov3D_precomp, 6 * P, "cov3D_precomp");
+    TORCH_CHECK(radii.numel() == P && radii.scalar_type() == torch::kInt32, "rasterize_gaussians_backward: radii must be int32 [P]");
+    TORCH_CHECK(sh.numel() == 0 || (sh.dim() == 3 && sh.size(0) == P && sh.size(2) == 3), "rasterize_gaussians_backward: shs must be [P, M, 3]");
+    TORCH_CHECK((size_t)geomBuffer.numel() >= gsr_geom_bytes((int32_t)P) && (size_t)imageBuffer.numel() >= gsr_image_bytes((int32_t)H, (int32_t)W) &&
+                (R == 0 || (size_t)binningBuffer.numel() >= gsr_binning_bytes((uint32_t)R, (int32_t)H, (int32_t)W)),
+                "rasterize_gaussians_backward: a state buffer is smaller than this (P, H, W, num_rendered) needs");
+  }
   const torch::Tensor m3 = f32c(means3D, dev), col = f32c(colors, dev), sc = f32c(scales, dev), rot = f32c(rotations, dev),
                       cov = f32c(cov3D_precomp, dev), shs = f32c(sh, dev), g = f32c(dL_dout_color, dev);
   Settings st = make_settings(background, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, H, W, scale_modifier, degree, M, false, dev);
@@ -157,5 +181,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("want_color_grad") = true);
   }
   m.def("mark_visible", &mark_visible);
-  m.def("abi_version", []() { return gsr_version(); });
+  m.def("abi_version", []() { return (int)GSR_VERSION; });   // the header this layer was COMPILED against (compare with the library's gsr_version())
 }

@@ -231,8 +231,9 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
-            if _C is not None and positions.is_cuda:
-                return _C.mark_visible(positions, self.raster_settings.viewmatrix, self.raster_settings.projmatrix)
+            native = _native() if positions.is_cuda else None
+            if native is not None:
+                return native.mark_visible(positions, self.raster_settings.viewmatrix, self.raster_settings.projmatrix)
             return _hip.mark_visible(positions, self.raster_settings.viewmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,

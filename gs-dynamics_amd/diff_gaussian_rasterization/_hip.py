@@ -473,13 +473,20 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                    "gsr_forward_batch_capacity")
             ring = _counts_slots.setdefault((dev.index, V), [])
             slot = next((sl for sl in ring if not sl[2]), None)
-            if slot is None:      # pinned staging + event, allocated once per ring entry (hipHostMalloc costs tens of microseconds)
-                if len(ring) >= _COUNTS_RING:
+            if slot is None and len(ring) >= _COUNTS_RING:
+                # Every slot is held by a call whose counts were never looked at.  A caller that raised between its forward and
+                # forward_counts_ok() (or dropped the states) leaves such a slot behind: take over the oldest one whose copy has
+                # completed -- its generation changes, so a late forward_counts_ok() of the abandoned call raises instead of reading
+                # another call's counts.
+                slot = next((sl for sl in ring if sl[1].query()), None)
+                if slot is None:
                     raise RuntimeError(f"rasterize_forward_batch(no_host_sync=True): {_COUNTS_RING} capacity-mode forwards are in flight "
                                        "without forward_counts_ok(); check each call's counts before issuing more")
-                slot = [torch.empty((V,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), False]
+            if slot is None:      # pinned staging + event, allocated once per ring entry (hipHostMalloc costs tens of microseconds)
+                slot = [torch.empty((V,), dtype=torch.int32, pin_memory=True), torch.cuda.Event(), False, 0]
                 ring.append(slot)
             slot[2] = True
+            slot[3] += 1          # generation
             counts_host, ev = slot[0], slot[1]
             counts_host.copy_(counts_dev, non_blocking=True)
             ev.record(torch.cuda.current_stream(dev))
@@ -491,7 +498,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                 state.pre = pre if v == 0 else None
                 state.batch = batch if v == 0 else None
                 state.geometry_of = geometry_of if v == 0 else None
-                state.pending = (ev, counts_host, counts_dev, int(cap_e), key, slot) if v == 0 else None
+                state.pending = (ev, counts_host, counts_dev, int(cap_e), key, slot, slot[3]) if v == 0 else None
                 state.act = act if v == 0 else None
                 state.raw_fused = (un_, ) if (v == 0 and rawp is not None) else None
                 states.append(state)
@@ -546,7 +553,9 @@ def forward_counts_ok(states) -> bool:
     pending = states[0].pending
     if pending is None:
         return True
-    ev, counts_host, _counts_dev, cap_e, key, slot = pending
+    ev, counts_host, _counts_dev, cap_e, key, slot, gen = pending
+    if slot[3] != gen:
+        raise RuntimeError("forward_counts_ok: this capacity-mode forward was abandoned (its counts slot serves a later call)")
     ev.synchronize()
     top = int(counts_host.max())
     slot[2] = False          # the ring entry may serve the next call
@@ -881,23 +890,26 @@ def _window(window11):
     return w
 
 
-_target_moments = {}     # id(target as the caller passed it) -> [weakref, version, fp32 contiguous image, moments | None, bytes]
+_target_moments = {}     # id(target as the caller passed it) -> [weakref, version, converted fp32 image | None, moments | None, bytes]
 _TARGET_CACHE_BYTES = 1 << 30   # converted targets + moments kept alive at most (cleared when exceeded)
+_TARGET_CACHE_ENTRIES = 256     # and at most this many records (a loader that hands over a fresh target every step)
 
 
 def _target_entry(t):
     """Cache record of a target image, keyed on the tensor object the CALLER holds (id + version, weakref-checked): the
     reference's loader hands over ``permute(2, 0, 1) / 255`` views, whose contiguous copy would otherwise be a fresh temporary
-    (and a fresh address) every step.  Returns [ref, version, contiguous fp32 image, moments or None, bytes]."""
+    (and a fresh address) every step.  Returns [ref, version, converted image or None, moments or None, bytes].  A target that
+    already is contiguous fp32 is NOT referenced from here (slot 2 stays None: the record must not keep its own key alive)."""
     e = _target_moments.get(id(t))
     if e is not None and e[0]() is t and e[1] == t._version:
         return e
-    conv = t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
-    nbytes = 0 if conv is t else conv.numel() * 4
-    if sum(x[4] for x in _target_moments.values()) + nbytes > _TARGET_CACHE_BYTES:
-        _target_moments.clear()
+    direct = t.is_contiguous() and t.dtype == torch.float32
+    conv = None if direct else t.contiguous().float()
+    nbytes = 0 if direct else conv.numel() * 4
     for k in [k for k, x in _target_moments.items() if x[0]() is None]:   # dead targets: drop their images
         del _target_moments[k]
+    if len(_target_moments) >= _TARGET_CACHE_ENTRIES or sum(x[4] for x in _target_moments.values()) + nbytes > _TARGET_CACHE_BYTES:
+        _target_moments.clear()
     e = _target_moments[id(t)] = [weakref.ref(t), t._version, conv, None, nbytes]
     return e
 
@@ -907,15 +919,15 @@ def _moments_of(win, t):
     (a target that changes every step would pay for a kernel it never profits from).  Returns (image, moments or None)."""
     known = id(t) in _target_moments and _target_moments[id(t)][0]() is t and _target_moments[id(t)][1] == t._version
     e = _target_entry(t)
+    img = t if e[2] is None else e[2]
     if known and e[3] is None:
         lib = load_library()
-        img = e[2]
         Cc, H, W = (int(d) for d in img.shape)
         m = torch.empty((2, Cc, H, W), dtype=torch.float32, device=img.device)
         _check(lib.gsr_target_moments(win, Cc, H, W, _ptr(img), _ptr(m), _stream(img.device)), "gsr_target_moments")
         e[3] = m
         e[4] += m.numel() * 4
-    return e[2], e[3]
+    return img, e[3]
 
 
 def _loss_table(targets, cam_rows, weights, channels, moments=None):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 111 /* 0.1.11: + image terms of all views of a step in one call (gsr_views_loss_*), shared terms, activations */
+#define GSR_VERSION 112 /* 0.1.12: gsr_fps scratch is gsr_fps_scratch_bytes(N, npoints) bytes (0.1.11 and earlier: N floats) */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).

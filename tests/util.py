@@ -69,3 +69,25 @@ def mixed_err(a, b, atol_frac=1e-4):
     if a.size == 0:
         return 0.0
     return float((np.abs(a - b) / (np.abs(b) + atol_frac * (np.abs(b).max() + 1e-30))).max())
+
+
+def row_err(a, b, floor_frac=1e-3):
+    """Row-wise (per-Gaussian) relative error: for every row i,  max_j |a_ij - b_ij| / (max_j |b_ij| + floor_frac * max|b|).
+    Returns (worst value, its row).  Tighter than ``rel_err``: a Gaussian whose gradient is 1e-3 of the tensor maximum must
+    still be right to the stated relative tolerance, not to 1e-4 of the LARGEST gradient in the tensor."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0, -1
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    num = np.abs(a2 - b2).max(1)
+    den = np.abs(b2).max(1) + floor_frac * (np.abs(b2).max() + 1e-300)
+    r = num / den
+    i = int(np.argmax(r))
+    return float(r[i]), i
+
+
+def row_err_quantiles(a, b, floor_frac=1e-3, qs=(0.5, 0.99, 0.9999)):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    r = np.abs(a2 - b2).max(1) / (np.abs(b2).max(1) + floor_frac * (np.abs(b2).max() + 1e-300))
+    return [float(np.quantile(r, q)) for q in qs]
