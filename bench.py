@@ -85,6 +85,8 @@ def main():
                          "The default keeps ALL gradients (the metric's 'all backward gradients'); an N = 1 run reports this variant as "
                          "``frozen_colours``")
     ap.add_argument("--no-extras", action="store_true", help="skip the get_loss-shaped step and the other secondary timings")
+    ap.add_argument("--with-rollout", action="store_true", help="--config 5: run gsdyn.predict.predict_episode (GNN rollout + sharded renders, "
+                    "one call per rank) over --steps frames and report rollout ms and render ms separately")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -347,6 +349,8 @@ def bench_config5(args, dev, rank, world):
     with torch.no_grad():
         data = {k: v.detach() for k, v in params2rendervar(params).items()}
     frames = max(args.steps, 1)
+    if args.with_rollout:
+        return bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS)
     shard = FrameShard(dev, W5, H5, ring_poses(CAMS, W5, H5), rank, world)
     pairs = shard.my_pairs(frames)
 
@@ -409,6 +413,53 @@ def bench_config5(args, dev, rank, world):
                                   "frac_of_hbm_peak": ab["fwd"] * cams_here / (dt / frames) / HBM_PEAK},
                          "per_kernel_us_per_frame": {k: round(v, 2) for k, v in sorted(per_step_us.items())}},
             "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
+    """BASELINE.json configs[4] end to end: predict.py's episode (/root/reference/src/predict.py:74-164) as ONE call per rank --
+    collect_scene_data (GNN rollout of --steps frames with rope.yaml-width random weights, smoothing, packing; every rank runs it) and
+    this rank's (frame, camera) renders.  Rollout and render times are reported separately; value = render throughput of the episode."""
+    from gsdyn.dynamics import DynamicsPredictor
+    from gsdyn.predict import predict_episode, ring_poses
+    cfg = dict(nf_particle=512, nf_relation=512, nf_effect=512, attr_dim=2, state_dim=0, action_dim=3, pstep=3,
+               rel_attr_dim=2, rel_group_dim=1, rel_distance_dim=3, n_his=3)
+    torch.manual_seed(0)
+    model = DynamicsPredictor(cfg, device=dev).eval()
+    frames = max(args.steps, 2)
+    p = {k: v.detach() for k, v in params.items()}
+    eef = torch.tensor([[0.0, 0.2, 0.0]], device=dev) + torch.tensor([[0.02, 0.0, 0.01]], device=dev) * torch.arange(frames, device=dev, dtype=torch.float32)[:, None]
+    # outlier filtering (Open3D's statistical filter in the reference, a dense cdist/top-k restatement here) is left out of the timed
+    # episode: it is data preparation done once per episode on frame 0 and costs seconds at 500k points either way
+    roll = dict(max_nobj=100, fps_radius=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=1000, remove_outliers=False)
+    poses = ring_poses(CAMS, W5, H5)
+    predict_episode(model, p, eef[:2], poses, W5, H5, rollout_cfg=roll, rank=rank, world=world)          # warm-up (capacities, allocator)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    out, _vis, tm = predict_episode(model, p, eef, poses, W5, H5, rollout_cfg=roll, rank=rank, world=world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, tm["rollout_ms"], tm["render_ms"]], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, roll_ms, rend_ms = (float(x) for x in tt)
+    if rank == 0:
+        renders = 2 * CAMS * frames
+        print(json.dumps({
+            "metric": "fwd Mpix/s, predict.py episode end to end (GNN rollout + colour + mask render per camera), 500k Gaussians, 1920x1080",
+            "value": renders * W5 * H5 / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": frames, "warmup": 1, "ms_per_step": dt / frames * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4] END TO END: gsdyn.predict.predict_episode = rollout (every rank) + (frame, camera) pairs "
+                                   "sharded round-robin, 4 cameras x (colour + mask)", "gaussians": tm["gaussians"], "image": [H5, W5], "cameras": CAMS,
+                       "frames": frames, "gnn": "DynamicsPredictor width 512, pstep 3, random weights, 100 bones"},
+            "rollout_ms_total": roll_ms, "rollout_ms_per_frame": roll_ms / max(frames - 1, 1), "render_ms_total": rend_ms,
+            "render_ms_per_frame_this_rank": rend_ms / frames, "render_only_Mpix_per_s": renders * W5 * H5 / (rend_ms * 1e-3) / 1e6,
+            "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

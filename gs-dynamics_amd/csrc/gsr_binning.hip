@@ -504,7 +504,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
   if (tid == 0) { empty_before_s = 0; n_empty_s = 0; }
   if (blockIdx.x == 0) {
     if (tid < 8) queue[tid] = 0;
-    if (tab.counts_out && tid < tab.V) tab.counts_out[tid] = tab.v[tid].offsets[tab.P];   // capacity mode: the counts for the host
+    // capacity mode: the counts for the host.  counts_out may be PINNED HOST memory (the caller then needs no copy on the stream --
+    // a 4 us blit plus a 6 us bubble between the forward and the backward): a system-scope store, visible once this kernel has ended
+    if (tab.counts_out && tid < tab.V)
+      __hip_atomic_store(&tab.counts_out[tid], tab.v[tid].offsets[tab.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before

@@ -456,7 +456,6 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             if per_view_col and colors_precomp.shape[0] != V:
                 raise ValueError("rasterize_forward_batch: per-view colours must be [V,P,3]")
             col_views = _ptr_array([colors_precomp[v] for v in range(V)]) if per_view_col else None
-            counts_dev = torch.empty((V,), dtype=torch.int32, device=dev)
             capv = (C.c_uint32 * V)(*([cap_e] * V))
             rawp = None
             if raw is not None:     # activations inside the preprocess kernel: its view-0 blocks write the activated values here
@@ -465,17 +464,12 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                 act = (rotations, opacities, scales)
                 un_, lo_, ls_ = (t.contiguous() for t in raw)
                 rawp = GsrRawParams(_ptr(un_), _ptr(lo_), _ptr(ls_), _ptr(rotations), _ptr(opacities), _ptr(scales), None, None, None)
-            _check(lib.gsr_forward_batch_capacity_raw(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                                      _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
-                                                      _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
-                                                      capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
-                                                      _ptr_array(depth_v), _ptr(counts_dev), C.byref(rawp) if rawp is not None else None, st),
-                   "gsr_forward_batch_capacity")
+            # the entry counts land in a pinned host slot straight from the tile-order kernel (device-mapped memory): no copy on the stream
             ring = _counts_slots.setdefault((dev.index, V), [])
             slot = next((sl for sl in ring if not sl[2]), None)
             if slot is None and len(ring) >= _COUNTS_RING:
                 # Every slot is held by a call whose counts were never looked at.  A caller that raised between its forward and
-                # forward_counts_ok() (or dropped the states) leaves such a slot behind: take over the oldest one whose copy has
+                # forward_counts_ok() (or dropped the states) leaves such a slot behind: take over the oldest one whose forward has
                 # completed -- its generation changes, so a late forward_counts_ok() of the abandoned call raises instead of reading
                 # another call's counts.
                 slot = next((sl for sl in ring if sl[1].query()), None)
@@ -488,7 +482,13 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             slot[2] = True
             slot[3] += 1          # generation
             counts_host, ev = slot[0], slot[1]
-            counts_host.copy_(counts_dev, non_blocking=True)
+            counts_dev = counts_host
+            _check(lib.gsr_forward_batch_capacity_raw(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                                      _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
+                                                      _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
+                                                      capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
+                                                      _ptr_array(depth_v), _ptr(counts_dev), C.byref(rawp) if rawp is not None else None, st),
+                   "gsr_forward_batch_capacity")
             ev.record(torch.cuda.current_stream(dev))
             states = []
             for v in range(V):

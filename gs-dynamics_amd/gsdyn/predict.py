@@ -7,7 +7,13 @@ cam`` goes to rank ``(frame * n_cams + cam) mod world`` -- and a rank renders al
 each) in ONE multi-view rasterizer call (``Renderer.render_cameras_with_mask``: the two renders of a camera share their tile
 lists and are blended in one tile pass).  There is NO collective on the render path; ``gather_frames`` optionally brings
 the images to one rank afterwards.  The scene data of a frame (the GNN rollout's output) is the same on every rank: the rollout
-is deterministic and cheap next to the renders, so every rank runs it (or rank 0 broadcasts it) -- that part is the caller's.
+is deterministic and cheap next to the renders, so every rank runs it.
+
+``predict_episode`` composes the whole of /root/reference/src/predict.py:74-164 for one episode -- ``collect_scene_data``
+(/root/reference/src/render/dynamics_module.py:174-257: activations, low-opacity and outlier filtering, the autoregressive GNN
+``rollout``, the smoothing over repeated frames) followed by this rank's share of the (frame, camera) renders and the RGBA
+composition of predict.py:115-128 -- as ONE call per rank.  PNG / ffmpeg output and the keypoint overlay stay with the caller
+(out of scope).
 """
 from __future__ import annotations
 
@@ -83,3 +89,74 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
     for p in parts:
         merged.update(p)
     return merged
+
+
+# ------------------------------------------------------------------------------------------ the whole of predict.py for one episode
+@torch.no_grad()
+def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
+                       dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
+                       remove_outliers: bool = True, thin_start_idx: int = 0):
+    """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
+    the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
+    frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
+    sampling (:194-212), then rollout -> smoothing -> per-frame render inputs.  Returns (scene_data, vis_data, timings)."""
+    import time
+    from . import dynamics as D
+    first = lambda t: t[0] if t.dim() == 3 else t   # noqa: E731
+    dev = params["means3D"].device
+    xyz_0, rgb_0 = first(params["means3D"]).float(), first(params["rgb_colors"]).float()
+    quat_0 = torch.nn.functional.normalize(first(params["unnorm_rotations"]).float())
+    opa_0 = torch.sigmoid(params["logit_opacities"].float())
+    scales_0 = torch.exp(params["log_scales"].float())
+    keep = opa_0[:, 0] >= low_opacity
+    xyz_0, rgb_0, quat_0, opa_0, scales_0 = xyz_0[keep], rgb_0[keep], quat_0[keep], opa_0[keep], scales_0[keep]
+    t0 = time.perf_counter()
+    inlier = D.remove_statistical_outliers(xyz_0) if remove_outliers else torch.arange(xyz_0.shape[0], device=dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    eef = torch.as_tensor(eef_xyz, dtype=torch.float32, device=dev)
+    if eef.dim() == 2:
+        eef = eef[:, None, :]
+    n_steps = min(int(eef.shape[0]), max_steps)
+    out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
+                    adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
+                    n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx)
+    out = D.smooth_frames(*out)
+    scene, vis = D.pack_scene_data(out[0], out[1], out[2], out[3], scales_0, out[4], out[5])
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    return scene, vis, {"outlier_filter_ms": (t1 - t0) * 1e3, "rollout_ms": (t2 - t1) * 1e3, "frames": n_steps, "gaussians": int(xyz_0.shape[0])}
+
+
+def compose_rgba(im: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """predict.py:125-128 on the device: colour un-premultiplied by the mask render, alpha = mean of the mask's channels.
+    [4,H,W], values in [0, 1] scale of the inputs (the reference multiplies by 255 and reverses the channel order for cv2)."""
+    return torch.cat([im / (mask + 1e-4), mask.mean(0, keepdim=True)], 0)
+
+
+@torch.no_grad()
+def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: int, *, rollout_cfg: dict, rank: Optional[int] = None,
+                    world: Optional[int] = None, gather_to: Optional[int] = None, bg=(0.0, 0.0, 0.0), rgba: bool = False):
+    """One episode of /root/reference/src/predict.py:74-164 on this rank: GNN rollout (every rank, identical), then this rank's
+    (frame, camera) pairs -- colour + all-ones mask render per pair, all cameras of a frame in one rasterizer call.
+    ``poses``: the cameras as (w2c, K); ``rollout_cfg``: the keyword arguments of ``collect_scene_data`` (max_nobj, fps_radius,
+    adj_thresh, topk, connect_all, dist_thresh, ...).  Returns (frames, vis_data, timings): ``frames`` = {(frame, cam): (image,
+    depth, mask)} of this rank -- or, with ``gather_to`` = a rank, the merged dict there and None elsewhere; with ``rgba`` the
+    image slot holds the composed RGBA instead."""
+    import time
+    dev = params["means3D"].device
+    scene, vis, tm = collect_scene_data(model, params, eef_xyz, **rollout_cfg)
+    shard = FrameShard(dev, w, h, poses, rank, world, bg=bg)
+    t0 = time.perf_counter()
+    frames = shard.render_episode(scene)
+    if rgba:
+        frames = {k: (compose_rgba(v[0], v[2]), v[1], v[2]) for k, v in frames.items()}
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    tm["render_ms"] = (time.perf_counter() - t0) * 1e3
+    tm["pairs_on_this_rank"] = len(frames)
+    if gather_to is not None:
+        frames = gather_frames(frames, dst=gather_to)
+    return frames, vis, tm

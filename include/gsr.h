@@ -141,7 +141,9 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
  * gsr_backward_scratch_bytes(P, capacity)).  The true counts are written to counts_dev[V] (device) at the end of the call;
  * a view whose count exceeds its capacity was rendered from a TRUNCATED list: the caller must read counts_dev before using
  * anything of that call and repeat it with enough room (gsdyn/step.py: loss_and_grads_views does, its images never leave
- * the library).  The kernels read the counts on the device (the word emit_entries leaves behind the offsets). */
+ * the library).  The kernels read the counts on the device (the word emit_entries leaves behind the offsets).
+ * counts_dev may be device memory or device-mapped PINNED HOST memory (hipHostMalloc): the counts are written with system-scope
+ * stores by the tile-order kernel, so a host that waits for any later event of the stream reads them without a copy. */
 int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                const float* rotations, const float* opacities, const float* colors_precomp,
                                const float* const* colors_views, const float* shs, const float* cov3D_precomp,

@@ -146,3 +146,45 @@ def test_device_rotation_fit_matches_the_literal_decision_tree(dev):
     det = torch.linalg.det(got.double())
     assert float((det - 1).abs().max()) < 1e-4
     assert torch.equal(got[130:140], torch.eye(3).expand(10, 3, 3))
+
+
+def test_predict_episode_on_the_device(dev, golden_dir):
+    """BASELINE.json configs[4] at reduced size as ONE call: GNN rollout -> smoothing -> packed scene data -> this rank's (frame,
+    camera) renders (/root/reference/src/predict.py:74-164) against the same pieces called one by one -- ``collect_scene_data``, then
+    per (frame, camera) the reference's two ``Renderer.render`` calls (colour, then colours = 1 as the mask, predict.py:115-123)."""
+    from gsdyn import synth_scene_params
+    from gsdyn.dynamics import DynamicsPredictor
+    from gsdyn.predict import FrameShard, collect_scene_data, compose_rgba, predict_episode, ring_poses, shard_pairs
+    from gsdyn.render import Renderer
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    P, W, H, CAMS, S = 30000, 480, 272, 4, 5
+    params = {k: v.detach() for k, v in synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    eef = torch.tensor([[0.0, 0.0, 0.0]], device=dev) + torch.tensor([[0.04, 0.0, 0.02]], device=dev) * torch.tensor([0.0, 1.0, 1.01, 2.0, 3.0], device=dev)[:, None]
+    roll = dict(max_nobj=100, fps_radius=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=1000)
+    poses = ring_poses(CAMS, W, H)
+    frames, vis, tm = predict_episode(model, params, eef, poses, W, H, rollout_cfg=roll, rank=0, world=1, rgba=True)
+    assert tm["frames"] == S and len(frames) == S * CAMS and len(vis) == S and tm["rollout_ms"] > 0 and tm["render_ms"] > 0
+    scene, vis2, _ = collect_scene_data(model, params, eef, **roll)
+    assert torch.equal(scene[2]["means3D"].new_tensor(vis[3]["kp"]), scene[2]["means3D"].new_tensor(vis2[3]["kp"]))
+    moved = (scene[-1]["means3D"] - scene[0]["means3D"]).norm(dim=-1)
+    assert float(moved.max()) > 1e-3 and torch.isfinite(scene[-1]["means3D"]).all()
+    # step 2 moved the end effector by less than dist_thresh: a repeated frame, smoothed into the midpoint of its neighbours
+    mid = torch.lerp(scene[1]["means3D"], scene[3]["means3D"], 0.5)
+    assert float((scene[2]["means3D"] - mid).abs().max()) < 1e-6
+    rdr = Renderer(dev, w=W, h=H)
+    for (f, c) in [(0, 0), (1, 3), (2, 1), (4, 2)]:
+        im, depth = rdr.render(poses[c][0], poses[c][1], scene[f], bg=(0.0, 0.0, 0.0))
+        ones = dict(scene[f])
+        ones["colors_precomp"] = torch.ones_like(scene[f]["colors_precomp"])
+        mask, _ = rdr.render(poses[c][0], poses[c][1], ones, bg=(0.0, 0.0, 0.0))
+        got = frames[(f, c)]
+        assert torch.equal(got[0], compose_rgba(im, mask)) and torch.equal(got[1], depth) and torch.equal(got[2], mask), (f, c)
+    # two ranks' shares (run one after the other on this GPU) partition the single-rank result
+    for r in range(2):
+        part, _, _ = predict_episode(model, params, eef, poses, W, H, rollout_cfg=roll, rank=r, world=2, rgba=True)
+        assert sorted(part) == sorted(shard_pairs(S, CAMS, r, 2))
+        for k, v in part.items():
+            assert all(torch.equal(a, b) for a, b in zip(v, frames[k])), k

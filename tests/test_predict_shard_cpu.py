@@ -87,7 +87,7 @@ def test_shard_pairs_partition():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_renders_equal_single_rank(tmp_path, world):
     _setup()
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -100,3 +100,73 @@ def test_sharded_renders_equal_single_rank(tmp_path, world):
         for i, t in enumerate(v):
             assert np.array_equal(z[f"{f}_{c}_{i}"], t.numpy()), (f, c, i)
         assert float(v[2].max()) <= 1.0 + 1e-5 and float(v[2].max()) > 0.1      # the mask render: accumulated alpha
+
+
+# ------------------------------------------------------------------------------------------ predict_episode: rollout + sharded renders as one call
+EP_P, EP_STEPS = 260, 5
+ROLL = dict(max_nobj=12, fps_radius=0.12, adj_thresh=0.35, topk=4, connect_all=False, dist_thresh=0.004, n_fps_all=60, remove_outliers=True)
+
+
+def _episode_inputs():
+    from gsdyn import synth_scene_params
+    from gsdyn.dynamics import DynamicsPredictor
+    cfg = dict(nf_particle=16, nf_relation=16, nf_effect=16, attr_dim=2, state_dim=0, action_dim=3, pstep=2, rel_attr_dim=2,
+               rel_group_dim=1, rel_distance_dim=3, n_his=3)
+    torch.manual_seed(0)
+    model = DynamicsPredictor(cfg).eval()
+    params = {k: v.detach() for k, v in synth_scene_params(EP_P, device="cpu", scale_lo=0.05, scale_hi=0.2).items()}
+    params["means3D"] = params["means3D"] * 0.4
+    eef = torch.tensor([[0.5, 0.1, 0.0]]) + torch.tensor([[0.03, 0.0, 0.01]]) * torch.tensor([0.0, 1.0, 1.05, 2.0, 3.0])[:, None]   # step 2 moves < dist_thresh? no: 0.0016
+    return model, params, eef
+
+
+def _episode_worker(rank, world, port, out_dir):
+    _setup()
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_double()
+    from gsdyn.predict import predict_episode, ring_poses
+    model, params, eef = _episode_inputs()
+    frames, vis, tm = predict_episode(model, params, eef, ring_poses(CAMS, W, H), W, H, rollout_cfg=ROLL, gather_to=0, rgba=True)
+    assert tm["frames"] == EP_STEPS and len(vis) == EP_STEPS
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "episode.npz"), **{f"{f}_{c}_{i}": t.numpy() for (f, c), v in frames.items() for i, t in enumerate(v)})
+    else:
+        assert frames is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
+    """predict_episode on 2 ranks == collect_scene_data (rollout -> smoothing -> packing) followed by the per-piece renders on one:
+    the composition of /root/reference/src/predict.py:74-164 (one call per rank, every rank rolls out, pairs dealt round-robin)."""
+    _setup()
+    mp.spawn(_episode_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    z = np.load(tmp_path / "episode.npz")
+    _install_double()
+    from gsdyn.dynamics import pack_scene_data, remove_statistical_outliers, rollout, smooth_frames
+    from gsdyn.predict import FrameShard, collect_scene_data, compose_rgba, ring_poses
+    model, params, eef = _episode_inputs()
+    scene, vis, tm = collect_scene_data(model, params, eef, **ROLL)
+    # the pieces, called one by one as the reference's collect_scene_data strings them together
+    op = torch.sigmoid(params["logit_opacities"])
+    keep = op[:, 0] >= 0.1
+    xyz0, rgb0 = params["means3D"][keep], params["rgb_colors"][keep]
+    q0 = torch.nn.functional.normalize(params["unnorm_rotations"])[keep]
+    inl = remove_statistical_outliers(xyz0)
+    out = rollout(model, xyz0, rgb0, q0, op[keep], eef[:, None, :], EP_STEPS, inl, max_nobj=ROLL["max_nobj"], fps_radius_value=ROLL["fps_radius"],
+                  adj_thresh=ROLL["adj_thresh"], topk=ROLL["topk"], connect_all=False, dist_thresh=ROLL["dist_thresh"], n_fps_all=ROLL["n_fps_all"])
+    out = smooth_frames(*out)
+    scene2, _ = pack_scene_data(out[0], out[1], out[2], out[3], torch.exp(params["log_scales"])[keep], out[4], out[5])
+    assert len(scene) == len(scene2) == EP_STEPS
+    for a, b in zip(scene, scene2):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert float((scene[-1]["means3D"] - scene[0]["means3D"]).abs().max()) > 1e-4      # the rollout moved the Gaussians
+    ref = FrameShard("cpu", W, H, ring_poses(CAMS, W, H), rank=0, world=1).render_episode(scene)
+    assert len(z.files) == 3 * EP_STEPS * CAMS
+    for (f, c), (im, depth, mask) in ref.items():
+        assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
+        assert np.array_equal(z[f"{f}_{c}_1"], depth.numpy()) and np.array_equal(z[f"{f}_{c}_2"], mask.numpy())
