@@ -353,6 +353,7 @@ MAX_BATCH = 16           # GSR_MAX_BATCH of include/gsr.h: views per library cal
 _counts_slots = {}       # (device, V) -> list of [pinned int32[V], event, in_flight] of the capacity-mode forward (a small ring:
                          # a slot is taken by one call and handed back by forward_counts_ok, so two calls never share counts)
 _COUNTS_RING = 8
+_COUNTS_EVENT = os.environ.get("GSR_COUNTS_EVENT") == "1"   # A/B: wait on an event recorded behind the forward instead of polling the pinned slot
 _entries_capacity = {}   # (device, P, H, W) -> list entries per view the capacity-mode forward sizes its buffers for
 _ENTRIES_SLACK = 1.5
 _binning_capacity = {}   # (device, P, H, W) -> bytes to pre-allocate per view for the binning state
@@ -472,7 +473,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                 # forward_counts_ok() (or dropped the states) leaves such a slot behind: take over the oldest one whose forward has
                 # completed -- its generation changes, so a late forward_counts_ok() of the abandoned call raises instead of reading
                 # another call's counts.
-                slot = next((sl for sl in ring if sl[1].query()), None)
+                slot = next((sl for sl in ring if (sl[1].query() if _COUNTS_EVENT else int(sl[0].min()) >= 0)), None)
                 if slot is None:
                     raise RuntimeError(f"rasterize_forward_batch(no_host_sync=True): {_COUNTS_RING} capacity-mode forwards are in flight "
                                        "without forward_counts_ok(); check each call's counts before issuing more")
@@ -483,13 +484,15 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             slot[3] += 1          # generation
             counts_host, ev = slot[0], slot[1]
             counts_dev = counts_host
+            counts_host.fill_(-1)     # sentinel (no view has 2^32 - 1 entries): forward_counts_ok polls for the kernel's stores
             _check(lib.gsr_forward_batch_capacity_raw(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
                                                       _ptr(None if per_view_col else colors_precomp), col_views, None, _ptr(cov3D_precomp),
                                                       _ptr_array(geoms), _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings),
                                                       capv, _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v),
                                                       _ptr_array(depth_v), _ptr(counts_dev), C.byref(rawp) if rawp is not None else None, st),
                    "gsr_forward_batch_capacity")
-            ev.record(torch.cuda.current_stream(dev))
+            if _COUNTS_EVENT:
+                ev.record(torch.cuda.current_stream(dev))
             states = []
             for v in range(V):
                 state = RasterState()
@@ -556,7 +559,18 @@ def forward_counts_ok(states) -> bool:
     ev, counts_host, _counts_dev, cap_e, key, slot, gen = pending
     if slot[3] != gen:
         raise RuntimeError("forward_counts_ok: this capacity-mode forward was abandoned (its counts slot serves a later call)")
-    ev.synchronize()
+    if _COUNTS_EVENT:
+        ev.synchronize()
+    else:
+        # The tile-order kernel writes the counts with system-scope stores into this pinned slot: poll for them instead of recording
+        # an event behind the forward (the event's signal packet costs ~6 us of idle GPU between render_fwd and render_bwd).
+        spins = 0
+        while int(counts_host.min()) < 0:
+            spins += 1
+            if spins > 20000:        # ~0.1 s: something is wrong (or the stores are not visible before the kernel ends): fall back
+                torch.cuda.current_stream(torch.device("cuda", key[0])).synchronize()
+                if int(counts_host.min()) < 0:
+                    raise RuntimeError("forward_counts_ok: the forward never wrote its entry counts")
     top = int(counts_host.max())
     slot[2] = False          # the ring entry may serve the next call
     _entries_capacity[key] = max(int(top * _ENTRIES_SLACK), 1024)

@@ -138,16 +138,20 @@ def compose_rgba(im: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: int, *, rollout_cfg: dict, rank: Optional[int] = None,
-                    world: Optional[int] = None, gather_to: Optional[int] = None, bg=(0.0, 0.0, 0.0), rgba: bool = False):
+                    world: Optional[int] = None, gather_to: Optional[int] = None, bg=(0.0, 0.0, 0.0), rgba: bool = False,
+                    scene_out: Optional[list] = None):
     """One episode of /root/reference/src/predict.py:74-164 on this rank: GNN rollout (every rank, identical), then this rank's
     (frame, camera) pairs -- colour + all-ones mask render per pair, all cameras of a frame in one rasterizer call.
     ``poses``: the cameras as (w2c, K); ``rollout_cfg``: the keyword arguments of ``collect_scene_data`` (max_nobj, fps_radius,
     adj_thresh, topk, connect_all, dist_thresh, ...).  Returns (frames, vis_data, timings): ``frames`` = {(frame, cam): (image,
     depth, mask)} of this rank -- or, with ``gather_to`` = a rank, the merged dict there and None elsewhere; with ``rgba`` the
-    image slot holds the composed RGBA instead."""
+    image slot holds the composed RGBA instead.  ``scene_out``: a list that receives the per-frame render inputs (the rollout's
+    torch ops -- index_add message passing, library GEMMs -- are not bit-reproducible from run to run on a GPU)."""
     import time
     dev = params["means3D"].device
     scene, vis, tm = collect_scene_data(model, params, eef_xyz, **rollout_cfg)
+    if scene_out is not None:
+        scene_out.extend(scene)
     shard = FrameShard(dev, w, h, poses, rank, world, bg=bg)
     t0 = time.perf_counter()
     frames = shard.render_episode(scene)

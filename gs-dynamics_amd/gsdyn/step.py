@@ -274,7 +274,8 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
 
 
 @torch.no_grad()
-def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_colour_grad: bool = True, _no_host_sync: bool = True):
+def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_colour_grad: bool = True, _no_host_sync: bool = True,
+                      _defer_counts: bool = False):
     """Forward + backward of the colour render of every camera in ``cams`` with the upstream gradient ``dL`` [V,3,H,W], as a
     straight sequence of library calls -- fused activations, ONE multi-view rasterizer forward (capacity mode: no host wait),
     ONE multi-view backward, fused activation backward -- without the autograd engine.  This is the rasterizer share of one
@@ -309,12 +310,54 @@ def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_co
             d_un, d_lo, d_ls = d_rot, d_op, d_sc      # already the gradients of the unactivated parameters
         else:
             d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
-        if not _hip.forward_counts_ok(states):      # the scene outgrew the remembered capacity (> 50 % more entries in one step)
+        if _defer_counts:      # stream capture (GraphedRenderStep): no host wait in here, the caller checks the counts after a replay
+            pass
+        elif not _hip.forward_counts_ok(states):      # the scene outgrew the remembered capacity (> 50 % more entries in one step)
             return render_step_views(params, cams, dL, colours_key, want_colour_grad, _no_host_sync=False)
     grads = {"means3D": d3, "unnorm_rotations": d_un, "logit_opacities": d_lo, "log_scales": d_ls, "means2D": d2, "radii": radii}
+    if _defer_counts:
+        grads["_states"] = states
     if want_colour_grad:
         grads[colours_key] = dc
     return ims, grads
+
+
+class GraphedRenderStep:
+    """``render_step_views`` captured ONCE into a hipGraph and replayed: the ~12 kernel launches of a step become one graph launch
+    (no per-launch host work, back-to-back dispatch on the GPU).  The parameter tensors, the camera records and ``dL`` are read in
+    place on every replay (Adam updates the parameters in place; write a new upstream gradient with ``dL.copy_``); images and
+    gradients come back in the same buffers each time.  The forward runs in capacity mode: after a replay ``ok()`` tells whether
+    every view's entry count fitted the captured buffers -- if not (the scene grew by more than 50 % since the capture) the
+    results of that replay are invalid and the step must be re-captured (``GraphedRenderStep(...)`` again)."""
+
+    def __init__(self, params, cams, dL, colours_key: str = "rgb_colors", want_colour_grad: bool = True, warmup: int = 2):
+        from diff_gaussian_rasterization import _hip
+        self._hip = _hip
+        self.args = (params, list(cams), dL, colours_key, want_colour_grad)
+        dev = params["means3D"].device
+        for _ in range(max(warmup, 1)):       # establishes the capacity, the pinned counts slot and the allocator's pools
+            render_step_views(*self.args)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self.graph, stream=side):
+                self.images, self.grads = render_step_views(*self.args, _defer_counts=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._states = self.grads.pop("_states")
+        pend = self._states[0].pending
+        if pend is None:
+            raise RuntimeError("GraphedRenderStep: the captured forward did not run in capacity mode")
+        self._counts_host, self._cap = pend[1], pend[3]
+
+    def replay(self):
+        self.graph.replay()
+        return self.images, self.grads
+
+    def ok(self) -> bool:
+        """After a replay has completed (synchronise first): did every view fit the captured capacity?"""
+        return int(self._counts_host.max()) <= self._cap
 
 
 @torch.no_grad()
