@@ -98,11 +98,12 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums;
+  o.block_sums = block_sums; o.ekey = g.ekey;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
   o.shares_lists = 0; o.fused_alias = 0; o.D_dev = nullptr;
+  o.ekey = g.ekey; o.rec_w = g.rec; o.tile_rows = nullptr;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
   o.offsets = g.offsets;
@@ -251,7 +252,7 @@ int check_geometry_of(int V, const int32_t* geometry_of) {
 int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
            void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
            const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st,
-           uint32_t* counts_dev = nullptr) {   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
+           uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
@@ -272,6 +273,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     gsr_carve_binning(binning_states[owner], num_rendered[owner], &bs);
     if (v == 0) {
       bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = counts_dev; bt.P = P;
+      bt.rows = tile_rows ? gsr_bin_rows(P) : 0;
       bt.order = order ? order : im.tile_order;
       bt.queue = queue ? queue : im.queue;
       render_header(rt, V, cam, bt.order, bt.queue);
@@ -280,6 +282,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
       return -2;
     }
     fill_bin_view(bt.v[v], P, num_rendered[v], g, bs, im, sums ? sums + (size_t)v * nblk : g.block_sums);
+    if (tile_rows) bt.v[v].tile_rows = tile_rows + (size_t)v * (gsr_bin_rows(P) + 1) * (size_t)gsr_bin_stride(cam.T);
     fill_render_view(rt.v[v], cam, g, bs, im, out_color[v], out_depth[v], nullptr, nullptr);
     if (owner != v) {   // lists, ranges and sort belong to the owner; this view only gets its offsets from emit
       bt.v[v].shares_lists = 1; bt.v[v].D = 0; bt.v[v].nblocks = 0; bt.v[v].ranges = im_owner.ranges;
@@ -400,7 +403,7 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   return stage2(V, s, P, num_rendered, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows);
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -431,7 +434,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   }
   if (!fits) return 1;
   return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows);
 }
 
 int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -472,7 +475,7 @@ int gsr_forward_batch_capacity_raw(int32_t V, const gsr_settings* s, int32_t P, 
                       geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw))
     return rc;
   return stage2(V, s, P, capacity_entries, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream, counts_dev);
+                b.queue, geometry_of, (hipStream_t)stream, counts_dev, b.tile_rows);
 }
 
 int gsr_backward_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, const float* means3D,
@@ -546,7 +549,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];

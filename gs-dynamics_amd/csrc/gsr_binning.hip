@@ -627,6 +627,239 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab,
   if (i == D - 1) ranges[t].y = D;
 }
 
+
+// ================================================================== tile-row binning (multi-view calls, T <= GSR_BIN_MAX_T)
+// A single-pass counting sort on the tile id, without global atomics and without moving the entries more than once:
+//   1. bin_count   a workgroup of 1024 threads owns GSR_BIN_G consecutive Gaussians of a view: it walks their tile sets (rect + mask)
+//                  and counts entries per tile in LDS (one counter per tile of the image), then stores its counters as ONE ROW of the
+//                  view's (workgroups x tiles) matrix -- plain coalesced stores.  The same kernel scans tiles_touched into
+//                  offsets[] (the Gaussian-major slots of the backward's partial records).
+//   2. bin_scan    per view: column prefix over the workgroups (in place), tile totals, exclusive scan over the tiles -> ranges.
+//                  (More than BIN_DIRECT_ROWS workgroups per view: bin_colprefix first, one thread per tile column.)
+//   3. bin_emit    the workgroups walk their Gaussians again: an entry of tile t goes to ranges[t].x + prefix_row[t] + (LDS atomic
+//                  on the workgroup's cursor of t) -- straight into its tile's segment, 8 bytes {gaussian id, depth bits}.
+//   4. tile_order, tile_sort as before.  Entries ARRIVE in a tile's segment in no particular order (LDS atomics); every path of
+//      tile_sort orders them by the unique 64-bit key (depth bits << 32 | gaussian id) -- the radix path by repairing runs of equal
+//      depth afterwards -- so the lists are the same bits as with the stable radix passes (the reference's order), run after run.
+// Against the radix path (emit, histogram, two scatter passes): 4 launches instead of 6 in front of the blend, entries written once
+// (8 B) instead of 12 + 12 + 8 B, nothing that depends on the entry count in any grid size (capacity mode needs no special case).
+#define BIN_THREADS 1024
+#define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
+#define BIN_DIRECT_ROWS 32
+#define BIN_BIG_AREA 64        // rects with more tiles are walked by the whole workgroup, not by their Gaussian's lane
+
+struct BinGauss { uint32_t minx, miny, w, area, mask; };
+__device__ __forceinline__ BinGauss bin_gauss(uint2 r, uint32_t mask) {
+  BinGauss b;
+  b.minx = r.x & 0xffffu; b.miny = r.x >> 16;
+  const uint32_t maxx = r.y & 0xffffu, maxy = r.y >> 16;
+  b.w = maxx - b.minx; b.area = b.w * (maxy - b.miny); b.mask = mask;
+  return b;
+}
+// f(tile id) for every tile of a Gaussian's set (small rects: the set bits of its mask, row-major; larger rects: all of it)
+template <typename F>
+__device__ __forceinline__ void bin_for_tiles(const BinGauss& b, int gx, F f) {
+  if (b.area <= 32u) {
+    uint32_t m = b.mask;
+    while (m) {
+      const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+      m &= m - 1u;
+      f((b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w);
+    }
+  } else {
+    for (uint32_t k = 0; k < b.area; ++k) f((b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w);
+  }
+}
+
+// Entries before Gaussian block jb (256 Gaussians per block): from the scanned array, or summed here from the per-block counts.
+__device__ __forceinline__ uint32_t bin_base_of_block(const GsrBinView& vw, int jb, uint32_t* s_red) {
+  if (vw.block_offsets) return vw.block_offsets[jb];
+  uint32_t part = 0;
+  for (int j = threadIdx.x; j < jb; j += BIN_THREADS) part += vw.block_sums[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  uint32_t tot = 0;
+#pragma unroll
+  for (int w = 0; w < BIN_THREADS / 64; ++w) tot += s_red[w];
+  __syncthreads();
+  return tot;
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinViews tab) {
+  extern __shared__ uint32_t s_cnt[];                 // [T] tile counters
+  __shared__ uint32_t s_red[BIN_THREADS / 64];
+  __shared__ uint32_t s_wave[BIN_THREADS / 64];
+  __shared__ uint32_t s_big[GSR_BIN_G];               // Gaussians (local index) whose rect is walked by the whole workgroup
+  __shared__ uint32_t s_nbig;
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  const int T = tab.T, gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g0 = (int)blockIdx.x * GSR_BIN_G;
+  const bool lists = !vw.shares_lists;
+  if (lists) for (int t = tid; t < T; t += BIN_THREADS) s_cnt[t] = 0;
+  if (tid == 0) s_nbig = 0;
+  // ---- offsets: exclusive prefix of tiles_touched over this workgroup's Gaussians (4 consecutive ones per thread)
+  const uint32_t base = bin_base_of_block(vw, g0 / GSR_BLOCK, s_red);     // (also the barrier behind the zeroing above)
+  uint32_t tt[BIN_PER_THREAD], sum = 0;
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) { const int g = g0 + tid * BIN_PER_THREAD + q; tt[q] = g < P ? vw.tiles_touched[g] : 0u; sum += tt[q]; }
+  uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    const int g = g0 + tid * BIN_PER_THREAD + q;
+    rc[q] = make_uint2(0u, 0u); ek[q] = rc[q];
+    if (lists && g < P && tt[q]) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; }
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  uint32_t run = base + inc - sum;
+  for (int w = 0; w < wv; ++w) run += s_wave[w];
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    const int g = g0 + tid * BIN_PER_THREAD + q;
+    if (g < P) {
+      vw.offsets[g] = run;
+      reinterpret_cast<uint32_t*>(vw.rec_w + GSR_REC_F4 * (size_t)g + 3)[2] = run;   // the blend backward reads it from the record
+    }
+    run += tt[q];
+  }
+  if (g0 + GSR_BIN_G >= P && tid == BIN_THREADS - 1) vw.offsets[P] = run;            // the last workgroup knows the view's entry count
+  if (!lists) return;
+  // ---- tile counts
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    if (!tt[q]) continue;
+    const BinGauss b = bin_gauss(rc[q], ek[q].y);
+    if (b.area > BIN_BIG_AREA) { s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)(tid * BIN_PER_THREAD + q); continue; }
+    bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
+  }
+  __syncthreads();
+  const uint32_t nbig = s_nbig;
+  for (uint32_t i = 0; i < nbig; ++i) {               // large rects (taken whole): every thread takes a slice of the tiles
+    const int g = g0 + (int)s_big[i];
+    const BinGauss b = bin_gauss(vw.rect[g], 0u);
+    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) atomicAdd(&s_cnt[(b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w], 1u);
+  }
+  if (nbig) __syncthreads();
+  uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * T;
+  for (int t = tid; t < T; t += BIN_THREADS) row[t] = s_cnt[t];
+}
+
+// More than BIN_DIRECT_ROWS workgroups per view: one thread per tile column turns the counts into exclusive prefixes over the
+// workgroups (in place) and leaves the column total in row `rows`.
+__global__ __launch_bounds__(GSR_BLOCK) void bin_colprefix_kernel(GsrBinViews tab) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (vw.shares_lists) return;
+  const int T = tab.T, rows = tab.rows, t = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (t >= T) return;
+  uint32_t* __restrict__ m = vw.tile_rows;
+  uint32_t run = 0;
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = m[(size_t)(r + u) * T + t];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { m[(size_t)(r + u) * T + t] = run; run += v[u]; }
+  }
+  for (; r < rows; ++r) { const uint32_t v = m[(size_t)r * T + t]; m[(size_t)r * T + t] = run; run += v; }
+  m[(size_t)rows * T + t] = run;
+}
+
+// Per view: (column prefix over the workgroups, unless bin_colprefix ran) + exclusive scan of the tile totals -> ranges.
+// Capacity mode clamps the ranges to the capacity the entry buffers were sized for.
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, int prefixed) {
+  __shared__ uint32_t s_wave[BIN_THREADS / 64];
+  __shared__ uint32_t s_carry;
+  const GsrBinView& vw = tab.v[blockIdx.x];
+  if (vw.shares_lists) return;
+  const int T = tab.T, rows = tab.rows, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t* __restrict__ m = vw.tile_rows;
+  const uint32_t cap = vw.D;                          // entries the buffers hold (the exact count outside capacity mode)
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += BIN_THREADS) {
+    const int t = t0 + tid;
+    uint32_t tot = 0;
+    if (t < T) {
+      if (prefixed) tot = m[(size_t)rows * T + t];
+      else {
+        uint32_t v[BIN_DIRECT_ROWS];
+#pragma unroll
+        for (int r = 0; r < BIN_DIRECT_ROWS; ++r) v[r] = r < rows ? m[(size_t)r * T + t] : 0u;
+#pragma unroll
+        for (int r = 0; r < BIN_DIRECT_ROWS; ++r) if (r < rows) { m[(size_t)r * T + t] = tot; tot += v[r]; }
+      }
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t start = s_carry + inc - tot;
+    for (int w = 0; w < wv; ++w) start += s_wave[w];
+    if (t < T) vw.ranges[t] = make_uint2(min(start, cap), min(start + tot, cap));
+    __syncthreads();
+    if (tid == BIN_THREADS - 1) s_carry = start + tot;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinViews tab) {
+  extern __shared__ uint32_t s_cur[];                 // [T] next free slot of every tile for this workgroup
+  __shared__ uint32_t s_big[GSR_BIN_G];
+  __shared__ uint32_t s_nbig;
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (vw.shares_lists) return;
+  const int T = tab.T, gx = tab.gx, tid = threadIdx.x;
+  const int g0 = (int)blockIdx.x * GSR_BIN_G;
+  const uint32_t cap = vw.D;
+  const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * T;
+  uint64_t* __restrict__ dg = vw.dg[0];
+  uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    const int g = g0 + tid * BIN_PER_THREAD + q;
+    rc[q] = make_uint2(0u, 0u); ek[q] = rc[q];
+    if (g < P && vw.tiles_touched[g]) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; }
+  }
+  if (tid == 0) s_nbig = 0;
+  for (int t = tid; t < T; t += BIN_THREADS) s_cur[t] = vw.ranges[t].x + row[t];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    const BinGauss b = bin_gauss(rc[q], ek[q].y);
+    if (b.area == 0u) continue;
+    if (b.area > BIN_BIG_AREA) { s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)(tid * BIN_PER_THREAD + q); continue; }
+    const uint64_t key = ((uint64_t)ek[q].x << 32) | (uint32_t)(g0 + tid * BIN_PER_THREAD + q);
+    bin_for_tiles(b, gx, [&](uint32_t t) {
+      const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+      if (slot < cap) dg[slot] = key;
+    });
+  }
+  __syncthreads();
+  const uint32_t nbig = s_nbig;
+  for (uint32_t i = 0; i < nbig; ++i) {
+    const int g = g0 + (int)s_big[i];
+    const BinGauss b = bin_gauss(vw.rect[g], 0u);
+    const uint64_t key = ((uint64_t)vw.ekey[g].x << 32) | (uint32_t)g;
+    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) {
+      const uint32_t slot = atomicAdd(&s_cur[(b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w], 1u);
+      if (slot < cap) dg[slot] = key;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ per-tile depth sort
 // Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
 // +inf padding above n never moves and pairs touching it are skipped.
@@ -850,6 +1083,46 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     if (d) atomicOr(&L.diff, d);
     __syncthreads();
     const int cur = tile_radix_sort(L, n, tid);
+    // Runs of EQUAL depth: the reference order breaks such ties by ascending Gaussian id.  With the stable radix passes over
+    // entries that arrive in id order nothing is left to do; entries placed by the tile-row binning arrive in no particular order,
+    // so every run is put in id order here -- by the thread that holds its first element (runs are rare and short; a long one, e.g.
+    // a whole tile of coplanar Gaussians, sends the tile to the 64-bit network below instead).
+    {
+      uint32_t* __restrict__ kk = L.r.key[cur];
+      uint32_t* __restrict__ vv = L.r.val[cur];
+      bool long_run = false;
+      for (uint32_t i = tid; i + 1 < n; i += GSR_BLOCK) {
+        if (kk[i] == kk[i + 1] && (i == 0 || kk[i - 1] != kk[i])) {
+          uint32_t j = i + 1;
+          while (j + 1 < n && kk[j + 1] == kk[i] && j - i < 32u) ++j;
+          if (j + 1 < n && kk[j + 1] == kk[i]) { long_run = true; continue; }
+          for (uint32_t a = i + 1; a <= j; ++a) {      // insertion sort of vv[i .. j]
+            const uint32_t x = vv[a];
+            uint32_t b = a;
+            while (b > i && vv[b - 1] > x) { vv[b] = vv[b - 1]; --b; }
+            vv[b] = x;
+          }
+        }
+      }
+      if (__syncthreads_or(long_run ? 1 : 0)) {        // rare: rebuild the 64-bit keys and sort them with the network
+        uint64_t e[(RCAP + GSR_BLOCK - 1) / GSR_BLOCK];
+#pragma unroll
+        for (int u = 0; u < (RCAP + GSR_BLOCK - 1) / GSR_BLOCK; ++u) {
+          const uint32_t i = (uint32_t)u * GSR_BLOCK + tid;
+          e[u] = i < n ? (((uint64_t)kk[i] << 32) | vv[i]) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < (RCAP + GSR_BLOCK - 1) / GSR_BLOCK; ++u) {
+          const uint32_t i = (uint32_t)u * GSR_BLOCK + tid;
+          if (i < n) L.net[i] = e[u];
+        }
+        __syncthreads();
+        tile_sort_network(L.net, n, tid);
+        for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)L.net[i];
+        return;
+      }
+    }
     for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = L.r.val[cur][i];
   } else if (n <= 2u * (uint32_t)RCAP) {
     for (uint32_t i = tid; i < n; i += GSR_BLOCK) L.net[i] = seg[i];
@@ -888,7 +1161,26 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
   tab.wave_cap = big ? 1024 : 512;
   int cur = 0;
-  if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
+  static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
+  const bool rows_path = tab.rows > 0 && tab.T <= GSR_BIN_MAX_T && !radix_only && maxD > 0 && P > 0;
+  if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
+    const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
+    { GSR_PROF("bin_count", st);
+      hipLaunchKernelGGL(bin_count_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
+    GSR_HIP_CHECK(hipGetLastError());
+    const int prefixed = tab.rows > BIN_DIRECT_ROWS ? 1 : 0;
+    if (prefixed) {
+      GSR_PROF("bin_colprefix", st);
+      hipLaunchKernelGGL(bin_colprefix_kernel, dim3((tab.T + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    { GSR_PROF("bin_scan", st);
+      hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed); }
+    GSR_HIP_CHECK(hipGetLastError());
+    { GSR_PROF("bin_emit", st);
+      hipLaunchKernelGGL(bin_emit_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
+    GSR_HIP_CHECK(hipGetLastError());
+  } else if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
     for (int v = 0; v < tab.V; ++v) GSR_HIP_CHECK(hipMemsetAsync(tab.v[v].ranges, 0, sizeof(uint2) * (size_t)tab.T, st));
   } else {
     const int tbits = ceil_log2_u32((uint32_t)tab.T);

@@ -34,6 +34,8 @@ struct GeomState {
   uint32_t* block_offsets;// [ceil(P/256)+1] their exclusive scan
   uint32_t* clamped;      // [P] bit ch set when SH colour channel was clamped at 0
   uint32_t* counters;     // [0] = num_rendered
+  uint2* ekey;            // [P] {depth bits, tile mask}: what the tile-row binning reads per Gaussian next to rect[] (coalesced 8 + 8 bytes
+                          //     instead of two 16-byte gathers from the 64-byte record)
 };
 struct ImageState {
   float* final_T;         // [H*W]
@@ -70,6 +72,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->block_offsets = (uint32_t*)take((nblk + 1) * 4);
   g->clamped = (uint32_t*)take(Pn * 4);
   g->counters = (uint32_t*)take(64);
+  g->ekey = (uint2*)take(Pn * 8);
   return off;
 }
 static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageState* im) {
@@ -157,6 +160,7 @@ struct GsrPreView {            // preprocess
   const float* colors;   // this view's precomputed colours [P,3] (nullptr: the colours shared by all views, or SH)
   float tanfovx, tanfovy;
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
+  uint2* ekey;
 };
 struct GsrPreViews {
   int V;
@@ -175,11 +179,15 @@ struct GsrBinView {            // emit .. tile_sort
   const uint32_t* D_dev;   // != nullptr: the entry count lives on the device (offsets[P], written by emit_entries): no host round trip
   uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
   uint32_t fused_alias;    // 1: additionally blended INSIDE its owner's tile pass (GsrRenderView::partner): no tickets for its busy tiles
+  const uint2* ekey;       // tile-row binning: {depth bits, tile mask} per Gaussian
+  float4* rec_w;           // the record array again, writable (the offset word of a record is filled in by the binning stage)
+  uint32_t* tile_rows;     // tile-row binning: [rows + 1][T] per-workgroup tile counts (-> exclusive prefixes over the workgroups), row `rows` = totals
 };
 struct GsrBinViews {
   int V, T, gx; uint4* order; uint32_t* queue;
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
   int wave_cap;                  // tile_sort: lists up to this length (512 / 1024) are sorted by one wave each (set by gsr_launch_binning)
+  int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
   GsrBinView v[GSR_MAX_BATCH];
 };
 struct GsrRenderView {         // blend forward / backward
@@ -197,10 +205,17 @@ struct GsrRenderViews {
 };
 
 // Batch state (V > 1): the structures shared by the views of one call.
+// Tile-row binning (gsr_binning.hip): a workgroup of 1024 threads owns GSR_BIN_G consecutive Gaussians of a view.
+#define GSR_BIN_G 4096
+#define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS (40 KiB + 16 KiB of other arrays: under the 64 KiB a workgroup
+                                    // may always have); larger tile grids take the radix path
+static inline int gsr_bin_rows(int P) { return ((P > 0 ? P : 1) + GSR_BIN_G - 1) / GSR_BIN_G; }
+static inline __host__ __device__ int gsr_bin_stride(int T) { return (T + 3) & ~3; }   // row stride of the matrix: rows stay 16-byte aligned
 struct BatchState {
   uint32_t* sums;    // [V][ceil(P/256)] per-preprocess-block entry counts of every view (one D2H copy)
   uint4* order;      // [V*T] {tile, list start, list end, view}: all tiles of the call, longest list first
   uint32_t* queue;   // [16] work-queue heads, see ImageState::queue
+  uint32_t* tile_rows;   // [V][rows + 1][T] tile-row binning matrix (nullptr when T > GSR_BIN_MAX_T)
 };
 static inline size_t gsr_carve_batch(void* base, int V, int32_t P, int32_t H, int32_t W, BatchState* b) {
   size_t off = 0;
@@ -211,6 +226,8 @@ static inline size_t gsr_carve_batch(void* base, int V, int32_t P, int32_t H, in
   b->sums = (uint32_t*)take((size_t)V * nblk * 4);
   b->order = (uint4*)take((size_t)V * (T ? T : 1) * 16);
   b->queue = (uint32_t*)take(64);
+  b->tile_rows = nullptr;
+  if (T <= GSR_BIN_MAX_T) b->tile_rows = (uint32_t*)take((size_t)V * (gsr_bin_rows(P) + 1) * (size_t)gsr_bin_stride((int)(T ? T : 1)) * 4);
   return off;
 }
 

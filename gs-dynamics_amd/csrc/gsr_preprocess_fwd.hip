@@ -243,6 +243,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     rec[GSR_REC_F4 * i + 2] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
     rec[GSR_REC_F4 * i + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(tmask));  // .z = offset (emit)
     rect[i] = rc;
+    vw.ekey[i] = make_uint2(__float_as_uint(c2.y), tmask);
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;

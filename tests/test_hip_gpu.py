@@ -439,6 +439,43 @@ def test_last_host_scanned_block_count(dev, P):
         assert np.array_equal(radii[0].cpu().numpy(), o2.radii)
 
 
+@pytest.mark.parametrize("P,W,H", [(300, 48, 32), (1500, 32, 32), (3000, 32, 32), (9000, 32, 32), (20000, 200, 120)])
+def test_tile_row_binning_lists_vs_oracle(dev, P, W, H):
+    """The multi-view entry points bin with the tile-row counting sort (gsr_binning.hip: bin_count / bin_scan / bin_emit): entries arrive
+    in their tile's segment in no particular order and every tile_sort path must still produce the reference order -- depth, ties by
+    ascending Gaussian id.  Lists, ranges, n_contrib and images of a 2-view call against the oracle, bit for bit, with many
+    equal-depth ties (duplicated positions: pairs, and one run of 150 identical depths that exceeds the in-place repair),
+    synchronous and capacity mode."""
+    from diff_gaussian_rasterization import _hip
+    wide = P <= 9000
+    g = random_gaussians(P, seed=70 + P, scale_lo=5.0 if wide else 0.02, scale_hi=9.0 if wide else 0.2, spread=0.5 if wide else 1.0)
+    if wide:
+        g["opacities"][:] = 0.03
+    half = P // 2
+    g["means3D"][half:2 * half] = g["means3D"][:half]          # pairs of Gaussians at one position: equal depth bits
+    g["means3D"][:min(150, P)] = g["means3D"][0]                # and a long run
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    cams = [ring_camera(W, H, v=1), ring_camera(W, H, v=3)]
+    rss = [_settings(c, dev) for c in cams]
+    o2s = [TiledOracle(c, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"], rotations=g["rotations"],
+                       nthreads=8) for c in cams]
+    _hip._entries_capacity.pop((dev.index, P, H, W), None)
+    for no_sync in (False, True):
+        im, radii, depth, states = _hip.rasterize_forward_batch(rss, t["means3D"], t["opacities"], t["colors_precomp"], None, t["scales"],
+                                                                t["rotations"], None, no_host_sync=no_sync)
+        assert (states[0].pending is not None) == no_sync and _hip.forward_counts_ok(states)
+        torch.cuda.synchronize()
+        for v, o2 in enumerate(o2s):
+            views = _hip.debug_views(states[v])
+            D = int(views["offsets"][-1])
+            views["point_list"] = views["point_list"][:D]
+            ok = ~o2.ambiguous
+            assert np.array_equal(radii[v].cpu().numpy(), o2.radii)
+            _check_lists(views, H, W, o2.point_list, o2.ranges, o2.n_contrib, ok, o2.means2D, o2.conic_opacity, o2.tiles_touched, o2.offsets)
+            assert mixed_err(im[v].cpu().numpy()[:, ok], o2.color[:, ok]) < TOL
+            assert mixed_err(depth[v].cpu().numpy()[:, ok], o2.depth[:, ok]) < TOL
+
+
 def test_early_termination_dense_scene(dev):
     g = random_gaussians(3000, seed=34, scale_lo=0.1, scale_hi=0.5, spread=0.6)
     g["opacities"][:] = 0.95
