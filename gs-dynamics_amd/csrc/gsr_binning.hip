@@ -491,18 +491,24 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(GsrBinViews ta
 // per-wave private histograms -- split into "tiles of work items before mine" and "the rest" -- so it knows the global bucket
 // starts and how many tiles of each bucket the workgroups before it will place; it then PLACES only its own work items.  No
 // inter-workgroup communication, no global atomics; the order inside a bucket is arbitrary as before.
-__global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int items_per_wg) {
-  __shared__ uint32_t h_before[ORD_WAVES][256];   // per wave: tiles per bucket in work items before this workgroup's
-  __shared__ uint32_t h_rest[ORD_WAVES][256];     // per wave: tiles per bucket in this workgroup's work items and later ones
-  __shared__ uint32_t start[256];                 // placement cursor of this workgroup per bucket
-  __shared__ uint32_t empty_before_s, n_busy_s, n_long_s, n_empty_s;
+struct TileOrderLds {
+  uint32_t h_before[ORD_WAVES][256];   // per wave: tiles per bucket in work items before this workgroup's
+  uint32_t h_rest[ORD_WAVES][256];     // per wave: tiles per bucket in this workgroup's work items and later ones
+  uint32_t start[256];                 // placement cursor of this workgroup per bucket
+  uint32_t empty_before_s, n_busy_s, n_long_s, n_empty_s;
+};
+// `bid`: the workgroup's index among those building the order (blockIdx.x of tile_order_kernel; 0 when another kernel builds the
+// whole order with one workgroup, see bin_scan_order_kernel)
+__device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int items_per_wg, int bid, TileOrderLds& L) {
+  auto& h_before = L.h_before; auto& h_rest = L.h_rest; auto& start = L.start;
+  uint32_t& empty_before_s = L.empty_before_s; uint32_t& n_busy_s = L.n_busy_s; uint32_t& n_long_s = L.n_long_s; uint32_t& n_empty_s = L.n_empty_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int T = tab.T;   // all tiles of all views, one order
   uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
   for (int i = tid; i < ORD_WAVES * 256; i += 1024) { (&h_before[0][0])[i] = 0; (&h_rest[0][0])[i] = 0; }
   if (tid == 0) { empty_before_s = 0; n_empty_s = 0; }
-  if (blockIdx.x == 0) {
+  if (bid == 0) {
     if (tid < 8) queue[tid] = 0;
     // capacity mode: the counts for the host.  counts_out may be PINNED HOST memory (the caller then needs no copy on the stream --
     // a 4 us blit plus a 6 us bubble between the forward and the backward): a system-scope store, visible once this kernel has ended
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
   // any is used (one memory latency per chunk instead of one per item); the view index is uniform, so the table
   // lookup stays a scalar load.
   const int n_it = (T + 1023) / 1024, n_items = tab.V * n_it;
-  const int k_lo = (int)blockIdx.x * items_per_wg, k_hi = min(n_items, k_lo + items_per_wg);
+  const int k_lo = bid * items_per_wg, k_hi = min(n_items, k_lo + items_per_wg);
   uint32_t empties_before = 0, empties_all = 0;    // wave-uniform counts (ballots)
   for (int k0 = 0; k0 < n_items; k0 += ORD_CHUNK) {
     uint2 r[ORD_CHUNK];
@@ -608,25 +614,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
     }
   }
   // the empty tiles (bucket 255) are sorted last and never enter the queues; queue[7] = entries of the order array
-  if (blockIdx.x == 0 && tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; queue[7] = n_busy + n_empty_s; }
+  if (bid == 0 && tid == 0) { queue[4] = n_busy; queue[6] = n_long_s; queue[7] = n_busy + n_empty_s; }
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
-  const GsrBinView& vw = tab.v[blockIdx.y];
-  const uint32_t* __restrict__ tkey = vw.tkey[cur];
-  uint2* __restrict__ ranges = vw.ranges;
-  const uint32_t D = bin_entries(vw);
-  uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  if (i >= D) return;
-  uint32_t t = tkey[i];
-  if (i == 0) ranges[t].x = 0;
-  else {
-    uint32_t pt = tkey[i - 1];
-    if (pt != t) { ranges[pt].y = i; ranges[t].x = i; }
-  }
-  if (i == D - 1) ranges[t].y = D;
+__global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int items_per_wg) {
+  __shared__ TileOrderLds L;
+  tile_order_body(tab, items_per_wg, (int)blockIdx.x, L);
 }
-
 
 // ================================================================== tile-row binning (multi-view calls, T <= GSR_BIN_MAX_T)
 // A single-pass counting sort on the tile id, without global atomics and without moving the entries more than once:
@@ -635,26 +629,37 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab,
 //                  view's (workgroups x tiles) matrix -- plain coalesced stores.  The same kernel scans tiles_touched into
 //                  offsets[] (the Gaussian-major slots of the backward's partial records).
 //   2. bin_scan    per view: column prefix over the workgroups (in place), tile totals, exclusive scan over the tiles -> ranges.
-//                  (More than BIN_DIRECT_ROWS workgroups per view: bin_colprefix first, one thread per tile column.)
+//                  (More than BIN_DIRECT_ROWS workgroups per view: bin_colprefix first, one thread per tile column.)  Calls with
+//                  few tiles (V * ceil(T / 1024) <= 4: one 800 x 800 view) run bin_scan_order instead: ONE workgroup scans and also
+//                  builds the longest-first tile order -- no tile_order launch.
 //   3. bin_emit    the workgroups walk their Gaussians again: an entry of tile t goes to ranges[t].x + prefix_row[t] + (LDS atomic
 //                  on the workgroup's cursor of t) -- straight into its tile's segment, 8 bytes {gaussian id, depth bits}.
 //   4. tile_order, tile_sort as before.  Entries ARRIVE in a tile's segment in no particular order (LDS atomics); every path of
 //      tile_sort orders them by the unique 64-bit key (depth bits << 32 | gaussian id) -- the radix path by repairing runs of equal
 //      depth afterwards -- so the lists are the same bits as with the stable radix passes (the reference's order), run after run.
-// Against the radix path (emit, histogram, two scatter passes): 4 launches instead of 6 in front of the blend, entries written once
-// (8 B) instead of 12 + 12 + 8 B, nothing that depends on the entry count in any grid size (capacity mode needs no special case).
+// Against the radix path (emit, histogram, two scatter passes): 3 - 4 launches instead of 6 in front of the tile sort, entries written
+// once (8 B) instead of 12 + 12 + 8 B, nothing that depends on the entry count in any grid size (capacity mode needs no special case).
 #define BIN_THREADS 1024
 #define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
 #define BIN_DIRECT_ROWS 32
+#define BIN_ROW_CHUNK 16
 #define BIN_BIG_AREA 64        // rects with more tiles are walked by the whole workgroup, not by their Gaussian's lane
 
-struct BinGauss { uint32_t minx, miny, w, area, mask; };
+struct BinGauss { uint32_t minx, miny, w, area, mask; float rw; };
 __device__ __forceinline__ BinGauss bin_gauss(uint2 r, uint32_t mask) {
   BinGauss b;
   b.minx = r.x & 0xffffu; b.miny = r.x >> 16;
   const uint32_t maxx = r.y & 0xffffu, maxy = r.y >> 16;
   b.w = maxx - b.minx; b.area = b.w * (maxy - b.miny); b.mask = mask;
+  b.rw = __builtin_amdgcn_rcpf((float)b.w);
   return b;
+}
+// Tile id of the k-th tile (row-major) of a Gaussian's rect.  k / w without an integer division (~40 VALU issues each on this
+// part, and the walk below is the whole cost of the count / emit kernels): (k + 0.5) * (1 / w) in fp32, off by less than 1e-3 for
+// every k the kernels see (k < 2^14, so k + 0.5 is exact), while the true quotient's fractional part stays >= 0.5 / w away from an integer.
+__device__ __forceinline__ uint32_t bin_tile_of(const BinGauss& b, uint32_t k, int gx) {
+  const uint32_t ky = (uint32_t)(((float)k + 0.5f) * b.rw);
+  return (b.miny + ky) * (uint32_t)gx + b.minx + (k - ky * b.w);
 }
 // f(tile id) for every tile of a Gaussian's set (small rects: the set bits of its mask, row-major; larger rects: all of it)
 template <typename F>
@@ -664,27 +669,11 @@ __device__ __forceinline__ void bin_for_tiles(const BinGauss& b, int gx, F f) {
     while (m) {
       const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
       m &= m - 1u;
-      f((b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w);
+      f(bin_tile_of(b, k, gx));
     }
   } else {
-    for (uint32_t k = 0; k < b.area; ++k) f((b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w);
+    for (uint32_t k = 0; k < b.area; ++k) f(bin_tile_of(b, k, gx));
   }
-}
-
-// Entries before Gaussian block jb (256 Gaussians per block): from the scanned array, or summed here from the per-block counts.
-__device__ __forceinline__ uint32_t bin_base_of_block(const GsrBinView& vw, int jb, uint32_t* s_red) {
-  if (vw.block_offsets) return vw.block_offsets[jb];
-  uint32_t part = 0;
-  for (int j = threadIdx.x; j < jb; j += BIN_THREADS) part += vw.block_sums[j];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
-  __syncthreads();
-  uint32_t tot = 0;
-#pragma unroll
-  for (int w = 0; w < BIN_THREADS / 64; ++w) tot += s_red[w];
-  __syncthreads();
-  return tot;
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinViews tab) {
@@ -694,33 +683,42 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   __shared__ uint32_t s_big[GSR_BIN_G];               // Gaussians (local index) whose rect is walked by the whole workgroup
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
-  const int T = tab.T, gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
   const bool lists = !vw.shares_lists;
-  if (lists) for (int t = tid; t < T; t += BIN_THREADS) s_cnt[t] = 0;
-  if (tid == 0) s_nbig = 0;
-  // ---- offsets: exclusive prefix of tiles_touched over this workgroup's Gaussians (4 consecutive ones per thread)
-  const uint32_t base = bin_base_of_block(vw, g0 / GSR_BLOCK, s_red);     // (also the barrier behind the zeroing above)
-  uint32_t tt[BIN_PER_THREAD], sum = 0;
-#pragma unroll
-  for (int q = 0; q < BIN_PER_THREAD; ++q) { const int g = g0 + tid * BIN_PER_THREAD + q; tt[q] = g < P ? vw.tiles_touched[g] : 0u; sum += tt[q]; }
+  // every global load of the kernel is issued here, ahead of the first wait (the launch is a chain of memory round trips otherwise)
+  uint32_t tt[BIN_PER_THREAD];
   uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < BIN_PER_THREAD; ++q) {
     const int g = g0 + tid * BIN_PER_THREAD + q;
-    rc[q] = make_uint2(0u, 0u); ek[q] = rc[q];
-    if (lists && g < P && tt[q]) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; }
+    tt[q] = 0; rc[q] = make_uint2(0u, 0u); ek[q] = rc[q];
+    if (g < P) { tt[q] = vw.tiles_touched[g]; if (lists) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; } }
   }
+  // entries before this workgroup's first Gaussian: from the scanned array, or summed here from the per-256-Gaussian counts
+  const int jb = g0 / GSR_BLOCK;
+  uint32_t part = 0;
+  if (vw.block_offsets) { if (tid == 0) part = vw.block_offsets[jb]; }
+  else for (int j = tid; j < jb; j += BIN_THREADS) part += vw.block_sums[j];
+  if (lists) for (int t = tid; t < T; t += BIN_THREADS) s_cnt[t] = 0;
+  if (tid == 0) s_nbig = 0;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) sum += tt[q];
   uint32_t inc = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t o = __shfl_up(inc, d, 64);
     if (lane >= d) inc += o;
   }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
   if (lane == 63) s_wave[wv] = inc;
+  if (lane == 0) s_red[wv] = part;
   __syncthreads();
-  uint32_t run = base + inc - sum;
-  for (int w = 0; w < wv; ++w) run += s_wave[w];
+  uint32_t run = inc - sum;
+#pragma unroll
+  for (int w = 0; w < BIN_THREADS / 64; ++w) { run += s_red[w]; if (w < wv) run += s_wave[w]; }
 #pragma unroll
   for (int q = 0; q < BIN_PER_THREAD; ++q) {
     const int g = g0 + tid * BIN_PER_THREAD + q;
@@ -745,11 +743,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   for (uint32_t i = 0; i < nbig; ++i) {               // large rects (taken whole): every thread takes a slice of the tiles
     const int g = g0 + (int)s_big[i];
     const BinGauss b = bin_gauss(vw.rect[g], 0u);
-    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) atomicAdd(&s_cnt[(b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w], 1u);
+    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
   }
   if (nbig) __syncthreads();
-  uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * T;
-  for (int t = tid; t < T; t += BIN_THREADS) row[t] = s_cnt[t];
+  uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
+  for (int t = tid; t < Ts; t += BIN_THREADS) row[t] = t < T ? s_cnt[t] : 0u;      // (the padding columns of the row stay zero)
 }
 
 // More than BIN_DIRECT_ROWS workgroups per view: one thread per tile column turns the counts into exclusive prefixes over the
@@ -757,48 +755,54 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
 __global__ __launch_bounds__(GSR_BLOCK) void bin_colprefix_kernel(GsrBinViews tab) {
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (vw.shares_lists) return;
-  const int T = tab.T, rows = tab.rows, t = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  if (t >= T) return;
+  const int Ts = gsr_bin_stride(tab.T), rows = tab.rows, t = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (t >= Ts) return;
   uint32_t* __restrict__ m = vw.tile_rows;
   uint32_t run = 0;
   int r = 0;
   for (; r + 8 <= rows; r += 8) {
     uint32_t v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = m[(size_t)(r + u) * T + t];
+    for (int u = 0; u < 8; ++u) v[u] = m[(size_t)(r + u) * Ts + t];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { m[(size_t)(r + u) * T + t] = run; run += v[u]; }
+    for (int u = 0; u < 8; ++u) { m[(size_t)(r + u) * Ts + t] = run; run += v[u]; }
   }
-  for (; r < rows; ++r) { const uint32_t v = m[(size_t)r * T + t]; m[(size_t)r * T + t] = run; run += v; }
-  m[(size_t)rows * T + t] = run;
+  for (; r < rows; ++r) { const uint32_t v = m[(size_t)r * Ts + t]; m[(size_t)r * Ts + t] = run; run += v; }
+  m[(size_t)rows * Ts + t] = run;
 }
 
-// Per view: (column prefix over the workgroups, unless bin_colprefix ran) + exclusive scan of the tile totals -> ranges.
-// Capacity mode clamps the ranges to the capacity the entry buffers were sized for.
-__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, int prefixed) {
-  __shared__ uint32_t s_wave[BIN_THREADS / 64];
-  __shared__ uint32_t s_carry;
-  const GsrBinView& vw = tab.v[blockIdx.x];
-  if (vw.shares_lists) return;
-  const int T = tab.T, rows = tab.rows, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// One view: (column prefix over the workgroups, unless bin_colprefix ran) + exclusive scan of the tile totals -> ranges.  A thread
+// owns FOUR consecutive tiles (16-byte loads and stores on the rows).  Capacity mode clamps the ranges to the capacity the entry
+// buffers were sized for.  Called by all BIN_THREADS threads of a workgroup.
+__device__ __forceinline__ void bin_scan_view(const GsrBinViews& tab, const GsrBinView& vw, int prefixed, uint32_t* s_wave, uint32_t* s_carry) {
+  const int T = tab.T, Ts = gsr_bin_stride(T), rows = tab.rows, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t* __restrict__ m = vw.tile_rows;
   const uint32_t cap = vw.D;                          // entries the buffers hold (the exact count outside capacity mode)
-  if (tid == 0) s_carry = 0;
+  if (tid == 0) *s_carry = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += BIN_THREADS) {
-    const int t = t0 + tid;
-    uint32_t tot = 0;
-    if (t < T) {
-      if (prefixed) tot = m[(size_t)rows * T + t];
+  for (int q0 = 0; q0 < Ts / 4; q0 += BIN_THREADS) {
+    const int q = q0 + tid;                           // tiles 4q .. 4q + 3
+    const bool live = q < Ts / 4;
+    uint4 tot = make_uint4(0u, 0u, 0u, 0u);
+    if (live) {
+      if (prefixed) tot = *reinterpret_cast<const uint4*>(m + (size_t)rows * Ts + 4 * q);
       else {
-        uint32_t v[BIN_DIRECT_ROWS];
+        for (int r0 = 0; r0 < rows; r0 += BIN_ROW_CHUNK) {
+          uint4 v[BIN_ROW_CHUNK];
 #pragma unroll
-        for (int r = 0; r < BIN_DIRECT_ROWS; ++r) v[r] = r < rows ? m[(size_t)r * T + t] : 0u;
+          for (int r = 0; r < BIN_ROW_CHUNK; ++r)
+            v[r] = r0 + r < rows ? *reinterpret_cast<const uint4*>(m + (size_t)(r0 + r) * Ts + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int r = 0; r < BIN_DIRECT_ROWS; ++r) if (r < rows) { m[(size_t)r * T + t] = tot; tot += v[r]; }
+          for (int r = 0; r < BIN_ROW_CHUNK; ++r)
+            if (r0 + r < rows) {
+              *reinterpret_cast<uint4*>(m + (size_t)(r0 + r) * Ts + 4 * q) = tot;
+              tot.x += v[r].x; tot.y += v[r].y; tot.z += v[r].z; tot.w += v[r].w;
+            }
+        }
       }
     }
-    uint32_t inc = tot;
+    const uint32_t mine = tot.x + tot.y + tot.z + tot.w;
+    uint32_t inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(inc, d, 64);
@@ -806,13 +810,43 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, 
     }
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
-    uint32_t start = s_carry + inc - tot;
+    uint32_t start = *s_carry + inc - mine;
     for (int w = 0; w < wv; ++w) start += s_wave[w];
-    if (t < T) vw.ranges[t] = make_uint2(min(start, cap), min(start + tot, cap));
+    if (live) {
+      const uint32_t c[4] = {tot.x, tot.y, tot.z, tot.w};
+      uint32_t st_ = start;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (4 * q + k < T) vw.ranges[4 * q + k] = make_uint2(min(st_, cap), min(st_ + c[k], cap));
+        st_ += c[k];
+      }
+    }
     __syncthreads();
-    if (tid == BIN_THREADS - 1) s_carry = start + tot;
+    if (tid == BIN_THREADS - 1) *s_carry = start + mine;
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, int prefixed) {   // grid: V
+  __shared__ uint32_t s_wave[BIN_THREADS / 64];
+  __shared__ uint32_t s_carry;
+  const GsrBinView& vw = tab.v[blockIdx.x];
+  if (vw.shares_lists) return;
+  bin_scan_view(tab, vw, prefixed, s_wave, &s_carry);
+}
+
+// Few tiles in the whole call (V * ceil(T / 1024) <= 4: e.g. ONE 800 x 800 view, the per-GPU share of a view-sharded step): a single
+// workgroup scans every view and then builds the longest-first tile order itself -- one launch instead of bin_scan + tile_order,
+// and one memory round trip less on the critical path of a short step.
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_order_kernel(GsrBinViews tab, int prefixed, int n_items) {
+  __shared__ uint32_t s_wave[BIN_THREADS / 64];
+  __shared__ uint32_t s_carry;
+  __shared__ TileOrderLds L;
+  for (int v = 0; v < tab.V; ++v)
+    if (!tab.v[v].shares_lists) bin_scan_view(tab, tab.v[v], prefixed, s_wave, &s_carry);
+  __threadfence_block();      // the ranges written above are read back below (by other threads of this workgroup)
+  __syncthreads();
+  tile_order_body(tab, n_items, 0, L);
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinViews tab) {
@@ -821,17 +855,17 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (vw.shares_lists) return;
-  const int T = tab.T, gx = tab.gx, tid = threadIdx.x;
+  const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
   const uint32_t cap = vw.D;
-  const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * T;
+  const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
   uint64_t* __restrict__ dg = vw.dg[0];
   uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
 #pragma unroll
-  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {          // all loads up front; a culled Gaussian has an empty rect
     const int g = g0 + tid * BIN_PER_THREAD + q;
     rc[q] = make_uint2(0u, 0u); ek[q] = rc[q];
-    if (g < P && vw.tiles_touched[g]) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; }
+    if (g < P) { rc[q] = vw.rect[g]; ek[q] = vw.ekey[g]; }
   }
   if (tid == 0) s_nbig = 0;
   for (int t = tid; t < T; t += BIN_THREADS) s_cur[t] = vw.ranges[t].x + row[t];
@@ -854,11 +888,28 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
     const BinGauss b = bin_gauss(vw.rect[g], 0u);
     const uint64_t key = ((uint64_t)vw.ekey[g].x << 32) | (uint32_t)g;
     for (uint32_t k = tid; k < b.area; k += BIN_THREADS) {
-      const uint32_t slot = atomicAdd(&s_cur[(b.miny + k / b.w) * (uint32_t)gx + b.minx + k % b.w], 1u);
+      const uint32_t slot = atomicAdd(&s_cur[bin_tile_of(b, k, gx)], 1u);
       if (slot < cap) dg[slot] = key;
     }
   }
 }
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab, int cur) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  const uint32_t* __restrict__ tkey = vw.tkey[cur];
+  uint2* __restrict__ ranges = vw.ranges;
+  const uint32_t D = bin_entries(vw);
+  uint32_t i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i >= D) return;
+  uint32_t t = tkey[i];
+  if (i == 0) ranges[t].x = 0;
+  else {
+    uint32_t pt = tkey[i - 1];
+    if (pt != t) { ranges[pt].y = i; ranges[t].x = i; }
+  }
+  if (i == D - 1) ranges[t].y = D;
+}
+
 
 // ------------------------------------------------------------------ per-tile depth sort
 // Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
@@ -1161,6 +1212,7 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
   tab.wave_cap = big ? 1024 : 512;
   int cur = 0;
+  bool order_done = false;
   static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
   const bool rows_path = tab.rows > 0 && tab.T <= GSR_BIN_MAX_T && !radix_only && maxD > 0 && P > 0;
   if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
@@ -1171,11 +1223,19 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     const int prefixed = tab.rows > BIN_DIRECT_ROWS ? 1 : 0;
     if (prefixed) {
       GSR_PROF("bin_colprefix", st);
-      hipLaunchKernelGGL(bin_colprefix_kernel, dim3((tab.T + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      hipLaunchKernelGGL(bin_colprefix_kernel, dim3((gsr_bin_stride(tab.T) + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     }
     GSR_HIP_CHECK(hipGetLastError());
-    { GSR_PROF("bin_scan", st);
-      hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed); }
+    const int n_items = tab.V * ((tab.T + 1023) / 1024);
+    static const bool no_fused_order = [] { const char* e = getenv("GSR_NO_FUSED_ORDER"); return e && *e && atoi(e) != 0; }();
+    order_done = n_items <= 4 && !no_fused_order;
+    if (order_done) {
+      GSR_PROF("bin_scan_order", st);
+      hipLaunchKernelGGL(bin_scan_order_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tab, prefixed, n_items);
+    } else {
+      GSR_PROF("bin_scan", st);
+      hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed);
+    }
     GSR_HIP_CHECK(hipGetLastError());
     { GSR_PROF("bin_emit", st);
       hipLaunchKernelGGL(bin_emit_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
@@ -1216,7 +1276,8 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     }
     GSR_HIP_CHECK(hipGetLastError());
   }
-  if (int rc = gsr_launch_tile_order(tab, st)) return rc;
+  if (!order_done)
+    if (int rc = gsr_launch_tile_order(tab, st)) return rc;
   if (maxD > 0 && P > 0) {
     { GSR_PROF("tile_sort", st);
     if (big)   // long lists on average: the big-LDS build
