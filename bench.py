@@ -56,6 +56,8 @@ def algorithmic_bytes(P, D, Npx):
 
 # kernel name (GSR_PROF label in libgsr_hip.so) -> section-8d group
 KERNEL_GROUP = {"preprocess_fwd": "preprocess_fwd", "scan_exclusive": "scan", "emit_entries": "emit_entries", "radix_hist": "sort",
+                "bin_count": "emit_entries", "bin_emit": "emit_entries", "bin_scan": "tile_ranges", "bin_scan_order": "tile_ranges",
+                "bin_colprefix": "tile_ranges",
                 "radix_scatter": "sort", "tile_sort": "sort", "tile_ranges": "tile_ranges", "tile_order": "tile_ranges",
                 "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd_views": "preprocess_bwd",
                 "preprocess_bwd": "preprocess_bwd"}
@@ -214,25 +216,86 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_step, t_event = float(t[0].item()), float(t[1].item())
 
-    # ---- per-kernel HIP-event pass (outside the timed region), same call pattern
+    D = float(np.mean(num_rendered)) if num_rendered else 0.0
+    Npx = H * W
+    mpix = total_views * Npx / t_step / 1e6
+    roofline = kernel_roofline(_hip, step, max(len(cams), 1), D, t_step, args.steps)
+
+    cfg3 = None
+    extras = None
+    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras:
+        # BASELINE.json configs[2] on the same box, same process: 4 views, colour render fwd + bwd, no optimiser step
+        p3, c3, d3 = make_problem(synth_ring_cameras(4, W, H, device=dev), list(range(4)))
+        D3 = float(np.mean(num_rendered[0::2])) if len(num_rendered) == 8 else D      # the 4-camera ring = cameras 0, 2, 4, 6 of the 8-ring
+        s3, _ = make_step(p3, c3, d3, False, False)
+        t3, t3e = timed(s3, args.steps, args.warmup)
+        cfg3 = {"workload": "BASELINE.json configs[2] = the configuration BASELINE.json's metric is quoted on: 4 views 800x800, 100k Gaussians, "
+                            "colour render fwd+bwd (all gradients), no optimiser step",
+                "metric": "fwd+bwd Mpix/s at 100k Gaussians, 4x800^2 views",
+                "value": 4 * Npx / t3 / 1e6, "unit": "Mpix/s", "ms_per_step": t3 * 1e3, "ms_per_step_event_median": t3e * 1e3,
+                "num_rendered_per_view": D3, "roofline": kernel_roofline(_hip, s3, 4, D3, t3, args.steps)}
+    frozen = None
+    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras and not args.frozen_colours and not args.autograd:
+        # the same step as the headline with rgb_colors frozen, as the reference trains (no dL/dcolour: six sums per list entry)
+        pf, cf, df = make_problem(all_cams, my_ids)
+        sf, _ = make_step(pf, cf, df, not args.no_optimizer, False, True)
+        tf, tfe = timed(sf, args.steps, args.warmup)
+        frozen = {"workload": "the headline step with rgb_colors.requires_grad = False (/root/reference/src/tracking/train_utils.py:133,155): "
+                              "every gradient the reference's optimiser uses, no dL/dcolour",
+                  "value": len(cams) * Npx / tf / 1e6, "unit": "Mpix/s", "ms_per_step": tf * 1e3, "ms_per_step_event_median": tfe * 1e3}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = run_extras(dev, synth_scene_params(P_GAUSS, seed=0, device=dev), synth_ring_cameras(4, W, H, device=dev),
+                            synth_ring_cameras, synth_scene_params)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(synth_scene_params(P_GAUSS, seed=0, device=dev), all_cams[0], dL_all[0], params2rendervar)
+
+    if rank == 0:
+        n_bucket = sum(p.numel() for p in bucket.params)
+        line = {
+            "metric": (f"fwd+bwd Mpix/s at 100k Gaussians, {total_views}x800^2 views" +
+                       (" (configs[3]: the 8-view strong-scaling step incl. Adam; BASELINE.json's own 4x800^2 configuration: see cfg3)"
+                        if (total_views == 8 and not args.weak) else "")),
+            "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_step * 1e3, "ms_per_step_event_median": t_event * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"weak scaling: {len(cams)} views per GPU of a {total_views}-camera ring" if args.weak else
+                                    f"configs[{3 if total_views == 8 else 2}]: {total_views}x800^2 views, 100k Gaussians, fwd+bwd" +
+                                    ("" if args.no_optimizer else "+Adam") + f", {world} GPU(s), strong scaling" +
+                                    (" (4x800^2 = cfg3)" if total_views == 8 else "") + f"; SynthScene-v1, view r -> rank r mod N ({len(cams)} on rank 0)") +
+                                   ", colour render fwd+bwd per view" + (" (rgb_colors frozen: no colour gradient)" if args.frozen_colours else "") +
+                                   ("" if world == 1 else f", 1 RCCL all-reduce of the {n_bucket}-float parameter-gradient bucket") +
+                                   ("" if args.no_optimizer else ", Adam step (FusedAdam)"),
+                       "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": len(cams), "image": [H, W],
+                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}", "grad_bucket_floats": n_bucket,
+                       "optimizer_in_timed_region": not args.no_optimizer,
+                       "call_pattern": "rasterize_gaussians_views + autograd" if args.autograd else
+                                       "gsdyn.step.render_step_views: activations, ONE multi-view forward (capacity mode), ONE multi-view backward, direct library calls"},
+            "roofline": roofline, "cfg3": cfg3, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def kernel_roofline(_hip, step, vpl, D, t_step, steps):
+    """The ``roofline`` object of a step: per-kernel HIP-event pass (outside the timed region, same call pattern), algorithmic bytes of
+    SURVEY.md section 8d per kernel group, dominant kernel = the slower blend kernel.  ``vpl``: views per launch on this rank."""
     for _ in range(2):
         step()
     torch.cuda.synchronize()
     _hip.profile_begin()
-    prof_steps = max(3, min(10, args.steps))
+    prof_steps = max(3, min(10, steps))
     for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     prof = _hip.profile_end()
-    vpl = max(len(cams), 1)                       # views per launch on this rank
     per_launch_us = {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}
     per_step_us = {k: 1e3 * ms / prof_steps for k, (ms, n) in prof.items()}
     busy_us = sum(per_step_us.values())
-
-    D = float(np.mean(num_rendered)) if num_rendered else 0.0
     Npx = H * W
     ab = algorithmic_bytes(P_GAUSS, D, Npx)
-    mpix = total_views * Npx / t_step / 1e6
     path_bytes = vpl * ab["total"]
     dom = max((k for k in per_step_us if k in ("render_fwd", "render_bwd")), key=lambda k: per_step_us[k], default="render_bwd")
     dom_us = per_launch_us.get(dom, float("nan"))
@@ -262,20 +325,21 @@ def main():
         "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
         "per_kernel_timing": "HIP events around every launch of the library (on the launch stream), separate pass after the timed region, same call pattern",
     }
-    # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_traffic.sh), corrected with the
+    # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_round.sh), corrected with the
     # calibration factors measured on known byte counts (tools/prof_calib.sh): REPLAYED from profiles/, not measured in this run
-    tj = _load_json("r02_pmc_traffic.json")
+    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r03", "r02")) if j), None) or \
+        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
     if tj and dom in tj and tj.get("views_per_launch") == vpl:
         roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
         roofline["traffic_detail"] = {"replayed": True, "source": tj.get("source"), **{k: tj[dom].get(k) for k in
                                       ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "fabric_bytes_per_launch", "note") if k in tj[dom]}}
     # VALU: measured issue model (profiles/r02_valu_table.json) + committed SQ counters (REPLAYED)
-    sj = _load_json("r02_sq_counters.json")
+    sj = next((j for j in (_load_json(f"{r}_sq_counters.json") for r in ("r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
     valu = {"peak_lane_instr_per_s_spec": VALU_PEAK,
             "measured_issue_model": "one wave-64 VALU op per ~2.2 SIMD-cycles at >= 2 waves per SIMD (1 per ~4.7 cycles from ONE wave); DPP ops ~3.0, "
                                     "v_exp/v_rcp/permlane-swap ~6.0 (tools/micro/valu_table.hip -> profiles/r02_valu_table.json)",
             "pixel_gaussian_pairs_per_view": 256.0 * D}
-    if sj and sj.get("views_per_launch") == vpl:
+    if sj:
         occ = {}
         for kname in ("render_fwd", "render_bwd"):
             if kname in sj and kname in per_launch_us:
@@ -286,56 +350,7 @@ def main():
         valu["measured"] = occ
         valu["measured_detail"] = {"replayed": True, "source": sj.get("source")}
     roofline["valu"] = valu
-
-    cfg3 = None
-    extras = None
-    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras:
-        # BASELINE.json configs[2] on the same box, same process: 4 views, colour render fwd + bwd, no optimiser step
-        p3, c3, d3 = make_problem(synth_ring_cameras(4, W, H, device=dev), list(range(4)))
-        s3, _ = make_step(p3, c3, d3, False, False)
-        t3, t3e = timed(s3, args.steps, args.warmup)
-        cfg3 = {"workload": "BASELINE.json configs[2]: 4 views 800x800, 100k Gaussians, colour render fwd+bwd, no optimiser step",
-                "value": 4 * Npx / t3 / 1e6, "unit": "Mpix/s", "ms_per_step": t3 * 1e3, "ms_per_step_event_median": t3e * 1e3}
-    frozen = None
-    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras and not args.frozen_colours and not args.autograd:
-        # the same step as the headline with rgb_colors frozen, as the reference trains (no dL/dcolour: six sums per list entry)
-        pf, cf, df = make_problem(all_cams, my_ids)
-        sf, _ = make_step(pf, cf, df, not args.no_optimizer, False, True)
-        tf, tfe = timed(sf, args.steps, args.warmup)
-        frozen = {"workload": "the headline step with rgb_colors.requires_grad = False (/root/reference/src/tracking/train_utils.py:133,155): "
-                              "every gradient the reference's optimiser uses, no dL/dcolour",
-                  "value": len(cams) * Npx / tf / 1e6, "unit": "Mpix/s", "ms_per_step": tf * 1e3, "ms_per_step_event_median": tfe * 1e3}
-    if rank == 0 and world == 1 and not args.no_extras:
-        extras = run_extras(dev, synth_scene_params(P_GAUSS, seed=0, device=dev), synth_ring_cameras(4, W, H, device=dev),
-                            synth_ring_cameras, synth_scene_params)
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(synth_scene_params(P_GAUSS, seed=0, device=dev), all_cams[0], dL_all[0], params2rendervar)
-
-    if rank == 0:
-        n_bucket = sum(p.numel() for p in bucket.params)
-        line = {
-            "metric": "fwd+bwd Mpix/s at 100k Gaussians, 800^2 views",
-            "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_step * 1e3, "ms_per_step_event_median": t_event * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"weak scaling: {len(cams)} views per GPU of a {total_views}-camera ring" if args.weak else
-                                    f"BASELINE.json configs[{3 if total_views == 8 else 2}]-shaped step: {total_views} views 800x800 of SynthScene-v1, "
-                                    f"view r -> rank r mod N ({len(cams)} on rank 0)") +
-                                   ", 100k Gaussians, colour render fwd+bwd per view" + (" (rgb_colors frozen: no colour gradient)" if args.frozen_colours else "") +
-                                   ("" if world == 1 else f", 1 RCCL all-reduce of the {n_bucket}-float parameter-gradient bucket") +
-                                   ("" if args.no_optimizer else ", Adam step (FusedAdam)"),
-                       "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": len(cams), "image": [H, W],
-                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}", "grad_bucket_floats": n_bucket,
-                       "optimizer_in_timed_region": not args.no_optimizer,
-                       "call_pattern": "rasterize_gaussians_views + autograd" if args.autograd else
-                                       "gsdyn.step.render_step_views: activations, ONE multi-view forward (capacity mode), ONE multi-view backward, direct library calls"},
-            "roofline": roofline, "cfg3": cfg3, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    return roofline
 
 
 def bench_config5(args, dev, rank, world):

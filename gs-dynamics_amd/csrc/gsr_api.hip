@@ -252,7 +252,7 @@ int check_geometry_of(int V, const int32_t* geometry_of) {
 int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
            void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
            const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st,
-           uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
+           uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr, int flags = 0) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
@@ -274,6 +274,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     if (v == 0) {
       bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = counts_dev; bt.P = P;
       bt.rows = tile_rows ? gsr_bin_rows(P) : 0;
+      bt.forward_only = (flags & GSR_FORWARD_ONLY) ? 1 : 0;
       bt.order = order ? order : im.tile_order;
       bt.queue = queue ? queue : im.queue;
       render_header(rt, V, cam, bt.order, bt.queue);
@@ -393,7 +394,7 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
                              void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                             void* stream) {
+                             int32_t flags, void* stream) {
   GsrRange _range("gsr_forward_render_batch");
   if (int rc = check_batch("gsr_forward_render_batch", V, s, batch_state)) return rc;
   if (!num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
@@ -403,7 +404,7 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   return stage2(V, s, P, num_rendered, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags);
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -412,7 +413,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
                       void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                      uint32_t* num_rendered_host, void* stream) {
+                      uint32_t* num_rendered_host, int32_t flags, void* stream) {
   GsrRange _range("gsr_forward_batch");
   if (int rc = check_batch("gsr_forward_batch", V, s, batch_state)) return rc;
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
@@ -434,7 +435,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   }
   if (!fits) return 1;
   return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags);
 }
 
 int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -549,7 +550,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; bt.forward_only = 0; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];

@@ -643,7 +643,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
 #define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
 #define BIN_DIRECT_ROWS 32
 #define BIN_ROW_CHUNK 16
-#define BIN_BIG_AREA 64        // rects with more tiles are walked by the whole workgroup, not by their Gaussian's lane
+#define BIN_BIG_AREA 64        // rects with more tiles are walked by a whole wave, not by their Gaussian's lane
+#define BIN_BIG_MAX 1024       // such Gaussians parked per workgroup (LDS); beyond it their lanes walk them after all
 
 struct BinGauss { uint32_t minx, miny, w, area, mask; float rw; };
 __device__ __forceinline__ BinGauss bin_gauss(uint2 r, uint32_t mask) {
@@ -680,12 +681,20 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   extern __shared__ uint32_t s_cnt[];                 // [T] tile counters
   __shared__ uint32_t s_red[BIN_THREADS / 64];
   __shared__ uint32_t s_wave[BIN_THREADS / 64];
-  __shared__ uint32_t s_big[GSR_BIN_G];               // Gaussians (local index) whose rect is walked by the whole workgroup
+  __shared__ uint2 s_big[BIN_BIG_MAX];                // rects of the Gaussians that are walked by a whole wave (area > BIN_BIG_AREA)
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
   const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
   const bool lists = !vw.shares_lists;
+  // forward-only calls: offsets[] and the offset word of the records have no reader (only the backward addresses record slots); a
+  // view that shares its lists has nothing else to do here.  (The word is ONE scattered 4-byte store per Gaussian and view into the
+  // 64-byte records: 57 of this kernel's 134 us at 500 k Gaussians x 8 views.)
+  const bool want_offsets = !tab.forward_only;
+  if (!lists && !want_offsets) {
+    if (blockIdx.x == 0 && tid == 0) vw.offsets[P] = 0;
+    return;
+  }
   // every global load of the kernel is issued here, ahead of the first wait (the launch is a chain of memory round trips otherwise)
   uint32_t tt[BIN_PER_THREAD];
   uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
 #pragma unroll
   for (int q = 0; q < BIN_PER_THREAD; ++q) {
     const int g = g0 + tid * BIN_PER_THREAD + q;
-    if (g < P) {
+    if (g < P && want_offsets) {
       vw.offsets[g] = run;
       reinterpret_cast<uint32_t*>(vw.rec_w + GSR_REC_F4 * (size_t)g + 3)[2] = run;   // the blend backward reads it from the record
     }
@@ -735,15 +744,17 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   for (int q = 0; q < BIN_PER_THREAD; ++q) {
     if (!tt[q]) continue;
     const BinGauss b = bin_gauss(rc[q], ek[q].y);
-    if (b.area > BIN_BIG_AREA) { s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)(tid * BIN_PER_THREAD + q); continue; }
+    if (b.area > BIN_BIG_AREA) {                      // a large rect (taken whole): parked for a whole wave (a lane walking hundreds
+      const uint32_t slot = atomicAdd(&s_nbig, 1u);   // of tiles alone would hold its wave up); a full list: the lane does walk it
+      if (slot < BIN_BIG_MAX) { s_big[slot] = rc[q]; continue; }
+    }
     bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
   }
   __syncthreads();
-  const uint32_t nbig = s_nbig;
-  for (uint32_t i = 0; i < nbig; ++i) {               // large rects (taken whole): every thread takes a slice of the tiles
-    const int g = g0 + (int)s_big[i];
-    const BinGauss b = bin_gauss(vw.rect[g], 0u);
-    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
+  const uint32_t nbig = min(s_nbig, (uint32_t)BIN_BIG_MAX);
+  for (uint32_t i = wv; i < nbig; i += BIN_THREADS / 64) {   // one wave per parked Gaussian, a lane per tile
+    const BinGauss b = bin_gauss(s_big[i], 0u);
+    for (uint32_t k = lane; k < b.area; k += 64) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
   }
   if (nbig) __syncthreads();
   uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
@@ -851,11 +862,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_order_kernel(GsrBinViews
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinViews tab) {
   extern __shared__ uint32_t s_cur[];                 // [T] next free slot of every tile for this workgroup
-  __shared__ uint32_t s_big[GSR_BIN_G];
+  __shared__ uint2 s_big[BIN_BIG_MAX];                // see bin_count_kernel
+  __shared__ uint64_t s_bigkey[BIN_BIG_MAX];
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
   if (vw.shares_lists) return;
-  const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x;
+  const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
   const uint32_t cap = vw.D;
   const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
@@ -874,20 +886,22 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
   for (int q = 0; q < BIN_PER_THREAD; ++q) {
     const BinGauss b = bin_gauss(rc[q], ek[q].y);
     if (b.area == 0u) continue;
-    if (b.area > BIN_BIG_AREA) { s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)(tid * BIN_PER_THREAD + q); continue; }
     const uint64_t key = ((uint64_t)ek[q].x << 32) | (uint32_t)(g0 + tid * BIN_PER_THREAD + q);
+    if (b.area > BIN_BIG_AREA) {
+      const uint32_t slot = atomicAdd(&s_nbig, 1u);
+      if (slot < BIN_BIG_MAX) { s_big[slot] = rc[q]; s_bigkey[slot] = key; continue; }
+    }
     bin_for_tiles(b, gx, [&](uint32_t t) {
       const uint32_t slot = atomicAdd(&s_cur[t], 1u);
       if (slot < cap) dg[slot] = key;
     });
   }
   __syncthreads();
-  const uint32_t nbig = s_nbig;
-  for (uint32_t i = 0; i < nbig; ++i) {
-    const int g = g0 + (int)s_big[i];
-    const BinGauss b = bin_gauss(vw.rect[g], 0u);
-    const uint64_t key = ((uint64_t)vw.ekey[g].x << 32) | (uint32_t)g;
-    for (uint32_t k = tid; k < b.area; k += BIN_THREADS) {
+  const uint32_t nbig = min(s_nbig, (uint32_t)BIN_BIG_MAX);
+  for (uint32_t i = wv; i < nbig; i += BIN_THREADS / 64) {
+    const BinGauss b = bin_gauss(s_big[i], 0u);
+    const uint64_t key = s_bigkey[i];
+    for (uint32_t k = lane; k < b.area; k += 64) {
       const uint32_t slot = atomicAdd(&s_cur[bin_tile_of(b, k, gx)], 1u);
       if (slot < cap) dg[slot] = key;
     }

@@ -188,6 +188,7 @@ struct GsrBinViews {
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
   int wave_cap;                  // tile_sort: lists up to this length (512 / 1024) are sorted by one wave each (set by gsr_launch_binning)
   int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
+  int forward_only;              // GSR_FORWARD_ONLY: no backward will read these states (the record-slot offsets are not produced)
   GsrBinView v[GSR_MAX_BATCH];
 };
 struct GsrRenderView {         // blend forward / backward

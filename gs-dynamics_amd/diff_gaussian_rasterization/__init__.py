@@ -158,8 +158,9 @@ class _RasterizeGaussiansViews(torch.autograd.Function):
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         sh_, col_, op_ = _prep(sh), _prep(colors_precomp), _prep(opacities)
         sc_, rot_, cov_ = _prep(scales), _prep(rotations), _prep(cov3Ds_precomp)
+        wants_grad = any(ctx.needs_input_grad)
         color, radii, depth, states = _hip.rasterize_forward_batch(list(settings_list), m3, op_, col_, sh_, sc_, rot_, cov_,
-                                                                   prepare_backward=any(ctx.needs_input_grad))
+                                                                   prepare_backward=wants_grad, **({} if wants_grad else {"forward_only": True}))
         ctx.states = states
         ctx.has = (sh_ is not None, col_ is not None, sc_ is not None, cov_ is not None)
         empty = m3.new_empty(0)

@@ -107,10 +107,10 @@ def load_library():
     lib.gsr_forward_preprocess_batch.restype = C.c_int
     lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, vp, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
-    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, C.POINTER(i32), PV, PV, vp]
+    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, C.POINTER(i32), PV, PV, i32, vp]
     lib.gsr_forward_batch.restype = C.c_int
     lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(sz), PV, vp,
-                                      C.POINTER(i32), PV, PV, C.POINTER(u32), vp])
+                                      C.POINTER(i32), PV, PV, C.POINTER(u32), i32, vp])
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = ([i32, PS, i32, C.POINTER(u32)] + [vp] * 5 + [PV] * 4 + [vp, C.POINTER(i32), PV, PV]
                                        + [vp, PV, vp, PV, vp, vp, vp, vp, vp])
@@ -262,9 +262,10 @@ def _dev_f32(t: torch.Tensor, dev: torch.device, n: int, name: str) -> torch.Ten
 class RasterState:
     """What forward hands to backward (the role of the reference extension's three opaque buffers)."""
     __slots__ = ("settings", "keep", "P", "num_rendered", "geom", "binning", "image", "H", "W", "pre", "batch", "geometry_of",
-                 "pending", "act", "raw_fused")
+                 "pending", "act", "raw_fused", "forward_only")
 
     def __init__(self):
+        self.forward_only = False  # batch forward with forward_only=True: the states cannot be differentiated
         self.act = None          # batch forward with raw=...: (rotations, opacities, scales) after their activations (view 0's state)
         self.raw_fused = None    # (unnorm_rotations,) when the activations ran inside the forward: the backward applies their chain too
 
@@ -381,8 +382,11 @@ def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False
         scratch=[torch.empty((b,), dtype=torch.uint8, device=dev) for b in scratch_bytes])
 
 
+FORWARD_ONLY = 1        # GSR_FORWARD_ONLY of include/gsr.h
+
+
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                            prepare_backward: bool = False, no_host_sync: bool = False, raw=None):
+                            prepare_backward: bool = False, no_host_sync: bool = False, raw=None, forward_only: bool = False):
     """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V]).
     ``raw = (unnorm_rotations, logit_opacities, log_scales)`` (then ``opacities`` / ``scales`` / ``rotations`` are None): the
     activations are applied inside the preprocess kernel when the call runs in capacity mode (``states[0].raw_fused``), by
@@ -521,14 +525,16 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
                                    _ptr(col_shared), col_views, _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
                                    _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
-                                   _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), Ds, st)
+                                   _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), Ds,
+                                   FORWARD_ONLY if forward_only else 0, st)
         if rc not in (0, 1):
             _check(rc, "gsr_forward_batch")
         need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
         if rc == 1:
             binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) if owner[v] else None for v in range(V)]
             _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                                _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), st),
+                                                _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v),
+                                                FORWARD_ONLY if forward_only else 0, st),
                    "gsr_forward_render_batch")
         _entries_capacity[key] = max(int(max(Ds[v] for v in range(V)) * _ENTRIES_SLACK), 1024)
         if rc == 1 or need * 2 < cap:
@@ -546,6 +552,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         state.geometry_of = geometry_of if v == 0 else None
         state.pending = None
         state.act = act if v == 0 else None
+        state.forward_only = bool(forward_only)
         states.append(state)
     return color, radii, depth, states
 
@@ -586,6 +593,8 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
     dev = means3D.device
     V = len(states)
     P = states[0].P
+    if states[0].forward_only:
+        raise RuntimeError("rasterize_backward_batch: these states come from a forward_only forward (no record-slot offsets were produced)")
     f32 = dict(dtype=torch.float32, device=dev)
     if shs is not None:  # SH colours: per-view backward + sum (the fused multi-view kernel covers precomputed colours)
         outs = [rasterize_backward(states[v], grad_color[v], means3D, radii[v], None, shs, scales, rotations, cov3D_precomp)

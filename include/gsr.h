@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 112 /* 0.1.12: gsr_fps scratch is gsr_fps_scratch_bytes(N, npoints) bytes (0.1.11 and earlier: N floats) */
+#define GSR_VERSION 113 /* 0.1.13: gsr_forward_batch / gsr_forward_render_batch take `flags` (GSR_FORWARD_ONLY); 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -115,10 +115,14 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                  const float* const* colors_views, const float* shs, const float* cov3D_precomp,
                                  void* const* geom_states,
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
+/* flags of the batch forward: GSR_FORWARD_ONLY = the caller will NOT run gsr_backward_batch on the states of this call (the
+ * no-grad renders of /root/reference/src/render/renderer.py:18-23, /root/reference/src/predict.py:115-123): the forward then skips
+ * what only the backward reads (the per-Gaussian record-slot offsets: one scattered store per Gaussian and view). */
+#define GSR_FORWARD_ONLY 1
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
                              void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                             void* stream);
+                             int32_t flags, void* stream);
 /* Both forward stages in ONE call: preprocess all views, synchronise once for the duplicate counts, and -- when
  * every view's binning state fits the buffer the caller provided (binning_bytes[v] >= gsr_binning_bytes(D_v)) --
  * launch the render stage straight away, with no host round trip through the caller in between (that round trip
@@ -131,7 +135,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
                       void* const* geom_states, int32_t* const* radii,
                       void* const* binning_states, const size_t* binning_bytes, void* const* image_states,
                       void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                      uint32_t* num_rendered_host, void* stream);
+                      uint32_t* num_rendered_host, int32_t flags, void* stream);
 /* Backward of all V views (precomputed colours only; with SH use gsr_backward per view): ONE blend-backward launch
  * over the combined tile queue, then ONE per-Gaussian kernel that loops over the views and writes the
  * gradients SUMMED over views.  Only dL_dmeans2D stays per view ([V] pointers to [P,3]). */

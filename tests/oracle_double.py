@@ -37,7 +37,7 @@ def rasterize_backward(state, grad_color, means3D, radii, colors_precomp, shs, s
 
 
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                            prepare_backward=False):
+                            prepare_backward=False, forward_only=False, **_kw):
     """V views, optionally with per-view colours ([V,P,3]) -- one oracle run per view."""
     per_view = colors_precomp is not None and colors_precomp.dim() == 3
     outs = [rasterize_forward(rs, means3D, opacities, colors_precomp[v] if per_view else colors_precomp, shs, scales, rotations,

@@ -3,11 +3,14 @@
 # SQ counters.  Outputs under gpurun_out/ (copy to profiles/ with the round prefix):
 #   kernel_stats.txt, pmc_traffic.json, sq_counters.json, sq_render.txt, marker_ranges.txt
 # --pmc passes use --kernel-trace only (no sys/hip/hsa/marker trace domains next to counters).
+# usage: tools/prof_round.sh [VIEWS]   (8 = bench.py default; 4 = --config 3, BASELINE.json's own 4 x 800^2 configuration)
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
-BENCH="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras"
+VIEWS=${1:-8}; export GSR_PROF_VIEWS=$VIEWS
+WL="--views $VIEWS"; [ "$VIEWS" = "4" ] && WL="--config 3"
+BENCH="python $R/bench.py $WL --steps 3 --warmup 2 --no-cpu-baseline --no-extras"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $O/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o run -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_stats.log 2>&1 || true
+rm -rf $O/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o run -- python $R/bench.py $WL --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_stats.log 2>&1 || true
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/prof_$c
   rocprofv3 --kernel-trace --output-format csv --pmc $c --kernel-include-regex "render_" -d $O/prof_$c -o run -- $BENCH > $O/prof_$c.log 2>&1 || true
@@ -19,13 +22,13 @@ for set in "$P1" "$P2"; do
   i=$((i+1)); rm -rf $O/prof_sq$i
   rocprofv3 --kernel-trace --output-format csv --pmc $set --kernel-include-regex "render_" -d $O/prof_sq$i -o run -- $BENCH > $O/prof_sq$i.log 2>&1 || true
 done
-rm -rf $O/prof_marker && rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/prof_marker -o run -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_marker.log 2>&1 || true
+rm -rf $O/prof_marker && rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/prof_marker -o run -- python $R/bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_marker.log 2>&1 || true
 cd $R
-python tools/prof_summarize.py stats $O/prof_stats > $O/kernel_stats.txt || true
+python tools/prof_summarize.py stats $O/prof_stats > $O/kernel_stats_v$VIEWS.txt || true
 python - <<'PY'
 import csv, glob, json, os, collections
 R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd()); O = os.path.join(R, "gpurun_out")
-P, Npx, V = 100_000, 640_000, 8
+P, Npx, V = 100_000, 640_000, int(os.environ.get("GSR_PROF_VIEWS", "8"))
 def kname(n):
     return "render_fwd" if "render_fwd" in n else "render_bwd" if "render_bwd" in n else None
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
@@ -52,20 +55,20 @@ for k, m in mean.items():
     cal[k] = {"FETCH_SIZE_KiB_raw": f_raw / 1024.0, "WRITE_SIZE_KiB_raw": w_raw / 1024.0, "fabric_bytes_per_launch": fetched + w_raw,
               "hbm_bytes_per_launch": fetched + written,
               "note": "hbm_bytes = bytes fetched (calibrated) + bytes stored; fabric_bytes counts the partial-sector cost of the scattered record stores too"}
-json.dump(cal, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
+json.dump(cal, open(os.path.join(O, f"pmc_traffic_v{V}.json"), "w"), indent=1)
 sq = {k: {n: v for n, v in m.items() if n.startswith("SQ_")} for k, m in mean.items()}
 sq.update({"views_per_launch": V, "clock_hz": 2.2e9,
            "source": "rocprofv3 --pmc SQ_* (two passes), tools/prof_round.sh; means per dispatch; *_CYCLES / ACTIVE / WAIT in quad-cycles"})
-json.dump(sq, open(os.path.join(O, "sq_counters.json"), "w"), indent=1)
-with open(os.path.join(O, "sq_render.txt"), "w") as fh:
-    fh.write("# rocprofv3 --pmc, bench.py default (one launch = 8 views); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles\n")
+json.dump(sq, open(os.path.join(O, f"sq_counters_v{V}.json"), "w"), indent=1)
+with open(os.path.join(O, f"sq_render_v{V}.txt"), "w") as fh:
+    fh.write(f"# rocprofv3 --pmc, bench.py (one launch = {V} views); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles\n")
     for k, m in mean.items():
         for n in sorted(m):
             fh.write(f"{k:12s} {n:24s} {m[n]:16.1f}\n")
         wc = m.get("SQ_WAVE_CYCLES", 0) or 1
         fh.write(f"{k}: VALU-active share of wave cycles {m.get('SQ_ACTIVE_INST_VALU', 0) / wc:.3f}, parked {m.get('SQ_WAIT_ANY', 0) / wc:.3f}, "
                  f"issue-stalled {m.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}, LDS array busy cycles {m.get('SQ_LDS_IDX_ACTIVE', 0):.0f}\n")
-print(json.dumps(cal, indent=1)); print(open(os.path.join(O, "sq_render.txt")).read())
+print(json.dumps(cal, indent=1)); print(open(os.path.join(O, f"sq_render_v{V}.txt")).read())
 # marker ranges: what a third-party timeline shows
 rows = collections.Counter()
 for f in glob.glob(os.path.join(O, "prof_marker", "**", "*marker_api_trace.csv"), recursive=True):
@@ -75,4 +78,4 @@ open(os.path.join(O, "marker_ranges.txt"), "w").write("# roctx ranges seen by ro
 print(open(os.path.join(O, "marker_ranges.txt")).read()[:1500])
 PY
 rm -rf $O/prof_FETCH_SIZE $O/prof_WRITE_SIZE $O/prof_sq1 $O/prof_sq2 $O/prof_stats $O/prof_marker
-cat $O/kernel_stats.txt | head -30
+cat $O/kernel_stats_v$VIEWS.txt | head -30

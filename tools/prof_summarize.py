@@ -17,7 +17,8 @@ def find(d, pat):
 
 def short(name):
     for tag in ("render_fwd", "render_bwd", "preprocess_fwd", "preprocess_bwd", "emit_entries", "radix_hist", "radix_scatter",
-                "tile_ranges_order", "tile_order", "tile_sort", "scan_exclusive", "mark_visible"):
+                "tile_ranges_order", "tile_order", "tile_sort", "scan_exclusive", "mark_visible", "bin_count", "bin_scan_order", "bin_scan", "bin_emit",
+                "bin_colprefix", "adam_step"):
         if tag in name:
             return tag
     name = name.replace("void ", "").replace("at::native::", "")
