@@ -100,23 +100,34 @@ struct PartialSum { float gmx, gmy, gA, gB, gC, gop, dr, dg, db; };
 __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__ partials, uint32_t e0, uint32_t e1, bool col = true) {
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2x = 0.f;
+  // FOUR records per trip, all of their loads issued before the first is used: the walk is a chain of memory round trips (a lane's
+  // records are contiguous, the lanes of a wave are ~150 bytes apart), and the trip count -- the longest rect of the wave -- was the
+  // kernel's time.  The additions keep their order (record e0 first).
+  constexpr int RU = 4;
   if (!col) {
-    for (uint32_t e = e0; e < e1; ++e) {
-      float4 q0;
-      float q1x, q1y;
-      gsr_load_partial6(partials, e, q0, q1x, q1y);
-      r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
-      r1.x += q1x; r1.y += q1y;
+    for (uint32_t e = e0; e < e1; e += RU) {
+      float4 q0[RU];
+      float q1x[RU], q1y[RU];
+#pragma unroll
+      for (int k = 0; k < RU; ++k) if (e + k < e1) gsr_load_partial6(partials, e + k, q0[k], q1x[k], q1y[k]);
+#pragma unroll
+      for (int k = 0; k < RU; ++k)
+        if (e + k < e1) { r0.x += q0[k].x; r0.y += q0[k].y; r0.z += q0[k].z; r0.w += q0[k].w; r1.x += q1x[k]; r1.y += q1y[k]; }
     }
     e0 = e1;
   }
-  for (uint32_t e = e0; e < e1; ++e) {
-    float4 q0, q1;
-    float q2x;
-    gsr_load_partial(partials, e, q0, q1, q2x);
-    r0.x += q0.x; r0.y += q0.y; r0.z += q0.z; r0.w += q0.w;
-    r1.x += q1.x; r1.y += q1.y; r1.z += q1.z; r1.w += q1.w;
-    r2x += q2x;
+  for (uint32_t e = e0; e < e1; e += RU) {
+    float4 q0[RU], q1[RU];
+    float q2x[RU];
+#pragma unroll
+    for (int k = 0; k < RU; ++k) if (e + k < e1) gsr_load_partial(partials, e + k, q0[k], q1[k], q2x[k]);
+#pragma unroll
+    for (int k = 0; k < RU; ++k)
+      if (e + k < e1) {
+        r0.x += q0[k].x; r0.y += q0[k].y; r0.z += q0[k].z; r0.w += q0[k].w;
+        r1.x += q1[k].x; r1.y += q1[k].y; r1.z += q1[k].z; r1.w += q1[k].w;
+        r2x += q2x[k];
+      }
   }
   PartialSum ps;
   // the blend backward stores the conic partials without their constant factors (dA: -1/2, dB: -1, dC: -1/2)
@@ -366,6 +377,104 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
   }
 }
 
+// ---- all views of a step at once, ONE WAVE PER VIEW (V >= 2) ------------------------------------------
+// The loop above walks the views strictly load -> chain -> load at 1.5 waves per SIMD: 62 us for 8 views of 100 k Gaussians, 22 % of the
+// HBM roofline.  Here a workgroup owns 64 Gaussians and has one wave per (non-alias) view: the view is wave-uniform (its matrices and
+// pointers stay scalar loads), every wave reduces its view's records and runs that view's chain for the 64 Gaussians, parks its 13
+// per-Gaussian sums in LDS ([view][value][lane]: conflict-free), and wave 0 adds the views up in view order -- the same order of
+// additions as the loop, hence the same bits -- and finishes with the view-independent part (scale / rotation chain, activations).
+// V x more waves in flight, no second pass over HBM.
+#define PBW_VALUES 13      // gcov[6], gm3[3], gop, gcol[3]
+__global__ __launch_bounds__(64 * GSR_MAX_BATCH) void preprocess_bwd_views_waves_kernel(
+    GsrBwdViews vw, int P, float mod, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D) {
+  extern __shared__ float s_part[];                  // [waves][PBW_VALUES + 1][64]  (+1: "this view saw the Gaussian")
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < P;
+  // wave wv's view: the wv-th view that is not a fused alias (uniform: scalar code)
+  int v = -1;
+  for (int u = 0, k = 0; u < vw.V; ++u)
+    if (!vw.v[u].fused_alias) { if (k == wv) { v = u; break; } ++k; }
+  const GsrBwdView& w = vw.v[v < 0 ? 0 : v];
+  float3 p = make_float3(0.f, 0.f, 0.f);
+  Cov3 cv;
+  if (live) {
+    p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    build_cov3(i, mod, scales, rotations, cov3D_precomp, cv);
+  }
+  float gm3[3] = {0.f, 0.f, 0.f}, gcol[3] = {0.f, 0.f, 0.f}, gop = 0.f, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float seen = 0.f;
+  if (live && v >= 0) {
+    float gm2[2] = {0.f, 0.f}, gm2a[2] = {0.f, 0.f};
+    const bool pair = w.partner_dL_dmeans2D != nullptr;
+    if (w.radii[i] > 0) {
+      seen = 1.f;
+      const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap),
+                                            pair || w.dL_dcolors != nullptr || dL_dcolors != nullptr);
+      gop = ps.gop;
+      if (pair) {
+        view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2, ps.dr, ps.dg, gm2a);
+      } else {
+        if (w.dL_dcolors) { w.dL_dcolors[3 * i] = ps.dr; w.dL_dcolors[3 * i + 1] = ps.dg; w.dL_dcolors[3 * i + 2] = ps.db; }
+        else { gcol[0] = ps.dr; gcol[1] = ps.dg; gcol[2] = ps.db; }
+        view_chain(w.view, w.proj, w.W, w.H, w.tanfovx, w.tanfovy, p, cv.c, ps, gcov, gm3, gm2);
+      }
+    } else if (w.dL_dcolors) {
+      w.dL_dcolors[3 * i] = 0.f; w.dL_dcolors[3 * i + 1] = 0.f; w.dL_dcolors[3 * i + 2] = 0.f;
+    }
+    if (pair) {
+      w.dL_dmeans2D[3 * i] = gm2a[0]; w.dL_dmeans2D[3 * i + 1] = gm2a[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+      float* m2b = w.partner_dL_dmeans2D;
+      m2b[3 * i] = gm2[0] - gm2a[0]; m2b[3 * i + 1] = gm2[1] - gm2a[1]; m2b[3 * i + 2] = 0.f;
+    } else {
+      w.dL_dmeans2D[3 * i] = gm2[0]; w.dL_dmeans2D[3 * i + 1] = gm2[1]; w.dL_dmeans2D[3 * i + 2] = 0.f;
+    }
+  }
+  float* mine = s_part + (size_t)wv * (PBW_VALUES + 1) * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mine[k * 64] = gcov[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { mine[(6 + k) * 64] = gm3[k]; mine[(10 + k) * 64] = gcol[k]; }
+  mine[9 * 64] = gop;
+  mine[PBW_VALUES * 64] = seen;
+  __syncthreads();
+  if (wv != 0 || !live) return;
+  // view order: the loop kernel adds view 0's terms to zero-initialised sums first -- start from this wave's own values (view order
+  // = wave order) and add the others in order
+  bool any = seen != 0.f;
+  for (int u = 1; u < nw; ++u) {
+    const float* q = s_part + (size_t)u * (PBW_VALUES + 1) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gcov[k] += q[k * 64];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gm3[k] += q[(6 + k) * 64]; gcol[k] += q[(10 + k) * 64]; }
+    gop += q[9 * 64];
+    any = any || q[PBW_VALUES * 64] != 0.f;
+  }
+  float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
+  dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
+  if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
+  if (vw.d_raw_rot) {
+    reinterpret_cast<float4*>(vw.d_raw_rot)[i] =
+        gsr_act_rotation_bwd(reinterpret_cast<const float4*>(vw.raw_rot)[i], make_float4(gq[0], gq[1], gq[2], gq[3]));
+    const float o = vw.act_op[i];
+    vw.d_raw_op[i] = gop * o * (1.0f - o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vw.d_raw_sc[3 * (size_t)i + k] = gs[k] * vw.act_sc[3 * (size_t)i + k];
+  }
+  if (dL_dopacity) dL_dopacity[i] = gop;
+  if (dL_dscales) { dL_dscales[3 * i] = gs[0]; dL_dscales[3 * i + 1] = gs[1]; dL_dscales[3 * i + 2] = gs[2]; }
+  if (dL_drot) { dL_drot[4 * i] = gq[0]; dL_drot[4 * i + 1] = gq[1]; dL_drot[4 * i + 2] = gq[2]; dL_drot[4 * i + 3] = gq[3]; }
+  if (dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = gcov[k];
+  }
+}
+
 }  // namespace gsr_preprocess_bwd
 using namespace gsr_preprocess_bwd;
 
@@ -399,6 +508,17 @@ int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_mo
                                     float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity, float* dL_dscales,
                                     float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
   if (P <= 0) return 0;
+  int nact = 0;
+  for (int v = 0; v < vw.V; ++v) nact += vw.v[v].fused_alias ? 0 : 1;
+  static const bool loop_only = [] { const char* e = getenv("GSR_BWD_VIEWS_LOOP"); return e && *e && atoi(e) != 0; }();
+  if (nact >= 2 && !loop_only) {      // one wave per view
+    { GSR_PROF("preprocess_bwd_views", st);
+      hipLaunchKernelGGL(preprocess_bwd_views_waves_kernel, dim3((P + 63) / 64), dim3(64 * nact), sizeof(float) * (size_t)nact * (PBW_VALUES + 1) * 64,
+                         st, vw, P, scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity,
+                         dL_dscales, dL_drotations, dL_dcov3D); }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   { GSR_PROF("preprocess_bwd_views", st);
     hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, vw, P,
                        scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity,
