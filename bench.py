@@ -581,9 +581,17 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         def fwd():
             with torch.no_grad():
                 GaussianRasterizer(raster_settings=cam)(**rv)
+        import diff_gaussian_rasterization as dgr
+        if dgr._C is not None:       # a FULL forward per call: the same frame rendered again would be served from the remembered tile lists
+            dgr._C.set_list_reuse(False)
         ms = _time_ms(fwd, 20, 5)
-        out["forward_only_cfg2"] = {"ms_per_view": ms, "Mpix_per_s": H * W / ms / 1e3,
-                                    "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only"}
+        ms_same = None
+        if dgr._C is not None:
+            dgr._C.set_list_reuse(True)
+            ms_same = _time_ms(fwd, 20, 5)
+        out["forward_only_cfg2"] = {"ms_per_view": ms, "Mpix_per_s": H * W / ms / 1e3, "ms_per_view_same_geometry_again": ms_same,
+                                    "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only (tile-list reuse off: every call "
+                                            "bins and sorts; *_same_geometry_again: the unchanged frame rendered again reuses the lists)"}
     except Exception as e:  # noqa: BLE001
         out["forward_only_cfg2"] = {"error": repr(e)}
     try:   # predict.py's frame (row A11): every camera rendered twice, colours and an all-ones mask (predict.py:100-123)

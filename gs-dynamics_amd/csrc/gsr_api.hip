@@ -98,7 +98,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums; o.ekey = g.ekey;
+  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
@@ -136,7 +136,7 @@ void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* ord
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).
 uint32_t* pinned_sums() {
   static thread_local uint32_t* p = nullptr;
-  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
+  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * (GSR_MAX_BATCH + 2) * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
     p = nullptr;
   return p;
 }
@@ -165,7 +165,7 @@ int check_inputs(const char* who, const float* means3D, const float* opacities, 
 int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
-           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr) {
+           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, uint64_t* fingerprint_host = nullptr) {
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -201,6 +201,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     GeomState g;
     gsr_carve_geom(geom_states[v], P, &g);
     fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
+    if (fingerprint_host && V == 1 && gsr_host_block_scan(P)) tab.v[v].block_hash = g.block_hash;
   }
   if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
     return rc;
@@ -215,9 +216,17 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
   }
   uint32_t* host = pinned_sums();
   if (!host) { gsr_set_error("gsr forward: pinned host allocation failed"); return -1; }
+  if (fingerprint_host) *fingerprint_host = 0;
   if (gsr_host_block_scan(P)) {
     GSR_HIP_CHECK(hipMemcpyAsync(host, sums, sizeof(uint32_t) * nblk * V, hipMemcpyDeviceToHost, st));
+    uint32_t* hash_host = host + (size_t)GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS;      // behind the counts (see pinned_sums)
+    if (tab.v[0].block_hash) GSR_HIP_CHECK(hipMemcpyAsync(hash_host, tab.v[0].block_hash, sizeof(uint2) * nblk, hipMemcpyDeviceToHost, st));
     GSR_HIP_CHECK(hipStreamSynchronize(st));
+    if (tab.v[0].block_hash) {
+      uint64_t fp = 0x243F6A8885A308D3ull ^ (uint64_t)P;
+      for (uint32_t b = 0; b < nblk; ++b) fp ^= ((uint64_t)hash_host[2 * b + 1] << 32) | hash_host[2 * b];
+      *fingerprint_host = fp ? fp : 1ull;        // 0 = "no fingerprint"
+    }
     for (int v = 0; v < V; ++v) {
       uint64_t tot = 0;
       for (uint32_t b = 0; b < nblk; ++b) tot += host[(size_t)v * nblk + b];
@@ -303,7 +312,16 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
                            const float* rotations, const float* opacities, const float* colors_precomp,
                            const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
                            uint32_t* num_rendered_host, void* stream) {
+  return gsr_forward_preprocess_fp(s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_state, radii,
+                                   num_rendered_host, nullptr, stream);
+}
+
+int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                              const float* rotations, const float* opacities, const float* colors_precomp,
+                              const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
+                              uint32_t* num_rendered_host, uint64_t* fingerprint_host, void* stream) {
   GsrRange _range("gsr_forward_preprocess");
+  if (fingerprint_host) *fingerprint_host = 0;
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
   if (num_rendered_host) *num_rendered_host = 0;
@@ -313,7 +331,7 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
   gsr_carve_geom(geom_state, P, &g);
   uint32_t D = 0;
   if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, nullptr, shs, cov3D_precomp, &geom_state,
-                      &radii, g.block_sums, &D, (hipStream_t)stream))
+                      &radii, g.block_sums, &D, (hipStream_t)stream, nullptr, fingerprint_host))
     return rc;
   if (num_rendered_host) *num_rendered_host = D;
   return 0;
@@ -326,6 +344,35 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
   void* geom = const_cast<void*>(geom_state);
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
                 nullptr, nullptr, (hipStream_t)stream);
+}
+
+int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
+                              const void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
+                              float* out_depth, void* stream) {
+  GsrRange _range("gsr_forward_render_shared");
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
+  if (P <= 0 || num_rendered == 0 || !geom_state || !owner_binning_state || !owner_image_state || !image_state || !out_color || !out_depth) {
+    gsr_set_error("gsr_forward_render_shared: NULL argument, or nothing rendered (use gsr_forward_render)");
+    return -2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GeomState g; ImageState im, im_owner; BinningState bs;
+  gsr_carve_geom(geom_state, P, &g);
+  gsr_carve_image(image_state, cam.H, cam.W, &im);
+  gsr_carve_image(const_cast<void*>(owner_image_state), cam.H, cam.W, &im_owner);
+  gsr_carve_binning(const_cast<void*>(owner_binning_state), num_rendered, &bs);
+  GsrBinViews bt;
+  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512;
+  bt.order = im.tile_order; bt.queue = im.queue;
+  fill_bin_view(bt.v[0], P, num_rendered, g, bs, im, g.block_sums);
+  if (int rc = gsr_launch_shared_lists(bt, P, num_rendered, im_owner.ranges, im_owner.tile_order, im_owner.queue, im.ranges, im.tile_order,
+                                       im.queue, st))
+    return rc;
+  GsrRenderViews rt;
+  render_header(rt, 1, cam, im.tile_order, im.queue);
+  fill_render_view(rt.v[0], cam, g, bs, im, out_color, out_depth, nullptr, nullptr);
+  return gsr_launch_render_fwd(rt, st);
 }
 
 int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const float* means3D,

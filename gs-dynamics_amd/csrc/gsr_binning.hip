@@ -1201,8 +1201,34 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
   }
 }
 
+// A view rendered from ANOTHER call's tile lists (gsr_forward_render_shared): its own image state gets the owner's ranges, tile
+// order and queue counts (the queue heads start at zero).
+__global__ __launch_bounds__(GSR_BLOCK) void copy_tile_state_kernel(int T, int n_order, const uint2* __restrict__ src_ranges,
+                                                                    const uint4* __restrict__ src_order, const uint32_t* __restrict__ src_queue,
+                                                                    uint2* __restrict__ ranges, uint4* __restrict__ order, uint32_t* __restrict__ queue) {
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i < T) ranges[i] = src_ranges[i];
+  if (i < n_order) order[i] = src_order[i];
+  if (i < 8) queue[i] = (i == 4 || i == 6 || i == 7) ? src_queue[i] : 0u;
+}
+
 }  // namespace gsr_binning
 using namespace gsr_binning;
+
+// offsets[] of a view whose lists are another call's (emit_entries in its offsets-only form), then the owner's tile state
+int gsr_launch_shared_lists(const GsrBinViews& tab_in, int P, uint32_t D, const uint2* owner_ranges, const uint4* owner_order,
+                            const uint32_t* owner_queue, uint2* ranges, uint4* order, uint32_t* queue, hipStream_t st) {
+  GsrBinViews tab = tab_in;
+  tab.v[0].shares_lists = 1;
+  { GSR_PROF("emit_entries", st);
+    hipLaunchKernelGGL(emit_entries_kernel, dim3(D / GSR_RADIX_EPB + 1u, 1), dim3(GSR_BLOCK), 0, st, P, tab, 0, 1); }
+  GSR_HIP_CHECK(hipGetLastError());
+  { GSR_PROF("copy_tile_state", st);
+    hipLaunchKernelGGL(copy_tile_state_kernel, dim3((tab.T + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, tab.T, tab.T, owner_ranges,
+                       owner_order, owner_queue, ranges, order, queue); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st) {
   { GSR_PROF("scan", st);

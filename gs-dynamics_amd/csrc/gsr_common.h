@@ -36,6 +36,8 @@ struct GeomState {
   uint32_t* counters;     // [0] = num_rendered
   uint2* ekey;            // [P] {depth bits, tile mask}: what the tile-row binning reads per Gaussian next to rect[] (coalesced 8 + 8 bytes
                           //     instead of two 16-byte gathers from the 64-byte record)
+  uint2* block_hash;      // [ceil(P/256)] 64-bit fingerprint per preprocess block of everything the tile lists depend on (single-view
+                          //     entry points: lets a second render with the same geometry reuse the first one's lists)
 };
 struct ImageState {
   float* final_T;         // [H*W]
@@ -73,6 +75,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->clamped = (uint32_t*)take(Pn * 4);
   g->counters = (uint32_t*)take(64);
   g->ekey = (uint2*)take(Pn * 8);
+  g->block_hash = (uint2*)take(nblk * 8);
   return off;
 }
 static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageState* im) {
@@ -161,6 +164,7 @@ struct GsrPreView {            // preprocess
   float tanfovx, tanfovy;
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
   uint2* ekey;
+  uint2* block_hash;     // nullptr: no fingerprint wanted
 };
 struct GsrPreViews {
   int V;
@@ -238,6 +242,8 @@ int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, cons
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
 int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);
+int gsr_launch_shared_lists(const GsrBinViews& tab, int P, uint32_t D, const uint2* owner_ranges, const uint4* owner_order,
+                            const uint32_t* owner_queue, uint2* ranges, uint4* order, uint32_t* queue, hipStream_t st);
 int gsr_launch_gather_counts(const GsrBinViews& tab, int P, uint32_t* counts_dev, hipStream_t st);   // counts_dev[v] = offsets_v[P]   // uses only V, T, order, queue, v[].ranges, v[].fused_alias
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st);
 int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st);

@@ -248,6 +248,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;
   }
+  // Fingerprint of what the tile lists depend on -- tile rect, tile mask, depth bits and the Gaussian's index -- XOR-ed over the
+  // block (the host XORs the blocks): two preprocess runs with equal fingerprints AND equal entry counts produce the same lists
+  // (up to a 2^-64 coincidence), whatever tensors the inputs came from.  Only when asked for (single-view entry points).
+  if (vw.block_hash) {
+    uint64_t h = ((uint64_t)(uint32_t)i + 1ull) * 0x9E3779B97F4A7C15ull;
+    h ^= (((uint64_t)rc.x << 32) | rc.y) * 0xC2B2AE3D27D4EB4Full;
+    h = (h << 31) | (h >> 33);
+    h ^= (((uint64_t)tmask << 32) | __float_as_uint(c2.y)) * 0x165667B19E3779F9ull;
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    if (!in_range) h = 0;
+    uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { hl ^= (uint32_t)__shfl_xor((int)hl, m, 64); hh ^= (uint32_t)__shfl_xor((int)hh, m, 64); }
+    __shared__ uint2 s_hash[GSR_BLOCK / GSR_WAVE];
+    if ((threadIdx.x & 63) == 0) s_hash[threadIdx.x >> 6] = make_uint2(hl, hh);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      vw.block_hash[blockIdx.x] = make_uint2(s_hash[0].x ^ s_hash[1].x ^ s_hash[2].x ^ s_hash[3].x, s_hash[0].y ^ s_hash[1].y ^ s_hash[2].y ^ s_hash[3].y);
+  }
   // per-block total of tiles_touched: feeds the two-level offsets scan (no full-length scan kernel)
   uint32_t wsum = tiles;
 #pragma unroll

@@ -11,6 +11,7 @@
 #include <c10/hip/HIPStream.h>
 #include <c10/hip/HIPGuard.h>
 
+#include <cstdlib>
 #include <string>
 #include <tuple>
 
@@ -62,6 +63,25 @@ Settings make_settings(const torch::Tensor& bg, const torch::Tensor& viewmatrix,
   return o;
 }
 
+// Tile-list reuse (include/gsr.h: gsr_forward_preprocess_fp / gsr_forward_render_shared).  The reference renders every camera twice with
+// the same geometry and other colours -- get_loss: colours then segmentation colours (/root/reference/src/tracking/train_utils.py:178,192),
+// predict.py: colours then an all-ones mask (:115-123) -- through two separate GaussianRasterizer calls whose geometry tensors are fresh
+// copies.  The layer remembers the LAST forward's lists (binning + image state tensors) with the fingerprint of what they depend on; a
+// forward whose preprocess yields the same (P, H, W, num_rendered, fingerprint) blends from those lists instead of emitting and sorting
+// its own: bit-identical outputs, ~55 us of GPU time less per second render at 100k / 800^2.  One entry per host thread; the tensors it
+// holds (~20 MB at that size) are released when another geometry replaces them.  GSR_NO_LIST_REUSE=1 / set_list_reuse(false) switch it off.
+struct ListCache {
+  bool valid = false;
+  int dev = -1;
+  int64_t P = 0, H = 0, W = 0;
+  uint32_t D = 0;
+  uint64_t fp = 0;
+  torch::Tensor binning, image;
+};
+thread_local ListCache g_lists;
+bool g_reuse = [] { const char* e = getenv("GSR_NO_LIST_REUSE"); return !(e && *e && atoi(e) != 0); }();
+int64_t g_reuse_hits = 0;
+
 // upstream: RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
 //           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered)
 //           -> (num_rendered, out_color, out_depth, radii, geomBuffer, binningBuffer, imgBuffer)        [the w-depth fork's tuple]
@@ -92,11 +112,25 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   torch::Tensor image = torch::empty({(int64_t)gsr_image_bytes((int32_t)H, (int32_t)W)}, u8);
   void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
   uint32_t D = 0;
-  check(gsr_forward_preprocess(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
-                               radii.data_ptr<int32_t>(), &D, stream), "gsr_forward_preprocess");
+  uint64_t fp = 0;
+  check(gsr_forward_preprocess_fp(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
+                                  radii.data_ptr<int32_t>(), &D, g_reuse ? &fp : nullptr, stream), "gsr_forward_preprocess");
+  ListCache& lc = g_lists;
+  if (g_reuse && fp != 0 && D > 0 && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.D == D && lc.fp == fp) {
+    // same geometry, same camera as the previous forward: its lists are this render's lists
+    check(gsr_forward_render_shared(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
+                                    color.data_ptr<float>(), depth.data_ptr<float>(), stream), "gsr_forward_render_shared");
+    ++g_reuse_hits;
+    return std::make_tuple((int64_t)D, color, depth, radii, geom, lc.binning, image);
+  }
   torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
   check(gsr_forward_render(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
                            depth.data_ptr<float>(), stream), "gsr_forward_render");
+  if (g_reuse && fp != 0 && D > 0) {
+    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.fp = fp; lc.binning = binning; lc.image = image;
+  } else {
+    lc = ListCache();
+  }
   return std::make_tuple((int64_t)D, color, depth, radii, geom, binning, image);
 }
 
@@ -181,5 +215,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("want_color_grad") = true);
   }
   m.def("mark_visible", &mark_visible);
+  m.def("set_list_reuse", [](bool on) { g_reuse = on; g_lists = ListCache(); });
+  m.def("list_reuse_hits", []() { return g_reuse_hits; });
+  m.def("drop_list_cache", []() { g_lists = ListCache(); });
   m.def("abi_version", []() { return (int)GSR_VERSION; });   // the header this layer was COMPILED against (compare with the library's gsr_version())
 }
