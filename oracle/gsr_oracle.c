@@ -38,6 +38,31 @@
 #include <omp.h>
 #endif
 
+typedef float gsro_f32;   /* a genuine binary32, whatever `float` means below */
+#ifdef GSRO_F64
+/* fp64 BUILD of the same restatement (oracle/Makefile: libgsr_oracle64.so; tests only): every `float` below is a double and every
+ * libm call its double form, so the identical sequence of operations is evaluated with 53-bit significands.  Used to tell how much of
+ * a difference between two fp32 evaluations (the HIP kernels and the fp32 build of this file) is conditioning: a Gaussian whose
+ * gradient is a small difference of large terms is off in ANY fp32 order.  The discrete decisions -- radii, tile rects, depth sort
+ * keys -- can be taken over from an fp32 run (gsro_set_overrides), so that both builds blend the same lists. */
+#define float double
+#define sqrtf sqrt
+#define expf exp
+#define logf log
+#define ceilf ceil
+#define floorf floor
+#define fabsf fabs
+#define fmaxf fmax
+#define fminf fmin
+#define powf pow
+#endif
+/* optional per-Gaussian decisions of another (fp32) run: radii [P], rect [P,4], binary32 depths [P] (NULL: computed here) */
+static const int32_t *g_over_radii = 0, *g_over_rect = 0;
+static const gsro_f32 *g_over_depth32 = 0;
+void gsro_set_overrides(const int32_t *radii, const int32_t *rect, const gsro_f32 *depth32) {
+  g_over_radii = radii; g_over_rect = rect; g_over_depth32 = depth32;
+}
+
 #define TILE 16
 #define NEAR_Z 0.2f
 #define ALPHA_MIN (1.0f / 255.0f)
@@ -233,6 +258,10 @@ static void preprocess_one(gsro_ctx *c, int i) {
   int miny = imin(c->gy, imax(0, f2i_sat((py - radius) / (float)TILE)));
   int maxx = imin(c->gx, imax(0, f2i_sat((px + radius + (float)(TILE - 1)) / (float)TILE)));
   int maxy = imin(c->gy, imax(0, f2i_sat((py + radius + (float)(TILE - 1)) / (float)TILE)));
+  if (g_over_rect) {   /* the other run's decisions: same Gaussians visible, same rects, same radii */
+    minx = g_over_rect[4 * i + 0]; miny = g_over_rect[4 * i + 1]; maxx = g_over_rect[4 * i + 2]; maxy = g_over_rect[4 * i + 3];
+    radius = (float)g_over_radii[i];
+  }
   if ((maxx - minx) * (maxy - miny) == 0) return;
 
   if (c->colors_precomp) {
@@ -334,15 +363,15 @@ gsro_ctx *gsro_forward(const gsro_camera *cam, int P, const float *means3D, cons
   c->means3D = means3D; c->scales = scales; c->rot = rot; c->opac = opac;
   c->colors_precomp = colors_precomp; c->shs = shs; c->cov3D_precomp = cov3D_precomp;
   size_t Pn = P > 0 ? (size_t)P : 1, N = (size_t)cam->H * cam->W;
-  c->means2D = (float *)calloc(2 * Pn, 4); c->depth = (float *)calloc(Pn, 4);
-  c->conic_opacity = (float *)calloc(4 * Pn, 4); c->rgb = (float *)calloc(3 * Pn, 4);
-  c->clamped = (uint8_t *)calloc(3 * Pn, 1); c->cov3D = (float *)calloc(6 * Pn, 4);
+  c->means2D = (float *)calloc(2 * Pn, sizeof(float)); c->depth = (float *)calloc(Pn, sizeof(float));
+  c->conic_opacity = (float *)calloc(4 * Pn, sizeof(float)); c->rgb = (float *)calloc(3 * Pn, sizeof(float));
+  c->clamped = (uint8_t *)calloc(3 * Pn, 1); c->cov3D = (float *)calloc(6 * Pn, sizeof(float));
   c->radii = (int32_t *)calloc(Pn, 4); c->rect = (int32_t *)calloc(4 * Pn, 4);
   c->tiles_touched = (uint32_t *)calloc(Pn, 4); c->offsets = (uint32_t *)calloc(Pn + 1, 4);
   c->ranges = (uint32_t *)calloc(2 * (size_t)c->T, 4);
-  c->final_T = (float *)calloc(N, 4); c->n_contrib = (uint32_t *)calloc(N, 4);
+  c->final_T = (float *)calloc(N, sizeof(float)); c->n_contrib = (uint32_t *)calloc(N, 4);
   c->ambiguous = (uint8_t *)calloc(N, 1);
-  c->out_color = (float *)calloc(3 * N, 4); c->out_depth = (float *)calloc(N, 4);
+  c->out_color = (float *)calloc(3 * N, sizeof(float)); c->out_depth = (float *)calloc(N, sizeof(float));
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -359,7 +388,8 @@ gsro_ctx *gsro_forward(const gsro_camera *cam, int P, const float *means3D, cons
   for (int i = 0; i < P; ++i) {
     if (c->radii[i] <= 0) continue;
     uint32_t off = c->offsets[i];
-    uint32_t dbits; memcpy(&dbits, &c->depth[i], 4);
+    gsro_f32 d32 = g_over_depth32 ? g_over_depth32[i] : (gsro_f32)c->depth[i];   /* sort key = binary32 depth bits, in every build */
+    uint32_t dbits; memcpy(&dbits, &d32, 4);
     for (int y = c->rect[4 * i + 1]; y < c->rect[4 * i + 3]; ++y)
       for (int x = c->rect[4 * i + 0]; x < c->rect[4 * i + 2]; ++x) {
         uint64_t key = (uint64_t)(uint32_t)(y * c->gx + x);
@@ -464,21 +494,21 @@ void gsro_backward(const gsro_ctx *c, const float *dL_dcolor, float *dL_dmeans3D
 #else
   (void)nthreads;
 #endif
-  float *part = (float *)calloc(9 * (size_t)(c->D ? c->D : 1), 4);
+  float *part = (float *)calloc(9 * (size_t)(c->D ? c->D : 1), sizeof(float));
 #pragma omp parallel for schedule(dynamic, 4)
   for (int t = 0; t < c->T; ++t) render_tile_bwd(c, t, dL_dcolor, part);
   /* scatter sorted-position partials to Gaussian-major entry slots e = offsets[g] + k,
    * k = row-major rank of the tile inside the Gaussian's rect; then reduce per Gaussian in k order */
-  float *acc = (float *)calloc(9 * (size_t)(P ? P : 1), 4);
+  float *acc = (float *)calloc(9 * (size_t)(P ? P : 1), sizeof(float));
   {
-    float *gm = (float *)calloc(9 * (size_t)(c->D ? c->D : 1), 4);
+    float *gm = (float *)calloc(9 * (size_t)(c->D ? c->D : 1), sizeof(float));
     for (int t = 0; t < c->T; ++t) {
       int tx = t % c->gx, ty = t / c->gx;
       for (uint32_t s = c->ranges[2 * t]; s < c->ranges[2 * t + 1]; ++s) {
         uint32_t g = c->point_list[s];
         const int32_t *r = c->rect + 4 * g;
         uint32_t k = (uint32_t)((ty - r[1]) * (r[2] - r[0]) + (tx - r[0]));
-        memcpy(gm + 9 * (size_t)(c->offsets[g] + k), part + 9 * (size_t)s, 36);
+        memcpy(gm + 9 * (size_t)(c->offsets[g] + k), part + 9 * (size_t)s, 9 * sizeof(float));
       }
     }
     for (int g = 0; g < P; ++g)
