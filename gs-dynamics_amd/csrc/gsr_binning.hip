@@ -929,13 +929,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(GsrBinViews tab,
 // Normalised bitonic network (every compare-exchange puts the minimum at the lower index), so virtual
 // +inf padding above n never moves and pairs touching it are skipped.
 template <typename PTR>
-__device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
+__device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid, const uint32_t NT = GSR_BLOCK) {
   uint32_t lg = 1;  // log2 of the padded size
   while ((1u << lg) < n) ++lg;
   const uint32_t npairs = (1u << lg) >> 1;
   for (uint32_t lk = 1; lk <= lg; ++lk) {  // merge size k = 2^lk; all index maths are shifts and masks
     const uint32_t k = 1u << lk, hk = k >> 1;
-    for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {  // mirror step
+    for (uint32_t p = tid; p < npairs; p += NT) {  // mirror step
       const uint32_t base = (p >> (lk - 1)) << lk, off = p & (hk - 1);
       const uint32_t l = base + off, r = base + (k - 1 - off);
       if (r < n) {
@@ -946,7 +946,7 @@ __device__ __forceinline__ void tile_sort_network(PTR a, uint32_t n, int tid) {
     __syncthreads();
     for (int lj = (int)lk - 2; lj >= 0; --lj) {
       const uint32_t j = 1u << lj;
-      for (uint32_t p = tid; p < npairs; p += GSR_BLOCK) {
+      for (uint32_t p = tid; p < npairs; p += NT) {
         const uint32_t l = ((p >> lj) << (lj + 1)) + (p & (j - 1)), r = l + j;
         if (r < n) {
           uint64_t x = a[l], y = a[r];
@@ -1033,21 +1033,22 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ seg,
 // ranks from wave-64 __ballot peer masks.  ~5 barriers per pass instead of one per compare-exchange stage.
 // Two builds of the kernel: RCAP = 2048 (36 KiB of LDS, 4 workgroups per CU) for ordinary scenes, RCAP = 4096
 // (68 KiB, 2 per CU) when the average list is long (dense scenes: the network path above RCAP is n log^2 n).
-template <int RCAP>
+template <int RCAP, int NW = 4>                          // NW: waves of the workgroup
 struct TileSortLds {
   union {
     struct { uint32_t key[2][RCAP]; uint32_t val[2][RCAP]; } r;   // radix path, n <= RCAP
     uint64_t net[2 * RCAP];                                       // network path, n <= 2 RCAP
   };
-  uint32_t whist[4][256];
+  uint32_t whist[NW][256];
   uint32_t wtot[4];
   uint32_t diff;
 };
 
-template <int RCAP>
-__device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP>& L, uint32_t n, int tid) {
+template <int RCAP, int NW>
+__device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP, NW>& L, uint32_t n, int tid) {
+  constexpr int NT = 64 * NW;
   const int lane = tid & 63, wv = tid >> 6;
-  const uint32_t q = ((n + 255u) >> 8) << 6;            // per-wave share, a multiple of 64
+  const uint32_t q = ((n + (uint32_t)NT - 1u) / (uint32_t)NT) << 6;   // per-wave share, a multiple of 64
   const uint32_t wstart = min(n, (uint32_t)wv * q), wstop = min(n, wstart + q);
   const uint32_t diff = L.diff;
   int cur = 0;
@@ -1057,25 +1058,30 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP>& L, uint32_t n,
     const uint32_t* __restrict__ vin = L.r.val[cur];
     uint32_t* __restrict__ kout = L.r.key[cur ^ 1];
     uint32_t* __restrict__ vout = L.r.val[cur ^ 1];
-    for (int i = tid; i < 4 * 256; i += GSR_BLOCK) (&L.whist[0][0])[i] = 0;
+    for (int i = tid; i < NW * 256; i += NT) (&L.whist[0][0])[i] = 0;
     __syncthreads();
     for (uint32_t i = wstart + lane; i < wstop; i += 64) atomicAdd(&L.whist[wv][(kin[i] >> shift) & 0xffu], 1u);
     __syncthreads();
-    {  // bin tid: total over waves, exclusive scan over the 256 bins, then per-wave bases
-      const uint32_t c0 = L.whist[0][tid], c1 = L.whist[1][tid], c2 = L.whist[2][tid], c3 = L.whist[3][tid];
-      const uint32_t tot = c0 + c1 + c2 + c3;
+    {  // bin tid (the first 256 threads): total over waves, exclusive scan over the 256 bins, then per-wave bases
+      uint32_t c[NW], tot = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c[w] = L.whist[w][tid]; tot += c[w]; }
+      }
       uint32_t inc = tot;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(inc, d, 64);
         if (lane >= d) inc += o;
       }
-      if (lane == 63) L.wtot[wv] = inc;
+      if (tid < 256 && lane == 63) L.wtot[wv] = inc;
       __syncthreads();
-      uint32_t base = inc - tot;
-      for (int w = 0; w < wv; ++w) base += L.wtot[w];
-      L.whist[0][tid] = base; L.whist[1][tid] = base + c0; L.whist[2][tid] = base + c0 + c1;
-      L.whist[3][tid] = base + c0 + c1 + c2;
+      if (tid < 256) {
+        uint32_t base = inc - tot;
+        for (int w = 0; w < wv; ++w) base += L.wtot[w];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { L.whist[w][tid] = base; base += c[w]; }
+      }
     }
     __syncthreads();
     volatile uint32_t* wbase = L.whist[wv];
@@ -1100,15 +1106,23 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP>& L, uint32_t n,
   return cur;
 }
 
-template <int RCAP>
-__global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, int cur) {
-  __shared__ TileSortLds<RCAP> L;
+// MODE 0: both kinds of ticket in one launch (blocks below n_long: a workgroup per long list, the others: a wave per short list).
+// The workgroup paths' LDS block then bounds the occupancy of the wave-sorted lists too: 2 workgroups per CU with the 68 KiB of the
+// RCAP = 4096 build.  So that build launches twice: MODE 2 = the wave tickets alone in a kernel WITHOUT any LDS (6 waves per SIMD, the
+// register limit), MODE 1 = the long tickets alone.
+template <int RCAP, int NW>
+__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur);
+
+// NW: waves per workgroup (4; the MODE 1 launch of the RCAP = 4096 build runs 16: a long list is sorted by 1024 threads -- the LDS
+// block allows two such workgroups per CU either way, with 4 waves each that is 2 waves per SIMD working through 5 barriers per pass)
+template <int RCAP, int MODE = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void tile_sort_kernel(GsrBinViews tab, int cur) {
   const int tid = threadIdx.x;
   // The order array leads with the longest lists.  Its first n_long tickets (n > TS_WAVE_CAP) take a whole workgroup
   // each; behind them every WAVE takes one ticket (register-resident wave sort, no barriers).
   const uint32_t n_busy = tab.queue[4], n_long = tab.queue[6];
-  if (blockIdx.x >= n_long) {
-    const uint32_t ticket = n_long + (blockIdx.x - n_long) * 4u + (uint32_t)(tid >> 6);
+  if (MODE == 2 || (MODE == 0 && blockIdx.x >= n_long)) {
+    const uint32_t ticket = n_long + (MODE == 2 ? blockIdx.x : blockIdx.x - n_long) * 4u + (uint32_t)(tid >> 6);
     if (ticket >= n_busy) return;
     const uint4 ord = tab.order[ticket];
     const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
@@ -1123,6 +1137,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     else wave_sort_tile<16>(seg, out, n, tid & 63);
     return;
   }
+  if constexpr (MODE != 2) {
+    if (blockIdx.x >= n_long) return;            // MODE 1: the wave tickets have their own launch
+    tile_sort_long_ticket<RCAP, NW>(tab, cur);
+  }
+}
+
+template <int RCAP, int NW>
+__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur) {
+  __shared__ TileSortLds<RCAP, NW> L;
+  constexpr uint32_t NT = 64 * NW;
+  const int tid = threadIdx.x;
   const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
   const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
   if (vw.shares_lists) return;
@@ -1139,7 +1164,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
     __syncthreads();
     const uint32_t k0 = (uint32_t)(seg[0] >> 32);
     uint32_t d = 0;
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint64_t e = seg[i];
       const uint32_t k = (uint32_t)(e >> 32);
       L.r.key[0][i] = k; L.r.val[0][i] = (uint32_t)e;
@@ -1156,7 +1181,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
       uint32_t* __restrict__ kk = L.r.key[cur];
       uint32_t* __restrict__ vv = L.r.val[cur];
       bool long_run = false;
-      for (uint32_t i = tid; i + 1 < n; i += GSR_BLOCK) {
+      for (uint32_t i = tid; i + 1 < n; i += NT) {
         if (kk[i] == kk[i + 1] && (i == 0 || kk[i - 1] != kk[i])) {
           uint32_t j = i + 1;
           while (j + 1 < n && kk[j + 1] == kk[i] && j - i < 32u) ++j;
@@ -1170,34 +1195,34 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(GsrBinViews tab, i
         }
       }
       if (__syncthreads_or(long_run ? 1 : 0)) {        // rare: rebuild the 64-bit keys and sort them with the network
-        uint64_t e[(RCAP + GSR_BLOCK - 1) / GSR_BLOCK];
+        uint64_t e[(RCAP + NT - 1) / NT];
 #pragma unroll
-        for (int u = 0; u < (RCAP + GSR_BLOCK - 1) / GSR_BLOCK; ++u) {
-          const uint32_t i = (uint32_t)u * GSR_BLOCK + tid;
+        for (int u = 0; u < (RCAP + NT - 1) / NT; ++u) {
+          const uint32_t i = (uint32_t)u * NT + tid;
           e[u] = i < n ? (((uint64_t)kk[i] << 32) | vv[i]) : 0ull;
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < (RCAP + GSR_BLOCK - 1) / GSR_BLOCK; ++u) {
-          const uint32_t i = (uint32_t)u * GSR_BLOCK + tid;
+        for (int u = 0; u < (RCAP + NT - 1) / NT; ++u) {
+          const uint32_t i = (uint32_t)u * NT + tid;
           if (i < n) L.net[i] = e[u];
         }
         __syncthreads();
-        tile_sort_network(L.net, n, tid);
-        for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)L.net[i];
+        tile_sort_network(L.net, n, tid, NT);
+        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)L.net[i];
         return;
       }
     }
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = L.r.val[cur][i];
+    for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = L.r.val[cur][i];
   } else if (n <= 2u * (uint32_t)RCAP) {
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) L.net[i] = seg[i];
+    for (uint32_t i = tid; i < n; i += NT) L.net[i] = seg[i];
     __syncthreads();
-    tile_sort_network(L.net, n, tid);
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)L.net[i];
+    tile_sort_network(L.net, n, tid, NT);
+    for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)L.net[i];
   } else {
     __syncthreads();
-    tile_sort_network((volatile uint64_t*)seg, n, tid);
-    for (uint32_t i = tid; i < n; i += GSR_BLOCK) point_list[rg.x + i] = (uint32_t)seg[i];
+    tile_sort_network((volatile uint64_t*)seg, n, tid, NT);
+    for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)seg[i];
   }
 }
 
@@ -1320,10 +1345,23 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     if (int rc = gsr_launch_tile_order(tab, st)) return rc;
   if (maxD > 0 && P > 0) {
     { GSR_PROF("tile_sort", st);
-    if (big)   // long lists on average: the big-LDS build
-      hipLaunchKernelGGL(tile_sort_kernel<4096>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
-    else
-      hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur); }
+    if (big) {  // long lists on average: the big-LDS build for the long tickets, the wave tickets in a launch of their own
+      hipLaunchKernelGGL((tile_sort_kernel<2048, 2>), dim3((tab.V * tab.T + 3) / 4), dim3(GSR_BLOCK), 0, st, tab, cur);
+      // Long tickets: measured at configs[4] size (500 k Gaussians, 1080p x 4 cameras; tile_sort us per frame, same box): 4096-entry LDS
+      // block with 4 / 8 / 16 waves per workgroup 507 / 429 / 733, 2048-entry block with 4 / 8 waves 309 / 349 -- workgroups per CU
+      // (36 KiB: four) count for more than lists of 2049 .. 4096 entries taking the LDS network instead of the radix sort.
+      const char* ls = getenv("GSR_LONG_SORT");      // (read per call: the tests switch builds inside one process)
+      const bool old_long = ls && ls[0] == '4';
+      if (old_long) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(tab.V * tab.T), dim3(256), 0, st, tab, cur);
+      else hipLaunchKernelGGL((tile_sort_kernel<2048, 1, 4>), dim3(tab.V * tab.T), dim3(256), 0, st, tab, cur);
+    } else
+      {
+        // ordinary scenes: the 1024-entry LDS block (20 KiB: eight workgroups per CU -- the wave-sorted lists are the bulk of the work
+        // and want the occupancy); GSR_TILE_SORT_RCAP=2048 keeps the 36 KiB build
+        const bool small_lds = !(force && force[0] == '2');
+        if (small_lds) hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
+        else hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
+      } }
     GSR_HIP_CHECK(hipGetLastError());
   }
   return 0;

@@ -233,6 +233,17 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
     return o2
 
 
+def _pin_tile_sort_build(monkeypatch, rcap):
+    """The builds of tile_sort (gsr_launch_binning): "1024" = the default for ordinary scenes (one launch, 20 KiB LDS block), "2048" = the
+    36 KiB block, "4096" = the dense-scene form (wave tickets in a launch without LDS + long tickets with the 2048-entry block),
+    "4096L" = the same with the long tickets on the 4096-entry block."""
+    monkeypatch.setenv("GSR_TILE_SORT_RCAP", {"1024": "1", "2048": "2048", "4096": "4096", "4096L": "4096"}[rcap])
+    if rcap == "4096L":
+        monkeypatch.setenv("GSR_LONG_SORT", "4096")
+    else:
+        monkeypatch.delenv("GSR_LONG_SORT", raising=False)
+
+
 def test_device_selftest(dev):
     from diff_gaussian_rasterization import _hip
     assert _hip.selftest(dev) == 0
@@ -381,26 +392,26 @@ def test_cov3d_precomp_vs_oracle(dev):
     _check_against_oracle(cam, g2, dev, seed=5)
 
 
-@pytest.mark.parametrize("rcap,P", [("2048", 6000), ("4096", 9000)])
+@pytest.mark.parametrize("rcap,P", [("1024", 6000), ("2048", 6000), ("4096", 9000), ("4096L", 9000)])
 def test_huge_tile_lists_take_the_global_sort_path(dev, monkeypatch, rcap, P):
     """More than 2 x RCAP entries per tile: the per-tile sort leaves LDS and runs its network in global memory
     (RCAP = radix capacity of the tile_sort build, pinned here; the library picks it from the average list length)."""
-    monkeypatch.setenv("GSR_TILE_SORT_RCAP", rcap)
+    _pin_tile_sort_build(monkeypatch, rcap)
     # Gaussians far wider than the image (sigma 45-80 pixels over 32): alpha = 0.017 .. 0.02 at every pixel, nowhere near the
     # 1/255 threshold, so (almost) no pixel is threshold-ambiguous although thousands of entries cover each one
     g = random_gaussians(P, seed=33, scale_lo=5.0, scale_hi=9.0, spread=0.5)
     g["opacities"][:] = 0.02
     o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=6, min_ok=0.98)
-    assert o2.hip_max_list > 2 * int(rcap)
+    assert o2.hip_max_list > 2 * int(rcap.rstrip("L"))
 
 
-@pytest.mark.parametrize("rcap", ["2048", "4096"])
+@pytest.mark.parametrize("rcap", ["1024", "2048", "4096", "4096L"])
 @pytest.mark.parametrize("P", [50, 100, 200, 400, 1500, 3000])
 def test_tile_sort_paths(dev, monkeypatch, P, rcap):
     """Per-tile list lengths that select each tile_sort path: <= 64 / 128 / 256 / 512 one wave in registers (1, 2, 4, 8
     keys per lane), <= RCAP LDS radix sort, <= 2 RCAP LDS network (beyond: test_huge_tile_lists...), for both builds of
     the kernel (RCAP 2048 / 4096)."""
-    monkeypatch.setenv("GSR_TILE_SORT_RCAP", rcap)
+    _pin_tile_sort_build(monkeypatch, rcap)
     g = random_gaussians(P, seed=40 + P, scale_lo=5.0, scale_hi=9.0, spread=0.5)   # wider than the image: see the test above
     g["opacities"][:] = 0.03
     o2 = _check_against_oracle(ring_camera(32, 32), g, dev, seed=8, min_ok=0.98)
