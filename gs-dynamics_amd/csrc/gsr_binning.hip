@@ -860,8 +860,17 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_order_kernel(GsrBinViews
   tile_order_body(tab, n_items, 0, L);
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinViews tab) {
+// `order_wgs` > 0: the launch carries the tile-order builder as well -- workgroups tab.rows .. tab.rows + order_wgs - 1 of grid row 0
+// run tile_order_body (they need the ranges only, like the emitting workgroups: the two run side by side on different CUs instead of
+// one launch after the other; 20 us of an 8-view step, 12 us of a one-view step).
+__global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinViews tab, int order_wgs, int items_per_wg) {
   extern __shared__ uint32_t s_cur[];                 // [T] next free slot of every tile for this workgroup
+  if ((int)blockIdx.x >= tab.rows) {
+    __shared__ TileOrderLds L;
+    if (blockIdx.y == 0) tile_order_body(tab, items_per_wg, (int)blockIdx.x - tab.rows, L);
+    return;
+  }
+  (void)order_wgs;
   __shared__ uint2 s_big[BIN_BIG_MAX];                // see bin_count_kernel
   __shared__ uint64_t s_bigkey[BIN_BIG_MAX];
   __shared__ uint32_t s_nbig;
@@ -1292,18 +1301,30 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     }
     GSR_HIP_CHECK(hipGetLastError());
     const int n_items = tab.V * ((tab.T + 1023) / 1024);
-    static const bool no_fused_order = [] { const char* e = getenv("GSR_NO_FUSED_ORDER"); return e && *e && atoi(e) != 0; }();
-    order_done = n_items <= 4 && !no_fused_order;
-    if (order_done) {
+    // GSR_BIN_ORDER: 0 (default) = the tile order is built INSIDE the emit launch by extra workgroups; 1 = small calls scan and order in
+    // one workgroup (bin_scan_order; round-3 first form); 2 = a tile_order launch of its own behind the emit
+    static const int order_mode = [] { const char* e = getenv("GSR_BIN_ORDER"); return e ? atoi(e) : 0; }();
+    if (order_mode == 1 && n_items <= 4) {
       GSR_PROF("bin_scan_order", st);
       hipLaunchKernelGGL(bin_scan_order_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tab, prefixed, n_items);
+      order_done = true;
     } else {
       GSR_PROF("bin_scan", st);
       hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed);
     }
     GSR_HIP_CHECK(hipGetLastError());
+    int order_wgs = 0, per_wg = 1;
+    if (!order_done && order_mode == 0) {
+      order_wgs = n_items < ORD_MAX_WG ? n_items : ORD_MAX_WG;
+      if (order_wgs < 1) order_wgs = 1;
+      per_wg = (n_items + order_wgs - 1) / order_wgs;
+      if (per_wg < 1) per_wg = 1;
+      order_wgs = (n_items + per_wg - 1) / per_wg;
+      if (order_wgs < 1) order_wgs = 1;
+      order_done = true;
+    }
     { GSR_PROF("bin_emit", st);
-      hipLaunchKernelGGL(bin_emit_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
+      hipLaunchKernelGGL(bin_emit_kernel, dim3(tab.rows + order_wgs, tab.V), dim3(BIN_THREADS), lds, st, P, tab, order_wgs, per_wg); }
     GSR_HIP_CHECK(hipGetLastError());
   } else if (maxD == 0 || P <= 0) {   // nothing visible in any view: every tile is empty
     for (int v = 0; v < tab.V; ++v) GSR_HIP_CHECK(hipMemsetAsync(tab.v[v].ranges, 0, sizeof(uint2) * (size_t)tab.T, st));
