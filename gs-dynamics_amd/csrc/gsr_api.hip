@@ -98,7 +98,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr;
+  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.skip = 0;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
@@ -115,7 +115,7 @@ void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, c
                       float* out_color, float* out_depth, const float* dL_dcolor, float4* partials) {
   o.point_list = bs.point_list; o.rec = g.rec; o.bg = cam.bg; o.final_T = im.final_T; o.n_contrib = im.n_contrib;
   o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
-  o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0;
+  o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0; o.colors = nullptr;
 }
 
 // Fused pairs: the FIRST alias of a view (same camera, other colours) is blended inside its owner's tile pass instead of
@@ -127,6 +127,19 @@ void pair_up(int V, const int32_t* geometry_of, const uint32_t* num_rendered, in
   for (int v = 0; v < V; ++v) {
     const int u = geometry_of[v];
     if (u != v && partner[u] < 0 && num_rendered[u] > 0) { partner[u] = v; fused[v] = 1; }
+  }
+}
+// Forward-only calls: the views pair_up will fuse into their owner's tile pass (when the owner renders anything at all) need no
+// preprocess and no records -- decided before the entry counts exist.
+void skippable_aliases(int V, const int32_t* geometry_of, const float* const* colors_views, int flags, int skip[GSR_MAX_BATCH]) {
+  static const bool off = [] { const char* e = getenv("GSR_NO_PAIR_FUSION"); return e && *e && atoi(e) != 0; }();
+  static const bool no_skip = [] { const char* e = getenv("GSR_NO_ALIAS_SKIP"); return e && *e && atoi(e) != 0; }();
+  int taken[GSR_MAX_BATCH];
+  for (int v = 0; v < V; ++v) { skip[v] = 0; taken[v] = 0; }
+  if (!geometry_of || !colors_views || off || no_skip || !(flags & GSR_FORWARD_ONLY)) return;
+  for (int v = 0; v < V; ++v) {
+    const int u = geometry_of[v];
+    if (u != v && !taken[u]) { taken[u] = 1; skip[v] = 1; }
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
@@ -165,7 +178,8 @@ int check_inputs(const char* who, const float* means3D, const float* opacities, 
 int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
-           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, uint64_t* fingerprint_host = nullptr) {
+           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, uint64_t* fingerprint_host = nullptr,
+           const int* skip = nullptr, const int32_t* geometry_of = nullptr) {
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -202,6 +216,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     gsr_carve_geom(geom_states[v], P, &g);
     fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
     if (fingerprint_host && V == 1 && gsr_host_block_scan(P)) tab.v[v].block_hash = g.block_hash;
+    if (skip && skip[v]) tab.v[v].skip = 1;
   }
   if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
     return rc;
@@ -230,6 +245,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     for (int v = 0; v < V; ++v) {
       uint64_t tot = 0;
       for (uint32_t b = 0; b < nblk; ++b) tot += host[(size_t)v * nblk + b];
+      if (skip && skip[v]) tot = num_rendered_host[geometry_of[v]];     // not preprocessed: its owner's lists are its lists
       if (tot > 0xffffffffull) { gsr_set_error("gsr forward: %llu tile entries overflow 32 bits", (unsigned long long)tot); return -3; }
       num_rendered_host[v] = (uint32_t)tot;
     }
@@ -241,7 +257,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
       GSR_HIP_CHECK(hipMemcpyAsync(host + v, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     GSR_HIP_CHECK(hipStreamSynchronize(st));
-    for (int v = 0; v < V; ++v) num_rendered_host[v] = host[v];
+    for (int v = 0; v < V; ++v) num_rendered_host[v] = (skip && skip[v]) ? host[geometry_of[v]] : host[v];
   }
   return 0;
 }
@@ -261,12 +277,13 @@ int check_geometry_of(int V, const int32_t* geometry_of) {
 int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered, void* const* geom_states,
            void* const* binning_states, void* const* image_states, float* const* out_color, float* const* out_depth,
            const uint32_t* sums, uint4* order, uint32_t* queue, const int32_t* geometry_of, hipStream_t st,
-           uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr, int flags = 0) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
+           uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr, int flags = 0, const float* const* colors_views = nullptr) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   GsrRenderViews rt;
-  int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH];
+  int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH], skip[GSR_MAX_BATCH];
   pair_up(V, geometry_of, num_rendered, partner, fused);
+  skippable_aliases(V, geometry_of, colors_views, flags, skip);
   const uint32_t nblk = (uint32_t)(((P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK);
   for (int v = 0; v < V; ++v) {
     GsrCam cam;
@@ -300,6 +317,10 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     }
     bt.v[v].fused_alias = (uint32_t)fused[v];
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
+    if (skip[v]) {      // no records of its own: only ever reached through its owner's tile pass (or painted as background)
+      if (!fused[v] && num_rendered[v] > 0) { gsr_set_error("gsr batch: view %d was not preprocessed but is not fused", v); return -2; }
+      rt.v[v].colors = colors_views[v];
+    }
     if (counts_dev && owner == v) bt.v[v].D_dev = g.offsets + P;
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
@@ -440,8 +461,8 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                             int32_t flags, void* stream) {
+                             void* batch_state, const int32_t* geometry_of, const float* const* colors_views, float* const* out_color,
+                             float* const* out_depth, int32_t flags, void* stream) {
   GsrRange _range("gsr_forward_render_batch");
   if (int rc = check_batch("gsr_forward_render_batch", V, s, batch_state)) return rc;
   if (!num_rendered || !geom_states || !binning_states || !image_states || !out_color || !out_depth) {
@@ -451,7 +472,7 @@ int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   return stage2(V, s, P, num_rendered, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags, colors_views);
 }
 
 int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
@@ -472,8 +493,10 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   if (P <= 0) return 1;  // nothing to preprocess: the caller takes the render-stage call (it paints the background)
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  int skip[GSR_MAX_BATCH];
+  skippable_aliases(V, geometry_of, colors_views, flags, skip);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream))
+                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, skip, geometry_of))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
   for (int v = 0; fits && v < V; ++v) {
@@ -482,7 +505,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   }
   if (!fits) return 1;
   return stage2(V, s, P, num_rendered_host, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
-                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags);
+                b.queue, geometry_of, (hipStream_t)stream, nullptr, b.tile_rows, flags, colors_views);
 }
 
 int gsr_forward_batch_capacity(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,

@@ -165,6 +165,8 @@ struct GsrPreView {            // preprocess
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
   uint2* ekey;
   uint2* block_hash;     // nullptr: no fingerprint wanted
+  int skip;              // 1: nothing to preprocess for this view (forward-only fused alias: its owner's tile pass reads its colours
+                         //    straight from its colour array, nobody reads a record of its own)
 };
 struct GsrPreViews {
   int V;
@@ -200,6 +202,7 @@ struct GsrRenderView {         // blend forward / backward
   float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
   const float* dL_dcolor; const uint2* rect; const uint32_t* offsets; float4* partials;
   const uint2* ranges;
+  const float* colors;   // != nullptr (fused alias of a forward-only call): this view's colours [P,3]; it has no records of its own
   int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
   int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
 };

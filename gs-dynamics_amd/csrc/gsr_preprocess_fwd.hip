@@ -66,6 +66,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
   // this block's view (blockIdx.y): its pointers come out of the kernarg table with scalar loads
   const GsrPreView& vw = tab.v[blockIdx.y];
+  if (vw.skip) return;
   const float* __restrict__ view = vw.view;
   const float* __restrict__ proj = vw.proj;
   const float* __restrict__ campos = vw.campos;

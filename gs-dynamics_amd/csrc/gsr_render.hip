@@ -125,7 +125,13 @@ struct FwdLdsT {
 // the partner's side of a fused pair (all nullptr / unused when !PAIR)
 struct FwdPartner {
   const float4* rec; const float* bg; float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
+  const float* colors;   // != nullptr: the partner's colours come from its [P,3] colour array (it has no records: forward-only calls)
 };
+__device__ __forceinline__ float3 fwd_partner_colour(const FwdPartner& pt, uint32_t g) {
+  if (pt.colors) return make_float3(pt.colors[3 * (size_t)g], pt.colors[3 * (size_t)g + 1], pt.colors[3 * (size_t)g + 2]);
+  const float4 q1 = pt.rec[GSR_REC_F4 * g + 1];
+  return make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x);
+}
 
 template <bool PAIR>
 __device__ __forceinline__ void fwd_tile(
@@ -160,7 +166,7 @@ __device__ __forceinline__ void fwd_tile(
     if (GSR_INDEX_AHEAD && tid + FWD_BATCH < n) g_ahead = point_list[rg.x + tid + FWD_BATCH];
     { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
-    if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
+    if (PAIR) np = fwd_partner_colour(pt, g);
   }
   GSR_TP(0);
   for (int base = 0; base < n; base += FWD_BATCH) {
@@ -180,7 +186,7 @@ __device__ __forceinline__ void fwd_tile(
         if (GSR_INDEX_AHEAD && nidx + FWD_BATCH < n) g_ahead = point_list[rg.x + nidx + FWD_BATCH];
         { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
-        if (PAIR) { const float4 q1 = pt.rec[GSR_REC_F4 * g + 1]; np = make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x); }
+        if (PAIR) np = fwd_partner_colour(pt, g);
       }
     }
     uint64_t bal[4];
@@ -591,7 +597,7 @@ __device__ __forceinline__ void bwd_tile(
   tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials
 
 __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
-  return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth};
+  return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth, p.colors};
 }
 
 // PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the

@@ -108,7 +108,7 @@ def load_library():
     lib.gsr_forward_preprocess_batch.restype = C.c_int
     lib.gsr_forward_preprocess_batch.argtypes = [i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, vp, C.POINTER(u32), vp]
     lib.gsr_forward_render_batch.restype = C.c_int
-    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, C.POINTER(i32), PV, PV, i32, vp]
+    lib.gsr_forward_render_batch.argtypes = [i32, PS, i32, C.POINTER(u32), PV, PV, PV, vp, C.POINTER(i32), PV, PV, PV, i32, vp]
     lib.gsr_forward_batch.restype = C.c_int
     lib.gsr_forward_batch.argtypes = ([i32, PS, i32] + [vp] * 5 + [PV, vp, vp] + [PV, PV, PV, C.POINTER(sz), PV, vp,
                                       C.POINTER(i32), PV, PV, C.POINTER(u32), i32, vp])
@@ -534,9 +534,13 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         if rc == 1:
             binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) if owner[v] else None for v in range(V)]
             _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                                _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v),
+                                                _ptr(batch), geometry_of, col_views, _ptr_array(color_v), _ptr_array(depth_v),
                                                 FORWARD_ONLY if forward_only else 0, st),
                    "gsr_forward_render_batch")
+        if forward_only and geometry_of is not None:      # a fused alias is not preprocessed in this mode: its radii are its owner's
+            for v in range(V):
+                if geo[v] != v:
+                    radii[v].copy_(radii[geo[v]])
         _entries_capacity[key] = max(int(max(Ds[v] for v in range(V)) * _ENTRIES_SLACK), 1024)
         if rc == 1 or need * 2 < cap:
             _binning_capacity[key] = int(need * _BINNING_SLACK)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 114 /* 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 115 /* 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -134,12 +134,15 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
 /* flags of the batch forward: GSR_FORWARD_ONLY = the caller will NOT run gsr_backward_batch on the states of this call (the
  * no-grad renders of /root/reference/src/render/renderer.py:18-23, /root/reference/src/predict.py:115-123): the forward then skips
- * what only the backward reads (the per-Gaussian record-slot offsets: one scattered store per Gaussian and view). */
+ * what only the backward reads (the per-Gaussian record-slot offsets: one scattered store per Gaussian and view), and a view that is
+ * blended inside its owner's tile pass (geometry_of + colors_views: the mask render next to the colour render) is not preprocessed at
+ * all -- the tile pass reads its colours from colors_views[v]; its radii[v] are then NOT written (they equal its owner's).
+ * gsr_forward_render_batch must be given the same colors_views / flags as the gsr_forward_batch call it completes. */
 #define GSR_FORWARD_ONLY 1
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
                              void* const* geom_states, void* const* binning_states, void* const* image_states,
-                             void* batch_state, const int32_t* geometry_of, float* const* out_color, float* const* out_depth,
-                             int32_t flags, void* stream);
+                             void* batch_state, const int32_t* geometry_of, const float* const* colors_views, float* const* out_color,
+                             float* const* out_depth, int32_t flags, void* stream);
 /* Both forward stages in ONE call: preprocess all views, synchronise once for the duplicate counts, and -- when
  * every view's binning state fits the buffer the caller provided (binning_bytes[v] >= gsr_binning_bytes(D_v)) --
  * launch the render stage straight away, with no host round trip through the caller in between (that round trip
