@@ -479,6 +479,42 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
   return gsr_rows_sum<PERM>(z);
 }
 
+// The nine sums WITHOUT the two row levels and without any LDS-crossbar step: after the in-row levels every 16-lane ROW holds its
+// own partial totals -- lanes with (lane & 15) = i < 8 the row's sum of v_i, lanes 8 .. 15 the row's sum of v8.  The caller adds the
+// four rows up with ONE ds_add_f32 per visit (36 active lanes, fire and forget) instead of ds_swizzle + wait + add + ds_bpermute +
+// wait + add + ds_write: the per-visit dependency chain then contains no LDS round trip at all.  (v8's xor-4 level is two masked
+// DPP adds here instead of the ds_swizzle of gsr_wave_sum9_packed.)
+__device__ __forceinline__ float gsr_wave_sum9_rows(float v0, float v1, float v2, float v3, float v4, float v5,
+                                                    float v6, float v7, float v8) {
+  const int lane = gsr_lane();
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float r01, r23, r45, r67, r8;
+  asm("s_nop 4\n\t"
+      "v_add_f32_dpp %0, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %4, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %4, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67), "=&v"(r8)
+      : "v"(v0), "v"(v4), "v"(v1), "v"(v5), "v"(v2), "v"(v6), "v"(v3), "v"(v7), "v"(v8));
+  const float q03 = (b0 ? r23 : r01) + gsr_dpp_get<0xB1>(b0 ? r01 : r23);
+  const float q47 = (b0 ? r67 : r45) + gsr_dpp_get<0xB1>(b0 ? r45 : r67);
+  const float q8 = r8 + gsr_dpp_get<0xB1>(r8);
+  const float p07 = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
+  const float p8 = q8 + gsr_dpp_get<0x4E>(q8);
+  float z;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+      : "=&v"(z) : "v"(p07), "v"(p8));
+  return z;
+}
+
 // Eight values (fused pair backward without colour gradients): 8 -> 4 -> 2 -> 1 registers, 20 VALU issues (see above).
 // Result z (in every lane): lane with (lane & 7) = i holds the wave total of v_i.
 __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float v2, float v3, float v4, float v5,

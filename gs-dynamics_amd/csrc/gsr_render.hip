@@ -302,6 +302,19 @@ __device__ __forceinline__ void fwd_tile(
 // Plain passes come in two batch sizes: 128 entries (39.7 KB of LDS, four workgroups per CU) for launches with few busy tiles --
 // there a tile's critical path sets the kernel's time, and it grows with the number of batches -- and 96 entries (29.9 KB, five per
 // CU) when the queue is long and latency hiding is what counts: -4 % kernel time at 4 views x 2500 tiles, +3 % at one view.
+// How the nine per-entry wave totals of a visit reach LDS.  Default: finish the reduction in the wave (two LDS-crossbar row levels),
+// nine lanes store.  GSR_BWD_LDS_ACCUM: stop after the in-row levels and let ONE ds_add_f32 (36 lanes: nine per 16-lane row) add the
+// four rows into the wave's slot -- no LDS round trip left in the visit's dependency chain; the slots are zeroed per batch.  Rows of
+// one instruction that hit the same address are added in lane order: deterministic.
+#ifdef GSR_BWD_LDS_ACCUM
+#define GSR_BWD_PARK9(a0, a1, a2, a3, a4, a5, a6, a7, a8)                                            \
+        { const float z = gsr_wave_sum9_rows(a0, a1, a2, a3, a4, a5, a6, a7, a8);                    \
+          if ((lane & 15) <= 8) atomicAdd(&L.sRed[wv][j][lane & 15], z); }
+#else
+#define GSR_BWD_PARK9(a0, a1, a2, a3, a4, a5, a6, a7, a8)                                            \
+        { const float z = gsr_wave_sum9_packed<ROWS_PERM>(a0, a1, a2, a3, a4, a5, a6, a7, a8);       \
+          if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */ }
+#endif
 #define GSR_BWD_BB(PAIR) ((PAIR) ? 96 : BWD_BATCH)
 template <bool PAIR, int NBB = GSR_BWD_BB(PAIR)>
 struct BwdLdsT {
@@ -457,6 +470,12 @@ __device__ __forceinline__ void bwd_tile(
 #pragma unroll
       for (int w = 0; w < 4; ++w) L.cnt[wv][w] = (uint32_t)__popcll(bal[w]);
     }
+#ifdef GSR_BWD_LDS_ACCUM
+    if (!PAIR && COL) {      // this batch's slots start from zero (the previous batch's combine is behind the barrier that ended it)
+      float4* z4 = reinterpret_cast<float4*>(&L.sRed[0][0][0]);
+      for (int i = tid; i < 4 * BB * 9 / 4; i += GSR_BLOCK) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#endif
     GSR_TP(1);
     __syncthreads();
     GSR_TP(2);
@@ -539,8 +558,7 @@ __device__ __forceinline__ void bwd_tile(
         const float v0 = tx, v1 = ty;                                                                         \
         const float v2 = tx * dx, v3 = tx * dy, v4 = ty * dy;                                                 \
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
-        const float z = gsr_wave_sum9_packed<ROWS_PERM>(v0, v1, v2, v3, v4, v5, v6, v7, v8);                  \
-        if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; /* one ds_write_b32 */                    \
+        GSR_BWD_PARK9(v0, v1, v2, v3, v4, v5, v6, v7, v8)                                                     \
         }                                                                                                     \
         GSR_MARK_ACTIVE(j)                                                                                    \
       }                                                                                                       \
