@@ -538,9 +538,12 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
                                                 FORWARD_ONLY if forward_only else 0, st),
                    "gsr_forward_render_batch")
         if forward_only and geometry_of is not None:      # a fused alias is not preprocessed in this mode: its radii are its owner's
-            for v in range(V):
-                if geo[v] != v:
-                    radii[v].copy_(radii[geo[v]])
+            if V % 2 == 0 and all(geo[v] == v - (v & 1) for v in range(V)):      # (colour, mask) pairs: one strided copy
+                radii[1::2].copy_(radii[0::2])
+            else:
+                for v in range(V):
+                    if geo[v] != v:
+                        radii[v].copy_(radii[geo[v]])
         _entries_capacity[key] = max(int(max(Ds[v] for v in range(V)) * _ENTRIES_SLACK), 1024)
         if rc == 1 or need * 2 < cap:
             _binning_capacity[key] = int(need * _BINNING_SLACK)
