@@ -340,7 +340,7 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
 // -- against 448-465 us with colours.  The kernel is latency-bound, not issue-bound (SQ counters: one VALU issue per ~4 SIMD
 // cycles), and the shorter reductions are one serial chain of DPP adds with nothing to interleave; why that costs this much is
 // not understood.  GSR_NOCOL_SUM6 selects the six-value form for retests.
-#ifdef GSR_NOCOL_SUM6
+#ifndef GSR_NOCOL_SUM9
 #define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum6_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5); \
                            if (red6 >= 0) L.sRed[wv][j][red6] = z; }
 #else
@@ -713,8 +713,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews ta
 #define GSR_TRACE_MAX 65536
 __device__ uint4 g_ticket_trace[GSR_TRACE_MAX];
 #endif
+// The 96-entry build is launched five workgroups per CU: it must stay within 96 VGPRs (five waves per SIMD).  The six-value reduction
+// of the no-colour-gradient build came out at 97 -- one register over, four waves per SIMD, the fifth workgroup of every CU waiting for
+// a slot: that was round 2's "six-value reduction is 17 % slower than nine values with zeros" (the nine-value build happened to need 96).
 template <bool PAIRS, int NBB = BWD_BATCH, bool COL = true>
-__global__ __launch_bounds__(GSR_BLOCK, BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
+__global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == 96) ? 5 : BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLdsAny<PAIRS, NBB> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
