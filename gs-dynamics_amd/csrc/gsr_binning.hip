@@ -1124,8 +1124,11 @@ __device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, in
 
 // NW: waves per workgroup (4; the MODE 1 launch of the RCAP = 4096 build runs 16: a long list is sorted by 1024 threads -- the LDS
 // block allows two such workgroups per CU either way, with 4 waves each that is 2 waves per SIMD working through 5 barriers per pass)
+#ifndef TS_MIN_WAVES
+#define TS_MIN_WAVES 7   // wave-sorted lists: 7 waves per SIMD (72 VGPRs) measured 47.0 -> 44.9 us at 8 views; 8 (64 VGPRs, spills): 47.4
+#endif
 template <int RCAP, int MODE = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void tile_sort_kernel(GsrBinViews tab, int cur) {
+__global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES : 1) void tile_sort_kernel(GsrBinViews tab, int cur) {
   const int tid = threadIdx.x;
   // The order array leads with the longest lists.  Its first n_long tickets (n > TS_WAVE_CAP) take a whole workgroup
   // each; behind them every WAVE takes one ticket (register-resident wave sort, no barriers).
