@@ -377,7 +377,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
 // additions as the loop, hence the same bits -- and finishes with the view-independent part (scale / rotation chain, activations).
 // V x more waves in flight, no second pass over HBM.
 #define PBW_VALUES 13      // gcov[6], gm3[3], gop, gcol[3]
-__global__ __launch_bounds__(64 * GSR_MAX_BATCH) void preprocess_bwd_views_waves_kernel(
+#ifndef PBW_MIN_WAVES
+#define PBW_MIN_WAVES 6   // 79 VGPRs: three 8-wave workgroups per CU instead of two (52 -> 48.5 us at 8 views; 8 waves per SIMD spills: 63.5)
+#endif
+__global__ __launch_bounds__(64 * GSR_MAX_BATCH, PBW_MIN_WAVES) void preprocess_bwd_views_waves_kernel(
     GsrBwdViews vw, int P, float mod, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
