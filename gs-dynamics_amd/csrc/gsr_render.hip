@@ -335,11 +335,9 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
 
 // COL = false (plain passes only): the caller wants no colour gradient -- six sums per entry instead of nine (15 instead of 24
 // VALU issues of reduction, four multiplies less) and 24-byte records.
-// The no-colour reduction.  Measured on one box (8 views, render_bwd per launch): nine-value reduction with three zero inputs
-// 438 us, the six-value reduction (gsr_wave_sum6_packed, 9 VALU issues fewer) 510-525 us, the eight-value one with two zeros 541 us
-// -- against 448-465 us with colours.  The kernel is latency-bound, not issue-bound (SQ counters: one VALU issue per ~4 SIMD
-// cycles), and the shorter reductions are one serial chain of DPP adds with nothing to interleave; why that costs this much is
-// not understood.  GSR_NOCOL_SUM6 selects the six-value form for retests.
+// The no-colour reduction is the six-value one (gsr_wave_sum6_packed).  Round 2 measured it 17 % SLOWER than the nine-value form
+// fed three zeros and kept the latter; the cause was the register count, not the chain of DPP adds (see render_bwd_persistent's
+// launch bounds): 433 -> 397 us per 8-view launch once the build fits five waves per SIMD.  GSR_NOCOL_SUM9 restores nine-with-zeros.
 #ifndef GSR_NOCOL_SUM9
 #define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum6_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5); \
                            if (red6 >= 0) L.sRed[wv][j][red6] = z; }
