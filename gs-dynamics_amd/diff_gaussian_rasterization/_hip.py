@@ -840,6 +840,15 @@ def mark_visible(positions, viewmatrix) -> torch.Tensor:
     return present.bool()
 
 
+def final_transmittance(state: RasterState) -> torch.Tensor:
+    """[H, W] float32 VIEW of the forward's per-pixel final transmittance T_final = prod (1 - alpha_i) over the blended entries
+    (1 where nothing was blended): the first H * W floats of the image state (include/gsr.h: layout of ``image_state``).
+    1 - T_final is the accumulated alpha, i.e. any channel of a render with colours = 1 on a black background.  Valid until the
+    state is released or reused."""
+    n = state.H * state.W
+    return state.image[:4 * n].view(torch.float32).reshape(state.H, state.W)
+
+
 def debug_views(state: RasterState):
     """Tensors copied out of the opaque state buffers (tests / benches only)."""
     lib = load_library()

@@ -43,13 +43,14 @@ class FrameShard:
     """This rank's share of an episode's renders.  ``poses``: list of (w2c, K) -- predict.py's four cameras."""
 
     def __init__(self, device, w: int, h: int, poses: Sequence, rank: Optional[int] = None, world: Optional[int] = None,
-                 bg=(0.0, 0.0, 0.0), near: float = 0.01, far: float = 100.0):
+                 bg=(0.0, 0.0, 0.0), near: float = 0.01, far: float = 100.0, mask_from_alpha: bool = True):
         if rank is None:
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         if world is None:
             world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank, self.world, self.poses, self.bg = int(rank), int(world), list(poses), tuple(bg)
         self.renderer = Renderer(device, w=w, h=h, near=near, far=far)
+        self.mask_from_alpha = bool(mask_from_alpha)   # the mask render = 1 - final transmittance of the colour render (gsdyn/render.py)
 
     def my_pairs(self, n_frames: int) -> List[Tuple[int, int]]:
         return shard_pairs(n_frames, len(self.poses), self.rank, self.world)
@@ -64,7 +65,8 @@ class FrameShard:
         cams = self.cams_of_frame(frame)
         if not cams:
             return {}
-        ims, depths, masks = self.renderer.render_cameras_with_mask([self.poses[c] for c in cams], timestep_data, bg=self.bg)
+        ims, depths, masks = self.renderer.render_cameras_with_mask([self.poses[c] for c in cams], timestep_data, bg=self.bg,
+                                                                        mask_from_alpha=self.mask_from_alpha)
         return {c: (ims[i], depths[i], masks[i]) for i, c in enumerate(cams)}
 
     @torch.no_grad()

@@ -55,6 +55,11 @@ typedef struct gsr_settings {
 /* ---- buffer sizes (bytes).  The three opaque state buffers play the role of the reference
  * extension's geomBuffer / binningBuffer / imgBuffer, but are sized by the caller up front. */
 size_t gsr_geom_bytes(int32_t P);
+/* The image state BEGINS with final_T[image_height * image_width] (float32): the per-pixel transmittance after the last blended
+ * entry, 1 where nothing was blended -- upstream's accum_alpha.  It is the one part of a state a caller may read (after any
+ * forward on that state): 1 - final_T is the accumulated alpha, i.e. every channel of a render with colours = 1 on a black
+ * background, which is how gsdyn.render produces predict.py's mask render (/root/reference/src/predict.py:119-121) without a
+ * second blend pass.  The rest of the three states is opaque. */
 size_t gsr_image_bytes(int32_t image_height, int32_t image_width);
 size_t gsr_binning_bytes(uint32_t num_rendered, int32_t image_height, int32_t image_width);
 size_t gsr_backward_scratch_bytes(int32_t P, uint32_t num_rendered);

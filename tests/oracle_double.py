@@ -46,6 +46,10 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             [o[3] for o in outs])
 
 
+def final_transmittance(state):
+    return torch.tensor(np.asarray(state.o2.final_T))
+
+
 def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
                              want_color_grad=True):
     per_view = colors_precomp is not None and colors_precomp.dim() == 3
@@ -62,3 +66,4 @@ def install(monkeypatch):
     monkeypatch.setattr(_hip, "rasterize_backward", rasterize_backward)
     monkeypatch.setattr(_hip, "rasterize_forward_batch", rasterize_forward_batch)
     monkeypatch.setattr(_hip, "rasterize_backward_batch", rasterize_backward_batch)
+    monkeypatch.setattr(_hip, "final_transmittance", final_transmittance)

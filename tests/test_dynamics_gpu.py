@@ -185,7 +185,11 @@ def test_predict_episode_on_the_device(dev, golden_dir):
         ones["colors_precomp"] = torch.ones_like(scene[f]["colors_precomp"])
         mask, _ = rdr.render(poses[c][0], poses[c][1], ones, bg=(0.0, 0.0, 0.0))
         got = frames[(f, c)]
-        assert torch.equal(got[0], compose_rgba(im, mask)) and torch.equal(got[1], depth) and torch.equal(got[2], mask), (f, c)
+        # the mask of the episode is 1 - final_T of the colour render; the reference's second render sums alpha_i T_i: equal up to fp32
+        # rounding (and so is the RGBA composed from it: im / (mask + 1e-4) amplifies a 1e-6 where the mask is ~1e-4)
+        assert torch.equal(got[1], depth) and float((got[2] - mask).abs().max()) <= 2e-5, (f, c)
+        d = (got[0] - compose_rgba(im, mask)).abs()
+        assert float(d.max()) < 5e-3 and float(d.mean()) < 1e-5, (f, c)
     # two ranks' shares (run one after the other on this GPU) partition the single-rank result
     for r in range(2):
         part = FrameShard(dev, W, H, poses, rank=r, world=2).render_episode(scene)

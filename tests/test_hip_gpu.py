@@ -979,13 +979,26 @@ def test_forward_only_renderer_colour_and_mask_in_one_call(dev):
     r = Renderer(dev, w=320, h=180)
     k = np.array([[300.0, 0, 160], [0, 300.0, 90], [0, 0, 1]])
     cams = [(look_at_w2c(np.array([3.5 * np.cos(a), 0.6, 3.5 * np.sin(a)]), np.zeros(3)), k) for a in (0.3, 1.9)]
-    ims, depths, masks = r.render_cameras_with_mask(cams, data, bg=(0.0, 0.0, 0.0))
+    ims, depths, masks = r.render_cameras_with_mask(cams, data, bg=(0.0, 0.0, 0.0))                                  # mask = 1 - final_T
+    ims2, depths2, masks2 = r.render_cameras_with_mask(cams, data, bg=(0.0, 0.0, 0.0), mask_from_alpha=False)       # mask blended (fused pair)
     ones = dict(data)
     ones["colors_precomp"] = torch.ones_like(data["colors_precomp"])
+    worst = 0.0
     for i, (w2c, kk) in enumerate(cams):
         im, depth = r.render(w2c, kk, data, bg=(0.0, 0.0, 0.0))
         mask, _ = r.render(w2c, kk, ones, bg=(0.0, 0.0, 0.0))
-        assert torch.equal(ims[i], im) and torch.equal(depths[i], depth) and torch.equal(masks[i], mask)
+        assert torch.equal(ims[i], im) and torch.equal(depths[i], depth)
+        assert torch.equal(ims2[i], im) and torch.equal(depths2[i], depth) and torch.equal(masks2[i], mask)
+        # sum_i alpha_i T_i (the second render) against 1 - prod (1 - alpha_i) (the colour render's final transmittance): the same
+        # number up to the fp32 rounding of the two evaluation orders
+        assert masks[i].shape == mask.shape and float(mask.max()) > 0.5
+        worst = max(worst, float((masks[i] - mask).abs().max()))
+    _margin("mask_from_alpha_vs_second_render", worst, 2e-5)
+    assert worst <= 2e-5
+    grey = (0.25, 0.5, 0.75)                       # a background: mask_ch = (1 - T) + T bg_ch
+    _, _, mg = r.render_cameras_with_mask(cams[:1], data, bg=grey)
+    mref, _ = r.render(cams[0][0], k, ones, bg=grey)
+    assert float((mg[0] - mref).abs().max()) <= 2e-5
     a, d, m = r.render_with_mask(cams[0][0], k, data)
     assert torch.equal(a, ims[0]) and torch.equal(m, masks[0]) and float(m.max()) <= 1.0 + 1e-5
 

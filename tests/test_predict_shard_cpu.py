@@ -32,6 +32,7 @@ def _install_double(calls=None):
         return oracle_double.rasterize_forward_batch(*a, **k)
     _hip.rasterize_forward = oracle_double.rasterize_forward
     _hip.rasterize_forward_batch = fwd_batch
+    _hip.final_transmittance = oracle_double.final_transmittance
 
 
 def _scene():
@@ -58,8 +59,8 @@ def _worker(rank, world, port, out_dir):
     assert shard.rank == rank and shard.world == world
     local = shard.render_episode(_scene())
     assert sorted(local) == sorted(shard_pairs(FRAMES, CAMS, rank, world))
-    # one rasterizer call per frame in which this rank owns a camera, 2 views (colour + mask) per owned camera
-    assert calls == [2 * len(shard.cams_of_frame(f)) for f in range(FRAMES) if shard.cams_of_frame(f)]
+    # one rasterizer call per frame in which this rank owns a camera, ONE view per owned camera (the mask comes from its final_T)
+    assert calls == [len(shard.cams_of_frame(f)) for f in range(FRAMES) if shard.cams_of_frame(f)]
     merged = gather_frames(local)
     if rank == 0:
         np.savez(os.path.join(out_dir, "merged.npz"), **{f"{f}_{c}_{i}": t.numpy() for (f, c), v in merged.items() for i, t in enumerate(v)})
