@@ -362,16 +362,21 @@ def bench_config5(args, dev, rank, world):
     P5, W5, H5, CAMS = 500_000, 1920, 1080, 4
     params = synth_scene_params(P5, seed=0, device=dev)
     with torch.no_grad():
-        data = {k: v.detach() for k, v in params2rendervar(params).items()}
+        data_in = {k: v.detach() for k, v in params2rendervar(params).items()}
+        # once per episode, as gsdyn.predict.collect_scene_data does: the Gaussians in Morton order of their positions (the binning
+        # stage's entry scatter coalesces when index neighbours are space neighbours; the images do not depend on the order)
+        from gsdyn.dynamics import spatial_order
+        perm = spatial_order(data_in["means3D"])
+        data = {k: v[perm].contiguous() for k, v in data_in.items()}
     frames = max(args.steps, 1)
     if args.with_rollout:
         return bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS)
     shard = FrameShard(dev, W5, H5, ring_poses(CAMS, W5, H5), rank, world)
     pairs = shard.my_pairs(frames)
 
-    def run(n_frames):
+    def run(n_frames, d=None):
         for f in range(n_frames):
-            shard.render_frame(f, data)
+            shard.render_frame(f, data if d is None else d)
 
     num_rendered = []
     orig_b = _hip.rasterize_forward_batch
@@ -415,6 +420,12 @@ def bench_config5(args, dev, rank, world):
     torch.cuda.synchronize()
     dt_blend = time.perf_counter() - t1
     shard.mask_from_alpha = True
+    run(2, data_in)                                  # the Gaussians in SynthScene-v1's own (random) index order
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run(frames, data_in)
+    torch.cuda.synchronize()
+    dt_input_order = time.perf_counter() - t1
     D = float(np.mean([d for d in num_rendered if d > 0])) if any(num_rendered) else 0.0
     Npx = W5 * H5
     ab = algorithmic_bytes(P5, D, Npx)
@@ -427,12 +438,14 @@ def bench_config5(args, dev, rank, world):
         print(json.dumps({
             "metric": "fwd Mpix/s, predict.py frame (colour + mask render per camera), 500k Gaussians, 1920x1080", "value": mpix, "unit": "Mpix/s",
             "n_gpus": world, "steps": frames, "warmup": args.warmup, "ms_per_step": dt / frames * 1e3, "higher_is_better": True,
-            "ms_per_step_mask_blended": dt_blend / frames * 1e3,
+            "ms_per_step_mask_blended": dt_blend / frames * 1e3, "ms_per_step_input_order": dt_input_order / frames * 1e3,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[4] render loop: 4 cameras x (colour + all-ones mask) per frame, (frame, camera) pairs "
                                    "sharded round-robin over ranks, no collective; the mask image = 1 - final transmittance of the colour "
                                    "render (the all-ones render's value up to fp32 rounding: ONE blend pass per camera; the frame with the mask "
-                                   "blended as well is ms_per_step_mask_blended); GNN rollout not included", "gaussians": P5, "image": [H5, W5],
+                                   "blended as well is ms_per_step_mask_blended); Gaussians handed over in Morton order of their positions, permuted once outside "
+                                   "the timed loop as collect_scene_data does per episode (SynthScene-v1's random index order: ms_per_step_input_order); "
+                                   "GNN rollout not included", "gaussians": P5, "image": [H5, W5],
                        "cameras": CAMS, "num_rendered_per_camera": D, "pairs_on_rank0_per_frame": cams_here},
             "roofline": {"bound": "hbm", "kernel": "render_fwd", "achieved": fwd_bytes / (fwd_us * 1e-6) / 1e9 if fwd_us == fwd_us else None,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": fwd_bytes / (fwd_us * 1e-6) / HBM_PEAK if fwd_us == fwd_us else None,

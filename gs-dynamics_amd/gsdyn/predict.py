@@ -97,11 +97,14 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
 @torch.no_grad()
 def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
                        dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
-                       remove_outliers: bool = True, thin_start_idx: int = 0):
+                       remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True):
     """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
     the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
-    sampling (:194-212), then rollout -> smoothing -> per-frame render inputs.  Returns (scene_data, vis_data, timings)."""
+    sampling (:194-212), then rollout -> smoothing -> per-frame render inputs.  Returns (scene_data, vis_data, timings).
+    ``spatial_sort`` (not in the reference): the per-frame arrays are handed to the renderer in Morton order of the frame-0
+    positions (``dynamics.spatial_order``: one permutation per episode, applied AFTER the rollout, whose farthest-point picks
+    depend on the index order) -- the same images up to exact depth ties, a twice faster entry scatter in the rasterizer."""
     import time
     from . import dynamics as D
     first = lambda t: t[0] if t.dim() == 3 else t   # noqa: E731
@@ -125,6 +128,10 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
                     adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
                     n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx)
     out = D.smooth_frames(*out)
+    if spatial_sort and int(xyz_0.shape[0]) > 1:
+        perm = D.spatial_order(out[0][0].to(dev)).to(out[0].device)
+        out = (out[0][:, perm], out[1][:, perm], out[2][:, perm], out[3][:, perm], out[4], out[5])
+        scales_0 = scales_0[perm.to(dev)]
     scene, vis = D.pack_scene_data(out[0], out[1], out[2], out[3], scales_0, out[4], out[5])
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)

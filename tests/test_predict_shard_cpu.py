@@ -150,7 +150,14 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
     from gsdyn.dynamics import pack_scene_data, remove_statistical_outliers, rollout, smooth_frames
     from gsdyn.predict import FrameShard, collect_scene_data, compose_rgba, ring_poses
     model, params, eef = _episode_inputs()
-    scene, vis, tm = collect_scene_data(model, params, eef, **ROLL)
+    scene_sorted, vis, tm = collect_scene_data(model, params, eef, **ROLL)          # as predict_episode runs it: Morton order
+    scene, _, _ = collect_scene_data(model, params, eef, spatial_sort=False, **ROLL)
+    from gsdyn.dynamics import spatial_order
+    perm = spatial_order(scene[0]["means3D"])
+    assert sorted(perm.tolist()) == list(range(scene[0]["means3D"].shape[0])) and not torch.equal(perm, torch.arange(perm.numel()))
+    for a, b in zip(scene_sorted, scene):          # one permutation for the whole episode, every per-Gaussian array
+        for k in a:
+            assert torch.equal(a[k], b[k][perm]), k
     # the pieces, called one by one as the reference's collect_scene_data strings them together
     op = torch.sigmoid(params["logit_opacities"])
     keep = op[:, 0] >= 0.1
@@ -166,7 +173,7 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert float((scene[-1]["means3D"] - scene[0]["means3D"]).abs().max()) > 1e-4      # the rollout moved the Gaussians
-    ref = FrameShard("cpu", W, H, ring_poses(CAMS, W, H), rank=0, world=1).render_episode(scene)
+    ref = FrameShard("cpu", W, H, ring_poses(CAMS, W, H), rank=0, world=1).render_episode(scene_sorted)
     assert len(z.files) == 3 * EP_STEPS * CAMS
     for (f, c), (im, depth, mask) in ref.items():
         assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
