@@ -781,6 +781,17 @@ int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_rela
   return gsr_launch_fit_rotations(n_bones, moments, n_related, rotations, (int*)code, (hipStream_t)stream);
 }
 
+int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,
+                  float* rotations, float* quats, int32_t* code, void* stream) {
+  GsrRange _range("gsr_fit_bones");
+  if (n_bones < 0 || (n_bones > 0 && (!bones || !motions || !relations || !rotations || !quats || !code)) || relations_row_stride < n_bones) {
+    gsr_set_error("gsr_fit_bones: bad argument");
+    return -2;
+  }
+  return gsr_launch_fit_bones(n_bones, bones, motions, (const long long*)relations, (long long)relations_row_stride, rotations, quats, (int*)code,
+                              (hipStream_t)stream);
+}
+
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
   GsrRange _range("gsr_fps");
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }

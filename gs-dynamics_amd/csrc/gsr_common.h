@@ -325,6 +325,8 @@ int gsr_launch_shared_terms_bwd(int P, int nfg, int K, int nbg, const float* mea
 int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind, long long* out, hipStream_t st);
 size_t gsr_fps_scratch_size(int N, int npoints);
 int gsr_launch_fit_rotations(int nb, const float* F, const float* n_adj, float* R, int* code, hipStream_t st);
+int gsr_launch_fit_bones(int nb, const float* bones, const float* motions, const long long* rel, long long rel_stride, float* R, float* quat,
+                         int* code, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);

@@ -71,7 +71,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_forward_batch_capacity", "gsr_forward_batch_capacity_raw",
            "gsr_backward_batch", "gsr_backward_batch_raw", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_lbs",
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_fit_bones", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
@@ -166,6 +166,8 @@ def load_library():
     lib.gsr_fps_scratch_bytes.argtypes = [i32, i32]
     lib.gsr_fit_rotations.restype = C.c_int
     lib.gsr_fit_rotations.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gsr_fit_bones.restype = C.c_int
+    lib.gsr_fit_bones.argtypes = [i32, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
     lib.gsr_lbs.argtypes = [i32, i32] + [vp] * 8 + [vp]
     lib.gsr_mark_visible.restype = C.c_int
@@ -808,6 +810,26 @@ def fit_rotations(moments: torch.Tensor, n_related: torch.Tensor):
         code = torch.empty((nb,), dtype=torch.int32, device=dev)
         _check(lib.gsr_fit_rotations(nb, _ptr(F), _ptr(n), _ptr(R), _ptr(code), _stream(dev)), "gsr_fit_rotations")
     return R, code
+
+
+def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):
+    """gsr_fit_bones: bones, motions [nb,3], relations [nb,nb] (int64 0/1; any row stride, unit column stride) on a HIP device ->
+    (rotations [nb,3,3], unit quaternions [nb,4], code [nb] int32)."""
+    lib = load_library()
+    _require_device(bones)
+    dev = bones.device
+    nb = int(bones.shape[0])
+    with _on(dev):
+        b = bones.to(torch.float32).contiguous()
+        m = motions.to(device=dev, dtype=torch.float32).contiguous()
+        rel = relations if (relations.dtype == torch.int64 and relations.dim() == 2 and (nb == 0 or relations.stride(1) == 1)) else relations.to(torch.int64).contiguous()
+        if tuple(rel.shape) != (nb, nb):
+            raise ValueError("fit_bones: relations must be [n_bones, n_bones]")
+        R = torch.empty((nb, 3, 3), dtype=torch.float32, device=dev)
+        q = torch.empty((nb, 4), dtype=torch.float32, device=dev)
+        code = torch.empty((nb,), dtype=torch.int32, device=dev)
+        _check(lib.gsr_fit_bones(nb, _ptr(b), _ptr(m), _ptr(rel), int(rel.stride(0)) if nb else 0, _ptr(R), _ptr(q), _ptr(code), _stream(dev)), "gsr_fit_bones")
+    return R, q, code
 
 
 def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat):

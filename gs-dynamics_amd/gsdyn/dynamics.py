@@ -393,6 +393,16 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
     (rotation from ``fit_bone_rotations``, translation = the bone's motion), blended with inverse-distance weights
     (distance clamped at 1e-4); orientations: weighted sum of the bones' unit quaternions, normalised, times the Gaussian's
     quaternion.  Returns (xyz_new [P,3], quat_new [P,4] or None, weights [P,n_bones])."""
+    if xyz.is_cuda and weights is None and bones.is_cuda:
+        # one launch for the bones (moment matrices, rotation fit, unit quaternions: gsr_fit_bones) and one for the Gaussians (gsr_lbs)
+        from diff_gaussian_rasterization import _hip
+        R, base_q, code = _hip.fit_bones(bones, motions, relations)
+        flagged = (code == 1).nonzero().squeeze(1)              # the one host round trip: rank-1 bones go to the host's LAPACK (normally none)
+        if flagged.numel():
+            R = fit_bone_rotations(bones, motions, relations)
+            base_q = torch.nn.functional.normalize(mat2quat(R), dim=-1)
+        return _hip.linear_blend_skinning(bones.float().contiguous(), R.contiguous(), motions.float().contiguous(), base_q.contiguous(),
+                                          xyz.float().contiguous(), None if quat is None else quat.float().contiguous())
     R = fit_bone_rotations(bones, motions, relations)
     base_q = torch.nn.functional.normalize(mat2quat(R), dim=-1)
     if xyz.is_cuda and weights is None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 115 /* 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -305,9 +305,18 @@ size_t gsr_fps_scratch_bytes(int32_t N, int32_t npoints);
 /* gsr_fit_rotations: one rotation per bone from its 3x3 moment matrix F_i = sum_j (new_j - new_i)(old_j - old_i)^T (row-major, fp32)
  *   and the number of related bones, with the decision tree of /root/reference/src/render/utils.py:147-205 (batched on the device:
  *   fp64 one-sided Jacobi SVD per bone).  code[i]: 0 = identity by rule (no related bone, F = 0, or full rank with det F < 0),
- *   2 = Kabsch rotation written, 1 = rank-1 bone LEFT AS IDENTITY for the caller: the reference's answer there depends on the sign
- *   convention of its SVD backend (the caller resolves those few bones with that backend). */
+ *   2 = Kabsch rotation written, 3 = rank-1 bone: the x axis turned onto the dominant left singular vector, signed as LAPACK signs
+ *   U[:, 0] (the reference's answer there depends on its SVD backend's convention; LAPACK's is -sign(F00) c0 / |c0| for F's first
+ *   column c0), 1 = rank-1 bone whose F has a vanishing first column, LEFT AS IDENTITY for the caller's own SVD backend. */
 int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_related, float* rotations, int32_t* code, void* stream);
+/* gsr_fit_bones: the moment matrices, gsr_fit_rotations and the bones' unit quaternions in one launch -- what interpolate_motions
+ * (/root/reference/src/render/utils.py:138-243) needs per bone: F_b = sum over the bones j with relations[b][j] != 0 of
+ * (new_j - new_b)(old_j - old_b)^T with old = bones, new = bones + motions (fp32, ascending j), rotations[b] as gsr_fit_rotations
+ * (same codes), quats[b] = normalize(mat2quat(rotations[b])) with the reference's branches (utils.py:71-111), (w, x, y, z).
+ * relations: n_bones rows of `relations_row_stride` int64 (>= n_bones; a [:n, :n] view of a larger square matrix needs no copy).
+ * A bone with code 1 has the identity and its quaternion: the caller replaces both (as for gsr_fit_rotations). */
+int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,
+                  float* rotations, float* quats, int32_t* code, void* stream);
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream);
 int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
             const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);

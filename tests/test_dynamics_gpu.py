@@ -146,6 +146,27 @@ def test_device_rotation_fit_matches_the_literal_decision_tree(dev):
     det = torch.linalg.det(got.double())
     assert float((det - 1).abs().max()) < 1e-4
     assert torch.equal(got[130:140], torch.eye(3).expand(10, 3, 3))
+    # gsr_fit_bones = moment matrices + the same fit + the bones' unit quaternions in one launch (what interpolate_motions calls): its
+    # rotations against the two-step path above, its quaternions against mat2quat + normalize of the SAME matrices evaluated by torch
+    # (every fp32 operation rounded separately in the kernel too: equal up to the summation order of the norm).  View of a larger
+    # relation matrix (row stride > n_bones), as rollout_step passes it.
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import mat2quat
+    big = torch.zeros((nb + 1, nb + 1), dtype=torch.long)
+    big[:nb, :nb] = rel
+    R2, q2, code = _hip.fit_bones(bones.to(dev), motions.to(dev), big.to(dev)[:nb, :nb])
+    c = code.cpu()
+    # rank-1 bones (here: one neighbour, or a patch bone whose neighbours are collinear) are resolved on the device with LAPACK's sign of
+    # U[:, 0] (code 3); none is left to the host in this scene (code 1 = a vanishing first column of F)
+    assert int((c == 3).sum()) >= 10 and int((c == 1).sum()) == 0 and float((R2.cpu() - got).abs().max()) < 2e-5
+    q_ref = torch.nn.functional.normalize(mat2quat(R2), dim=-1)
+    assert float((q2 - q_ref).abs().max()) < 3e-7 and float((q2.norm(dim=-1) - 1).abs().max()) < 1e-6
+    xyz = torch.rand(5000, 3, generator=g).to(dev)
+    quat = torch.nn.functional.normalize(torch.randn(5000, 4, generator=g), dim=-1).to(dev)
+    from gsdyn.dynamics import interpolate_motions
+    a = interpolate_motions(bones.to(dev), motions.to(dev), rel.to(dev), xyz, quat=quat)                    # gsr_fit_bones + gsr_lbs
+    b = interpolate_motions(bones, motions, rel, xyz.cpu(), quat=quat.cpu())                               # the torch expressions on the host
+    assert float((a[0].cpu() - b[0]).abs().max()) < 1e-4 and float((a[1].cpu() - b[1]).abs().max()) < 5e-4      # (fp32 weights of 160 bones, two summation orders; the blended quaternions cancel partly)
 
 
 def test_predict_episode_on_the_device(dev, golden_dir):
