@@ -781,6 +781,18 @@ int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_rela
   return gsr_launch_fit_rotations(n_bones, moments, n_related, rotations, (int*)code, (hipStream_t)stream);
 }
 
+int gsr_fps_thin(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float radius, int32_t thin_start_idx, int64_t* out_idx,
+                 int64_t* thin_idx, int32_t* thin_count, void* stream) {
+  GsrRange _range("gsr_fps_thin");
+  if (N <= 0 || N > 1024 || npoints <= 0 || npoints > N || !pos || !out_idx || !thin_idx || !thin_count || start_idx < 0 || start_idx >= N ||
+      thin_start_idx < 0 || thin_start_idx >= npoints) {
+    gsr_set_error("gsr_fps_thin: bad argument (1 <= npoints <= N <= 1024, start indices in range)");
+    return -2;
+  }
+  return gsr_launch_fps_thin(N, pos, npoints, start_idx, radius, thin_start_idx, (long long*)out_idx, (long long*)thin_idx, (int*)thin_count,
+                             (hipStream_t)stream);
+}
+
 int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,
                   float* rotations, float* quats, int32_t* code, void* stream) {
   GsrRange _range("gsr_fit_bones");

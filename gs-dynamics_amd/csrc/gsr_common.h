@@ -327,6 +327,8 @@ size_t gsr_fps_scratch_size(int N, int npoints);
 int gsr_launch_fit_rotations(int nb, const float* F, const float* n_adj, float* R, int* code, hipStream_t st);
 int gsr_launch_fit_bones(int nb, const float* bones, const float* motions, const long long* rel, long long rel_stride, float* R, float* quat,
                          int* code, hipStream_t st);
+int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
+                        int* thin_count, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);

@@ -55,6 +55,82 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos
   }
 }
 
+// ---------------------------------------------------------------- bones of a rollout step: sampling + thinning in one launch
+// downsample_vertices of the rollout (/root/reference/src/render/dynamics_module.py:44-51): `npoints` farthest points of a SMALL cloud
+// (N <= 1024: the 1000 tracked particles; one point and its running minimum per thread, in registers), then the radius thinning of
+// /root/reference/src/data/utils.py:50-65 on the picked points (start at `thin_start`, keep adding the point farthest from the kept
+// set until every point lies within `radius` of it).  Sampling: the arithmetic and the tie rule of fps_kernel.  Thinning: distances
+// as torch.norm evaluates them on the host, sqrt(fma(dz, dz, fma(dy, dy, dx * dx))), first maximum on ties -- the host path's picks.
+// One launch and ONE 4-byte read-back (the count) instead of a sampling launch, a device -> host copy of the points, ~100 numpy
+// steps and a host -> device copy of the indices.
+__device__ __forceinline__ void block_argmax_first(float& best, int& besti, float* s_val, int* s_idx, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(besti, off, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if (lane == 0) { s_val[wv] = best; s_idx[wv] = besti; }
+  __syncthreads();
+  best = s_val[0]; besti = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) {
+    const float v = s_val[w]; const int i = s_idx[w];
+    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+  }
+}
+__global__ __launch_bounds__(1024) void fps_thin_small_kernel(const float* __restrict__ pos, int N, int npoints, int start, float radius,
+                                                              int thin_start, long long* __restrict__ out_idx,
+                                                              long long* __restrict__ thin_idx, int* __restrict__ thin_count) {
+  __shared__ float s_val[2][16];
+  __shared__ int s_idx[2][16];
+  __shared__ float sp[3 * 1024];          // the picked points, in pick order
+  __shared__ float sa[3 * 1024];          // the whole cloud (a pick's coordinates come from LDS, not from a global round trip per pick)
+  const int tid = threadIdx.x;
+  const bool have = tid < N;
+  const float px = have ? pos[3 * tid] : 0.f, py = have ? pos[3 * tid + 1] : 0.f, pz = have ? pos[3 * tid + 2] : 0.f;
+  sa[3 * tid] = px; sa[3 * tid + 1] = py; sa[3 * tid + 2] = pz;
+  __syncthreads();
+  float mind = __builtin_inff();
+  int cur = start;
+  for (int k = 0; k < npoints; ++k) {
+    if (tid == cur) { out_idx[k] = cur; sp[3 * k] = px; sp[3 * k + 1] = py; sp[3 * k + 2] = pz; }
+    const float cx = sa[3 * cur], cy = sa[3 * cur + 1], cz = sa[3 * cur + 2];
+    float best = -1.0f;
+    int besti = 0x7fffffff;
+    if (have) {
+      const float dx = px - cx, dy = py - cy, dz = pz - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      mind = fminf(mind, d);
+      best = mind; besti = tid;
+    }
+    block_argmax_first(best, besti, s_val[k & 1], s_idx[k & 1], tid);     // (two LDS buffers: one barrier per pick)
+    cur = besti;
+  }
+  __syncthreads();                         // sp[] complete
+  // ---- thinning over the npoints picks: thread i < npoints owns pick i
+  const bool mine = tid < npoints;
+  const float qx = mine ? sp[3 * tid] : 0.f, qy = mine ? sp[3 * tid + 1] : 0.f, qz = mine ? sp[3 * tid + 2] : 0.f;
+  auto dist_to = [&](int j) {
+    const float dx = qx - sp[3 * j], dy = qy - sp[3 * j + 1], dz = qz - sp[3 * j + 2];
+    return __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))));
+  };
+  int kept = 0, nxt = thin_start;
+  float dist = __builtin_inff();
+  for (int it = 0; it < npoints; ++it) {
+    if (tid == 0) thin_idx[kept] = nxt;
+    ++kept;
+    if (mine) dist = fminf(dist, dist_to(nxt));
+    float best = mine ? dist : -1.0f;
+    int besti = mine ? tid : 0x7fffffff;
+    block_argmax_first(best, besti, s_val[it & 1], s_idx[it & 1], tid);
+    if (!(best > radius)) break;           // uniform: every thread reduced the same 16 candidates
+    nxt = besti;
+  }
+  if (tid == 0) *thin_count = kept;
+}
+
 // ---------------------------------------------------------------- farthest point sampling, several workgroups
 // The single-workgroup kernel above streams the whole cloud from memory once per pick (20 us per pick at 100 k points).  Here every
 // workgroup keeps a slice of the cloud AND its running minimum distances in LDS (2048 points = 32 KB), so a pick costs one pass
@@ -360,6 +436,14 @@ int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind,
   }
   { GSR_PROF("fps", st);
     hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(1024), 0, st, pos, N, npoints, start, mind, out); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
+                        int* thin_count, hipStream_t st) {
+  { GSR_PROF("fps_thin", st);
+    hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(1024), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -71,7 +71,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_forward_batch_capacity", "gsr_forward_batch_capacity_raw",
            "gsr_backward_batch", "gsr_backward_batch_raw", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_fit_bones", "gsr_lbs",
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_fit_bones", "gsr_fps_thin", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
@@ -166,6 +166,8 @@ def load_library():
     lib.gsr_fps_scratch_bytes.argtypes = [i32, i32]
     lib.gsr_fit_rotations.restype = C.c_int
     lib.gsr_fit_rotations.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gsr_fps_thin.restype = C.c_int
+    lib.gsr_fps_thin.argtypes = [i32, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp]
     lib.gsr_fit_bones.restype = C.c_int
     lib.gsr_fit_bones.argtypes = [i32, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
@@ -810,6 +812,25 @@ def fit_rotations(moments: torch.Tensor, n_related: torch.Tensor):
         code = torch.empty((nb,), dtype=torch.int32, device=dev)
         _check(lib.gsr_fit_rotations(nb, _ptr(F), _ptr(n), _ptr(R), _ptr(code), _stream(dev)), "gsr_fit_rotations")
     return R, code
+
+
+def fps_thin(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0, thin_start_idx: int = 0):
+    """gsr_fps_thin: pos [N,3] (N <= 1024) on a HIP device -> (fps indices [npoints] int64, kept positions in that list [M] int64) -- one
+    launch, one 4-byte read-back for M."""
+    lib = load_library()
+    _require_device(pos)
+    dev = pos.device
+    N = int(pos.shape[0])
+    npoints = min(int(npoints), N)
+    with _on(dev):
+        p = pos.to(torch.float32).contiguous()
+        out = torch.empty((npoints,), dtype=torch.int64, device=dev)
+        thin = torch.empty((npoints,), dtype=torch.int64, device=dev)
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+        _check(lib.gsr_fps_thin(N, _ptr(p), npoints, int(start_idx), float(radius), int(thin_start_idx), _ptr(out), _ptr(thin), _ptr(cnt),
+                                _stream(dev)), "gsr_fps_thin")
+        m = int(cnt.item())
+    return out, thin[:m]
 
 
 def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):

@@ -18,7 +18,7 @@ are checked without a GPU); on a HIP device the two kernels take over.
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Optional, Dict, Tuple
 
 import numpy as np
 import torch
@@ -77,7 +77,7 @@ def fps_radius(pcd: torch.Tensor, radius: float, start_idx: int = 0) -> Tuple[to
 
 # ------------------------------------------------------------------------------------------ relations
 def construct_edges(states: torch.Tensor, adj_thresh: float, mask: torch.Tensor, tool_mask: torch.Tensor, topk: int = 10,
-                    connect_all: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                    connect_all: bool = False, n_tool: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Relations between particles as index lists (receiver, sender), ordered like the rows of the reference's ``Rr/Rs``
     (/root/reference/src/data/dataset.py:88-147): a pair is related when both particles are valid, not both tools, closer
     than ``adj_thresh`` and -- among object particles -- the sender is one of the receiver's ``topk`` nearest (itself
@@ -89,7 +89,8 @@ def construct_edges(states: torch.Tensor, adj_thresh: float, mask: torch.Tensor,
     tools = tool_mask[:, None] & tool_mask[None, :]
     dis = torch.where(valid & ~tools, dis, torch.full_like(dis, 1e10))
     adj = dis < adj_thresh * adj_thresh
-    n_tool = int(tool_mask.sum())
+    if n_tool is None:
+        n_tool = int(tool_mask.sum())          # (a device -> host read: callers that know the count pass it)
     n_obj = N - n_tool
     k = min(N, int(topk))
     near = torch.topk(dis[:n_obj, :n_obj], k=min(k, n_obj), dim=-1, largest=False)[1]
@@ -122,13 +123,21 @@ def relations_to_matrix(receivers: torch.Tensor, senders: torch.Tensor, N: int) 
 
 
 # ------------------------------------------------------------------------------------------ GNN
+def _linear_relu(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """relu(x W^T + b).  Inference on a device: ONE call (the GEMM library's bias + ReLU epilogue through torch._addmm_activation) instead
+    of a GEMM and an elementwise launch -- the rollout is bound by the number of launches the host can issue, not by their work."""
+    if x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 2 and hasattr(torch, "_addmm_activation"):
+        return torch._addmm_activation(lin.bias, x.reshape(-1, x.shape[-1]), lin.weight.t()).reshape(x.shape[:-1] + (lin.weight.shape[0],))
+    return torch.relu(lin(x))
+
+
 class _MLP3(nn.Module):      # Linear-ReLU x3, parameters under ``model.{0,2,4}`` like the reference's Encoder
     def __init__(self, i, h, o):
         super().__init__()
         self.model = nn.Sequential(nn.Linear(i, h), nn.ReLU(), nn.Linear(h, h), nn.ReLU(), nn.Linear(h, o), nn.ReLU())
 
     def forward(self, x):
-        return self.model(x)
+        return _linear_relu(self.model[4], _linear_relu(self.model[2], _linear_relu(self.model[0], x)))
 
 
 class _Prop(nn.Module):      # relu(linear(x) [+ res]), parameter under ``linear``
@@ -137,8 +146,9 @@ class _Prop(nn.Module):      # relu(linear(x) [+ res]), parameter under ``linear
         self.linear = nn.Linear(i, o)
 
     def forward(self, x, res=None):
-        y = self.linear(x)
-        return torch.relu(y if res is None else y + res)
+        if res is None:
+            return _linear_relu(self.linear, x)
+        return torch.relu(self.linear(x) + res)
 
 
 class _Head(nn.Module):      # parameters ``linear_0/1/2``
@@ -147,7 +157,7 @@ class _Head(nn.Module):      # parameters ``linear_0/1/2``
         self.linear_0, self.linear_1, self.linear_2 = nn.Linear(i, h), nn.Linear(h, h), nn.Linear(h, o)
 
     def forward(self, x):
-        return self.linear_2(torch.relu(self.linear_1(torch.relu(self.linear_0(x)))))
+        return self.linear_2(_linear_relu(self.linear_1, _linear_relu(self.linear_0, x)))
 
 
 class DynamicsPredictor(nn.Module):
@@ -183,6 +193,8 @@ class DynamicsPredictor(nn.Module):
         if receivers is None:
             receivers, senders, w = self._indices(Rr, Rs)
         else:
+            if B == 1 and receivers.dim() == 1 and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0:
+                return self._forward_index(state, attrs, p_instance, action, receivers, senders)
             if receivers.dim() == 1:
                 receivers, senders = receivers[None].expand(B, -1), senders[None].expand(B, -1)
             w = torch.ones(receivers.shape, dtype=attrs.dtype, device=attrs.device)
@@ -221,6 +233,42 @@ class DynamicsPredictor(nn.Module):
         pred_motion = self.non_rigid_predictor(effect[:, :n_p])
         pred_pos = state[:, -1, :n_p] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
         return pred_pos, pred_motion
+
+
+    def _forward_index(self, state, attrs, p_instance, action, receivers, senders):
+        """``forward`` for ONE graph with index-form relations (every relation real: no padding weights) -- the rollout's call.  The same
+        arithmetic on [N, F] / [E, F] matrices with plain row gathers: about half the launches of the batched form."""
+        c = self.model_config
+        N, n_p, n_his = attrs.shape[1], p_instance.shape[1], c["n_his"]
+        a = attrs[0]
+        state_t = state[0].transpose(0, 1).reshape(N, n_his * state.shape[3])
+        parts = [a]
+        if c["state_dim"] == 3:
+            parts.append(state_t)
+        elif c["state_dim"] == 1:
+            parts.append(state_t.view(N, n_his, 3)[..., 2])
+        if self.motion_dim > 0:
+            s4 = state_t.view(N, n_his, 3)
+            parts.append((s4[:, 1:] - s4[:, :-1]).reshape(N, (n_his - 1) * 3))
+        if c["action_dim"] > 0:
+            parts.append(action[0])
+        p_inputs = torch.cat(parts, 1)
+        g = torch.cat([p_instance[0], torch.zeros(N - n_p, p_instance.shape[2], dtype=a.dtype, device=a.device)], 0)
+        both = torch.cat([a, g, state_t], 1)                                  # one gather per side for the three relation features
+        br, bs = both[receivers], both[senders]
+        na, ng = a.shape[1], g.shape[1]
+        rel_inputs = torch.cat([br[:, :na], bs[:, :na], (br[:, na:na + ng] - bs[:, na:na + ng]).abs().sum(1, keepdim=True),
+                                br[:, na + ng:] - bs[:, na + ng:]], 1)
+        particle_encode = self.particle_encoder(p_inputs)
+        relation_encode = self.relation_encoder(rel_inputs)
+        effect = particle_encode
+        for _ in range(c["pstep"]):
+            e_rel = self.relation_propagator(torch.cat([relation_encode, effect[receivers], effect[senders]], 1))
+            agg = torch.zeros_like(effect).index_add_(0, receivers, e_rel)
+            effect = self.particle_propagator(torch.cat([particle_encode, agg], 1), res=effect)
+        pred_motion = self.non_rigid_predictor(effect[:n_p])
+        pred_pos = state[0, -1, :n_p] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
+        return pred_pos[None], pred_motion[None]
 
 
 # ------------------------------------------------------------------------------------------ rotations
@@ -423,6 +471,27 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
 
 
 # ------------------------------------------------------------------------------------------ one rollout step
+_STEP_CONSTANTS: Dict = {}
+
+
+def _step_constants(nobj: int, dev):
+    """The inputs of a rollout step that depend on the particle count only (object / tool attributes, masks, instance column, the
+    object particles' zero action): built once per (count, device) instead of ten small launches per step."""
+    key = (int(nobj), str(dev))
+    c = _STEP_CONSTANTS.get(key)
+    if c is None:
+        if len(_STEP_CONSTANTS) > 64:
+            _STEP_CONSTANTS.clear()
+        attrs = torch.zeros((1, nobj + 1, 2), device=dev)
+        attrs[0, :nobj, 0] = 1.0
+        attrs[0, nobj:, 1] = 1.0
+        mask = torch.ones(nobj + 1, dtype=torch.bool, device=dev)
+        tool = torch.zeros(nobj + 1, dtype=torch.bool, device=dev)
+        tool[nobj] = True
+        c = _STEP_CONSTANTS[key] = (attrs, mask, tool, torch.ones((1, nobj, 1), device=dev), torch.zeros((nobj, 3), device=dev))
+    return c
+
+
 @torch.no_grad()
 def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_history: torch.Tensor, eef_next: torch.Tensor,
                  all_xyz: torch.Tensor, all_quat: torch.Tensor, adj_thresh: float, topk: int, connect_all: bool = False):
@@ -431,20 +500,11 @@ def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_h
     eef_next [1,3].  Returns (pred_particles [nobj,3], xyz_new, quat_new, (receivers, senders))."""
     dev = particle_history.device
     n_his, nobj = particle_history.shape[0], particle_history.shape[1]
-    states = torch.zeros((1, n_his, nobj + 1, 3), device=dev)
-    states[0, :, :nobj] = particle_history
-    states[0, :, nobj:] = eef_history
-    action = torch.zeros((1, nobj + 1, 3), device=dev)
-    action[0, nobj:] = eef_next - eef_history[-1]
-    attrs = torch.zeros((1, nobj + 1, 2), device=dev)
-    attrs[0, :nobj, 0] = 1.0
-    attrs[0, nobj:, 1] = 1.0
-    mask = torch.ones(nobj + 1, dtype=torch.bool, device=dev)
-    tool = torch.zeros(nobj + 1, dtype=torch.bool, device=dev)
-    tool[nobj] = True
-    recv, send = construct_edges(states[0, -1], adj_thresh, mask, tool, topk=topk, connect_all=connect_all)
-    pred, _ = model(state=states, attrs=attrs, p_instance=torch.ones((1, nobj, 1), device=dev), action=action,
-                    receivers=recv, senders=send)
+    attrs, mask, tool, p_inst, zero_act = _step_constants(nobj, dev)
+    states = torch.cat([particle_history, eef_history], 1)[None]                      # [1, n_his, nobj + 1, 3]
+    action = torch.cat([zero_act, (eef_next - eef_history[-1]).reshape(1, 3)], 0)[None]
+    recv, send = construct_edges(states[0, -1], adj_thresh, mask, tool, topk=topk, connect_all=connect_all, n_tool=1)
+    pred, _ = model(state=states, attrs=attrs, p_instance=p_inst, action=action, receivers=recv, senders=send)
     bones = particle_history[-1]
     rel = relations_to_matrix(recv, send, nobj + 1)[:nobj, :nobj]
     xyz_new, quat_new, _ = interpolate_motions(bones, pred[0] - bones, rel, all_xyz, quat=all_quat)
@@ -456,6 +516,11 @@ def downsample_vertices(xyz: torch.Tensor, max_nobj: int, radius: float, start_i
     """Bones for the graph (/root/reference/src/render/dynamics_module.py:44-51): ``max_nobj`` farthest points, thinned until every
     one of them lies within ``radius`` of a kept one.  Returns (points [M,3], indices into ``xyz`` [M]).  (The reference draws the
     thinning's first index at random; here it is ``start_idx``.)"""
+    if xyz.is_cuda and 0 < xyz.shape[0] <= 1024 and 0 <= start_idx < min(int(max_nobj), xyz.shape[0]):
+        from diff_gaussian_rasterization import _hip      # sampling + thinning in one launch (gsr_fps_thin), one 4-byte read-back
+        idx1, idx2 = _hip.fps_thin(xyz, max_nobj, radius, 0, start_idx)
+        idx = idx1[idx2]
+        return xyz[idx], idx
     idx1 = farthest_point_sampler(xyz[None], max_nobj, start_idx=0)[0]
     _, idx2 = fps_radius(xyz[idx1], radius, start_idx=start_idx)
     idx = idx1[idx2.to(idx1.device)]
@@ -479,7 +544,8 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     inl = torch.as_tensor(inlier_idx_all, device=dev, dtype=torch.long)
     all_pos = xyz_0
     fps_all_idx = farthest_point_sampler(xyz_0[inl][None], n_fps_all, start_idx=0)[0]
-    fps_all_pos = all_pos[inl][fps_all_idx]
+    track = inl[fps_all_idx]                       # the Gaussians that carry the particle history: all_pos[inl][fps_all_idx] == all_pos[track]
+    fps_all_pos = all_pos[track]
     hist = fps_all_pos[None].repeat(n_his, 1, 1)
     eef_hist = eef_xyz[0][None].repeat(n_his, 1, 1)
     eef_pos = eef_xyz[0]
@@ -489,8 +555,16 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
     eef = rep(eef_xyz[0])
     xyz_bones[0, :p0.shape[0]] = p0.to(store)
+    # which steps repeat the previous frame: decided from the end-effector targets alone -- on the host, once, with the arithmetic of the
+    # reference's per-step test (fp32 norm of the difference to the last target that was acted on)
+    eef_host = eef_xyz.detach().to("cpu", torch.float32)
+    skip, last = [False] * n_steps, eef_host[0]
     for i in range(1, n_steps):
-        if float(torch.norm(eef_xyz[i] - eef_pos)) < dist_thresh:
+        skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
+        if not skip[i]:
+            last = eef_host[i]
+    for i in range(1, n_steps):
+        if skip[i]:
             for a in (quat, xyz, rgb, opa, xyz_bones, eef):
                 a[i] = a[i - 1]
             continue
@@ -500,7 +574,7 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
                                                  adj_thresh, topk, connect_all)
         eef_hist = torch.cat([eef_hist[1:], eef_next[None]], 0)
         eef_pos = eef_next
-        fps_all_pos = all_pos[inl][fps_all_idx]
+        fps_all_pos = all_pos[track]
         hist = torch.cat([hist[1:], fps_all_pos[None]], 0)
         quat[i], xyz[i], rgb[i], opa[i] = all_rot.to(store), all_pos.to(store), rgb[i - 1], opa[i - 1]
         xyz_bones[i, :bones.shape[0]] = pred.to(store)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones, gsr_fps_thin; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -309,6 +309,13 @@ size_t gsr_fps_scratch_bytes(int32_t N, int32_t npoints);
  *   U[:, 0] (the reference's answer there depends on its SVD backend's convention; LAPACK's is -sign(F00) c0 / |c0| for F's first
  *   column c0), 1 = rank-1 bone whose F has a vanishing first column, LEFT AS IDENTITY for the caller's own SVD backend. */
 int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_related, float* rotations, int32_t* code, void* stream);
+/* gsr_fps_thin: the bones of a rollout step in one launch (downsample_vertices, /root/reference/src/render/dynamics_module.py:44-51):
+ * out_idx[npoints] = farthest point sampling of pos[N,3] as gsr_fps (N <= 1024, first pick start_idx); then the radius thinning of
+ * /root/reference/src/data/utils.py:50-65 over those picks: thin_idx[0 .. *thin_count) = positions in out_idx of the kept points
+ * (first thin_start_idx, then the point farthest from the kept set while that distance exceeds `radius`; distances as torch.norm
+ * evaluates them in fp32, first maximum on ties).  thin_count: device int32. */
+int gsr_fps_thin(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float radius, int32_t thin_start_idx, int64_t* out_idx,
+                 int64_t* thin_idx, int32_t* thin_count, void* stream);
 /* gsr_fit_bones: the moment matrices, gsr_fit_rotations and the bones' unit quaternions in one launch -- what interpolate_motions
  * (/root/reference/src/render/utils.py:138-243) needs per bone: F_b = sum over the bones j with relations[b][j] != 0 of
  * (new_j - new_b)(old_j - old_b)^T with old = bones, new = bones + motions (fp32, ascending j), rotations[b] as gsr_fit_rotations

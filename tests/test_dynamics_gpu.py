@@ -226,3 +226,24 @@ def test_predict_episode_on_the_device(dev, golden_dir):
             # the same way, tools/episode_repro_check.py).  So: no bound on single pixels, bounds on the mean and on how many differ.
             d = (v[0] - part[k][0]).abs()
             assert float(d.mean()) < 5e-5 and float((d > 1e-2).float().mean()) < 5e-3, k
+
+
+def test_bones_sampling_and_thinning_in_one_launch(dev):
+    """gsr_fps_thin (what ``downsample_vertices`` calls on a device: farthest point sampling of the <= 1024 tracked particles + the
+    radius thinning of /root/reference/src/data/utils.py:50-65, one launch) picks the same points as the two-step host path
+    (``farthest_point_sampler`` + ``fps_radius`` on CPU tensors), for several clouds, radii and start indices."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import downsample_vertices, farthest_point_sampler, fps_radius
+    g = torch.Generator().manual_seed(5)
+    for N, npts, radius, start in ((1000, 100, 0.3, 0), (1000, 100, 0.12, 7), (1024, 128, 0.5, 3), (317, 100, 0.05, 0), (40, 100, 0.2, 1), (1, 1, 0.1, 0)):
+        xyz = torch.rand(N, 3, generator=g) * 2 - 1
+        if N > 10:
+            xyz[5] = xyz[4]                                     # a duplicate point: zero distances and ties
+        idx1 = farthest_point_sampler(xyz[None], npts, start_idx=0)[0]
+        _, idx2 = fps_radius(xyz[idx1], radius, start_idx=start)
+        want = idx1[idx2]
+        got1, got2 = _hip.fps_thin(xyz.to(dev), npts, radius, 0, start)
+        assert torch.equal(got1.cpu(), idx1), (N, npts)
+        assert torch.equal(got2.cpu(), idx2), (N, npts, radius, int(idx2.numel()), int(got2.numel()))
+        pts, idx = downsample_vertices(xyz.to(dev), npts, radius, start)
+        assert torch.equal(idx.cpu(), want) and torch.equal(pts.cpu(), xyz[want])
