@@ -63,69 +63,100 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos
 // as torch.norm evaluates them on the host, sqrt(fma(dz, dz, fma(dy, dy, dx * dx))), first maximum on ties -- the host path's picks.
 // One launch and ONE 4-byte read-back (the count) instead of a sampling launch, a device -> host copy of the points, ~100 numpy
 // steps and a host -> device copy of the indices.
+// Arg-max with "first maximum" over a workgroup of FT_THREADS threads whose thread t owns the CONSECUTIVE items 4 t .. 4 t + 3
+// (so a lower lane holds lower indices).  (best, besti) = the thread's own candidate (best >= 0, or -1 with besti = INT_MAX when
+// it has none).  Wave level: the maximum by DPP (values are non-negative: the zeros a masked DPP step reads are neutral), then the
+// first lane holding it (ballot + ffs) -- no LDS crossbar trip; workgroup level: one LDS word pair per wave and ONE barrier (two
+// buffers, alternated by the caller), every thread reduces the FT_THREADS / 64 candidates itself.
+#define FT_THREADS 256
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float ft_dpp_max(float v) {
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false)));
+}
 __device__ __forceinline__ void block_argmax_first(float& best, int& besti, float* s_val, int* s_idx, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float ov = __shfl_xor(best, off, 64);
-    const int oi = __shfl_xor(besti, off, 64);
-    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-  }
-  if (lane == 0) { s_val[wv] = best; s_idx[wv] = besti; }
+  float m = fmaxf(best, 0.0f);
+  m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
+  m = ft_dpp_max<0x142, 0xA>(m); m = ft_dpp_max<0x143, 0xC>(m);
+  const float wmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+  const uint64_t who = __ballot(best == wmax && best >= 0.0f);
+  float cv = -1.0f;
+  int ci = 0x7fffffff;
+  if (who) { cv = wmax; ci = __shfl(besti, __ffsll((long long)who) - 1, 64); }
+  if (lane == 0) { s_val[wv] = cv; s_idx[wv] = ci; }
   __syncthreads();
   best = s_val[0]; besti = s_idx[0];
 #pragma unroll
-  for (int w = 1; w < 16; ++w) {
+  for (int w = 1; w < FT_THREADS / 64; ++w) {
     const float v = s_val[w]; const int i = s_idx[w];
     if (v > best || (v == best && i < besti)) { best = v; besti = i; }
   }
 }
-__global__ __launch_bounds__(1024) void fps_thin_small_kernel(const float* __restrict__ pos, int N, int npoints, int start, float radius,
-                                                              int thin_start, long long* __restrict__ out_idx,
-                                                              long long* __restrict__ thin_idx, int* __restrict__ thin_count) {
-  __shared__ float s_val[2][16];
-  __shared__ int s_idx[2][16];
+__global__ __launch_bounds__(FT_THREADS) void fps_thin_small_kernel(const float* __restrict__ pos, int N, int npoints, int start, float radius,
+                                                                  int thin_start, long long* __restrict__ out_idx,
+                                                                  long long* __restrict__ thin_idx, int* __restrict__ thin_count) {
+  __shared__ float s_val[2][FT_THREADS / 64];
+  __shared__ int s_idx[2][FT_THREADS / 64];
   __shared__ float sp[3 * 1024];          // the picked points, in pick order
   __shared__ float sa[3 * 1024];          // the whole cloud (a pick's coordinates come from LDS, not from a global round trip per pick)
   const int tid = threadIdx.x;
-  const bool have = tid < N;
-  const float px = have ? pos[3 * tid] : 0.f, py = have ? pos[3 * tid + 1] : 0.f, pz = have ? pos[3 * tid + 2] : 0.f;
-  sa[3 * tid] = px; sa[3 * tid + 1] = py; sa[3 * tid + 2] = pz;
+  float px[4], py[4], pz[4], mind[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = 4 * tid + q;
+    const bool have = i < N;
+    px[q] = have ? pos[3 * i] : 0.f; py[q] = have ? pos[3 * i + 1] : 0.f; pz[q] = have ? pos[3 * i + 2] : 0.f;
+    sa[3 * i] = px[q]; sa[3 * i + 1] = py[q]; sa[3 * i + 2] = pz[q];
+    mind[q] = __builtin_inff();
+  }
   __syncthreads();
-  float mind = __builtin_inff();
   int cur = start;
   for (int k = 0; k < npoints; ++k) {
-    if (tid == cur) { out_idx[k] = cur; sp[3 * k] = px; sp[3 * k + 1] = py; sp[3 * k + 2] = pz; }
     const float cx = sa[3 * cur], cy = sa[3 * cur + 1], cz = sa[3 * cur + 2];
+    if (tid == 0) { out_idx[k] = cur; sp[3 * k] = cx; sp[3 * k + 1] = cy; sp[3 * k + 2] = cz; }
     float best = -1.0f;
     int besti = 0x7fffffff;
-    if (have) {
-      const float dx = px - cx, dy = py - cy, dz = pz - cz;
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      mind = fminf(mind, d);
-      best = mind; besti = tid;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * tid + q;
+      if (i < N) {
+        const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        mind[q] = fminf(mind[q], d);
+        if (mind[q] > best) { best = mind[q]; besti = i; }      // ascending i: the thread's first maximum
+      }
     }
     block_argmax_first(best, besti, s_val[k & 1], s_idx[k & 1], tid);     // (two LDS buffers: one barrier per pick)
     cur = besti;
   }
   __syncthreads();                         // sp[] complete
-  // ---- thinning over the npoints picks: thread i < npoints owns pick i
-  const bool mine = tid < npoints;
-  const float qx = mine ? sp[3 * tid] : 0.f, qy = mine ? sp[3 * tid + 1] : 0.f, qz = mine ? sp[3 * tid + 2] : 0.f;
-  auto dist_to = [&](int j) {
-    const float dx = qx - sp[3 * j], dy = qy - sp[3 * j + 1], dz = qz - sp[3 * j + 2];
-    return __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))));
-  };
+  // ---- thinning over the npoints picks: thread t owns picks 4 t .. 4 t + 3
+  float qx[4], qy[4], qz[4], dist[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = 4 * tid + q;
+    const bool mine = i < npoints;
+    qx[q] = mine ? sp[3 * i] : 0.f; qy[q] = mine ? sp[3 * i + 1] : 0.f; qz[q] = mine ? sp[3 * i + 2] : 0.f;
+    dist[q] = __builtin_inff();
+  }
   int kept = 0, nxt = thin_start;
-  float dist = __builtin_inff();
   for (int it = 0; it < npoints; ++it) {
     if (tid == 0) thin_idx[kept] = nxt;
     ++kept;
-    if (mine) dist = fminf(dist, dist_to(nxt));
-    float best = mine ? dist : -1.0f;
-    int besti = mine ? tid : 0x7fffffff;
+    const float nx = sp[3 * nxt], ny = sp[3 * nxt + 1], nz = sp[3 * nxt + 2];
+    float best = -1.0f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * tid + q;
+      if (i < npoints) {
+        const float dx = qx[q] - nx, dy = qy[q] - ny, dz = qz[q] - nz;
+        dist[q] = fminf(dist[q], __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))));
+        if (dist[q] > best) { best = dist[q]; besti = i; }
+      }
+    }
     block_argmax_first(best, besti, s_val[it & 1], s_idx[it & 1], tid);
-    if (!(best > radius)) break;           // uniform: every thread reduced the same 16 candidates
+    if (!(best > radius)) break;           // uniform: every thread reduced the same candidates
     nxt = besti;
   }
   if (tid == 0) *thin_count = kept;
@@ -443,7 +474,7 @@ int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind,
 int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
                         int* thin_count, hipStream_t st) {
   { GSR_PROF("fps_thin", st);
-    hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(1024), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }
+    hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(FT_THREADS), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
