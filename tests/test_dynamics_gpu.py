@@ -247,3 +247,32 @@ def test_bones_sampling_and_thinning_in_one_launch(dev):
         assert torch.equal(got2.cpu(), idx2), (N, npts, radius, int(idx2.numel()), int(got2.numel()))
         pts, idx = downsample_vertices(xyz.to(dev), npts, radius, start)
         assert torch.equal(idx.cpu(), want) and torch.equal(pts.cpu(), xyz[want])
+
+
+def test_graphed_propagation_equals_eager(dev, golden_dir):
+    """The rollout's GNN step replayed from a hipGraph (padded shapes, dummy rows / relations, static buffers) against the eager
+    propagation: the same graph sizes the rollout meets (bone counts and relation counts that change from step to step, shrinking
+    as well as growing, inside one padded shape and across two)."""
+    import gsdyn.dynamics as D
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = D.DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    g = torch.Generator().manual_seed(3)
+    n_his = cfg["n_his"]
+    worst = 0.0
+    with torch.no_grad():
+        for nobj, E in ((100, 520), (100, 300), (97, 511), (100, 640), (60, 90), (100, 520)):
+            N = nobj + 1
+            state = (torch.rand(1, n_his, N, 3, generator=g) * 0.4).to(dev)
+            attrs = torch.zeros(1, N, 2, device=dev); attrs[0, :nobj, 0] = 1; attrs[0, nobj:, 1] = 1      # noqa: E702
+            pin = torch.ones(1, nobj, 1, device=dev)
+            action = torch.zeros(1, N, 3, device=dev); action[0, nobj:] = 0.01                             # noqa: E702
+            recv = torch.randint(0, N, (E,), generator=g).to(dev); send = torch.randint(0, N, (E,), generator=g).to(dev)   # noqa: E702
+            D._GRAPH_ROLLOUT = False
+            want = model(state=state, attrs=attrs, p_instance=pin, action=action, receivers=recv, senders=send)[0]
+            D._GRAPH_ROLLOUT = True
+            got = model(state=state, attrs=attrs, p_instance=pin, action=action, receivers=recv, senders=send)[0]
+            assert got.shape == want.shape == (1, nobj, 3) and torch.isfinite(got).all()
+            worst = max(worst, float((got - want).abs().max()))
+    assert len(model._graphs) == 4 and worst < 2e-6, (len(model._graphs), worst)      # padded shapes (128, 640), (128, 384), (128, 512), (64, 128)
