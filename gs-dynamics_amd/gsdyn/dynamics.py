@@ -315,7 +315,7 @@ class DynamicsPredictor(nn.Module):
                     run()
             torch.cuda.current_stream(fin.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (another thread may be rendering: predict_episode(overlap=True))
                 out = run()
             ent = cache[key] = (graph, fbuf, ibuf, out)
         graph, fbuf, ibuf, out = ent
@@ -586,13 +586,14 @@ def downsample_vertices(xyz: torch.Tensor, max_nobj: int, radius: float, start_i
 @torch.no_grad()
 def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_steps: int, inlier_idx_all, *, max_nobj: int,
             fps_radius_value: float, adj_thresh: float, topk: int, connect_all: bool, dist_thresh: float, n_fps_all: int = 1000,
-            thin_start_idx: int = 0, storage_device=None):
+            thin_start_idx: int = 0, storage_device=None, after_step=None):
     """The autoregressive loop of /root/reference/src/render/dynamics_module.py:53-172.  1000 (``n_fps_all``) farthest points of the
     inlier Gaussians carry the particle history; per step the bones are re-sampled from them, the GNN predicts the bones' next
     positions from the last ``n_his`` states and the end-effector motion, and all Gaussians follow the bones
     (``interpolate_motions``).  A step whose end-effector target moved less than ``dist_thresh`` repeats the previous frame.
     Everything stays on the device of ``xyz_0`` (the reference shuttles every frame to the CPU); ``storage_device`` moves the
-    per-frame arrays elsewhere if wanted.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
+    per-frame arrays elsewhere if wanted.  ``after_step(i, arrays, repeated)`` is called once frame i is written (arrays = the six
+    result arrays, ``repeated`` = the frame copied its predecessor): the hook of a consumer that does not wait for the whole episode.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
     eef [S,1,3])."""
     dev = xyz_0.device
     store = dev if storage_device is None else torch.device(storage_device)
@@ -611,6 +612,9 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
     eef = rep(eef_xyz[0])
     xyz_bones[0, :p0.shape[0]] = p0.to(store)
+    arrays = (xyz, rgb, quat, opa, xyz_bones, eef)
+    if after_step is not None:
+        after_step(0, arrays, False)
     # which steps repeat the previous frame: decided from the end-effector targets alone -- on the host, once, with the arithmetic of the
     # reference's per-step test (fp32 norm of the difference to the last target that was acted on)
     eef_host = eef_xyz.detach().to("cpu", torch.float32)
@@ -623,6 +627,8 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
         if skip[i]:
             for a in (quat, xyz, rgb, opa, xyz_bones, eef):
                 a[i] = a[i - 1]
+            if after_step is not None:
+                after_step(i, arrays, True)
             continue
         eef_next = eef_xyz[i]
         bones, fps_idx = downsample_vertices(fps_all_pos, max_nobj, fps_radius_value, thin_start_idx)
@@ -635,6 +641,8 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
         quat[i], xyz[i], rgb[i], opa[i] = all_rot.to(store), all_pos.to(store), rgb[i - 1], opa[i - 1]
         xyz_bones[i, :bones.shape[0]] = pred.to(store)
         eef[i] = eef_pos.to(store)
+        if after_step is not None:
+            after_step(i, arrays, False)
     return xyz, rgb, quat, opa, xyz_bones, eef
 
 
@@ -644,14 +652,20 @@ def smooth_frames(xyz, rgb, quat, opa, xyz_bones, eef):
     moved = (xyz - torch.cat([xyz[0:1], xyz[:-1]], 0)).norm(dim=-1).sum(-1).nonzero().squeeze(1)
     cps = torch.cat([torch.zeros(1, dtype=moved.dtype, device=moved.device), moved]).tolist()
     for a, b in zip(cps[:-1], cps[1:]):
-        if b - a < 2:
-            continue
-        w = torch.linspace(0, 1, b - a + 1, device=xyz.device)
-        for arr in (xyz, rgb, quat, opa, xyz_bones, eef):
-            ww = w.to(arr.device)[(slice(None),) + (None,) * (arr.dim() - 1)]
-            arr[a:b] = torch.lerp(arr[a][None], arr[b][None], ww)[:-1]
+        smooth_segment((xyz, rgb, quat, opa, xyz_bones, eef), a, b)
     quat[:] = torch.nn.functional.normalize(quat, dim=-1)
     return xyz, rgb, quat, opa, xyz_bones, eef
+
+
+def smooth_segment(arrays, a: int, b: int) -> None:
+    """Frames a .. b - 1 of every array become the linear interpolation from frame a to frame b (a and b: consecutive frames in which
+    the Gaussians moved; frame a keeps its value: weight 0).  In place; nothing to do for b - a < 2."""
+    if b - a < 2:
+        return
+    w = torch.linspace(0, 1, b - a + 1, device=arrays[0].device)
+    for arr in arrays:
+        ww = w.to(arr.device)[(slice(None),) + (None,) * (arr.dim() - 1)]
+        arr[a:b] = torch.lerp(arr[a][None], arr[b][None], ww)[:-1]
 
 
 def spatial_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:

@@ -17,6 +17,8 @@ composition of predict.py:115-128 -- as ONE call per rank.  PNG / ffmpeg output 
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -97,14 +99,18 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
 @torch.no_grad()
 def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
                        dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
-                       remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True):
+                       remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True, on_frame=None):
     """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
     the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
     sampling (:194-212), then rollout -> smoothing -> per-frame render inputs.  Returns (scene_data, vis_data, timings).
     ``spatial_sort`` (not in the reference): the per-frame arrays are handed to the renderer in Morton order of the frame-0
     positions (``dynamics.spatial_order``: one permutation per episode, applied AFTER the rollout, whose farthest-point picks
-    depend on the index order) -- the same images up to exact depth ties, a twice faster entry scatter in the rasterizer."""
+    depend on the index order) -- the same images up to exact depth ties, a twice faster entry scatter in the rasterizer.
+    ``on_frame(t, frame_dict, event)``: STREAMING mode -- every frame is handed over as soon as it is final (a frame in which the
+    Gaussians moved: at once; the repeated frames before it: interpolated right then), with a device event recorded behind its
+    last producer on the current stream; the returned scene data are those same per-frame dicts.  Same values as the batch mode
+    (the interpolation is ``smooth_segment`` either way)."""
     import time
     from . import dynamics as D
     first = lambda t: t[0] if t.dim() == 3 else t   # noqa: E731
@@ -124,6 +130,43 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     if eef.dim() == 2:
         eef = eef[:, None, :]
     n_steps = min(int(eef.shape[0]), max_steps)
+    if on_frame is not None:
+        # ---- streaming: frames leave in order as they become final
+        perm = D.spatial_order(xyz_0) if (spatial_sort and int(xyz_0.shape[0]) > 1) else None     # frame 0 IS xyz_0
+        pick = (lambda t: t) if perm is None else (lambda t: t[perm])
+        scales_p = pick(scales_0)
+        scene, state = [], {"cp": 0, "next": 0}
+
+        def emit(arrays, upto):                   # frames state["next"] .. upto are final
+            xyz, rgb, quat, opa = arrays[0], arrays[1], arrays[2], arrays[3]
+            for t in range(state["next"], upto + 1):
+                m = pick(xyz[t])
+                d = {"means3D": m, "colors_precomp": pick(rgb[t]), "rotations": pick(torch.nn.functional.normalize(quat[t], dim=-1)),
+                     "opacities": pick(opa[t]), "scales": scales_p, "means2D": torch.zeros_like(m)}
+                scene.append(d)
+                ev = None
+                if dev.type == "cuda":
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                on_frame(t, d, ev)
+            state["next"] = upto + 1
+
+        def after_step(i, arrays, repeated):
+            if repeated:
+                return                              # final only once the next moving frame is known
+            D.smooth_segment(arrays, state["cp"], i)
+            state["cp"] = i
+            emit(arrays, i)
+
+        out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
+                        adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
+                        n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, after_step=after_step)
+        emit(out, n_steps - 1)                      # trailing repeats of the last moving frame
+        vis = [{"kp": out[4][t].cpu().numpy(), "tool_kp": out[5][t].cpu().numpy()} for t in range(n_steps)]
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        return scene, vis, {"outlier_filter_ms": (t1 - t0) * 1e3, "rollout_ms": (t2 - t1) * 1e3, "frames": n_steps, "gaussians": int(xyz_0.shape[0])}
     out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
                     adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
                     n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx)
@@ -148,16 +191,23 @@ def compose_rgba(im: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: int, *, rollout_cfg: dict, rank: Optional[int] = None,
                     world: Optional[int] = None, gather_to: Optional[int] = None, bg=(0.0, 0.0, 0.0), rgba: bool = False,
-                    scene_out: Optional[list] = None):
+                    scene_out: Optional[list] = None, overlap: bool = False):
     """One episode of /root/reference/src/predict.py:74-164 on this rank: GNN rollout (every rank, identical), then this rank's
     (frame, camera) pairs -- colour + all-ones mask render per pair, all cameras of a frame in one rasterizer call.
     ``poses``: the cameras as (w2c, K); ``rollout_cfg``: the keyword arguments of ``collect_scene_data`` (max_nobj, fps_radius,
     adj_thresh, topk, connect_all, dist_thresh, ...).  Returns (frames, vis_data, timings): ``frames`` = {(frame, cam): (image,
     depth, mask)} of this rank -- or, with ``gather_to`` = a rank, the merged dict there and None elsewhere; with ``rgba`` the
     image slot holds the composed RGBA instead.  ``scene_out``: a list that receives the per-frame render inputs (the rollout's
-    torch ops -- index_add message passing, library GEMMs -- are not bit-reproducible from run to run on a GPU)."""
+    torch ops -- index_add message passing, library GEMMs -- are not bit-reproducible from run to run on a GPU).
+    ``overlap`` (HIP devices; opt-in): the renders run on a second stream, issued by a second host thread, WHILE the rollout goes on
+    -- the rollout is bound by the host issuing small launches and leaves the GPU idle most of the time, the renders are GPU-bound;
+    each frame is rendered as soon as it is final (``collect_scene_data(on_frame=...)``).  Same values as the sequential form.
+    Measured at configs[4] size on two MI355X boxes: 2.29 - 2.44 ms per frame on one, 3.8 - 4.0 on the other, against 2.7 - 2.8
+    sequential on both -- two host threads that both spin on device synchronisations need the cores for it; hence not the default."""
     import time
     dev = params["means3D"].device
+    if overlap and dev.type == "cuda":
+        return _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg, rank, world, gather_to, bg, rgba, scene_out)
     scene, vis, tm = collect_scene_data(model, params, eef_xyz, **rollout_cfg)
     if scene_out is not None:
         scene_out.extend(scene)
@@ -170,6 +220,62 @@ def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: in
         torch.cuda.synchronize(dev)
     tm["render_ms"] = (time.perf_counter() - t0) * 1e3
     tm["pairs_on_this_rank"] = len(frames)
+    if gather_to is not None:
+        frames = gather_frames(frames, dst=gather_to)
+    return frames, vis, tm
+
+
+def _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg, rank, world, gather_to, bg, rgba, scene_out):
+    """predict_episode with the renders of finished frames overlapping the rollout of later ones: a worker thread with its own HIP
+    stream takes (frame, inputs, event) items off a queue, waits for the event on its stream, renders this rank's cameras of the
+    frame.  The main thread only rolls out."""
+    import queue
+    import threading
+    import time
+    dev = params["means3D"].device
+    shard = FrameShard(dev, w, h, poses, rank, world, bg=bg)
+    todo: "queue.Queue" = queue.Queue()
+    frames, failure = {}, []
+
+    def worker():
+        try:
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(device=dev)
+            with torch.no_grad(), torch.cuda.stream(stream):
+                while True:
+                    item = todo.get()
+                    if item is None:
+                        break
+                    f, d, ev = item
+                    if failure:
+                        continue
+                    if ev is not None:
+                        stream.wait_event(ev)
+                    for c, v in shard.render_frame(f, d).items():
+                        frames[(f, c)] = (compose_rgba(v[0], v[2]), v[1], v[2]) if rgba else v
+            stream.synchronize()
+        except BaseException as e:      # noqa: BLE001 -- handed to the caller's thread
+            failure.append(e)
+
+    th = threading.Thread(target=worker, name="gsdyn-render", daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    # (a high-priority stream for the rollout's small launches was measured WORSE: 2.81 vs 2.38 ms per frame)
+    try:
+        scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=lambda f, d, ev: todo.put((f, d, ev)), **rollout_cfg)
+    finally:
+        todo.put(None)
+        th.join()
+    if failure:
+        raise failure[0]
+    torch.cuda.synchronize(dev)
+    if scene_out is not None:
+        scene_out.extend(scene)
+    tm["episode_ms"] = (time.perf_counter() - t0) * 1e3
+    tm["render_ms"] = float("nan")                      # not separable: the renders ran under the rollout
+    tm["pairs_on_this_rank"] = len(frames)
+    tm["overlapped"] = True
+    frames = dict(sorted(frames.items()))
     if gather_to is not None:
         frames = gather_frames(frames, dst=gather_to)
     return frames, vis, tm

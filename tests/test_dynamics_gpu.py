@@ -211,6 +211,19 @@ def test_predict_episode_on_the_device(dev, golden_dir):
         assert torch.equal(got[1], depth) and float((got[2] - mask).abs().max()) <= 2e-5, (f, c)
         d = (got[0] - compose_rgba(im, mask)).abs()          # (worst case: a 2e-5 mask difference at the smallest non-zero mask, 1/255)
         assert float(d.max()) < 2e-2 and float(d.mean()) < 1e-5, (f, c)
+    # the renders overlapped with the rollout (second host thread + second stream, frames streamed out as they become final): the same
+    # episode -- its own rollout, so compared like two rollouts below; three times, for the threads' sake
+    for _ in range(3):
+        sc_o = []
+        fr_o, vis_o, tm_o = predict_episode(model, params, eef, poses, W, H, rollout_cfg=roll, rank=0, world=1, rgba=True, scene_out=sc_o, overlap=True)
+        assert tm_o["overlapped"] and sorted(fr_o) == sorted(frames) and len(sc_o) == S
+        for a, b in zip(sc_o, scene):
+            for k in a:
+                np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), atol=2e-5, err_msg=k)
+        for k, v in fr_o.items():
+            d = (v[2] - frames[k][2]).abs()                  # the masks (accumulated alpha): no division by small numbers
+            assert float(d.mean()) < 5e-5 and float((d > 1e-2).float().mean()) < 5e-3, k
+            assert v[0].shape == frames[k][0].shape and torch.isfinite(v[0]).all() and torch.equal(v[1] > 0, frames[k][1] > 0) or float(((v[1] > 0) != (frames[k][1] > 0)).float().mean()) < 1e-3
     # two ranks' shares (run one after the other on this GPU) partition the single-rank result
     for r in range(2):
         part = FrameShard(dev, W, H, poses, rank=r, world=2).render_episode(scene)

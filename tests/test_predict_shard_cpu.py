@@ -158,6 +158,16 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
     for a, b in zip(scene_sorted, scene):          # one permutation for the whole episode, every per-Gaussian array
         for k in a:
             assert torch.equal(a[k], b[k][perm]), k
+    # streaming mode (frames handed over while the rollout goes on: predict_episode(overlap=True)) == batch mode, bit for bit, in order
+    got = []
+    scene_stream, vis_stream, _ = collect_scene_data(model, params, eef, on_frame=lambda t, d, ev: got.append((t, d, ev)), **ROLL)
+    assert [t for t, _, _ in got] == list(range(EP_STEPS)) and all(ev is None for _, _, ev in got) and len(scene_stream) == EP_STEPS
+    for (t, d, _), b in zip(got, scene_sorted):
+        assert d is scene_stream[t]
+        for k in b:
+            assert torch.equal(d[k], b[k]), (t, k)
+    for a, b in zip(vis_stream, vis):
+        assert np.array_equal(a["kp"], b["kp"]) and np.array_equal(a["tool_kp"], b["tool_kp"])
     # the pieces, called one by one as the reference's collect_scene_data strings them together
     op = torch.sigmoid(params["logit_opacities"])
     keep = op[:, 0] >= 0.1
