@@ -219,6 +219,9 @@ __device__ __forceinline__ void fwd_tile(
     // entry's record is fetched from LDS while this one is evaluated, and the blend itself is predicated
     // (w = 0 when the pair does not contribute) instead of branched, so consecutive iterations overlap.
     if (__ballot(!done) != 0ull) {
+#ifdef GSR_PRIO_FBLEND
+      __builtin_amdgcn_s_setprio(GSR_PRIO_FBLEND);     // A/B hook: the blend walk of a batch at raised wave priority -- measured: no effect (203 us either way)
+#endif
       const float4* __restrict__ wA = L.sA[wv];
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
@@ -265,6 +268,9 @@ __device__ __forceinline__ void fwd_tile(
         GSR_FWD_ENTRY(ea, eb, ec, ed)
       }
 #undef GSR_FWD_ENTRY
+#ifdef GSR_PRIO_FBLEND
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     GSR_TP(5);
   }
@@ -433,6 +439,9 @@ __device__ __forceinline__ void bwd_tile(
   }
   GSR_TP(0);
   for (int base = 0; base < max_last; base += BB) {
+#ifdef GSR_PRIO_STAGE
+    __builtin_amdgcn_s_setprio(GSR_PRIO_STAGE);      // A/B: classification + staging of a batch (gates the barrier) at raised priority
+#endif
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
     const int m_all = min(BB, max_last - base);
     const float4 a = na, b = nb, d = np;
@@ -489,6 +498,9 @@ __device__ __forceinline__ void bwd_tile(
       }
     }
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
+#ifdef GSR_PRIO_STAGE
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     GSR_TP(3);
     uint64_t active_lo = 0ull, active_hi = 0ull;
@@ -500,6 +512,20 @@ __device__ __forceinline__ void bwd_tile(
     const float4* __restrict__ wD = L.sD[wv];
     // One list entry: re-evaluate alpha; when some pixel of the quad used the entry, back out T, form the nine partials,
     // reduce them over the wave and park the totals.
+#ifndef GSR_PRIO_VISIT
+#define GSR_PRIO_VISIT 1      /* wave priority (s_setprio) inside a contributing visit; 0 = leave it alone.  Measured, 8 views, one box, 3 rounds each:
+                                 0: 441.7 us, 1 / 2 / 3: 433.6 / 431.9 / 431.9 us per launch; raising the staging phase as well or instead: 437.8 / 448 */
+#endif
+#ifndef GSR_PRIO_COMBINE
+#define GSR_PRIO_COMBINE 0    /* ... and while a batch's totals are combined and stored */
+#endif
+#if GSR_PRIO_VISIT
+#define GSR_BWD_PRIO_IN __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT);
+#define GSR_BWD_PRIO_OUT __builtin_amdgcn_s_setprio(0);
+#else
+#define GSR_BWD_PRIO_IN
+#define GSR_BWD_PRIO_OUT
+#endif
 #define GSR_BWD_ENTRY(ea, eb, ec, ed)                                                                           \
     {                                                                                                         \
       const int j = __builtin_amdgcn_readfirstlane((int)__float_as_uint(ec.y)); /* batch index, wave-uniform */ \
@@ -510,6 +536,7 @@ __device__ __forceinline__ void bwd_tile(
       const float G0 = __builtin_amdgcn_exp2f(power);  /* power is in log2 units (pre-scaled conic) */        \
       const bool hit = (pos < last) && power <= 0.0f && eb.y * G0 >= GSR_ALPHA_MIN; /* = min(0.99, .) >= 1/255 */ \
       if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
+        GSR_BWD_PRIO_IN                                                                                        \
         /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
            alpha = 0, 1/(1-alpha) = 1, T and the accumulated colour are unchanged (an alpha = 0 entry only flushes \
            the pending (last_alpha, last colour) pair, which the next real entry would have done with the same    \
@@ -559,6 +586,7 @@ __device__ __forceinline__ void bwd_tile(
         GSR_BWD_PARK9(v0, v1, v2, v3, v4, v5, v6, v7, v8)                                                     \
         }                                                                                                     \
         GSR_MARK_ACTIVE(j)                                                                                    \
+        GSR_BWD_PRIO_OUT                                                                                       \
       }                                                                                                       \
     }
     // two entries per trip on ping-pong registers: the record of entry j+1 (j+2) is fetched from LDS while entry j (j+1) is
@@ -582,6 +610,7 @@ __device__ __forceinline__ void bwd_tile(
     GSR_TP(4);
     __syncthreads();
     GSR_TP(5);
+    if (GSR_PRIO_COMBINE) __builtin_amdgcn_s_setprio(GSR_PRIO_COMBINE);
     if (tid < m_all) {
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 #pragma unroll
@@ -598,6 +627,7 @@ __device__ __forceinline__ void bwd_tile(
       if (PAIR || COL) gsr_store_partial(partials, e, r0, r1, r2.x);
       else GSR_NOCOL_STORE6(partials, e, r0, r1.x, r1.y);
     }
+    if (GSR_PRIO_COMBINE) __builtin_amdgcn_s_setprio(0);
     GSR_TP(6);
     __syncthreads();
     GSR_TP(7);
