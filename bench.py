@@ -658,7 +658,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         ms_f, ms_r = _time_ms(frame_fused, 10, 3), _time_ms(frame_reference, 5, 2)
         out["predict_frame_4cams"] = {"ms_per_frame": ms_f, "ms_per_frame_reference_calls": ms_r, "Mpix_per_s": 8 * H * W / ms_f / 1e3,
                                       "what": "predict.py frame: 4 cameras x (colour + all-ones mask render), 100k Gaussians, 800x800, forward only; "
-                                              "fused = one multi-view call, each camera's pair blended in one tile pass; reference_calls = 8 Renderer.render calls"}
+                                              "fused = one multi-view call, ONE blend per camera, the mask from its final transmittance (gsdyn.render); reference_calls = 8 Renderer.render calls"}
     except Exception as e:  # noqa: BLE001
         out["predict_frame_4cams"] = {"error": repr(e)}
     try:   # BASELINE.json configs[0]-shaped rollout step on the device (row N4): rope.yaml GNN dims, random weights
