@@ -295,7 +295,7 @@ class DynamicsPredictor(nn.Module):
         N, E = int(a.shape[0]), int(receivers.shape[0])
         n_cap, e_cap = ((N + 1 + 31) // 32) * 32, max(128, ((E + 127) // 128) * 128)
         widths = (state_t.shape[1], a.shape[1], g.shape[1], act.shape[1])
-        key = (n_cap, e_cap, widths, str(a.device))
+        key = (n_cap, e_cap, widths, str(a.device), self.non_rigid_predictor.linear_2.weight.data_ptr())      # (a captured graph reads THESE weight buffers)
         cache = self.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         fin = torch.cat([state_t, a, g, act], 1)
