@@ -793,6 +793,27 @@ int gsr_fps_thin(int32_t N, const float* pos, int32_t npoints, int32_t start_idx
                              (hipStream_t)stream);
 }
 
+int gsr_lbs_valid(int32_t P, int32_t n_bones, const int32_t* n_valid, const float* bones, const float* rotations, const float* translations,
+                  const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream) {
+  GsrRange _range("gsr_lbs");
+  if (P < 0 || n_bones <= 0 || !n_valid || !bones || !rotations || !translations || !bone_quats || (P > 0 && (!xyz || !out_xyz))) {
+    gsr_set_error("gsr_lbs_valid: bad argument");
+    return -2;
+  }
+  return gsr_launch_lbs(P, n_bones, bones, rotations, translations, bone_quats, xyz, quat, out_xyz, out_quat, (hipStream_t)stream, (const int*)n_valid);
+}
+
+int gsr_construct_edges(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                        int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, void* stream) {
+  GsrRange _range("gsr_construct_edges");
+  if (!positions || !n_valid || !receivers || !senders || !count || n_obj_cap < 1 || n_obj_cap > 127 || topk < 1 || topk > 16 || e_cap < 1) {
+    gsr_set_error("gsr_construct_edges: bad argument (1 <= n_obj_cap <= 127, 1 <= topk <= 16)");
+    return -2;
+  }
+  return gsr_launch_construct_edges(positions, n_obj_cap, (const int*)n_valid, thresh_sq, topk, (long long)dummy_index, e_cap, (long long*)receivers,
+                                    (long long*)senders, (int*)count, (hipStream_t)stream);
+}
+
 int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,
                   float* rotations, float* quats, int32_t* code, void* stream) {
   GsrRange _range("gsr_fit_bones");

@@ -330,7 +330,9 @@ int gsr_launch_fit_bones(int nb, const float* bones, const float* motions, const
 int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
                         int* thin_count, hipStream_t st);
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
-                   const float* quat, float* out_xyz, float* out_quat, hipStream_t st);
+                   const float* quat, float* out_xyz, float* out_quat, hipStream_t st, const int* nb_valid = nullptr);
+int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
+                               long long* recv, long long* send, int* count, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
 int gsr_debug_fwd_timing(unsigned long long* out16);

@@ -160,6 +160,81 @@ __global__ __launch_bounds__(FT_THREADS) void fps_thin_small_kernel(const float*
     nxt = besti;
   }
   if (tid == 0) *thin_count = kept;
+  for (int i = kept + tid; i < npoints; i += FT_THREADS) thin_idx[i] = thin_start;   // padding: a valid position (fixed-shape consumers gather with it)
+}
+
+// ---------------------------------------------------------------- relations of a rollout step, fixed shapes
+// construct_edges (gsdyn.dynamics; /root/reference/src/data/dataset.py:88-147) for the rollout's graph -- object particles 0 .. n_obj_cap - 1
+// of which the first *n_valid are real, ONE tool particle at index n_obj_cap -- as one launch with padded outputs: receiver / sender
+// lists of e_cap entries (row-major order of the adjacency matrix, as torch's nonzero gives them; unused entries = `dummy`) and the
+// count.  A pair is related when both ends are real, not both tools, closer than thr (squared distance (dx*dx + dy*dy) + dz*dz < thr2,
+// rounded as the torch expression) and -- among objects -- the sender is one of the receiver's topk nearest objects (itself included;
+// equal distances: the lower index first).  One workgroup, one receiver per thread.
+#define CE_THREADS 128
+#define CE_MAXK 16
+__global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float* __restrict__ pos, int n_obj_cap, const int* __restrict__ n_valid_p,
+                                                                   float thr2, int topk, long long dummy, int e_cap,
+                                                                   long long* __restrict__ recv, long long* __restrict__ send,
+                                                                   int* __restrict__ count) {
+  __shared__ float sp[3 * CE_THREADS];
+  __shared__ int s_wave[CE_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int N = n_obj_cap + 1, n_valid = min(*n_valid_p, n_obj_cap);
+  if (tid < N) { sp[3 * tid] = pos[3 * tid]; sp[3 * tid + 1] = pos[3 * tid + 1]; sp[3 * tid + 2] = pos[3 * tid + 2]; }
+  __syncthreads();
+  const bool is_tool = tid == n_obj_cap, is_obj = tid < n_valid;
+  const float px = tid < N ? sp[3 * tid] : 0.f, py = tid < N ? sp[3 * tid + 1] : 0.f, pz = tid < N ? sp[3 * tid + 2] : 0.f;
+  auto d2 = [&](int j) {
+    const float dx = px - sp[3 * j], dy = py - sp[3 * j + 1], dz = pz - sp[3 * j + 2];
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  };
+  // the receiver's k nearest objects (k = min(topk, n_valid)): insertion into a sorted list, ties keep the lower index in front
+  const int k = min(min(topk, CE_MAXK), n_valid);
+  float nv[CE_MAXK];
+  int ni[CE_MAXK];
+#pragma unroll
+  for (int q = 0; q < CE_MAXK; ++q) { nv[q] = __builtin_inff(); ni[q] = -1; }
+  if (is_obj) {
+    for (int j = 0; j < n_valid; ++j) {
+      float v = d2(j);
+      int vi = j;
+#pragma unroll
+      for (int q = 0; q < CE_MAXK; ++q) {
+        if (q < k && v < nv[q]) { const float tv = nv[q]; const int ti = ni[q]; nv[q] = v; ni[q] = vi; v = tv; vi = ti; }
+      }
+    }
+  }
+  auto related = [&](int j) -> bool {
+    if (!(is_obj || is_tool)) return false;
+    const bool j_tool = j == n_obj_cap, j_obj = j < n_valid;
+    if (!(j_tool || j_obj) || (is_tool && j_tool)) return false;
+    if (!(d2(j) < thr2)) return false;
+    if (is_obj && j_obj) {
+      bool in = false;
+#pragma unroll
+      for (int q = 0; q < CE_MAXK; ++q) in = in || (q < k && ni[q] == j);
+      return in;
+    }
+    return true;
+  };
+  int c = 0;
+  if (tid < N) for (int j = 0; j < N; ++j) c += related(j) ? 1 : 0;
+  int inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  int base = inc - c;
+  for (int w = 0; w < wv; ++w) base += s_wave[w];
+  const int total = s_wave[0] + s_wave[1];
+  if (tid < N)
+    for (int j = 0; j < N; ++j)
+      if (related(j)) { if (base < e_cap) { recv[base] = tid; send[base] = j; } ++base; }
+  if (tid == 0) *count = min(total, e_cap);
+  for (int e = total + tid; e < e_cap; e += CE_THREADS) { recv[e] = dummy; send[e] = dummy; }
 }
 
 // ---------------------------------------------------------------- farthest point sampling, several workgroups
@@ -243,8 +318,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const flo
                                                         const float* __restrict__ R, const float* __restrict__ t,
                                                         const float* __restrict__ bq, const float* __restrict__ xyz,
                                                         const float* __restrict__ quat, float* __restrict__ out_xyz,
-                                                        float* __restrict__ out_quat) {
+                                                        float* __restrict__ out_quat, const int* __restrict__ nb_valid) {
   __shared__ float sB[LBS_CHUNK][3], sR[LBS_CHUNK][9], sT[LBS_CHUNK][3], sQ[LBS_CHUNK][4];
+  if (nb_valid) nb = min(nb, *nb_valid);      // fixed-shape callers: only the first *nb_valid bones are real
   const int p = blockIdx.x * GSR_BLOCK + threadIdx.x;
   const bool live = p < P;
   float x = 0.f, y = 0.f, z = 0.f;
@@ -480,11 +556,19 @@ int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float r
 }
 
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
-                   const float* quat, float* out_xyz, float* out_quat, hipStream_t st) {
+                   const float* quat, float* out_xyz, float* out_quat, hipStream_t st, const int* nb_valid) {
   if (P <= 0) return 0;
   { GSR_PROF("lbs", st);
     hipLaunchKernelGGL(lbs_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, nb, bones, R, t, bq, xyz, quat,
-                       out_xyz, out_quat); }
+                       out_xyz, out_quat, nb_valid); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
+                               long long* recv, long long* send, int* count, hipStream_t st) {
+  { GSR_PROF("construct_edges", st);
+    hipLaunchKernelGGL(construct_edges_kernel, dim3(1), dim3(CE_THREADS), 0, st, pos, n_obj_cap, n_valid, thr2, topk, dummy, e_cap, recv, send, count); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

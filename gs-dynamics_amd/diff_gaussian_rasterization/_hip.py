@@ -71,7 +71,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_forward_batch_capacity", "gsr_forward_batch_capacity_raw",
            "gsr_backward_batch", "gsr_backward_batch_raw", "gsr_debug_phase_timing",
-           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_fit_bones", "gsr_fps_thin", "gsr_lbs",
+           "gsr_image_loss_blocks", "gsr_image_loss_forward", "gsr_image_loss_backward", "gsr_fps", "gsr_fps_scratch_bytes", "gsr_fit_rotations", "gsr_fit_bones", "gsr_fps_thin", "gsr_construct_edges", "gsr_lbs_valid", "gsr_lbs",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
@@ -166,6 +166,10 @@ def load_library():
     lib.gsr_fps_scratch_bytes.argtypes = [i32, i32]
     lib.gsr_fit_rotations.restype = C.c_int
     lib.gsr_fit_rotations.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gsr_construct_edges.restype = C.c_int
+    lib.gsr_construct_edges.argtypes = [vp, i32, vp, C.c_float, i32, C.c_int64, i32, vp, vp, vp, vp]
+    lib.gsr_lbs_valid.restype = C.c_int
+    lib.gsr_lbs_valid.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_fps_thin.restype = C.c_int
     lib.gsr_fps_thin.argtypes = [i32, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp]
     lib.gsr_fit_bones.restype = C.c_int
@@ -814,6 +818,43 @@ def fit_rotations(moments: torch.Tensor, n_related: torch.Tensor):
     return R, code
 
 
+def fps_thin_padded(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0, thin_start_idx: int = 0):
+    """gsr_fps_thin without the read-back: (fps indices [npoints], kept positions PADDED to [npoints] with thin_start_idx, count [1] int32
+    on the device) -- for callers with fixed shapes (a rollout step replayed from a graph)."""
+    lib = load_library()
+    _require_device(pos)
+    dev = pos.device
+    N = int(pos.shape[0])
+    if not (0 < N <= 1024 and 0 < npoints <= N):
+        raise ValueError("fps_thin_padded: 1 <= npoints <= N <= 1024")
+    with _on(dev):
+        p = pos.to(torch.float32).contiguous()
+        out = torch.empty((npoints,), dtype=torch.int64, device=dev)
+        thin = torch.empty((npoints,), dtype=torch.int64, device=dev)
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+        _check(lib.gsr_fps_thin(N, _ptr(p), int(npoints), int(start_idx), float(radius), int(thin_start_idx), _ptr(out), _ptr(thin), _ptr(cnt),
+                                _stream(dev)), "gsr_fps_thin")
+    return out, thin, cnt
+
+
+def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: float, topk: int, e_cap: int, dummy: int):
+    """gsr_construct_edges: pos [n_obj_cap + 1, 3] (the tool last), n_valid [1] int32 on the device -> (receivers [e_cap], senders [e_cap]
+    int64 padded with ``dummy``, count [1] int32)."""
+    import numpy as np
+    lib = load_library()
+    _require_device(pos)
+    dev = pos.device
+    with _on(dev):
+        p = pos.to(torch.float32).contiguous()
+        recv = torch.empty((e_cap,), dtype=torch.int64, device=dev)
+        send = torch.empty((e_cap,), dtype=torch.int64, device=dev)
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+        thr2 = float(np.float32(float(thresh) * float(thresh)))          # the scalar a float32 tensor is compared with
+        _check(lib.gsr_construct_edges(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
+                                       _ptr(cnt), _stream(dev)), "gsr_construct_edges")
+    return recv, send, cnt
+
+
 def fps_thin(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0, thin_start_idx: int = 0):
     """gsr_fps_thin: pos [N,3] (N <= 1024) on a HIP device -> (fps indices [npoints] int64, kept positions in that list [M] int64) -- one
     launch, one 4-byte read-back for M."""
@@ -853,7 +894,7 @@ def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tenso
     return R, q, code
 
 
-def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat):
+def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat, n_valid=None):
     """gsr_lbs: returns (xyz_new [P,3], quat_new [P,4] or None, None) -- the [P, n_bones] weight matrix of the reference is
     never materialised."""
     lib = load_library()
@@ -865,8 +906,12 @@ def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat)
     with _on(dev):
         out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None
-        _check(lib.gsr_lbs(P, nb, _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
-                           _ptr(out_xyz), _ptr(out_q), _stream(dev)), "gsr_lbs")
+        if n_valid is not None:      # only the first n_valid[0] bones (device int32) are real: fixed-shape callers
+            _check(lib.gsr_lbs_valid(P, nb, _ptr(n_valid), _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
+                                     _ptr(out_xyz), _ptr(out_q), _stream(dev)), "gsr_lbs_valid")
+        else:
+            _check(lib.gsr_lbs(P, nb, _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
+                               _ptr(out_xyz), _ptr(out_q), _stream(dev)), "gsr_lbs")
     return out_xyz, out_q, None
 
 

@@ -528,6 +528,7 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
 # ------------------------------------------------------------------------------------------ one rollout step
 _STEP_CONSTANTS: Dict = {}
 _GRAPH_ROLLOUT = os.environ.get("GSDYN_GRAPH_ROLLOUT", "1") != "0"     # 0: the GNN propagation of a rollout step runs eagerly (A/B, debugging)
+_GRAPH_ROLLOUT_STEP = os.environ.get("GSDYN_GRAPH_ROLLOUT_STEP", "1") != "0"   # 0: only the propagation is graphed, the rest of a step runs eagerly
 
 
 def _step_constants(nobj: int, dev):
@@ -565,6 +566,94 @@ def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_h
     rel = relations_to_matrix(recv, send, nobj + 1)[:nobj, :nobj]
     xyz_new, quat_new, _ = interpolate_motions(bones, pred[0] - bones, rel, all_xyz, quat=all_quat)
     return pred[0], xyz_new, quat_new, (recv, send)
+
+
+class _GraphedStep:
+    """ONE rollout step -- bone sampling + thinning, relations, GNN propagation, rotation fit, skinning of all Gaussians, the history
+    shift -- captured as a hipGraph over static buffers and replayed per frame: one launch from the host instead of ~70, and no host
+    round trip (the bone count and the relation count stay on the device: every shape is padded -- ``max_nobj`` bone rows of which
+    the first ``n_valid`` are real, the tool particle at row ``max_nobj``, relation lists of ``E_CAP`` entries whose unused tail
+    points at a dummy row; gsr_fps_thin / gsr_construct_edges / gsr_lbs_valid are the fixed-shape forms of the pieces).  The
+    arithmetic per real bone / relation / Gaussian is the eager path's."""
+    E_CAP_PER_BONE = 8
+
+    def __init__(self, model, P, n_track, n_his, max_nobj, radius, thin_start, adj_thresh, topk, dev):
+        from diff_gaussian_rasterization import _hip
+        self.model, self.max_nobj, self.dev = model, int(max_nobj), dev
+        nb, N = self.max_nobj, self.max_nobj + 1
+        self.n_cap = ((N + 1 + 31) // 32) * 32
+        self.e_cap = ((nb * (int(topk) + 2) + 127) // 128) * 128
+        z = lambda *sh, **k: torch.zeros(sh, device=dev, **k)  # noqa: E731
+        self.track = z(n_track, dtype=torch.long)
+        self.pos_track, self.hist, self.eef_hist, self.eef_next = z(n_track, 3), z(n_his, n_track, 3), z(n_his, 1, 3), z(1, 3)
+        self.all_pos, self.all_rot = z(P, 3), z(P, 4)
+        self.pred, self.n_valid, self.bad = z(nb, 3), z(1, dtype=torch.int32), z(1, dtype=torch.long)
+        c = model.model_config
+        a = z(self.n_cap, c["attr_dim"]); a[:nb, 0] = 1.0; a[nb, 1] = 1.0                      # noqa: E702
+        g = z(self.n_cap, 1); g[:nb] = 1.0                                                      # noqa: E702
+        pad_rows = z(self.n_cap - N, n_his * 3)
+        act_obj, act_pad = z(nb, 3), z(self.n_cap - N, 3)
+
+        def body():
+            idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
+            bones_hist = self.hist[:, idx1[thin]]                                             # [n_his, nb, 3]; rows >= cnt repeat a real particle
+            states = torch.cat([bones_hist, self.eef_hist], 1)                                 # tool at row nb
+            recv, send, _ = _hip.construct_edges_padded(states[-1], cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1)
+            state_t = torch.cat([states.transpose(0, 1).reshape(N, n_his * 3), pad_rows], 0)
+            act = torch.cat([act_obj, self.eef_next - self.eef_hist[-1], act_pad], 0)
+            pos_all, _ = model._propagate(state_t, a, g, act, recv, send)
+            bones, pred = bones_hist[-1], pos_all[:nb]
+            rel = torch.zeros((self.n_cap, self.n_cap), dtype=torch.long, device=dev)
+            rel.view(-1).index_fill_(0, recv * self.n_cap + send, 1)                           # (rel[recv, send] = 1 sorts its indices: not capturable)
+            R, q, code = _hip.fit_bones(bones, pred - bones, rel[:nb, :nb])
+            xyz_new, quat_new, _ = _hip.linear_blend_skinning(bones, R, pred - bones, q, self.all_pos, self.all_rot, n_valid=cnt)
+            self.all_pos.copy_(xyz_new); self.all_rot.copy_(quat_new)                           # noqa: E702
+            new_track = xyz_new[self.track]
+            self.pos_track.copy_(new_track)
+            self.hist.copy_(torch.cat([self.hist[1:], new_track[None]], 0))
+            self.eef_hist.copy_(torch.cat([self.eef_hist[1:], self.eef_next[None]], 0))
+            valid = (torch.arange(nb, device=dev) < cnt)
+            self.pred.copy_(pred * valid[:, None])                                             # the reference leaves the unused bone rows at zero
+            self.n_valid.copy_(cnt)
+            self.bad.add_(((code == 1) & valid).sum())                                         # rank-1 bones the device could not resolve (none, normally)
+        self._body, self.graph = body, None
+
+    def load(self, track, pos_track, hist, eef_hist, all_pos, all_rot):
+        for dst, src in ((self.track, track), (self.pos_track, pos_track), (self.hist, hist), (self.eef_hist, eef_hist),
+                         (self.all_pos, all_pos), (self.all_rot, all_rot)):
+            dst.copy_(src)
+        self.bad.zero_()
+        if self.graph is None:                       # capture once: two real runs on a side stream, then the state put back
+            keep = [t.clone() for t in (self.pos_track, self.hist, self.eef_hist, self.all_pos, self.all_rot)]
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._body()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._body()
+            self.graph = graph
+            for dst, src in zip((self.pos_track, self.hist, self.eef_hist, self.all_pos, self.all_rot), keep):
+                dst.copy_(src)
+            self.bad.zero_()
+
+    def step(self, eef_next):
+        self.eef_next.copy_(eef_next.reshape(1, 3))
+        self.graph.replay()
+
+
+def _graphed_step_for(model, P, n_track, n_his, max_nobj, radius, thin_start, adj_thresh, topk, dev):
+    key = (int(P), int(n_track), int(n_his), int(max_nobj), float(radius), int(thin_start), float(adj_thresh), int(topk), str(dev),
+           model.non_rigid_predictor.linear_2.weight.data_ptr())
+    cache = model.__dict__.setdefault("_step_graphs", {})
+    ent = cache.get(key)
+    if ent is None:
+        if len(cache) >= 4:
+            cache.clear()
+        ent = cache[key] = _GraphedStep(model, P, n_track, n_his, max_nobj, radius, thin_start, adj_thresh, topk, dev)
+    return ent
 
 
 # ------------------------------------------------------------------------------------------ the whole rollout (predict.py's scene data)
@@ -623,6 +712,30 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
         skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
         if not skip[i]:
             last = eef_host[i]
+    c = model.model_config
+    gs = None
+    if (dev.type == "cuda" and _GRAPH_ROLLOUT and _GRAPH_ROLLOUT_STEP and store == dev and not connect_all and n_fps_all <= 1024 and max_nobj <= 126
+            and topk <= 16 and 0 <= thin_start_idx < min(max_nobj, n_fps_all) and c["state_dim"] in (0, 3) and c["action_dim"] == 3
+            and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["attr_dim"] >= 2
+            and not torch.is_grad_enabled() and any(not k for k in skip[1:])):
+        # every step as ONE graph replay (see _GraphedStep); the eager loop below is the fallback and the CPU path
+        gs = _graphed_step_for(model, xyz_0.shape[0], fps_all_pos.shape[0], n_his, max_nobj, fps_radius_value, thin_start_idx, adj_thresh, topk, dev)
+        gs.load(track, fps_all_pos, hist, eef_hist, xyz_0, quat_0)
+        for i in range(1, n_steps):
+            if skip[i]:
+                for a in (quat, xyz, rgb, opa, xyz_bones, eef):
+                    a[i] = a[i - 1]
+            else:
+                gs.step(eef_xyz[i])
+                quat[i], xyz[i], rgb[i], opa[i] = gs.all_rot, gs.all_pos, rgb[i - 1], opa[i - 1]
+                xyz_bones[i], eef[i] = gs.pred, eef_xyz[i]
+            if after_step is not None:
+                after_step(i, arrays, skip[i])
+        if int(gs.bad.item()) == 0:
+            return xyz, rgb, quat, opa, xyz_bones, eef
+        # a rank-1 bone whose moment matrix has a vanishing first column (the host's LAPACK decides those): the eager loop redoes the episode
+        if after_step is not None:
+            raise RuntimeError("rollout: a bone needs the host's SVD; run with GSDYN_GRAPH_ROLLOUT_STEP=0 when streaming frames")
     for i in range(1, n_steps):
         if skip[i]:
             for a in (quat, xyz, rgb, opa, xyz_bones, eef):

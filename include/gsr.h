@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones, gsr_fps_thin; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -316,6 +316,16 @@ int gsr_fit_rotations(int32_t n_bones, const float* moments, const float* n_rela
  * evaluates them in fp32, first maximum on ties).  thin_count: device int32. */
 int gsr_fps_thin(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float radius, int32_t thin_start_idx, int64_t* out_idx,
                  int64_t* thin_idx, int32_t* thin_count, void* stream);
+/* Fixed-shape forms for a rollout step that is replayed from a hipGraph (no host round trip for the bone count or the relation count):
+ * gsr_fps_thin pads thin_idx[*thin_count .. npoints) with thin_start_idx; gsr_construct_edges = the relations of the rollout's graph
+ * (gsdyn.dynamics.construct_edges, /root/reference/src/data/dataset.py:88-147: object particles 0 .. n_obj_cap - 1 of which the first
+ * *n_valid are real, one tool particle at index n_obj_cap; related = both real, not both tools, squared distance < thresh_sq, and among
+ * objects the sender one of the receiver's topk nearest, itself included) as index lists of e_cap entries in the adjacency matrix's
+ * row-major order, padded with dummy_index, *count = the real ones; gsr_lbs_valid = gsr_lbs over the first *n_valid bones. */
+int gsr_construct_edges(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                        int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, void* stream);
+int gsr_lbs_valid(int32_t P, int32_t n_bones, const int32_t* n_valid, const float* bones, const float* rotations, const float* translations,
+                  const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);
 /* gsr_fit_bones: the moment matrices, gsr_fit_rotations and the bones' unit quaternions in one launch -- what interpolate_motions
  * (/root/reference/src/render/utils.py:138-243) needs per bone: F_b = sum over the bones j with relations[b][j] != 0 of
  * (new_j - new_b)(old_j - old_b)^T with old = bones, new = bones + motions (fp32, ascending j), rotations[b] as gsr_fit_rotations

@@ -289,3 +289,58 @@ def test_graphed_propagation_equals_eager(dev, golden_dir):
             assert got.shape == want.shape == (1, nobj, 3) and torch.isfinite(got).all()
             worst = max(worst, float((got - want).abs().max()))
     assert len(model._graphs) == 4 and worst < 2e-6, (len(model._graphs), worst)      # padded shapes (128, 640), (128, 384), (128, 512), (64, 128)
+
+
+def test_fixed_shape_relations_kernel(dev):
+    """gsr_construct_edges (padded relation lists, counts on the device) against ``construct_edges`` in torch: the same pairs in the
+    same order for several bone counts, thresholds and k; the tool sits at the last row of the padded layout."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import construct_edges
+    g = torch.Generator().manual_seed(9)
+    cap = 100
+    for n_valid, thr, k in ((100, 0.6, 5), (73, 0.35, 5), (100, 0.2, 3), (1, 0.6, 5), (40, 5.0, 8)):
+        pos = torch.rand(cap + 1, 3, generator=g)
+        pos[cap] = pos[:n_valid].mean(0)                                    # the tool, in the middle of the objects
+        # torch restatement on the COMPACT layout (objects 0 .. n_valid - 1, tool last), indices mapped to the padded layout
+        comp = torch.cat([pos[:n_valid], pos[cap:]], 0)
+        mask = torch.ones(n_valid + 1, dtype=torch.bool); tool = torch.zeros(n_valid + 1, dtype=torch.bool); tool[n_valid] = True    # noqa: E702
+        r, s_ = construct_edges(comp, thr, mask, tool, topk=k)
+        remap = torch.cat([torch.arange(n_valid), torch.tensor([cap])])
+        want = torch.stack([remap[r], remap[s_]], 1)
+        # the padded kernel lists receivers in row order of the PADDED matrix: the tool row (index cap) comes last either way
+        recv, send, cnt = _hip.construct_edges_padded(pos.to(dev), torch.tensor([n_valid], dtype=torch.int32, device=dev), thr, k, 1024, 127)
+        m = int(cnt.item())
+        got = torch.stack([recv[:m], send[:m]], 1).cpu()
+        assert m == want.shape[0] and torch.equal(got, want), (n_valid, thr, k, m, want.shape[0])
+        assert bool((recv[m:] == 127).all()) and bool((send[m:] == 127).all())
+
+
+def test_whole_step_graph_equals_eager_rollout(dev, golden_dir):
+    """The rollout with every step replayed from ONE hipGraph (padded bones / relations, counts on the device: _GraphedStep) against
+    the eager loop (only the propagation graphed): the same frames up to the summation order of the GNN's index_add, repeated
+    (skipped) steps included; a second episode reuses the captured graph."""
+    import gsdyn.dynamics as D
+    from gsdyn import synth_scene_params
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = D.DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    P, S = 20000, 6
+    params = {k: v.detach() for k, v in synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    xyz0, rgb0 = params["means3D"], params["rgb_colors"]
+    q0 = torch.nn.functional.normalize(params["unnorm_rotations"])
+    op0 = torch.sigmoid(params["logit_opacities"])
+    inl = torch.arange(P, device=dev)
+    for ep in range(2):
+        eef = (torch.tensor([[0.0, 0.0, 0.0]], device=dev) + torch.tensor([[0.04, 0.0, 0.02 + 0.01 * ep]], device=dev)
+               * torch.tensor([0.0, 1.0, 1.01, 2.0, 3.0, 4.0], device=dev)[:, None])[:, None, :]
+        kw = dict(max_nobj=100, fps_radius_value=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=1000)
+        D._GRAPH_ROLLOUT_STEP = False
+        want = D.rollout(model, xyz0, rgb0, q0, op0, eef, S, inl, **kw)
+        D._GRAPH_ROLLOUT_STEP = True
+        got = D.rollout(model, xyz0, rgb0, q0, op0, eef, S, inl, **kw)
+        assert len(model._step_graphs) == 1
+        for a, b, name in zip(got, want, ("xyz", "rgb", "quat", "opa", "bones", "eef")):
+            assert a.shape == b.shape and torch.isfinite(a).all(), name
+            assert float((a - b).abs().max()) < 2e-5, (ep, name, float((a - b).abs().max()))
+        assert float((got[0][-1] - got[0][0]).norm(dim=-1).max()) > 1e-3 and torch.equal(got[0][2], got[0][1])     # it moved; step 2 repeated step 1
