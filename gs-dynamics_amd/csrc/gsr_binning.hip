@@ -642,7 +642,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
 #define BIN_THREADS 1024
 #define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
 #define BIN_DIRECT_ROWS 32
+#ifndef BIN_ROW_CHUNK
 #define BIN_ROW_CHUNK 16
+#endif
 #define BIN_BIG_AREA 64        // rects with more tiles are walked by a whole wave, not by their Gaussian's lane
 #define BIN_BIG_MAX 1024       // such Gaussians parked per workgroup (LDS); beyond it their lanes walk them after all
 
