@@ -572,7 +572,10 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
     for (int q = 0; q < 4; ++q) { st4[q] = run; run += c4[q]; }
     if (lane == 63) n_busy_s = run;   // buckets 0..254 only: bucket 255 (empty tiles) is never counted in the histograms
     // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
-    if (lane == (tab.wave_cap == 1024 ? 31 : 47)) n_long_s = st4[0] + c4[0] + c4[1] + c4[2];
+    if (tab.wave_cap == 2048) {      // lists of more than 2032 entries share bucket 0: they are the workgroup tickets; queue[3] = where the lists
+      if (lane == 0) n_long_s = st4[0] + c4[0];                                   // of at most 1024 entries start (bucket 127)
+      if (bid == 0 && lane == 31) queue[3] = st4[0] + c4[0] + c4[1] + c4[2];
+    } else if (lane == (tab.wave_cap == 1024 ? 31 : 47)) n_long_s = st4[0] + c4[0] + c4[1] + c4[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) start[lane * 4 + q] = st4[q] + h_before[0][lane * 4 + q];
   }
@@ -989,7 +992,7 @@ __device__ __forceinline__ uint32_t gsr_lane_xor(uint32_t v) {   // value of lan
 template <int MASK, int NR>
 __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
   constexpr int L = MASK & 63, R = MASK >> 6;
-  constexpr int HB = MASK >= 512 ? 512 : MASK >= 256 ? 256 : MASK >= 128 ? 128 : MASK >= 64 ? 64 : MASK >= 32 ? 32 : MASK >= 16 ? 16 : MASK >= 8 ? 8 : MASK >= 4 ? 4 : MASK >= 2 ? 2 : 1;
+  constexpr int HB = MASK >= 1024 ? 1024 : MASK >= 512 ? 512 : MASK >= 256 ? 256 : MASK >= 128 ? 128 : MASK >= 64 ? 64 : MASK >= 32 ? 32 : MASK >= 16 ? 16 : MASK >= 8 ? 8 : MASK >= 4 ? 4 : MASK >= 2 ? 2 : 1;
   uint64_t y[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -1011,6 +1014,7 @@ __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
 template <int LK, int NR>
 __device__ __forceinline__ void wave_sort_stage(uint64_t (&x)[NR], int lane) {   // merge size k = 2^LK
   wave_sort_step<(1 << LK) - 1, NR>(x, lane);
+  if constexpr (LK >= 11) wave_sort_step<512, NR>(x, lane);
   if constexpr (LK >= 10) wave_sort_step<256, NR>(x, lane);
   if constexpr (LK >= 9) wave_sort_step<128, NR>(x, lane);
   if constexpr (LK >= 8) wave_sort_step<64, NR>(x, lane);
@@ -1032,6 +1036,7 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ seg,
   if constexpr (NR >= 4) wave_sort_stage<8, NR>(x, lane);
   if constexpr (NR >= 8) wave_sort_stage<9, NR>(x, lane);
   if constexpr (NR >= 16) wave_sort_stage<10, NR>(x, lane);
+  if constexpr (NR >= 32) wave_sort_stage<11, NR>(x, lane);
 #pragma unroll
   for (int r = 0; r < NR; ++r) { const uint32_t e = (uint32_t)(r * 64 + lane); if (e < n) out[e] = (uint32_t)x[r]; }
 }
@@ -1126,17 +1131,35 @@ __device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, in
 
 // NW: waves per workgroup (4; the MODE 1 launch of the RCAP = 4096 build runs 16: a long list is sorted by 1024 threads -- the LDS
 // block allows two such workgroups per CU either way, with 4 waves each that is 2 waves per SIMD working through 5 barriers per pass)
+#ifndef TS_W32_WAVES
+#define TS_W32_WAVES 4
+#endif
 #ifndef TS_MIN_WAVES
 #define TS_MIN_WAVES 7   // wave-sorted lists: 7 waves per SIMD (72 VGPRs) measured 47.0 -> 44.9 us at 8 views; 8 (64 VGPRs, spills): 47.4
 #endif
+// MODE 3 (dense scenes, wave_cap = 2048): the lists of 1025 .. 2032 entries -- 83 % of the entries of a configs[4] frame -- each by ONE wave
+// with 32 keys per lane in registers (tickets [n_long, queue[3])), a launch of its own (its register count would cost the shorter lists
+// their occupancy); MODE 2 then starts at queue[3].
 template <int RCAP, int MODE = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES : 1) void tile_sort_kernel(GsrBinViews tab, int cur) {
+__global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES : (MODE == 3 ? TS_W32_WAVES : 1)) void tile_sort_kernel(GsrBinViews tab, int cur) {
   const int tid = threadIdx.x;
+  if constexpr (MODE == 3) {
+    const uint32_t n_long3 = tab.queue[6], n_mid = tab.queue[3];
+    const uint32_t ticket = n_long3 + blockIdx.x * 4u + (uint32_t)(tid >> 6);
+    if (ticket >= n_mid) return;
+    const uint4 ord = tab.order[ticket];
+    const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
+    if (vw.shares_lists) return;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(ord.z - ord.y);
+    wave_sort_tile<32>(vw.dg[cur] + ord.y, vw.point_list + ord.y, n, tid & 63);
+    return;
+  }
   // The order array leads with the longest lists.  Its first n_long tickets (n > TS_WAVE_CAP) take a whole workgroup
   // each; behind them every WAVE takes one ticket (register-resident wave sort, no barriers).
   const uint32_t n_busy = tab.queue[4], n_long = tab.queue[6];
   if (MODE == 2 || (MODE == 0 && blockIdx.x >= n_long)) {
-    const uint32_t ticket = n_long + (MODE == 2 ? blockIdx.x : blockIdx.x - n_long) * 4u + (uint32_t)(tid >> 6);
+    const uint32_t first = (MODE == 2 && tab.wave_cap == 2048) ? tab.queue[3] : n_long;      // (wave_cap 2048: MODE 3 took [n_long, queue[3]))
+    const uint32_t ticket = first + (MODE == 2 ? blockIdx.x : blockIdx.x - n_long) * 4u + (uint32_t)(tid >> 6);
     if (ticket >= n_busy) return;
     const uint4 ord = tab.order[ticket];
     const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
@@ -1289,7 +1312,8 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   for (int v = 0; v < tab.V; ++v) { maxD = tab.v[v].D > maxD ? tab.v[v].D : maxD; maxblk = tab.v[v].nblocks > maxblk ? tab.v[v].nblocks : maxblk; }
   const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
-  tab.wave_cap = big ? 1024 : 512;
+  static const bool wave32_off = [] { const char* e = getenv("GSR_WAVE_SORT_2048"); return e && *e && atoi(e) == 0; }();
+  tab.wave_cap = big ? (wave32_off ? 1024 : 2048) : 512;
   int cur = 0;
   bool order_done = false;
   static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
@@ -1373,6 +1397,7 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     { GSR_PROF("tile_sort", st);
     if (big) {  // long lists on average: the big-LDS build for the long tickets, the wave tickets in a launch of their own
       hipLaunchKernelGGL((tile_sort_kernel<2048, 2>), dim3((tab.V * tab.T + 3) / 4), dim3(GSR_BLOCK), 0, st, tab, cur);
+      if (tab.wave_cap == 2048) hipLaunchKernelGGL((tile_sort_kernel<2048, 3>), dim3((tab.V * tab.T + 3) / 4), dim3(GSR_BLOCK), 0, st, tab, cur);
       // Long tickets: measured at configs[4] size (500 k Gaussians, 1080p x 4 cameras; tile_sort us per frame, same box): 4096-entry LDS
       // block with 4 / 8 / 16 waves per workgroup 507 / 429 / 733, 2048-entry block with 4 / 8 waves 309 / 349 -- workgroups per CU
       // (36 KiB: four) count for more than lists of 2049 .. 4096 entries taking the LDS network instead of the radix sort.
