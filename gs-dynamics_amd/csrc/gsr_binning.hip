@@ -644,7 +644,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
 // once (8 B) instead of 12 + 12 + 8 B, nothing that depends on the entry count in any grid size (capacity mode needs no special case).
 #define BIN_THREADS 1024
 #define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
+#ifndef BIN_DIRECT_ROWS
 #define BIN_DIRECT_ROWS 32
+#endif
 #ifndef BIN_ROW_CHUNK
 #define BIN_ROW_CHUNK 16
 #endif

@@ -214,7 +214,10 @@ struct GsrRenderViews {
 
 // Batch state (V > 1): the structures shared by the views of one call.
 // Tile-row binning (gsr_binning.hip): a workgroup of 1024 threads owns GSR_BIN_G consecutive Gaussians of a view.
-#define GSR_BIN_G 4096
+#ifndef GSR_BIN_G
+#define GSR_BIN_G 2048              // Gaussians per counting / emitting workgroup.  Measured (100 k Gaussians, step us at 1 / 2 / 4 / 8 views): 4096: 228 / 318 /
+                                    // 488 / 850, 2048: 220 / 306 / 479 / 850, 1024: 219 / 308 / 479; configs[4] frame: the same; 8192: worse everywhere
+#endif
 #define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS (40 KiB + 16 KiB of other arrays: under the 64 KiB a workgroup
                                     // may always have); larger tile grids take the radix path
 static inline int gsr_bin_rows(int P) { return ((P > 0 ? P : 1) + GSR_BIN_G - 1) / GSR_BIN_G; }
