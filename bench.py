@@ -5,12 +5,15 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1: launc
 over RCCL).  One STEP = one optimiser step of the tracking loop's rasterizer path over one batch of synthetic views
 (/root/reference/src/tracking/train_gs.py:25-39):
 
-  default -- STRONG scaling on BASELINE.json configs[3]: ONE fixed step of 8 views (800x800) of SynthScene-v1 (100 000
-             Gaussians); rank r renders views r, r+N, ... (N = 1: all 8).  Timed region = fused activations + colour render
-             forward + backward for the rank's views (fixed seeded dL/dcolour) + ONE all-reduce of the flat 17-float-per-
-             Gaussian parameter-gradient bucket (N > 1, RCCL) + the Adam step (FusedAdam, one launch).
-             value = 8*H*W / t_step.  ``--config 3`` (= ``--views 4 --no-optimizer``) is BASELINE.json configs[2] exactly (the
-             headline of round 1); an N = 1 run also measures that configuration and reports it as ``cfg3``.
+  default, N = 1 -- BASELINE.json's metric configuration (configs[2]): 4 views (800x800) of SynthScene-v1 (100 000 Gaussians), fused
+             activations + colour render forward + backward with ALL gradients (fixed seeded dL/dcolour), no optimiser step.
+             value = 4*H*W / t_step.  The same JSON line carries ``scale_n1``: the 8-view + Adam step below on this one GPU.
+  default, N > 1 -- STRONG scaling on BASELINE.json configs[3]: ONE fixed step of 8 views; rank r renders views r, r+N, ...
+             Timed region = fused activations + forward + backward for the rank's views (the per-Gaussian backward kernel writes the
+             parameter gradients straight into the flat 17-float-per-Gaussian bucket) + ONE RCCL all-reduce of that bucket + the Adam
+             step (FusedAdam, one launch).  value = 8*H*W / t_step; compare with the N = 1 run's ``scale_n1.value``.  The line also
+             reports ``rccl_ranks`` (sum of ones over the communicator), per-rank step time min / max, and the all-reduce alone.
+             ``--config 3`` = ``--views 4 --no-optimizer``; ``--views 8`` on one GPU = the scale_n1 step as the top-level line.
   --weak  -- weak scaling: every rank renders ``--views`` (default 4) views of a 4N-camera ring, then all-reduce + Adam.
   --config 5 -- forward only, BASELINE.json configs[4]: 500k Gaussians, 1920x1080, predict.py's frame (4 cameras x colour +
              mask render), (frame, camera) pairs sharded over the ranks, no collective (gsdyn/predict.py).
@@ -127,67 +130,16 @@ def main():
     from gsdyn.dp import GradBucket, shard_views
     from gsdyn.step import params2rendervar_fused, render_step_views
 
-    if args.weak:
-        vpr = args.views or 4
-        total_views = vpr * world
-        my_ids = list(range(vpr * rank, vpr * rank + vpr))
-    else:
-        total_views = args.views or 8
-        my_ids = shard_views(total_views, rank, world)
-    all_cams = synth_ring_cameras(total_views, W, H, device=dev)
+    rccl_ranks = None
+    if world > 1 and not single_dev:      # one RCCL all-reduce of ones before anything is timed: the communicator exists and spans `world` ranks
+        ones = torch.ones((1,), device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, world)
+
     rng = np.random.default_rng(1234)
-    dL_all = torch.tensor(rng.uniform(-1, 1, (total_views, 3, H, W)).astype(np.float32), device=dev)
     GRAD_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
-
-    def make_problem(cams_of_step, view_ids):
-        params = synth_scene_params(P_GAUSS, seed=0, device=dev)
-        params["rgb_colors"].requires_grad_(True)      # colour gradient computed and reduced: the 17-float bucket of section 8e
-        cams = [cams_of_step[i] for i in view_ids]
-        dL = dL_all[view_ids].contiguous() if view_ids else dL_all[:0]
-        return params, cams, dL
-
-    def make_step(params, cams, dL, with_opt, with_reduce, frozen_colours=False):
-        if frozen_colours:   # the reference's own setting: rgb_colors never gets a gradient (train_utils.py:133) and has lr 0 (:155)
-            params["rgb_colors"].requires_grad_(False)
-        bucket = GradBucket(params)
-        opt = initialize_optimizer(params, 4.0) if with_opt else None     # gsdyn.optim.FusedAdam: one launch for all groups
-        m2 = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True) if args.autograd else None
-
-        def step():
-            bucket.zero()
-            if cams:
-                if args.autograd:
-                    rv = params2rendervar_fused(params)
-                    im, _, _ = rasterize_gaussians_views(cams, rv["means3D"], m2, rv["opacities"], colors_precomp=rv["colors_precomp"],
-                                                         scales=rv["scales"], rotations=rv["rotations"])
-                    im.backward(gradient=dL)
-                    m2.grad = None
-                else:
-                    _, g = render_step_views(params, cams, dL, want_colour_grad=not frozen_colours)
-                    for k in GRAD_KEYS:
-                        params[k].grad = g.get(k)
-            if with_reduce:
-                bucket.all_reduce()          # packs the gradients into the flat bucket, ONE all-reduce, .grad = bucket slices
-            if opt is not None:
-                opt.step()
-        return step, bucket
-
-    params, cams, dL = make_problem(all_cams, my_ids)
-    step, bucket = make_step(params, cams, dL, not args.no_optimizer, world > 1, args.frozen_colours)
-
-    # entry counts per view, once (spy on the backend call; not in the timed region)
-    num_rendered = []
-    orig_b = _hip.rasterize_forward_batch
-
-    def spy_b(*a, **k):
-        k["no_host_sync"] = False
-        out = orig_b(*a, **k)
-        num_rendered.extend(st.num_rendered for st in out[3])
-        return out
-    _hip.rasterize_forward_batch = spy_b
-    step()
-    _hip.rasterize_forward_batch = orig_b
-    torch.cuda.synchronize()
+    Npx = H * W
 
     def timed(fn, steps, warmup):
         """(wall mean s, median of per-step HIP-event s) of `steps` steps after `warmup`, bracketed as the contract says."""
@@ -204,75 +156,151 @@ def main():
             fn()
             b.record()
         torch.cuda.synchronize()
+        t_local = (time.perf_counter() - t0) / steps       # this rank's own time, before it waits for the others
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        return dt, statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3
+        return dt, statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3, t_local
 
-    t_step, t_event = timed(step, args.steps, args.warmup)
-    if world > 1:
-        t = torch.tensor([t_step, t_event], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_step, t_event = float(t[0].item()), float(t[1].item())
+    def measure(total_views, view_ids, with_opt, frozen_colours, want_roofline=True):
+        """One configuration: the step over `view_ids` of a `total_views`-camera ring (this rank's share), timed per the contract."""
+        cams_all = synth_ring_cameras(total_views, W, H, device=dev)
+        dL_all = torch.tensor(np.random.default_rng(1234).uniform(-1, 1, (total_views, 3, H, W)).astype(np.float32), device=dev)
+        params = synth_scene_params(P_GAUSS, seed=0, device=dev)
+        params["rgb_colors"].requires_grad_(not frozen_colours)   # default: colour gradient computed and reduced (the 17-float bucket of 8e);
+        cams = [cams_all[i] for i in view_ids]                     # frozen: the reference's own setting (train_utils.py:133, lr 0 at :155)
+        dL = dL_all[view_ids].contiguous() if view_ids else dL_all[:0]
+        bucket = GradBucket(params)
+        opt = initialize_optimizer(params, 4.0) if with_opt else None     # gsdyn.optim.FusedAdam: one launch for all groups
+        m2 = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True) if args.autograd else None
+        with_reduce = world > 1
+        grad_out = bucket.views() if with_reduce else None     # the backward writes straight into the all-reduce bucket (no packing copy)
+        ar_ev = [None]           # (start, end) HIP events around the all-reduce of ONE step, set by the separate pass below
 
-    D = float(np.mean(num_rendered)) if num_rendered else 0.0
-    Npx = H * W
-    mpix = total_views * Npx / t_step / 1e6
-    roofline = kernel_roofline(_hip, step, max(len(cams), 1), D, t_step, args.steps)
+        def step():
+            bucket.zero()
+            if cams:
+                if args.autograd:
+                    rv = params2rendervar_fused(params)
+                    im, _, _ = rasterize_gaussians_views(cams, rv["means3D"], m2, rv["opacities"], colors_precomp=rv["colors_precomp"],
+                                                         scales=rv["scales"], rotations=rv["rotations"])
+                    im.backward(gradient=dL)
+                    m2.grad = None
+                else:
+                    _, g = render_step_views(params, cams, dL, want_colour_grad=not frozen_colours, grad_out=grad_out)
+                    for k in GRAD_KEYS:
+                        params[k].grad = g.get(k)
+            if with_reduce:
+                if ar_ev[0] is not None:
+                    ar_ev[0][0].record()
+                bucket.all_reduce()          # gradients already sit in the flat bucket: ONE all-reduce, .grad = bucket slices
+                if ar_ev[0] is not None:
+                    ar_ev[0][1].record()
+            if opt is not None:
+                opt.step()
 
-    cfg3 = None
-    extras = None
-    if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras:
-        # BASELINE.json configs[2] on the same box, same process: 4 views, colour render fwd + bwd, no optimiser step
-        p3, c3, d3 = make_problem(synth_ring_cameras(4, W, H, device=dev), list(range(4)))
-        D3 = float(np.mean(num_rendered[0::2])) if len(num_rendered) == 8 else D      # the 4-camera ring = cameras 0, 2, 4, 6 of the 8-ring
-        s3, _ = make_step(p3, c3, d3, False, False)
-        t3, t3e = timed(s3, args.steps, args.warmup)
-        cfg3 = {"workload": "BASELINE.json configs[2] = the configuration BASELINE.json's metric is quoted on: 4 views 800x800, 100k Gaussians, "
-                            "colour render fwd+bwd (all gradients), no optimiser step",
-                "metric": "fwd+bwd Mpix/s at 100k Gaussians, 4x800^2 views",
-                "value": 4 * Npx / t3 / 1e6, "unit": "Mpix/s", "ms_per_step": t3 * 1e3, "ms_per_step_event_median": t3e * 1e3,
-                "num_rendered_per_view": D3, "roofline": kernel_roofline(_hip, s3, 4, D3, t3, args.steps)}
-    frozen = None
+        # entry counts per view, once (spy on the backend call; not in the timed region)
+        num_rendered = []
+        orig_b = _hip.rasterize_forward_batch
+
+        def spy_b(*a, **k):
+            k["no_host_sync"] = False
+            out = orig_b(*a, **k)
+            num_rendered.extend(st.num_rendered for st in out[3])
+            return out
+        _hip.rasterize_forward_batch = spy_b
+        step()
+        _hip.rasterize_forward_batch = orig_b
+        torch.cuda.synchronize()
+        t_step, t_event, t_local = timed(step, args.steps, args.warmup)
+        t_min = t_max = t_local
+        if world > 1:
+            t = torch.tensor([t_step, t_event, t_local, -t_local], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_step, t_event, t_max, t_min = float(t[0]), float(t[1]), float(t[2]), -float(t[3])
+        allreduce_us = None
+        if with_reduce:      # the all-reduce alone, HIP events around bucket.all_reduce() on the compute stream, a separate pass of 5 steps
+            spans = []
+            for _ in range(5):
+                ar_ev[0] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                step()
+                torch.cuda.synchronize()
+                spans.append(ar_ev[0][0].elapsed_time(ar_ev[0][1]) * 1e3)
+                ar_ev[0] = None
+            tt = torch.tensor([statistics.median(spans)], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            allreduce_us = float(tt[0])
+        D = float(np.mean(num_rendered)) if num_rendered else 0.0
+        res = {"value": total_views * Npx / t_step / 1e6, "unit": "Mpix/s", "ms_per_step": t_step * 1e3, "ms_per_step_event_median": t_event * 1e3,
+               "num_rendered_per_view": D, "views_total": total_views, "views_on_rank0": len(cams), "optimizer_in_timed_region": bool(with_opt),
+               "rank_step_ms_min": t_min * 1e3, "rank_step_ms_max": t_max * 1e3, "allreduce_us": allreduce_us,
+               "grad_bucket_floats": sum(p.numel() for p in bucket.params)}
+        if want_roofline:
+            res["roofline"] = kernel_roofline(_hip, step, max(len(cams), 1), D, t_step, args.steps)
+        return res
+
+    default_n1 = world == 1 and not args.weak and args.config == 4 and args.views is None and not args.no_optimizer
+    if args.weak:
+        vpr = args.views or 4
+        total_views = vpr * world
+        my_ids = list(range(vpr * rank, vpr * rank + vpr))
+    else:
+        total_views = args.views or 8
+        my_ids = shard_views(total_views, rank, world)
+
+    scale_n1 = frozen = extras = cpu_baseline = None
+    if default_n1:
+        # ONE GPU, no flags: the top-level line is the configuration BASELINE.json's metric is quoted on (configs[2]: 4 x 800^2, fwd + bwd,
+        # all gradients, no optimiser); the 8-view + Adam step of configs[3] -- what `--gpus N` times on N > 1 -- rides along as `scale_n1`
+        main_res = measure(4, list(range(4)), False, args.frozen_colours)
+        scale_n1 = measure(8, list(range(8)), True, args.frozen_colours)
+        scale_n1["workload"] = ("configs[3] on ONE GPU: the fixed 8-view step (8x800^2, 100k Gaussians) fwd+bwd + Adam, all 8 views on this rank -- "
+                                "the N = 1 point of the strong-scaling curve `bench.py --gpus N` measures (N > 1: views r, r+N, ... per rank + 1 RCCL all-reduce)")
+        total_views, my_ids, with_opt = 4, list(range(4)), False
+    else:
+        with_opt = not args.no_optimizer
+        main_res = measure(total_views, my_ids, with_opt, args.frozen_colours)
     if rank == 0 and world == 1 and not args.weak and args.config == 4 and not args.no_extras and not args.frozen_colours and not args.autograd:
-        # the same step as the headline with rgb_colors frozen, as the reference trains (no dL/dcolour: six sums per list entry)
-        pf, cf, df = make_problem(all_cams, my_ids)
-        sf, _ = make_step(pf, cf, df, not args.no_optimizer, False, True)
-        tf, tfe = timed(sf, args.steps, args.warmup)
-        frozen = {"workload": "the headline step with rgb_colors.requires_grad = False (/root/reference/src/tracking/train_utils.py:133,155): "
-                              "every gradient the reference's optimiser uses, no dL/dcolour",
-                  "value": len(cams) * Npx / tf / 1e6, "unit": "Mpix/s", "ms_per_step": tf * 1e3, "ms_per_step_event_median": tfe * 1e3}
+        # the 8-view step with rgb_colors frozen, as the reference trains (no dL/dcolour: six sums per list entry)
+        frozen = measure(8, list(range(8)), True, True, want_roofline=False)
+        frozen["workload"] = ("the 8-view + Adam step with rgb_colors.requires_grad = False (/root/reference/src/tracking/train_utils.py:133,155): "
+                              "every gradient the reference's optimiser uses, no dL/dcolour")
     if rank == 0 and world == 1 and not args.no_extras:
         extras = run_extras(dev, synth_scene_params(P_GAUSS, seed=0, device=dev), synth_ring_cameras(4, W, H, device=dev),
                             synth_ring_cameras, synth_scene_params)
-
-    cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(synth_scene_params(P_GAUSS, seed=0, device=dev), all_cams[0], dL_all[0], params2rendervar)
+        cam0 = synth_ring_cameras(total_views, W, H, device=dev)[0]
+        dL0 = torch.tensor(rng.uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev)
+        cpu_baseline = run_cpu_baseline(synth_scene_params(P_GAUSS, seed=0, device=dev), cam0, dL0, params2rendervar)
 
     if rank == 0:
-        n_bucket = sum(p.numel() for p in bucket.params)
+        n_on0 = main_res["views_on_rank0"]
+        cfg_name = "configs[2]" if (total_views == 4 and not with_opt and world == 1) else ("configs[3]" if total_views == 8 and not args.weak else "custom")
+        if args.weak:
+            workload = f"weak scaling: {n_on0} views per GPU of a {total_views}-camera ring, 100k Gaussians, 800x800, fwd+bwd" + ("+Adam" if with_opt else "")
+        else:
+            workload = (f"{cfg_name}: {total_views}x800^2 views, 100k Gaussians, fwd+bwd (all grads)" + ("+Adam" if with_opt else ", no optimiser") +
+                        f", {world} GPU(s)" + (" strong scaling" if world > 1 or total_views == 8 else "") + "; SynthScene-v1")
+        workload += (f"; view r -> rank r mod N ({n_on0} on rank 0), colour render fwd+bwd per view" +
+                     (" (rgb_colors frozen: no colour gradient)" if args.frozen_colours else "") +
+                     ("" if world == 1 else f", backward writes into the {main_res['grad_bucket_floats']}-float bucket, 1 RCCL all-reduce") +
+                     (", Adam step (FusedAdam)" if with_opt else "") +
+                     ("; the 8-view + Adam step of configs[3] on this GPU: see scale_n1" if default_n1 else ""))
         line = {
-            "metric": (f"fwd+bwd Mpix/s at 100k Gaussians, {total_views}x800^2 views" +
-                       (" (configs[3]: the 8-view strong-scaling step incl. Adam; BASELINE.json's own 4x800^2 configuration: see cfg3)"
-                        if (total_views == 8 and not args.weak) else "")),
-            "value": mpix, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_step * 1e3, "ms_per_step_event_median": t_event * 1e3, "higher_is_better": True,
+            "metric": f"fwd+bwd Mpix/s at 100k Gaussians, {total_views}x800^2 views",
+            "value": main_res["value"], "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "ms_per_step_event_median": main_res["ms_per_step_event_median"], "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"weak scaling: {len(cams)} views per GPU of a {total_views}-camera ring" if args.weak else
-                                    f"configs[{3 if total_views == 8 else 2}]: {total_views}x800^2 views, 100k Gaussians, fwd+bwd" +
-                                    ("" if args.no_optimizer else "+Adam") + f", {world} GPU(s), strong scaling" +
-                                    (" (4x800^2 = cfg3)" if total_views == 8 else "") + f"; SynthScene-v1, view r -> rank r mod N ({len(cams)} on rank 0)") +
-                                   ", colour render fwd+bwd per view" + (" (rgb_colors frozen: no colour gradient)" if args.frozen_colours else "") +
-                                   ("" if world == 1 else f", 1 RCCL all-reduce of the {n_bucket}-float parameter-gradient bucket") +
-                                   ("" if args.no_optimizer else ", Adam step (FusedAdam)"),
-                       "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": len(cams), "image": [H, W],
-                       "num_rendered_per_view": D, "parallelism": f"view-sharded dp{world}", "grad_bucket_floats": n_bucket,
-                       "optimizer_in_timed_region": not args.no_optimizer,
+            "config": {"workload": workload, "gaussians": P_GAUSS, "views_total": total_views, "views_on_rank0": n_on0, "image": [H, W],
+                       "num_rendered_per_view": main_res["num_rendered_per_view"], "parallelism": f"view-sharded dp{world}",
+                       "grad_bucket_floats": main_res["grad_bucket_floats"], "optimizer_in_timed_region": with_opt,
                        "call_pattern": "rasterize_gaussians_views + autograd" if args.autograd else
                                        "gsdyn.step.render_step_views: activations, ONE multi-view forward (capacity mode), ONE multi-view backward, direct library calls"},
-            "roofline": roofline, "cfg3": cfg3, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
+            "roofline": main_res.get("roofline"),
+            "rccl_ranks": rccl_ranks, "rank_step_ms_min": main_res["rank_step_ms_min"], "rank_step_ms_max": main_res["rank_step_ms_max"],
+            "allreduce_us": main_res["allreduce_us"],
+            "scale_n1": scale_n1, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line))
     if world > 1:
@@ -324,17 +352,20 @@ def kernel_roofline(_hip, step, vpl, D, t_step, steps):
         "per_kernel_us_per_launch": {k: round(v, 2) for k, v in sorted(per_launch_us.items())},
         "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
         "per_kernel_timing": "HIP events around every launch of the library (on the launch stream), separate pass after the timed region, same call pattern",
+        "frac_source": "in-run HIP events (this run); the rocprofv3 --kernel-trace --stats averages of the same command are committed as "
+                       f"profiles/r04_kernel_stats_v{vpl}.txt (blend kernels read 3-5 % longer there, the small kernels shorter)",
     }
     # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_round.sh), corrected with the
     # calibration factors measured on known byte counts (tools/prof_calib.sh): REPLAYED from profiles/, not measured in this run
-    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r03", "r02")) if j), None) or \
-        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
+    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r04", "r03", "r02")) if j), None) or \
+        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r04", "r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
     if tj and dom in tj and tj.get("views_per_launch") == vpl:
         roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
         roofline["traffic_detail"] = {"replayed": True, "source": tj.get("source"), **{k: tj[dom].get(k) for k in
                                       ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "fabric_bytes_per_launch", "note") if k in tj[dom]}}
     # VALU: measured issue model (profiles/r02_valu_table.json) + committed SQ counters (REPLAYED)
-    sj = next((j for j in (_load_json(f"{r}_sq_counters.json") for r in ("r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
+    sj = next((j for j in (_load_json(n) for r in ("r04", "r03", "r02") for n in (f"{r}_sq_counters_v{vpl}.json", f"{r}_sq_counters.json"))
+               if j and j.get("views_per_launch") == vpl), None)
     valu = {"peak_lane_instr_per_s_spec": VALU_PEAK,
             "measured_issue_model": "one wave-64 VALU op per ~2.2 SIMD-cycles at >= 2 waves per SIMD (1 per ~4.7 cycles from ONE wave); DPP ops ~3.0, "
                                     "v_exp/v_rcp/permlane-swap ~6.0 (tools/micro/valu_table.hip -> profiles/r02_valu_table.json)",

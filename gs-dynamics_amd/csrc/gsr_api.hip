@@ -1,6 +1,9 @@
 // gsr_api.hip -- extern "C" entry points of libgsr_hip.so (declared in include/gsr.h) and the
 // device self-test.  Host-side orchestration only: buffer carving, kernel sequencing, the one
 // device->host read of num_rendered.  No allocation, no global state beyond a thread-local error string.
+#include <atomic>
+#include <chrono>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -942,6 +945,23 @@ int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t H, int32_t W, 
 }
 
 int gsr_selftest(void* stream) { return gsr_run_selftest((hipStream_t)stream); }
+
+int64_t gsr_wait_counts(const volatile int32_t* counts, int32_t n, int64_t spin_us, int64_t timeout_us) {
+  if (!counts || n <= 0) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t it = 0;; ++it) {
+    int32_t lo = 0x7fffffff, hi = -1;
+    for (int32_t i = 0; i < n; ++i) { const int32_t c = counts[i]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+    if (lo >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return (int64_t)hi; }
+    if ((it & 63) == 63) {
+      const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (us > timeout_us) return -1;
+      if (us > spin_us) sched_yield();
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+}
 
 int gsr_debug_phase_timing(uint64_t* out16) { return gsr_debug_fwd_timing((unsigned long long*)out16); }
 

@@ -1319,9 +1319,23 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   int cur = 0;
   bool order_done = false;
   static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
-  const bool rows_path = tab.rows > 0 && tab.T <= GSR_BIN_MAX_T && !radix_only && maxD > 0 && P > 0;
+  const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
+  // static + dynamic LDS of the two walks against what a workgroup may have on THIS device (160 KiB on gfx950; a 64 KiB part
+  // would fail the launch for T above ~3800): the radix path is the fallback, as for tile grids above GSR_BIN_MAX_T
+  static const size_t lds_static = [] {
+    hipFuncAttributes a{}, b{};
+    size_t m = 0;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(bin_emit_kernel)) == hipSuccess) m = a.sharedSizeBytes;
+    if (hipFuncGetAttributes(&b, reinterpret_cast<const void*>(bin_count_kernel)) == hipSuccess && b.sharedSizeBytes > m) m = b.sharedSizeBytes;
+    return m ? m : (size_t)(52 << 10);
+  }();
+  static const size_t lds_limit = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) return (size_t)v;
+    return (size_t)(64 << 10);
+  }();
+  const bool rows_path = tab.rows > 0 && tab.T <= GSR_BIN_MAX_T && !radix_only && maxD > 0 && P > 0 && lds_static + lds <= lds_limit;
   if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
-    const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
     { GSR_PROF("bin_count", st);
       hipLaunchKernelGGL(bin_count_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
     GSR_HIP_CHECK(hipGetLastError());

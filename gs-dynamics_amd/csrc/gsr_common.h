@@ -218,8 +218,11 @@ struct GsrRenderViews {
 #define GSR_BIN_G 2048              // Gaussians per counting / emitting workgroup.  Measured (100 k Gaussians, step us at 1 / 2 / 4 / 8 views): 4096: 228 / 318 /
                                     // 488 / 850, 2048: 220 / 306 / 479 / 850, 1024: 219 / 308 / 479; configs[4] frame: the same; 8192: worse everywhere
 #endif
-#define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS (40 KiB + 16 KiB of other arrays: under the 64 KiB a workgroup
-                                    // may always have); larger tile grids take the radix path
+#define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS: 4 T dynamic bytes (40 KiB at the limit) next to the kernels' static
+                                    // arrays -- ~50 KiB in bin_emit_kernel since the tile-order builder moved into it (TileOrderLds 33.8 KiB, s_big /
+                                    // s_bigkey 8 KiB each): ~83 KiB at 1080p, ~90 KiB at the limit, i.e. gfx950's 160 KiB at one workgroup per CU.
+                                    // gsr_launch_binning checks static + dynamic bytes against the device's limit and takes the radix path
+                                    // otherwise (as larger tile grids do)
 static inline int gsr_bin_rows(int P) { return ((P > 0 ? P : 1) + GSR_BIN_G - 1) / GSR_BIN_G; }
 static inline __host__ __device__ int gsr_bin_stride(int T) { return (T + 3) & ~3; }   // row stride of the matrix: rows stay 16-byte aligned
 struct BatchState {

@@ -106,8 +106,7 @@ __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__
   constexpr int RU = 4;
   // `col` = false: the blend backward wrote the six geometry sums only (24 of the 36 bytes).  The walk reads whole records all the same
   // -- the same cache lines, and the three-load form measured FASTER than a two-load one (52.5 vs 58 us at 8 views) -- the colour sums
-  // then hold whatever the scratch held and are not used by any caller that passed col = false.
-  (void)col;
+  // then hold whatever the scratch held and are zeroed below (garbage must not propagate).
   for (uint32_t e = e0; e < e1; e += RU) {
     float4 q0[RU], q1[RU];
     float q2x[RU];
@@ -124,7 +123,8 @@ __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__
   PartialSum ps;
   // the blend backward stores the conic partials without their constant factors (dA: -1/2, dB: -1, dC: -1/2)
   ps.gmx = r0.x; ps.gmy = r0.y; ps.gA = -0.5f * r0.z; ps.gB = -r0.w; ps.gC = -0.5f * r1.x; ps.gop = r1.y;
-  ps.dr = r1.z; ps.dg = r1.w; ps.db = r2x;
+  // !col: those twelve bytes were never written (possibly NaN patterns): they must not reach any sum or LDS slot
+  ps.dr = col ? r1.z : 0.f; ps.dg = col ? r1.w : 0.f; ps.db = col ? r2x : 0.f;
   return ps;
 }
 

@@ -76,6 +76,7 @@ struct ListCache {
   int64_t P = 0, H = 0, W = 0;
   uint32_t D = 0;
   uint64_t fp = 0;
+  void* stream = nullptr;   // the stream the lists were produced on: a forward on ANOTHER stream is not ordered behind their writes -- it bins its own
   torch::Tensor binning, image;
 };
 thread_local ListCache g_lists;
@@ -116,7 +117,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   check(gsr_forward_preprocess_fp(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
                                   radii.data_ptr<int32_t>(), &D, g_reuse ? &fp : nullptr, stream), "gsr_forward_preprocess");
   ListCache& lc = g_lists;
-  if (g_reuse && fp != 0 && D > 0 && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.D == D && lc.fp == fp) {
+  if (g_reuse && fp != 0 && D > 0 && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.D == D && lc.fp == fp && lc.stream == stream) {
     // same geometry, same camera as the previous forward: its lists are this render's lists
     check(gsr_forward_render_shared(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
                                     color.data_ptr<float>(), depth.data_ptr<float>(), stream), "gsr_forward_render_shared");
@@ -127,7 +128,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   check(gsr_forward_render(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
                            depth.data_ptr<float>(), stream), "gsr_forward_render");
   if (g_reuse && fp != 0 && D > 0) {
-    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.fp = fp; lc.binning = binning; lc.image = image;
+    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.fp = fp; lc.stream = stream; lc.binning = binning; lc.image = image;
   } else {
     lc = ListCache();
   }

@@ -75,7 +75,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_rigidity_blocks", "gsr_rigidity_forward", "gsr_rigidity_backward",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
-           "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping")
+           "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping", "gsr_wait_counts")
 
 
 def load_library():
@@ -150,6 +150,8 @@ def load_library():
     lib.gsr_activate_forward.argtypes = [i32] + [vp] * 7
     lib.gsr_activate_backward.restype = C.c_int
     lib.gsr_activate_backward.argtypes = [i32] + [vp] * 10
+    lib.gsr_wait_counts.restype = C.c_int64
+    lib.gsr_wait_counts.argtypes = [vp, i32, C.c_int64, C.c_int64]
     lib.gsr_radius_bookkeeping.restype = C.c_int
     lib.gsr_radius_bookkeeping.argtypes = [i32, i32, i32, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
@@ -379,15 +381,25 @@ def _ptr_array(tensors):
     return arr
 
 
-def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False):
+def _alloc_backward(dev, V, P, scratch_bytes, with_scale_rot, per_view_col=False, grad_out=None):
     """Output + scratch tensors of the batched backward.  The forward allocates them ahead of its stage-1 wait, where
-    the host has slack; between that wait and the backward launch the host is the critical path of a step."""
+    the host has slack; between that wait and the backward launch the host is the critical path of a step.
+    ``grad_out``: optional dict of caller-owned fp32 tensors the backward writes INSTEAD of fresh ones -- keys ``d_means3D`` [P,3],
+    ``d_colors`` [P,3], ``d_opacity`` [P,1], ``d_scales`` [P,3], ``d_rot`` [P,4] (e.g. slices of an all-reduce bucket: no copy later)."""
     f32 = dict(dtype=torch.float32, device=dev)
+
+    def out(name, shape):
+        t = None if grad_out is None else grad_out.get(name)
+        if t is None:
+            return torch.empty(shape, **f32)
+        if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise ValueError(f"grad_out[{name!r}] must be a contiguous float32 tensor of shape {tuple(shape)} on {dev}")
+        return t
     return dict(
-        d_means3D=torch.empty((P, 3), **f32), d_means2D=torch.empty((V, P, 3), **f32),
-        d_colors=torch.empty((V, P, 3) if per_view_col else (P, 3), **f32),
-        d_opacity=torch.empty((P, 1), **f32), d_scales=torch.empty((P, 3), **f32) if with_scale_rot else None,
-        d_rot=torch.empty((P, 4), **f32) if with_scale_rot else None, d_cov=torch.empty((P, 6), **f32),
+        d_means3D=out("d_means3D", (P, 3)), d_means2D=torch.empty((V, P, 3), **f32),
+        d_colors=torch.empty((V, P, 3), **f32) if per_view_col else out("d_colors", (P, 3)),
+        d_opacity=out("d_opacity", (P, 1)), d_scales=out("d_scales", (P, 3)) if with_scale_rot else None,
+        d_rot=out("d_rot", (P, 4)) if with_scale_rot else None, d_cov=torch.empty((P, 6), **f32),
         scratch=[torch.empty((b,), dtype=torch.uint8, device=dev) for b in scratch_bytes])
 
 
@@ -395,7 +407,8 @@ FORWARD_ONLY = 1        # GSR_FORWARD_ONLY of include/gsr.h
 
 
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                            prepare_backward: bool = False, no_host_sync: bool = False, raw=None, forward_only: bool = False):
+                            prepare_backward: bool = False, no_host_sync: bool = False, raw=None, forward_only: bool = False,
+                            grad_out=None):
     """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V]).
     ``raw = (unnorm_rotations, logit_opacities, log_scales)`` (then ``opacities`` / ``scales`` / ``rotations`` are None): the
     activations are applied inside the preprocess kernel when the call runs in capacity mode (``states[0].raw_fused``), by
@@ -464,7 +477,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             pre = None
             if prepare_backward:
                 pre = _alloc_backward(dev, V, P, [int(lib.gsr_backward_scratch_bytes(P, cap_e))] * V, cov3D_precomp is None,
-                                      colors_precomp is not None and colors_precomp.dim() == 3)
+                                      colors_precomp is not None and colors_precomp.dim() == 3, grad_out)
             color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
             per_view_col = colors_precomp is not None and colors_precomp.dim() == 3
             if per_view_col and colors_precomp.shape[0] != V:
@@ -524,7 +537,7 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
         pre = None
         if prepare_backward and cap and shs is None:   # scratch sized like the binning buffers: from the last call
             pre = _alloc_backward(dev, V, P, [_scratch_capacity.get(key, 0)] * V, cov3D_precomp is None,
-                                  colors_precomp is not None and colors_precomp.dim() == 3)
+                                  colors_precomp is not None and colors_precomp.dim() == 3, grad_out)
         color_v, depth_v = [color[v] for v in range(V)], [depth[v] for v in range(V)]
         per_view_col = colors_precomp is not None and colors_precomp.dim() == 3   # [V,P,3]: every view its own colours
         if per_view_col and colors_precomp.shape[0] != V:
@@ -573,6 +586,19 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
     return color, radii, depth, states
 
 
+def detach_counts_slot(states) -> None:
+    """Take the pinned counts slot of a capacity-mode forward OUT of the ring for good: a captured graph (gsdyn.step.GraphedRenderStep)
+    rewrites its slot on every replay and never hands it back through forward_counts_ok, so the ring's take-over rule (oldest slot whose
+    counts have arrived) must never give it to an eager call -- that call would read the graph's counts as its own."""
+    pending = states[0].pending
+    if pending is None:
+        return
+    slot = pending[5]
+    for ring in _counts_slots.values():
+        if any(sl is slot for sl in ring):
+            ring[:] = [sl for sl in ring if sl is not slot]
+
+
 def forward_counts_ok(states) -> bool:
     """After a capacity-mode forward: wait for its entry counts (long since on the host when the caller did anything in
     between), remember them for the next call's capacity, and tell whether every view fitted.  True for a synchronous forward."""
@@ -587,13 +613,14 @@ def forward_counts_ok(states) -> bool:
     else:
         # The tile-order kernel writes the counts with system-scope stores into this pinned slot: poll for them instead of recording
         # an event behind the forward (the event's signal packet costs ~6 us of idle GPU between render_fwd and render_bwd).
-        spins = 0
-        while int(counts_host.min()) < 0:
-            spins += 1
-            if spins > 20000:        # ~0.1 s: something is wrong (or the stores are not visible before the kernel ends): fall back
-                torch.cuda.current_stream(torch.device("cuda", key[0])).synchronize()
-                if int(counts_host.min()) < 0:
-                    raise RuntimeError("forward_counts_ok: the forward never wrote its entry counts")
+        # The wait itself is C (gsr_wait_counts: reads the pinned words, pauses, yields after 200 us; ctypes drops the interpreter lock):
+        # round 3 spun here with ~330 Tensor.min() calls per step through the torch dispatcher -- a core per rank at 100 %.
+        lib = load_library()
+        top = int(lib.gsr_wait_counts(counts_host.data_ptr(), int(counts_host.numel()), 200, 100_000))
+        if top < 0:                  # 0.1 s: something is wrong (or the stores are not visible before the kernel ends): fall back
+            torch.cuda.current_stream(torch.device("cuda", key[0])).synchronize()
+            if int(counts_host.min()) < 0:
+                raise RuntimeError("forward_counts_ok: the forward never wrote its entry counts")
     top = int(counts_host.max())
     slot[2] = False          # the ring entry may serve the next call
     _entries_capacity[key] = max(int(top * _ENTRIES_SLACK), 1024)
@@ -602,7 +629,7 @@ def forward_counts_ok(states) -> bool:
 
 
 def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp, shs, scales, rotations, cov3D_precomp,
-                             want_color_grad: bool = True):
+                             want_color_grad: bool = True, grad_out=None):
     """Backward of all views.  Returns gradients already SUMMED over views (dmeans3D[P,3], dcolors, dopacity[P,1],
     dscales, drotations, dcov3D, dsh) plus the per-view means2D gradients [V,P,3]."""
     lib = load_library()
@@ -628,7 +655,7 @@ def rasterize_backward_batch(states, grad_color, means3D, radii, colors_precomp,
         pre, states[0].pre = states[0].pre, None   # one use only: autograd may keep the returned tensors as .grad
         if pre is None:
             pre = _alloc_backward(dev, V, P, [lib.gsr_backward_scratch_bytes(P, stt.num_rendered) for stt in states],
-                                  cov3D_precomp is None, per_view_col)
+                                  cov3D_precomp is None, per_view_col, grad_out)
         d_means3D, d_means2D, d_colors, d_opacity = pre["d_means3D"], pre["d_means2D"], pre["d_colors"], pre["d_opacity"]
         d_scales, d_rot, d_cov, scratch = pre["d_scales"], pre["d_rot"], pre["d_cov"], pre["scratch"]
 
@@ -745,12 +772,16 @@ def activate_forward(unnorm_rotations, logit_opacities, log_scales):
     return rot, op, sc
 
 
-def activate_backward(unnorm_rotations, opacities, scales, d_rot, d_op, d_sc):
+def activate_backward(unnorm_rotations, opacities, scales, d_rot, d_op, d_sc, out=None):
+    """``out`` = (d_unnorm_rotations, d_logit_opacities, d_log_scales) caller-owned contiguous fp32 tensors to write instead of fresh
+    ones (entries may be None)."""
     lib = load_library()
     dev = unnorm_rotations.device
     P = int(unnorm_rotations.shape[0])
     with _on(dev):
-        d_u, d_l, d_s = torch.empty_like(unnorm_rotations), torch.empty_like(opacities), torch.empty_like(scales)
+        o = out if out is not None else (None, None, None)
+        pick = lambda t, like: t if (t is not None and t.is_contiguous() and t.dtype == torch.float32 and t.shape == like.shape) else torch.empty_like(like)  # noqa: E731
+        d_u, d_l, d_s = pick(o[0], unnorm_rotations), pick(o[1], opacities), pick(o[2], scales)
         c = lambda t: None if t is None else t.contiguous()   # noqa: E731
         d_rot, d_op, d_sc = c(d_rot), c(d_op), c(d_sc)
         _check(lib.gsr_activate_backward(P, _ptr(unnorm_rotations), _ptr(opacities), _ptr(scales), _ptr(d_rot), _ptr(d_op), _ptr(d_sc),

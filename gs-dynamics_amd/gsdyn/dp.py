@@ -3,8 +3,9 @@ is single-GPU: no torch.distributed anywhere under /root/reference/src).
 
 One process per GPU.  Gaussian parameters are replicated; the views of a step are sharded over ranks
 (rank r renders views r, r+world, ...).  The only exchange per optimiser step is ONE all-reduce(SUM) of
-a flat fp32 bucket that IS the parameters' ``.grad`` storage (gradients are views into the bucket, so
-there is no gather/scatter copy), plus one small bucket of densification statistics
+a flat fp32 bucket (``GradBucket``): the direct step's backward writes its gradients straight into the bucket's slices
+(``render_step_views(grad_out=bucket.views())``: no copy; gradients that come out of autograd as tensors of their own are packed with
+one ``torch.cat``), and after the reduce every ``.grad`` is its slice of the bucket; plus one small bucket of densification statistics
 (/root/reference/src/tracking/external.py:138-142, /root/reference/src/tracking/train_utils.py:243-245).
 On ROCm the ``nccl`` backend is RCCL; the 6.8 MB bucket at 100k Gaussians is latency-bound on the
 fully-connected xGMI mesh, so a single call per step is the right shape (no per-tensor collectives).
@@ -28,11 +29,15 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
 class GradBucket:
     """Flat fp32 buffer for the gradients of all trainable parameters (dict order): ONE all-reduce per step.
 
-    ``zero()`` drops the ``.grad`` tensors (PyTorch's ``zero_grad(set_to_none=True)``), so the first backward of a
-    step hands its gradient tensors over without an accumulate kernel and nothing has to be cleared.
-    ``all_reduce()`` packs them into the flat buffer with one ``torch.cat``, reduces, and re-points every ``.grad``
-    at its slice.  With a single rank nothing is packed at all.  (Pre-attached bucket views, the usual DDP layout,
-    cost a fill plus one accumulate kernel per parameter per step -- ~55 us of a 1.2 ms four-view step.)"""
+    ``zero()`` drops the ``.grad`` tensors (PyTorch's ``zero_grad(set_to_none=True)``), so the first backward of a step hands its
+    gradient tensors over without an accumulate kernel and nothing has to be cleared.
+    ``views()`` are the bucket's slices shaped like their parameters: a producer that can write its result anywhere -- the rasterizer's
+    backward (``gsdyn.step.render_step_views(..., grad_out=bucket.views())``) -- writes the gradients STRAIGHT into the bucket and sets
+    ``.grad`` to those slices; ``all_reduce()`` then finds every gradient in place and reduces without a copy.  Gradients that
+    arrive as tensors of their own (autograd, ``loss_and_grads_views``) are packed with one ``torch.cat`` as before; parameters without
+    a gradient this step contribute zeros (their slice is cleared only when something wrote to the bucket since it was last known
+    to be zero).  With a single rank nothing is packed or reduced at all.  (Pre-attached bucket views that autograd ACCUMULATES into,
+    the usual DDP layout, cost a fill plus one accumulate kernel per parameter per step -- ~55 us of a 1.2 ms four-view step.)"""
 
     def __init__(self, params: Dict[str, torch.nn.Parameter]):
         self.names = [k for k, p in params.items() if p.requires_grad]
@@ -46,25 +51,65 @@ class GradBucket:
             n = p.numel()
             self.slices[k] = (off, off + n)
             off += n
+        self._views = {k: self.flat[s:e].view_as(p) for (k, (s, e)), p in zip(self.slices.items(), self.params)}
+        self._clean = {k: self.flat._version for k in self.names}   # slice k held zeros when the bucket had this version
+
+    def views(self) -> Dict[str, torch.Tensor]:
+        """name -> the parameter's slice of the flat buffer (shaped like the parameter): where an in-place producer puts its gradient."""
+        return self._views
 
     def zero(self):
         for p in self.params:
             p.grad = None
 
+    def _in_place(self, k, p) -> bool:
+        g = p.grad
+        return g is not None and g.data_ptr() == self._views[k].data_ptr() and g.numel() == p.numel() and g.dtype == torch.float32
+
     def pack(self):
-        """Gather the current gradients into the flat buffer (missing ones as zeros) and re-point .grad at it."""
-        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params]
-        if pieces:
+        """Bring every gradient into the flat buffer (missing ones as zeros) and re-point ``.grad`` at it.  Gradients that already ARE
+        their bucket slice cost nothing."""
+        placed = [self._in_place(k, p) for k, p in zip(self.names, self.params)]
+        if self.params and not any(placed):           # nothing was produced in place: one cat over all pieces, as before
+            pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params]
             torch.cat(pieces, out=self.flat)
+            missing = [k for k, p in zip(self.names, self.params) if p.grad is None]
+            self._clean = {k: self.flat._version for k in missing}
+        else:
+            ver = self.flat._version
+            todo = []                                 # (start, end) of slices to clear, adjacent ones merged
+            now_clean = []
+            for k, p, here in zip(self.names, self.params, placed):
+                if here:
+                    self._clean.pop(k, None)
+                elif p.grad is not None:              # a tensor of its own next to in-place ones
+                    self._views[k].copy_(p.grad.reshape(self._views[k].shape))
+                    self._clean.pop(k, None)
+                else:
+                    now_clean.append(k)
+                    if self._clean.get(k) != ver:
+                        s, e = self.slices[k]
+                        if todo and todo[-1][1] == s:
+                            todo[-1] = (todo[-1][0], e)
+                        else:
+                            todo.append((s, e))
+            # a producer writing through raw pointers does not bump the version: slices it owns are never in _clean (popped above)
+            for s, e in todo:
+                self.flat[s:e].zero_()
+            for k in now_clean:                       # after every write of this call (copy_ / zero_ bump the version)
+                self._clean[k] = self.flat._version
         for k, p in zip(self.names, self.params):
-            s, e = self.slices[k]
-            p.grad = self.flat[s:e].view_as(p)
+            p.grad = self._views[k]
         return self.flat
 
     def all_reduce(self, group=None, async_op: bool = False):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.pack()
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            clean = list(self._clean)
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            for k in clean:                      # zeros on every rank sum to zeros: still clean at the buffer's new version
+                self._clean[k] = self.flat._version
+            return work
         return None
 
 
@@ -113,7 +158,8 @@ class ViewShardedStep:
             direct = self.frozen_colours and dev.type == "cuda" and 2 * len(mine) <= 16 and \
                 (is_initial_timestep or "rev_ptr" in variables)
             if direct:   # the same kernels called back to back, no autograd graph (host time / 3)
-                loss, variables, aux = loss_and_grads_views(self.params, mine, variables, is_initial_timestep, self.weights)
+                loss, variables, aux = loss_and_grads_views(self.params, mine, variables, is_initial_timestep, self.weights,
+                                                            grad_out=self.bucket.views() if self.world > 1 else None)
             else:
                 loss, variables, aux = get_loss_views(self.params, mine, variables, is_initial_timestep, self.weights,
                                                       frozen_colours=self.frozen_colours)

@@ -715,6 +715,7 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     c = model.model_config
     gs = None
     if (dev.type == "cuda" and _GRAPH_ROLLOUT and _GRAPH_ROLLOUT_STEP and store == dev and not connect_all and n_fps_all <= 1024 and max_nobj <= 126
+            and max_nobj <= fps_all_pos.shape[0]     # fewer tracked inliers than bones: fps_thin_padded needs npoints <= N -- the eager loop clamps
             and topk <= 16 and 0 <= thin_start_idx < min(max_nobj, n_fps_all) and c["state_dim"] in (0, 3) and c["action_dim"] == 3
             and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["attr_dim"] >= 2
             and not torch.is_grad_enabled() and any(not k for k in skip[1:])):

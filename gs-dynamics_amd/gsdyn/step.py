@@ -208,16 +208,20 @@ def _acc_grad(p, g):
 
 
 @torch.no_grad()
-def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights, _no_host_sync: bool = True):
+def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w: LossWeights, _no_host_sync: bool = True, grad_out=None):
     """``get_loss_views(..., frozen_colours=True)`` followed by ``loss.backward()``, as a straight sequence of library calls
     (activations, rasterizer, image terms, shared terms and their backward passes in reverse) without the autograd engine:
     same kernels, same values, about a third of the host time -- which is what bounds the reference's own loop shape, one camera
     per iteration (/root/reference/src/tracking/train_gs.py:25-39: ~0.3 ms of GPU work per iteration).  The gradients are ADDED
     to the ``.grad`` of means3D / unnorm_rotations / logit_opacities / log_scales / cam_m / cam_c (colours are frozen: lr 0 in
     the tracking schedule).  Needs a HIP device, at most 8 cameras per call, and at t > 0 the tensors of ``make_rigidity_variables``.
+    ``grad_out`` (``GradBucket.views()``): the gradients of means3D / unnorm_rotations / logit_opacities / log_scales are written into
+    these caller-owned tensors (the all-reduce bucket's slices) when the parameter has no ``.grad`` yet -- nothing to pack afterwards.
     Returns (loss, variables, aux) with aux = dict(means2D_grad=[2V,P,3] (rows 0, 2, ... = colour renders), radii=[V,P])."""
     from diff_gaussian_rasterization import _hip
     from .losses import _SHARED_KEYS, _window_1d
+    go = {} if grad_out is None else {k: grad_out[k] for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales")
+                                       if k in grad_out and params[k].grad is None and params[k].requires_grad}
     V = len(datas)
     m3 = params["means3D"]
     dev = m3.device
@@ -253,12 +257,16 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
         # the image terms do not depend on the list sizes; the rasterizer's backward does (its scratch is sized by the capacity):
         # look at the counts now -- the GPU still has the image-term kernels queued, so the host wait hides behind them
         if not _hip.forward_counts_ok(states):     # more entries than the buffers were sized for (the scene grew by > 50 % in one step)
-            return loss_and_grads_views(params, datas, variables, is_initial_timestep, w, _no_host_sync=False)
+            return loss_and_grads_views(params, datas, variables, is_initial_timestep, w, _no_host_sync=False, grad_out=grad_out)
+        if "means3D" in go and states[0].pre is not None:      # (the pre-allocated outputs of the forward are fresh tensors: keep all but d_means3D)
+            states[0].pre["d_means3D"] = go["means3D"]
         d3, d2, _dc, d_op, d_sc, d_rot, _dcov, _dsh = _hip.rasterize_backward_batch(states, d_ims, m3, radii, colours, None, sc, rot, None,
-                                                                                  want_color_grad=False)
+                                                                                  want_color_grad=False,
+                                                                                  grad_out={"d_means3D": go["means3D"]} if "means3D" in go else None)
         if shared is not None:
             _hip.shared_terms_backward(m3, rot, shared, w5, one, accumulate_into=(d3, d_rot), work=work)
-        d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc)
+        d_un, d_lo, d_ls = _hip.activate_backward(params["unnorm_rotations"], op, sc, d_rot, d_op, d_sc,
+                                                  out=(go.get("unnorm_rotations"), go.get("logit_opacities"), go.get("log_scales")))
         for k, g in (("means3D", d3), ("unnorm_rotations", d_un), ("logit_opacities", d_lo), ("log_scales", d_ls), ("cam_m", d_cm),
                      ("cam_c", d_cc)):
             if params[k].requires_grad:
@@ -275,13 +283,17 @@ def loss_and_grads_views(params, datas, variables, is_initial_timestep: bool, w:
 
 @torch.no_grad()
 def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_colour_grad: bool = True, _no_host_sync: bool = True,
-                      _defer_counts: bool = False):
+                      _defer_counts: bool = False, grad_out=None):
     """Forward + backward of the colour render of every camera in ``cams`` with the upstream gradient ``dL`` [V,3,H,W], as a
     straight sequence of library calls -- fused activations, ONE multi-view rasterizer forward (capacity mode: no host wait),
     ONE multi-view backward, fused activation backward -- without the autograd engine.  This is the rasterizer share of one
     ``train_gs.py`` iteration (/root/reference/src/tracking/train_gs.py:25-39) for this rank's views, the step `bench.py` times.
     Returns (images [V,3,H,W], grads) with grads = dict of the PARAMETER gradients summed over the views (means3D,
-    unnorm_rotations, logit_opacities, log_scales and, if wanted, the colour array) plus ``means2D`` [V,P,3] and ``radii`` [V,P]."""
+    unnorm_rotations, logit_opacities, log_scales and, if wanted, the colour array) plus ``means2D`` [V,P,3] and ``radii`` [V,P].
+    ``grad_out``: dict parameter name -> caller-owned tensor shaped like the parameter (``gsdyn.dp.GradBucket.views()``): the per-Gaussian
+    backward kernel writes those parameter gradients there -- straight into the all-reduce bucket, no packing copy afterwards -- and the
+    returned dict holds these very tensors.  (Only with the activations fused into the rasterizer's kernels -- the steady state; the first
+    call of a shape and an overflow repeat return fresh tensors, which the bucket then packs as before.)"""
     from diff_gaussian_rasterization import _hip
     m3 = params["means3D"]
     dev = m3.device
@@ -298,9 +310,15 @@ def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_co
             ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, op, colours, None, sc, rot, None,
                                                                       prepare_backward=True, no_host_sync=_no_host_sync)
         else:
+            go = None
+            if grad_out is not None:     # fused mode: d_rot / d_opacity / d_scales come back as the gradients of the RAW parameters
+                go = {a: grad_out.get(b) for a, b in (("d_means3D", "means3D"), ("d_rot", "unnorm_rotations"), ("d_opacity", "logit_opacities"),
+                                                        ("d_scales", "log_scales"), ("d_colors", colours_key if want_colour_grad else None))}
             ims, radii, _depth, states = _hip.rasterize_forward_batch(list(cams), m3, None, colours, None, None, None, None,
-                                                                      prepare_backward=True, no_host_sync=_no_host_sync, raw=raw)
+                                                                      prepare_backward=True, no_host_sync=_no_host_sync, raw=raw, grad_out=go)
             rot, op, sc = states[0].act
+            if go is not None and states[0].raw_fused is None and states[0].pre is not None:
+                states[0].pre = None     # activations NOT fused this time: the backward's outputs are gradients of the ACTIVATED tensors
         # The backward is queued right behind the forward, BEFORE the forward's entry counts are known on the host: on lists
         # that overflowed their capacity it is still memory-safe (emit never writes past the capacity, record reads are clamped
         # to it), its results are then simply dropped and the step is repeated synchronously.
@@ -313,7 +331,7 @@ def render_step_views(params, cams, dL, colours_key: str = "rgb_colors", want_co
         if _defer_counts:      # stream capture (GraphedRenderStep): no host wait in here, the caller checks the counts after a replay
             pass
         elif not _hip.forward_counts_ok(states):      # the scene outgrew the remembered capacity (> 50 % more entries in one step)
-            return render_step_views(params, cams, dL, colours_key, want_colour_grad, _no_host_sync=False)
+            return render_step_views(params, cams, dL, colours_key, want_colour_grad, _no_host_sync=False, grad_out=grad_out)
     grads = {"means3D": d3, "unnorm_rotations": d_un, "logit_opacities": d_lo, "log_scales": d_ls, "means2D": d2, "radii": radii}
     if _defer_counts:
         grads["_states"] = states
@@ -350,6 +368,7 @@ class GraphedRenderStep:
         if pend is None:
             raise RuntimeError("GraphedRenderStep: the captured forward did not run in capacity mode")
         self._counts_host, self._cap = pend[1], pend[3]
+        _hip.detach_counts_slot(self._states)     # the replays own this pinned slot from now on: it leaves the ring of the eager calls
 
     def replay(self):
         self.graph.replay()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 116 /* 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 117 /* 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -425,6 +425,15 @@ typedef struct gsr_kernel_time {
 } gsr_kernel_time;
 int gsr_profile_begin(void);
 int gsr_profile_end(gsr_kernel_time* out, int32_t max_entries, int32_t* n_out);
+
+/* Host side of the capacity-mode forward (gsr_forward_batch_capacity*): the tile-order kernel stores every view's entry count with
+ * system-scope stores into the caller's PINNED host array `counts` (pre-set to -1 by the caller).  gsr_wait_counts spins on that
+ * array from C -- no device call, no stream synchronisation, nothing of the caller's runtime (a Python caller's interpreter lock is
+ * released for the duration by ctypes) -- until all `n` values are >= 0 and returns their maximum; -1 after `timeout_us`
+ * microseconds.  Between polls it yields the core (`sched_yield`) once `spin_us` microseconds have passed, so that N ranks of a
+ * node waiting at the same time do not each hold a core at 100 %.  Replaces the reference-side pattern of a blocking
+ * num_rendered read inside the forward (upstream rasterizer_impl.cu; called from /root/reference/src/tracking/train_utils.py:178). */
+int64_t gsr_wait_counts(const volatile int32_t* counts, int32_t n, int64_t spin_us, int64_t timeout_us);
 
 const char* gsr_last_error(void);
 int gsr_version(void);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points_work_without_a_gpu():
     from diff_gaussian_rasterization import _hip
     lib = _hip.load_library()
-    assert lib.gsr_version() == 116
+    assert lib.gsr_version() == 117
     g1, g2 = lib.gsr_geom_bytes(1000), lib.gsr_geom_bytes(100000)
     assert 0 < g1 < g2 and g2 % 256 == 0
     assert lib.gsr_image_bytes(800, 800) >= 800 * 800 * 8 + 2500 * 8
@@ -125,3 +125,26 @@ def test_autograd_glue_with_test_double(monkeypatch):
     assert rv["means2D"].grad is not None and rv["means2D"].grad.shape == (60, 3)
     assert params["means3D"].grad is not None and params["log_scales"].grad is not None
     assert params["rgb_colors"].grad is None     # requires_grad False in the reference (train_utils.py:133)
+
+
+def test_wait_counts_is_a_host_only_poll():
+    """gsr_wait_counts (ABI 117): spins on a host array from C -- returns the maximum once every word is >= 0 (a second thread plays the
+    tile-order kernel's system-scope stores), -1 on timeout; no device involved."""
+    import ctypes
+    import threading
+    import time
+    import numpy as np
+    from diff_gaussian_rasterization import _hip
+    lib = _hip.load_library()
+    a = np.full(4, -1, np.int32)
+    assert lib.gsr_wait_counts(a.ctypes.data, 4, 50, 2000) == -1              # nobody writes: timeout after ~2 ms
+    def writer():
+        time.sleep(0.02)
+        a[:3] = (7, 123456, 5)
+        time.sleep(0.01)
+        a[3] = 9
+    t = threading.Thread(target=writer)
+    t.start()
+    assert lib.gsr_wait_counts(a.ctypes.data, 4, 50, 2_000_000) == 123456       # ctypes released the GIL: the writer thread ran
+    t.join()
+    assert lib.gsr_wait_counts(None, 0, 0, 0) == 0

@@ -143,3 +143,48 @@ def test_grad_bucket_layout():
     assert params["means3D"].grad.data_ptr() == flat[s:e].data_ptr()  # after packing, .grad IS the bucket slice
     params["means3D"].grad.add_(1.0)
     assert torch.all(b.flat[s:e] == 2.0)
+
+
+def test_grad_bucket_in_place_producers_skip_the_pack_copy(monkeypatch):
+    """A producer that wrote its gradient into ``views()`` (the direct step's backward): ``pack`` finds it in place -- no ``torch.cat`` --,
+    copies a gradient that arrived as a tensor of its own, and clears the slice of a parameter without a gradient only when the bucket
+    was written since that slice was last known to be zero."""
+    _setup_paths()
+    from gsdyn import synth_scene_params
+    from gsdyn.dp import GradBucket
+    params = synth_scene_params(10, device="cpu")
+    b = GradBucket(params)
+    views = b.views()
+    assert set(views) == set(b.names) and all(views[k].shape == params[k].shape for k in b.names)
+    calls = {"cat": 0, "zero": 0}
+    real_cat, real_zero = torch.cat, torch.Tensor.zero_
+    monkeypatch.setattr(torch, "cat", lambda *a, **k: (calls.__setitem__("cat", calls["cat"] + 1), real_cat(*a, **k))[1])
+    monkeypatch.setattr(torch.Tensor, "zero_", lambda self: (calls.__setitem__("zero", calls["zero"] + 1), real_zero(self))[1])
+    for step in range(3):
+        b.zero()
+        views["means3D"].data.fill_(float(step + 1))            # "kernel" writes through the raw pointer ...
+        params["means3D"].grad = views["means3D"]                # ... and the step hands the slice over as .grad
+        params["log_scales"].grad = torch.full_like(params["log_scales"], 2.0)       # a tensor of its own (autograd)
+        flat = b.pack()
+        s, e = b.slices["means3D"]
+        assert torch.all(flat[s:e] == step + 1)
+        s, e = b.slices["log_scales"]
+        assert torch.all(flat[s:e] == 2.0) and params["log_scales"].grad.data_ptr() == flat[s:e].data_ptr()
+        for k in b.names:
+            if k not in ("means3D", "log_scales"):
+                s, e = b.slices[k]
+                assert torch.all(flat[s:e] == 0.0), k
+    assert calls["cat"] == 0 and calls["zero"] == 0      # steady state: no copy of the in-place gradients, no clearing of the known-zero slices
+    # a user who scribbles into a slice that is later missing: it is cleared again
+    b.zero()
+    views["seg_colors"].add_(5.0)
+    params["means3D"].grad = views["means3D"]
+    flat = b.pack()
+    s, e = b.slices["seg_colors"]
+    assert torch.all(flat[s:e] == 0.0)
+    # nothing in place: the one-cat path, as before
+    b.zero()
+    params["means3D"].grad = torch.ones_like(params["means3D"])
+    n = calls["cat"]
+    flat = b.pack()
+    assert calls["cat"] == n + 1 and float(flat.sum()) == 30.0

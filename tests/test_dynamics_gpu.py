@@ -344,3 +344,30 @@ def test_whole_step_graph_equals_eager_rollout(dev, golden_dir):
             assert a.shape == b.shape and torch.isfinite(a).all(), name
             assert float((a - b).abs().max()) < 2e-5, (ep, name, float((a - b).abs().max()))
         assert float((got[0][-1] - got[0][0]).norm(dim=-1).max()) > 1e-3 and torch.equal(got[0][2], got[0][1])     # it moved; step 2 repeated step 1
+
+
+def test_small_scene_with_fewer_tracked_points_than_bones_takes_the_eager_loop(dev, golden_dir):
+    """with fewer tracked inliers than ``max_nobj`` the graphed step's padded sampler (1 <= npoints <= N) cannot serve the
+    scene; the gate sends it to the eager loop, whose sampler clamps -- the rollout runs and equals the eager result."""
+    import gsdyn.dynamics as D
+    from gsdyn import synth_scene_params
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = D.DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    P, S = 60, 4                                                    # 60 Gaussians, max_nobj = 100 bones asked for
+    params = {k: v.detach() for k, v in synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    q0 = torch.nn.functional.normalize(params["unnorm_rotations"])
+    op0 = torch.sigmoid(params["logit_opacities"])
+    eef = (torch.tensor([[0.04, 0.0, 0.02]], device=dev) * torch.arange(S, device=dev, dtype=torch.float32)[:, None])[:, None, :]
+    # collect_scene_data passes n_fps_all = min(n_fps_all, inlier count): 60 tracked particles for 100 bones
+    kw = dict(max_nobj=100, fps_radius_value=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=P)
+    D._GRAPH_ROLLOUT_STEP = True
+    got = D.rollout(model, params["means3D"], params["rgb_colors"], q0, op0, eef, S, torch.arange(P, device=dev), **kw)
+    D._GRAPH_ROLLOUT_STEP = False
+    try:
+        want = D.rollout(model, params["means3D"], params["rgb_colors"], q0, op0, eef, S, torch.arange(P, device=dev), **kw)
+    finally:
+        D._GRAPH_ROLLOUT_STEP = True
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.isfinite(a).all() and float((a - b).abs().max()) < 2e-5

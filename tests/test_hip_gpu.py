@@ -29,12 +29,16 @@ def _margin(tag, err, scale):
 
 # Row-wise (per-Gaussian) gradient bounds, next to the norm-wise one (util.row_err: |a - b| / (|b| + 1e-3 max|b|) per Gaussian):
 #   * 99.9 % of the Gaussians within ROW_TOL = 1e-4 of their OWN gradient,
-#   * every Gaussian within ROW_TOL_WORST.  Both sides of these comparisons are fp32: a Gaussian whose gradient is the small difference
-#     of large per-pixel terms (scales / rotations through the 3D covariance) is conditioned worse than 1e-4 in ANY fp32 evaluation
-#     order, the oracle's included -- measured worst rows are 1e-5 .. 2e-4 (profiles/r03_pytest_gpu_margins.log).
+#   * every Gaussian within ROW_TOL_WORST = 2e-4 (round 4; 5e-4 before).  Both sides of these comparisons are fp32: a Gaussian whose
+#     gradient is the small difference of large per-pixel terms (scales / rotations through the 3D covariance) is conditioned worse
+#     than 1e-4 in ANY fp32 evaluation order, the oracle's included -- measured worst rows are 1e-5 .. 1.43e-4 in every comparison but
+#     one (profiles/r03_pytest_gpu_row_margins.log): scales row 4946 of the 5 000-Gaussian 256x192 scene, 2.035e-4 against the fp32
+#     oracle, where the fp32 oracle itself sits 1.1e-4 from its own fp64 build (test_row_wise_error_against_the_fp64_oracle); that
+#     one case passes ROW_TOL_WORST_P5000 = 2.5e-4 explicitly.
 # The worst row of every comparison goes to gpurun_out/row_margins.log (GSR_ROW_MARGINS_LOG overrides).
 ROW_TOL = 1e-4
-ROW_TOL_WORST = 5e-4
+ROW_TOL_WORST = 2e-4
+ROW_TOL_WORST_P5000 = 2.5e-4
 _ROW_LOG = os.environ.get("GSR_ROW_MARGINS_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "row_margins.log"))
 
 
@@ -178,7 +182,7 @@ def _check_lists(views, H, W, o_point_list, o_ranges, o_n_contrib, ok, o_means2D
 AMBIGUOUS_PIXEL_BOUND = 4e-3     # one flipped alpha >= 1/255 decision moves a pixel by at most (1/255) * T * colour
 
 
-def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min_ok=0.995, backward=True):
+def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min_ok=0.995, backward=True, tol_worst=ROW_TOL_WORST):
     """Forward + backward of the HIP path vs oracle O2 on the same inputs (``backward=False``: forward only, under the
     caller's no-grad inputs -- the forward-only configs).
 
@@ -227,7 +231,7 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         e = rel_err(v, gr[k])
         worst[k] = e
         assert e < TOL, f"grad {k}: rel err {e:.3e}"
-        _row_check(f"oracle P={g['means3D'].shape[0]} {W}x{H} seed {seed} grad {k}", v, gr[k])
+        _row_check(f"oracle P={g['means3D'].shape[0]} {W}x{H} seed {seed} grad {k}", v, gr[k], tol_worst=tol_worst)
     if os.environ.get("GSR_TEST_VERBOSE"):
         print("parity margins:", {k: f"{e:.2e}" for k, e in worst.items()}, "colour", f"{mixed_err(color[:, ok], o2.color[:, ok]):.2e}")
     return o2
@@ -307,11 +311,18 @@ def test_committed_multi_view_goldens(dev, golden_dir):
             assert mixed_err(im[vi].detach().cpu().numpy()[:, ok[vi]], z[f"{n}/color"][vi][:, ok[vi]]) < TOL, (n, vi)
             assert mixed_err(depth[vi].detach().cpu().numpy()[:, ok[vi]], z[f"{n}/depth"][vi][:, ok[vi]]) < TOL, (n, vi)
             assert rel_err(m2.grad[vi].cpu().numpy(), z[f"{n}/grad_means2D"][vi]) < TOL, (n, vi)
+            _row_check(f"golden views {n} view {vi} grad means2D", m2.grad[vi].cpu().numpy(), z[f"{n}/grad_means2D"][vi])
         gc = colours.grad.cpu().numpy()
         want_c = z[f"{n}/grad_colours_per_view"]
         assert rel_err(gc, want_c if per_view_col else want_c.sum(0)) < TOL, n
+        if per_view_col:
+            for vi in range(V):
+                _row_check(f"golden views {n} view {vi} grad colours", gc[vi], want_c[vi])
+        else:
+            _row_check(f"golden views {n} grad colours (view sum)", gc, want_c.sum(0))
         for k in ("means3D", "opacities", "scales", "rotations"):
             assert rel_err(inp[k].grad.cpu().numpy(), z[f"{n}/grad_sum_{k}"]) < TOL, (n, k)
+            _row_check(f"golden views {n} grad {k} (view sum)", inp[k].grad.cpu().numpy(), z[f"{n}/grad_sum_{k}"])
 
 
 def test_sh_colours_through_the_multi_view_call(dev):
@@ -354,7 +365,8 @@ def test_sh_colours_through_the_multi_view_call(dev):
 @pytest.mark.parametrize("P,W,H,seed", [(1, 16, 16, 1), (37, 33, 17, 2), (700, 130, 94, 3), (5000, 256, 192, 4)])
 def test_random_scenes_vs_oracle(dev, P, W, H, seed):
     g = random_gaussians(P, seed=seed, scale_lo=0.02, scale_hi=0.25)
-    _check_against_oracle(ring_camera(W, H, v=seed, bg=(0.1, 0.3, 0.5)), g, dev, seed=seed)
+    _check_against_oracle(ring_camera(W, H, v=seed, bg=(0.1, 0.3, 0.5)), g, dev, seed=seed,
+                          tol_worst=ROW_TOL_WORST_P5000 if P == 5000 else ROW_TOL_WORST)
 
 
 def test_reference_list_mode_is_bit_identical(dev, monkeypatch, golden_dir):
@@ -1456,6 +1468,68 @@ def test_config5_size_forward(dev):
     assert mixed_err(color.cpu().numpy()[:, ok], o2.color[:, ok]) < TOL
     assert mixed_err(depth.cpu().numpy()[:, ok], o2.depth[:, ok]) < TOL
     print("config5: num_rendered", o2.num_rendered, "ambiguous px", int(o2.ambiguous.sum()))
+
+
+def test_config5_frame_as_bench_times_it(dev):
+    """What ``bench.py --config 5`` times, at its size and with its knobs: ``Renderer.render_cameras_with_mask`` = ONE forward-only
+    multi-view call for predict.py's four cameras (/root/reference/src/predict.py:100-123) on 500k Gaussians at 1920x1080, handed
+    over in Morton order (``spatial_order``, as ``collect_scene_data`` does per episode): tile-row binning at T = 8160, the dense-scene
+    per-tile sorts (wave tickets with 32 keys per lane, long tickets on the 2048-entry block), GSR_FORWARD_ONLY, the mask from the
+    colour render's final transmittance.  Per camera against oracle O2 on the same (permuted) arrays: radii and tile lists bit-exact,
+    colour / depth / final_T within tolerance, mask = 1 - final_T of the oracle."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import spatial_order
+    from gsdyn.predict import ring_poses
+    from gsdyn.render import Renderer
+    P, W, H, CAMS = 500_000, 1920, 1080, 4
+    from gsdyn import params2rendervar, synth_scene_params
+    with torch.no_grad():       # bench_config5's scene: SynthScene-v1 at 500k (D = 6.0 M entries per camera, lists up to ~2000)
+        data_in = {k: v.detach() for k, v in params2rendervar(synth_scene_params(P, seed=0, device=dev)).items()}
+    perm = spatial_order(data_in["means3D"])
+    assert sorted(perm.cpu().tolist()) == list(range(P))
+    data = {k: v[perm].contiguous() for k, v in data_in.items()}
+    g = {k: data[k].cpu().numpy() for k in ("means3D", "colors_precomp", "rotations", "opacities", "scales")}
+    rdr = Renderer(dev, w=W, h=H)
+    poses = ring_poses(CAMS, W, H)
+    got = {}
+    orig = _hip.rasterize_forward_batch
+
+    def spy(*a, **k):
+        assert k.get("forward_only") is True and len(a[0]) == CAMS          # one plain view per camera, no-grad flags
+        out = orig(*a, **k)
+        got["radii"], got["states"], got["cams"] = out[1], out[3], a[0]
+        return out
+    _hip.rasterize_forward_batch = spy
+    try:
+        ims, depths, masks = rdr.render_cameras_with_mask(poses, data, bg=(0.0, 0.0, 0.0))
+    finally:
+        _hip.rasterize_forward_batch = orig
+    torch.cuda.synchronize()
+    assert len(ims) == CAMS and ims[0].shape == (3, H, W) and masks[0].shape == (3, H, W)
+    longest = 0
+    for i in range(CAMS):
+        rs = got["cams"][i]
+        cam = OracleCamera(H, W, float(rs.tanfovx), float(rs.tanfovy), rs.bg.cpu().numpy(), 1.0, rs.viewmatrix.cpu().numpy().reshape(-1),
+                           rs.projmatrix.cpu().numpy().reshape(-1), 0, rs.campos.cpu().numpy())
+        o2 = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"],
+                         rotations=g["rotations"], nthreads=min(64, os.cpu_count() or 8))
+        ok = ~o2.ambiguous
+        assert ok.mean() > 0.98
+        v = _hip.debug_views(got["states"][i])
+        assert np.array_equal(got["radii"][i].cpu().numpy(), o2.radii), i
+        _check_lists(v, H, W, o2.point_list, o2.ranges, o2.n_contrib, ok, o2.means2D, o2.conic_opacity, o2.tiles_touched, o2.offsets)
+        rg = v["ranges"].cpu().numpy().astype(np.int64)
+        longest = max(longest, int((rg[:, 1] - rg[:, 0]).max()))
+        assert mixed_err(ims[i].cpu().numpy()[:, ok], o2.color[:, ok]) < TOL, i
+        assert mixed_err(depths[i].cpu().numpy()[:, ok], o2.depth[:, ok]) < TOL, i
+        assert mixed_err(v["final_T"].cpu().numpy()[ok], o2.final_T[ok]) < TOL, i
+        m = masks[i].cpu().numpy()
+        assert np.array_equal(m[0], m[1]) and np.array_equal(m[0], m[2])
+        want = 1.0 - o2.final_T                                   # black background: every mask channel = sum_i alpha_i T_i = 1 - T_final
+        _margin(f"cfg5 mask cam {i}", float(np.abs(m[0][ok] - want[ok]).max()), 1e-4)
+        assert float(np.abs(m[0][ok] - want[ok]).max()) <= 1e-4 * max(1.0, float(np.abs(want).max())), i
+    assert longest > 1024, f"the scene does not reach the dense-scene sort paths (longest list {longest})"
+    print("config5 frame: longest tile list", longest)
 
 
 def test_end_to_end_fit(dev):
