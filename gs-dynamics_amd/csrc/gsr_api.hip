@@ -101,11 +101,11 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.skip = 0;
+  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.skip = 0; o.tile_rows = nullptr;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
-  o.shares_lists = 0; o.fused_alias = 0; o.D_dev = nullptr;
+  o.shares_lists = 0; o.fused_alias = 0; o.D_dev = nullptr; o.owner = 0;
   o.ekey = g.ekey; o.rec_w = g.rec; o.tile_rows = nullptr;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
@@ -182,7 +182,9 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
            uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, uint64_t* fingerprint_host = nullptr,
-           const int* skip = nullptr, const int32_t* geometry_of = nullptr) {
+           const int* skip = nullptr, const int32_t* geometry_of = nullptr, uint32_t* tile_rows = nullptr) {
+  // tile_rows != nullptr (multi-view entry points): the batch state's matrix of the tile-row binning -- when the call's tile grid takes
+  // that path with the first walk fused (gsr_fused_count_ok) the preprocess launch counts the rows itself
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -221,7 +223,12 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     if (fingerprint_host && V == 1 && gsr_host_block_scan(P)) tab.v[v].block_hash = g.block_hash;
     if (skip && skip[v]) tab.v[v].skip = 1;
   }
-  if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
+  const bool count_rows = tile_rows != nullptr && gsr_fused_count_ok(cam0.T);
+  if (count_rows)
+    for (int v = 0; v < V; ++v)
+      if (!geometry_of || geometry_of[v] == v)    // (a view that shares another view's lists has nothing to count)
+        tab.v[v].tile_rows = tile_rows + (size_t)v * (gsr_bin_rows(P) + 1) * (size_t)gsr_bin_stride(cam0.T);
+  if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st, count_rows))
     return rc;
   if (!num_rendered_host) {   // capacity mode: the counts stay on the device (emit_entries adds the block sums up itself)
     if (!gsr_host_block_scan(P))
@@ -303,6 +310,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     if (v == 0) {
       bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = counts_dev; bt.P = P;
       bt.rows = tile_rows ? gsr_bin_rows(P) : 0;
+      bt.counted = (tile_rows && P > 0 && gsr_fused_count_ok(cam.T)) ? 1 : 0;     // stage1 took the same decision
       bt.forward_only = (flags & GSR_FORWARD_ONLY) ? 1 : 0;
       bt.order = order ? order : im.tile_order;
       bt.queue = queue ? queue : im.queue;
@@ -313,6 +321,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     }
     fill_bin_view(bt.v[v], P, num_rendered[v], g, bs, im, sums ? sums + (size_t)v * nblk : g.block_sums);
     if (tile_rows) bt.v[v].tile_rows = tile_rows + (size_t)v * (gsr_bin_rows(P) + 1) * (size_t)gsr_bin_stride(cam.T);
+    bt.v[v].owner = owner;
     fill_render_view(rt.v[v], cam, g, bs, im, out_color[v], out_depth[v], nullptr, nullptr);
     if (owner != v) {   // lists, ranges and sort belong to the owner; this view only gets its offsets from emit
       bt.v[v].shares_lists = 1; bt.v[v].D = 0; bt.v[v].nblocks = 0; bt.v[v].ranges = im_owner.ranges;
@@ -387,7 +396,7 @@ int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_ren
   gsr_carve_image(const_cast<void*>(owner_image_state), cam.H, cam.W, &im_owner);
   gsr_carve_binning(const_cast<void*>(owner_binning_state), num_rendered, &bs);
   GsrBinViews bt;
-  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512;
+  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.counted = 0; bt.forward_only = 0; bt.wave_cap = 512;
   bt.order = im.tile_order; bt.queue = im.queue;
   fill_bin_view(bt.v[0], P, num_rendered, g, bs, im, g.block_sums);
   if (int rc = gsr_launch_shared_lists(bt, P, num_rendered, im_owner.ranges, im_owner.tile_order, im_owner.queue, im.ranges, im.tile_order,
@@ -458,8 +467,9 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
   if (P <= 0) return 0;
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
+  // (no geometry_of at this entry point: every view counts its rows -- a view that turns out to share lists leaves its rows unused)
   return stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp, geom_states,
-                radii, b.sums, num_rendered_host, (hipStream_t)stream);
+                radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, b.tile_rows);
 }
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
@@ -499,7 +509,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   int skip[GSR_MAX_BATCH];
   skippable_aliases(V, geometry_of, colors_views, flags, skip);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, skip, geometry_of))
+                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, skip, geometry_of, b.tile_rows))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
   for (int v = 0; fits && v < V; ++v) {
@@ -546,7 +556,7 @@ int gsr_forward_batch_capacity_raw(int32_t V, const gsr_settings* s, int32_t P, 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw))
+                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw, nullptr, nullptr, geometry_of, b.tile_rows))
     return rc;
   return stage2(V, s, P, capacity_entries, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
                 b.queue, geometry_of, (hipStream_t)stream, counts_dev, b.tile_rows);
@@ -623,7 +633,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; bt.forward_only = 0; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; bt.counted = 0; bt.forward_only = 0; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];

@@ -513,7 +513,9 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
     // capacity mode: the counts for the host.  counts_out may be PINNED HOST memory (the caller then needs no copy on the stream --
     // a 4 us blit plus a 6 us bubble between the forward and the backward): a system-scope store, visible once this kernel has ended
     if (tab.counts_out && tid < tab.V)
-      __hip_atomic_store(&tab.counts_out[tid], tab.v[tid].offsets[tab.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (counted rows: a view that shares lists gets its offsets[P] from the emitting workgroups of THIS launch -- its owner's, from
+      //  bin_scan, is the same number: same camera, same tiles_touched)
+      __hip_atomic_store(&tab.counts_out[tid], tab.v[tab.counted ? tab.v[tid].owner : tid].offsets[tab.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before
@@ -642,48 +644,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(GsrBinViews tab, int i
 //      depth afterwards -- so the lists are the same bits as with the stable radix passes (the reference's order), run after run.
 // Against the radix path (emit, histogram, two scatter passes): 3 - 4 launches instead of 6 in front of the tile sort, entries written
 // once (8 B) instead of 12 + 12 + 8 B, nothing that depends on the entry count in any grid size (capacity mode needs no special case).
-#define BIN_THREADS 1024
-#define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
-#ifndef BIN_DIRECT_ROWS
-#define BIN_DIRECT_ROWS 32
-#endif
-#ifndef BIN_ROW_CHUNK
-#define BIN_ROW_CHUNK 16
-#endif
-#define BIN_BIG_AREA 64        // rects with more tiles are walked by a whole wave, not by their Gaussian's lane
-#define BIN_BIG_MAX 1024       // such Gaussians parked per workgroup (LDS); beyond it their lanes walk them after all
-
-struct BinGauss { uint32_t minx, miny, w, area, mask; float rw; };
-__device__ __forceinline__ BinGauss bin_gauss(uint2 r, uint32_t mask) {
-  BinGauss b;
-  b.minx = r.x & 0xffffu; b.miny = r.x >> 16;
-  const uint32_t maxx = r.y & 0xffffu, maxy = r.y >> 16;
-  b.w = maxx - b.minx; b.area = b.w * (maxy - b.miny); b.mask = mask;
-  b.rw = __builtin_amdgcn_rcpf((float)b.w);
-  return b;
-}
-// Tile id of the k-th tile (row-major) of a Gaussian's rect.  k / w without an integer division (~40 VALU issues each on this
-// part, and the walk below is the whole cost of the count / emit kernels): (k + 0.5) * (1 / w) in fp32, off by less than 1e-3 for
-// every k the kernels see (k < 2^14, so k + 0.5 is exact), while the true quotient's fractional part stays >= 0.5 / w away from an integer.
-__device__ __forceinline__ uint32_t bin_tile_of(const BinGauss& b, uint32_t k, int gx) {
-  const uint32_t ky = (uint32_t)(((float)k + 0.5f) * b.rw);
-  return (b.miny + ky) * (uint32_t)gx + b.minx + (k - ky * b.w);
-}
-// f(tile id) for every tile of a Gaussian's set (small rects: the set bits of its mask, row-major; larger rects: all of it)
-template <typename F>
-__device__ __forceinline__ void bin_for_tiles(const BinGauss& b, int gx, F f) {
-  if (b.area <= 32u) {
-    uint32_t m = b.mask;
-    while (m) {
-      const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
-      m &= m - 1u;
-      f(bin_tile_of(b, k, gx));
-    }
-  } else {
-    for (uint32_t k = 0; k < b.area; ++k) f(bin_tile_of(b, k, gx));
-  }
-}
-
+// (BIN_THREADS, BinGauss, bin_tile_of, bin_for_tiles: gsr_common.h -- shared with the counting form of preprocess_fwd)
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinViews tab) {
   extern __shared__ uint32_t s_cnt[];                 // [T] tile counters
   __shared__ uint32_t s_red[BIN_THREADS / 64];
@@ -843,6 +804,9 @@ __device__ __forceinline__ void bin_scan_view(const GsrBinViews& tab, const GsrB
     if (tid == BIN_THREADS - 1) *s_carry = start + mine;
     __syncthreads();
   }
+  // the view's entry count (all tiles' totals, unclamped): bin_count_kernel knew it from its offsets scan; with the rows counted by the
+  // preprocess launch (tab.counted) nobody else has it before the tile-order workgroups of the emit launch read it
+  if (tab.counted && tid == 0) vw.offsets[tab.P] = *s_carry;
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, int prefixed) {   // grid: V
@@ -882,9 +846,53 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
   __shared__ uint64_t s_bigkey[BIN_BIG_MAX];
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
-  if (vw.shares_lists) return;
   const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
+  if (tab.counted && !tab.forward_only) {
+    // The rows were counted by the preprocess launch: the scan of tiles_touched into offsets[] (the Gaussian-major slots of the backward's
+    // records, + the offset word of the 64-byte records) that rode in bin_count_kernel happens here -- also for a view that shares
+    // another view's lists (its own backward pass addresses its own records).
+    __shared__ uint32_t s_red[BIN_THREADS / 64];
+    __shared__ uint32_t s_wsum[BIN_THREADS / 64];
+    uint32_t tt[BIN_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < BIN_PER_THREAD; ++q) {
+      const int g = g0 + tid * BIN_PER_THREAD + q;
+      tt[q] = g < P ? vw.tiles_touched[g] : 0u;
+    }
+    const int jb = g0 / GSR_BLOCK;
+    uint32_t part = 0;
+    if (vw.block_offsets) { if (tid == 0) part = vw.block_offsets[jb]; }
+    else for (int j = tid; j < jb; j += BIN_THREADS) part += vw.block_sums[j];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < BIN_PER_THREAD; ++q) sum += tt[q];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (lane == 63) s_wsum[wv] = inc;
+    if (lane == 0) s_red[wv] = part;
+    __syncthreads();
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; ++w) { run += s_red[w]; if (w < wv) run += s_wsum[w]; }
+#pragma unroll
+    for (int q = 0; q < BIN_PER_THREAD; ++q) {
+      const int g = g0 + tid * BIN_PER_THREAD + q;
+      if (g < P) {
+        vw.offsets[g] = run;
+        reinterpret_cast<uint32_t*>(vw.rec_w + GSR_REC_F4 * (size_t)g + 3)[2] = run;   // the blend backward reads it from the record
+      }
+      run += tt[q];
+    }
+    if (vw.shares_lists && g0 + GSR_BIN_G >= P && tid == BIN_THREADS - 1) vw.offsets[P] = run;   // (an owner's count came from bin_scan)
+  }
+  if (vw.shares_lists) return;
   const uint32_t cap = vw.D;
   const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
   uint64_t* __restrict__ dg = vw.dg[0];
@@ -1307,6 +1315,36 @@ static int ceil_log2_u32(uint32_t n) {
   return b;
 }
 
+static size_t bin_lds_limit() {
+  static const size_t v = [] {
+    int dev = 0, a = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && a > 0) return (size_t)a;
+    return (size_t)(64 << 10);
+  }();
+  return v;
+}
+static size_t bin_lds_static() {     // the larger static LDS block of the two walks (bin_emit carries the tile-order builder)
+  static const size_t v = [] {
+    hipFuncAttributes a{}, b{};
+    size_t m = 0;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(bin_emit_kernel)) == hipSuccess) m = a.sharedSizeBytes;
+    if (hipFuncGetAttributes(&b, reinterpret_cast<const void*>(bin_count_kernel)) == hipSuccess && b.sharedSizeBytes > m) m = b.sharedSizeBytes;
+    return m ? m : (size_t)(52 << 10);
+  }();
+  return v;
+}
+// static + dynamic LDS of the two walks against what a workgroup may have on THIS device (160 KiB on gfx950; a 64 KiB part would
+// fail the launch for T above ~3800): the radix path is the fallback, as for tile grids above GSR_BIN_MAX_T
+bool gsr_rows_path_ok(int T) {
+  static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
+  return !radix_only && T > 0 && T <= GSR_BIN_MAX_T && bin_lds_static() + sizeof(uint32_t) * (size_t)T <= bin_lds_limit();
+}
+bool gsr_fused_count_ok(int T) {     // GSR_FUSED_COUNT=1: the counting form of preprocess_fwd instead of the separate bin_count launch.  OFF by
+  // default: measured no faster (profiles/r04_rejected_fused_count.txt)
+  static const bool on = [] { const char* e = getenv("GSR_FUSED_COUNT"); return e && *e && atoi(e) != 0; }();
+  return on && gsr_rows_path_ok(T) && gsr_preprocess_count_static_lds() + sizeof(uint32_t) * (size_t)T <= bin_lds_limit();
+}
+
 int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   if (tab_in.V <= 0 || tab_in.T <= 0) return 0;
   GsrBinViews tab = tab_in;
@@ -1318,26 +1356,13 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   tab.wave_cap = big ? (wave32_off ? 1024 : 2048) : 512;
   int cur = 0;
   bool order_done = false;
-  static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
   const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
-  // static + dynamic LDS of the two walks against what a workgroup may have on THIS device (160 KiB on gfx950; a 64 KiB part
-  // would fail the launch for T above ~3800): the radix path is the fallback, as for tile grids above GSR_BIN_MAX_T
-  static const size_t lds_static = [] {
-    hipFuncAttributes a{}, b{};
-    size_t m = 0;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(bin_emit_kernel)) == hipSuccess) m = a.sharedSizeBytes;
-    if (hipFuncGetAttributes(&b, reinterpret_cast<const void*>(bin_count_kernel)) == hipSuccess && b.sharedSizeBytes > m) m = b.sharedSizeBytes;
-    return m ? m : (size_t)(52 << 10);
-  }();
-  static const size_t lds_limit = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) return (size_t)v;
-    return (size_t)(64 << 10);
-  }();
-  const bool rows_path = tab.rows > 0 && tab.T <= GSR_BIN_MAX_T && !radix_only && maxD > 0 && P > 0 && lds_static + lds <= lds_limit;
+  const bool rows_path = tab.rows > 0 && gsr_rows_path_ok(tab.T) && maxD > 0 && P > 0;
   if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
-    { GSR_PROF("bin_count", st);
-      hipLaunchKernelGGL(bin_count_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab); }
+    if (!tab.counted) {          // (counted: the preprocess launch stored the rows -- preprocess_fwd_count_kernel)
+      GSR_PROF("bin_count", st);
+      hipLaunchKernelGGL(bin_count_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab);
+    }
     GSR_HIP_CHECK(hipGetLastError());
     const int prefixed = tab.rows > BIN_DIRECT_ROWS ? 1 : 0;
     if (prefixed) {

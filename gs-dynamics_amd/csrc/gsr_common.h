@@ -167,6 +167,9 @@ struct GsrPreView {            // preprocess
   uint2* block_hash;     // nullptr: no fingerprint wanted
   int skip;              // 1: nothing to preprocess for this view (forward-only fused alias: its owner's tile pass reads its colours
                          //    straight from its colour array, nobody reads a record of its own)
+  uint32_t* tile_rows;   // counting form (preprocess_fwd_count_kernel): this view's (workgroups x tiles) matrix of the tile-row binning --
+                         //    the workgroup's per-tile entry counts go to its row (what bin_count_kernel does in a launch of its own);
+                         //    nullptr: the view shares another view's lists, nothing to count
 };
 struct GsrPreViews {
   int V;
@@ -184,6 +187,7 @@ struct GsrBinView {            // emit .. tile_sort
   uint32_t D, nblocks;     // entries and radix blocks of the view -- or, with D_dev set, the CAPACITY the buffers were sized for
   const uint32_t* D_dev;   // != nullptr: the entry count lives on the device (offsets[P], written by emit_entries): no host round trip
   uint32_t shares_lists;   // 1: same camera as an earlier view of the call -- its tile lists are that view's (no binning of its own)
+  int32_t owner;           // index of the view whose lists this one uses (itself unless shares_lists)
   uint32_t fused_alias;    // 1: additionally blended INSIDE its owner's tile pass (GsrRenderView::partner): no tickets for its busy tiles
   const uint2* ekey;       // tile-row binning: {depth bits, tile mask} per Gaussian
   float4* rec_w;           // the record array again, writable (the offset word of a record is filled in by the binning stage)
@@ -194,6 +198,8 @@ struct GsrBinViews {
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
   int wave_cap;                  // tile_sort: lists up to this length (512 / 1024) are sorted by one wave each (set by gsr_launch_binning)
   int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
+  int counted;                   // 1: the rows were counted by the preprocess launch (preprocess_fwd_count_kernel): no bin_count launch;
+                                 //    bin_scan publishes the views' entry counts (offsets[P]) and bin_emit scans tiles_touched into offsets[]
   int forward_only;              // GSR_FORWARD_ONLY: no backward will read these states (the record-slot offsets are not produced)
   GsrBinView v[GSR_MAX_BATCH];
 };
@@ -247,7 +253,12 @@ static inline size_t gsr_carve_batch(void* base, int V, int32_t P, int32_t H, in
 
 int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, hipStream_t st);
+                          const float* shs, const float* cov3D_precomp, hipStream_t st, bool count_rows = false);
+size_t gsr_preprocess_count_static_lds();
+// Will a multi-view call of this tile grid take the tile-row binning, with its first walk (the per-workgroup tile counts) fused into the
+// preprocess launch?  Decided from (T, device, environment) alone, so the preprocess stage and the render stage of a call agree.
+bool gsr_rows_path_ok(int T);
+bool gsr_fused_count_ok(int T);
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
 int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);
@@ -652,23 +663,77 @@ __device__ __forceinline__ float qmin_on_horizontal_edge(float A, float B, float
   const float dx = fminf(fmaxf(-B * dy * invA, dxlo), dxhi);
   return C * dy * dy + (2.0f * B * dy + A * dx) * dx;
 }
+// Minimum of the (convex) form over the rectangle [dxlo, dxhi] x [dylo, dyhi] (offsets from the mean) when the mean is NOT inside it.
+// Only the edges that FACE the mean can hold it (round 4; four edges were evaluated before): take any point p of the rectangle -- the
+// segment from the mean to p enters the rectangle through the nearer vertical edge (when the mean lies outside the x-range) or the
+// nearer horizontal edge (outside the y-range), at a point p' of that edge, and the form grows along the segment away from the mean,
+// so q(p') <= q(p).  One or two edge minimisations instead of four: 70 -> ~42 VALU per tested rectangle (the per-tile loop of
+// preprocess_fwd is half of that kernel; the per-quad tests of the blend kernels' staging lanes).
+__device__ __forceinline__ float gsr_qmin_facing_edges(float A, float B, float C, float invA, float invC, float dxlo, float dxhi, float dylo, float dyhi) {
+  const bool in_x = dxlo <= 0.0f && dxhi >= 0.0f, in_y = dylo <= 0.0f && dyhi >= 0.0f;
+  const float dxe = dxlo > 0.0f ? dxlo : dxhi, dye = dylo > 0.0f ? dylo : dyhi;   // the nearer edge of each pair
+  const float qv = qmin_on_vertical_edge(A, B, C, invC, dxe, dylo, dyhi);
+  const float qh = qmin_on_horizontal_edge(A, B, C, invA, dye, dxlo, dxhi);
+  const float inf = __builtin_inff();
+  return fminf(in_x ? inf : qv, in_y ? inf : qh);
+}
 // Can alpha reach 1/255 anywhere on the pixel rectangle [x0, x1] x [y0, y1]?  Exact minimum of the (convex) quadratic form
-// over the rectangle -- 0 when the mean is inside, else the least edge minimum -- against tau2 = 2 ln(255 o) + 0.04: conservative.
+// over the rectangle -- 0 when the mean is inside, else the least minimum over the facing edges -- against tau2 = 2 ln(255 o) + 0.04:
+// conservative.
 __device__ __forceinline__ bool gsr_rect_reachable(float mx, float my, float A, float B, float C, float invA, float invC, float tau2,
                                                    int x0, int y0, int x1, int y1) {
   const float dxlo = (float)x0 - mx, dxhi = (float)x1 - mx, dylo = (float)y0 - my, dyhi = (float)y1 - my;
   if (dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f) return true;
-  float q = qmin_on_vertical_edge(A, B, C, invC, dxlo, dylo, dyhi);
-  q = fminf(q, qmin_on_vertical_edge(A, B, C, invC, dxhi, dylo, dyhi));
-  q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dylo, dxlo, dxhi));
-  q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dyhi, dxlo, dxhi));
-  return q <= tau2;
+  return gsr_qmin_facing_edges(A, B, C, invA, invC, dxlo, dxhi, dylo, dyhi) <= tau2;
 }
 // Tile set of a Gaussian: its (tight) tile rect, and -- for rects of at most 32 tiles -- a bit per tile of the rect
 // (row-major) telling whether the tile is in the set.  Larger rects are taken whole.
 __device__ __forceinline__ uint32_t gsr_tile_rank(uint32_t mask, uint32_t area, uint32_t r) {   // rank of rect tile r in the set
   return area <= 32u ? (uint32_t)__popc(mask & ((1u << r) - 1u)) : r;
 }
+// ---- tile-row binning helpers (gsr_binning.hip; the counting form of preprocess_fwd)
+#define BIN_THREADS 1024
+#define BIN_PER_THREAD (GSR_BIN_G / BIN_THREADS)
+#ifndef BIN_DIRECT_ROWS
+#define BIN_DIRECT_ROWS 32
+#endif
+#ifndef BIN_ROW_CHUNK
+#define BIN_ROW_CHUNK 16
+#endif
+#define BIN_BIG_AREA 64        // rects with more tiles are walked by a whole wave, not by their Gaussian's lane
+#define BIN_BIG_MAX 1024       // such Gaussians parked per workgroup (LDS); beyond it their lanes walk them after all
+
+struct BinGauss { uint32_t minx, miny, w, area, mask; float rw; };
+__device__ __forceinline__ BinGauss bin_gauss(uint2 r, uint32_t mask) {
+  BinGauss b;
+  b.minx = r.x & 0xffffu; b.miny = r.x >> 16;
+  const uint32_t maxx = r.y & 0xffffu, maxy = r.y >> 16;
+  b.w = maxx - b.minx; b.area = b.w * (maxy - b.miny); b.mask = mask;
+  b.rw = __builtin_amdgcn_rcpf((float)b.w);
+  return b;
+}
+// Tile id of the k-th tile (row-major) of a Gaussian's rect.  k / w without an integer division (~40 VALU issues each on this
+// part, and the walk below is the whole cost of the count / emit kernels): (k + 0.5) * (1 / w) in fp32, off by less than 1e-3 for
+// every k the kernels see (k < 2^14, so k + 0.5 is exact), while the true quotient's fractional part stays >= 0.5 / w away from an integer.
+__device__ __forceinline__ uint32_t bin_tile_of(const BinGauss& b, uint32_t k, int gx) {
+  const uint32_t ky = (uint32_t)(((float)k + 0.5f) * b.rw);
+  return (b.miny + ky) * (uint32_t)gx + b.minx + (k - ky * b.w);
+}
+// f(tile id) for every tile of a Gaussian's set (small rects: the set bits of its mask, row-major; larger rects: all of it)
+template <typename F>
+__device__ __forceinline__ void bin_for_tiles(const BinGauss& b, int gx, F f) {
+  if (b.area <= 32u) {
+    uint32_t m = b.mask;
+    while (m) {
+      const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+      m &= m - 1u;
+      f(bin_tile_of(b, k, gx));
+    }
+  } else {
+    for (uint32_t k = 0; k < b.area; ++k) f(bin_tile_of(b, k, gx));
+  }
+}
+
 // Reference (slow, LDS-crossbar) version used by the self-test.
 __device__ __forceinline__ float gsr_wave_sum_shfl(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -59,28 +59,27 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float* __restric
 
 __device__ __forceinline__ int sext16_(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
-__global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
-    GsrPreViews tab, int P, int W, int H, int gx, int gy, float mod, int sh_degree, int M,
+// What the rest of a launch needs to know about one preprocessed Gaussian (everything else went to memory).
+struct PreOut { uint32_t tiles; uint2 rc; uint32_t tmask; uint32_t depth_bits; };
+
+// One Gaussian of one view: cull, project, covariance, conic, radius, rect / alpha box / tile mask, colour; every per-Gaussian output
+// stored.  `i` may be out of range (in_range = false: nothing loaded, nothing stored, an empty result).
+__device__ __forceinline__ PreOut preprocess_gaussian(
+    const GsrPreViews& tab, const GsrPreView& vw, const int i, const int P, float4* __restrict__ s_rec, const bool write_act, int W, int H, int gx, int gy,
+    float mod, int sh_degree, int M,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
-  // this block's view (blockIdx.y): its pointers come out of the kernarg table with scalar loads
-  const GsrPreView& vw = tab.v[blockIdx.y];
-  if (vw.skip) return;
+  const bool in_range = i < P;
   const float* __restrict__ view = vw.view;
   const float* __restrict__ proj = vw.proj;
   const float* __restrict__ campos = vw.campos;
-  if (vw.colors) colors_precomp = vw.colors;
   const float tanfovx = vw.tanfovx, tanfovy = vw.tanfovy;
   float4* __restrict__ rec = vw.rec;
   uint2* __restrict__ rect = vw.rect;
   uint32_t* __restrict__ tiles_touched = vw.tiles_touched;
   uint32_t* __restrict__ clamped_out = vw.clamped;
   int32_t* __restrict__ radii = vw.radii;
-  uint32_t* __restrict__ block_sums = vw.block_sums;
-  __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
-  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  const bool in_range = i < P;
   // defaults for a culled Gaussian
   int32_t radius_i = 0;
   uint32_t tiles = 0;
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     act_o = gsr_act_opacity(tab.raw_op[i]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) act_s[k] = gsr_act_scale(tab.raw_sc[3 * (size_t)i + k]);
-    if (blockIdx.y == 0) {
+    if (write_act) {
       reinterpret_cast<float4*>(tab.rot_out)[i] = act_q;
       tab.op_out[i] = act_o;
 #pragma unroll
@@ -238,17 +237,67 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
       }
     }
   }
+#ifndef GSR_PRE_LDS_STORE
+#define GSR_PRE_LDS_STORE 1
+#endif
+#if GSR_PRE_LDS_STORE
+  {
+    // The 64 records of a wave are 4 KiB of CONTIGUOUS memory, but a lane holds one whole record: stored straight from the registers,
+    // each of the four 16-byte stores touches a quarter of 64 different lines.  Transposed through the wave's LDS block instead, store k
+    // writes the wave's k-th KiB -- whole lines.  Part p of lane l sits at float4 index 4 l + (p ^ ((l >> 1) & 3)): the XOR keeps both the
+    // 8-lane groups of the 16-byte LDS writes and the 16-lane groups of the reads conflict-free.
+    float4* __restrict__ R = s_rec;
+    const int l = (int)(threadIdx.x & 63), sw = (l >> 1) & 3;
+    R[4 * l + (0 ^ sw)] = a4;
+    R[4 * l + (1 ^ sw)] = b4;
+    R[4 * l + (2 ^ sw)] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
+    R[4 * l + (3 ^ sw)] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(tmask));  // .z = offset (emit)
+    const int i0 = i - l;                       // the wave's first Gaussian (wave-uniform)
+    const int r = l >> 2, pp = l & 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 16 * k + r;                // record (lane of the wave) whose part pp this lane stores
+      const float4 v = R[4 * rr + (pp ^ ((rr >> 1) & 3))];
+      if (i0 + rr < P) rec[GSR_REC_F4 * (size_t)i0 + 64 * k + l] = v;
+    }
+  }
+#endif
   if (in_range) {
+#if !GSR_PRE_LDS_STORE
     rec[GSR_REC_F4 * i + 0] = a4;
     rec[GSR_REC_F4 * i + 1] = b4;
     rec[GSR_REC_F4 * i + 2] = make_float4(c2.x, c2.y, __uint_as_float(box.x), __uint_as_float(box.y));
     rec[GSR_REC_F4 * i + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(tmask));  // .z = offset (emit)
+#endif
     rect[i] = rc;
     vw.ekey[i] = make_uint2(__float_as_uint(c2.y), tmask);
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;
   }
+  PreOut o;
+  o.tiles = tiles; o.rc = rc; o.tmask = tmask; o.depth_bits = __float_as_uint(c2.y);
+  return o;
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
+    GsrPreViews tab, int P, int W, int H, int gx, int gy, float mod, int sh_degree, int M,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
+  // this block's view (blockIdx.y): its pointers come out of the kernarg table with scalar loads
+  const GsrPreView& vw = tab.v[blockIdx.y];
+  if (vw.skip) return;
+  if (vw.colors) colors_precomp = vw.colors;
+  uint32_t* __restrict__ block_sums = vw.block_sums;
+  __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  const bool in_range = i < P;
+  __shared__ float4 s_rec[GSR_BLOCK / GSR_WAVE][256];      // a wave's 64 records on their way to memory (see preprocess_gaussian)
+  const PreOut po = preprocess_gaussian(tab, vw, i, P, s_rec[threadIdx.x >> 6], blockIdx.y == 0, W, H, gx, gy, mod, sh_degree, M, means3D, scales, rotations,
+                                        opacities, colors_precomp, shs, cov3D_precomp, tight_lists);
+  const uint32_t tiles = po.tiles, tmask = po.tmask;
+  const uint2 rc = po.rc;
   // Fingerprint of what the tile lists depend on -- tile rect, tile mask, depth bits and the Gaussian's index -- XOR-ed over the
   // block (the host XORs the blocks): two preprocess runs with equal fingerprints AND equal entry counts produce the same lists
   // (up to a 2^-64 coincidence), whatever tensors the inputs came from.  Only when asked for (single-view entry points).
@@ -256,7 +305,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
     uint64_t h = ((uint64_t)(uint32_t)i + 1ull) * 0x9E3779B97F4A7C15ull;
     h ^= (((uint64_t)rc.x << 32) | rc.y) * 0xC2B2AE3D27D4EB4Full;
     h = (h << 31) | (h >> 33);
-    h ^= (((uint64_t)tmask << 32) | __float_as_uint(c2.y)) * 0x165667B19E3779F9ull;
+    h ^= (((uint64_t)tmask << 32) | po.depth_bits) * 0x165667B19E3779F9ull;
     h *= 0x9E3779B97F4A7C15ull;
     h ^= h >> 29;
     if (!in_range) h = 0;
@@ -278,6 +327,74 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
 }
 
+// The counting form (round 4): preprocess + the first walk of the tile-row binning in ONE launch.  A workgroup of BIN_THREADS threads owns
+// GSR_BIN_G consecutive Gaussians of a view (thread t: Gaussians g0 + t, g0 + t + BIN_THREADS, ... -- coalesced), preprocesses them and,
+// with their tile rects and masks still in registers, counts the entries per tile in LDS and stores the counters as ITS ROW of the
+// view's (workgroups x tiles) matrix -- what bin_count_kernel (gsr_binning.hip) did in a launch of its own after re-reading rect / ekey /
+// tiles_touched: one dependent launch and one pass over 20 bytes per Gaussian fewer in front of the blend.  The offsets[] scan that
+// rode in bin_count_kernel moves to bin_emit_kernel, the view's entry count (offsets[P]) to bin_scan.
+#ifndef GSR_PRECOUNT_WPE
+#define GSR_PRECOUNT_WPE 4      // waves per SIMD the register allocation is bounded for: 4 = one 1024-thread workgroup per CU (79 VGPRs, no spill);
+#endif                          // 8 = two per CU (64 VGPRs, 60 bytes of scratch per lane)
+__global__ __launch_bounds__(BIN_THREADS, GSR_PRECOUNT_WPE) void preprocess_fwd_count_kernel(
+    GsrPreViews tab, int P, int W, int H, int gx, int gy, float mod, int sh_degree, int M,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
+  extern __shared__ uint32_t s_cnt[];                 // [T] tile counters
+  __shared__ uint32_t s_wave_sum[BIN_THREADS / GSR_WAVE];
+  __shared__ float4 s_rec[BIN_THREADS / GSR_WAVE][256];
+  __shared__ uint2 s_big[BIN_BIG_MAX];                // rects walked by a whole wave (see bin_count_kernel)
+  __shared__ uint32_t s_nbig;
+  const GsrPreView& vw = tab.v[blockIdx.y];
+  if (vw.skip) return;
+  if (vw.colors) colors_precomp = vw.colors;
+  const int T = gx * gy, Ts = gsr_bin_stride(T), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g0 = (int)blockIdx.x * GSR_BIN_G;
+  const bool count = vw.tile_rows != nullptr;
+  if (count) for (int t = tid; t < T; t += BIN_THREADS) s_cnt[t] = 0;
+  if (tid == 0) s_nbig = 0;
+  PreOut po[BIN_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {          // (fully unrolled: po[] stays in registers)
+    const int i = g0 + q * BIN_THREADS + tid;
+    po[q] = preprocess_gaussian(tab, vw, i, P, s_rec[wv], blockIdx.y == 0, W, H, gx, gy, mod, sh_degree, M, means3D, scales, rotations, opacities,
+                                colors_precomp, shs, cov3D_precomp, tight_lists);
+    // per-256-Gaussian totals of tiles_touched, as the 256-thread form writes them (the host's entry count, the offsets scan of bin_emit)
+    uint32_t wsum = po[q].tiles;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m, 64);
+    if (lane == 0) s_wave_sum[wv] = wsum;
+    __syncthreads();                                    // (also orders the zeroing of s_cnt before the first count below)
+    if (tid < BIN_THREADS / GSR_BLOCK) {
+      const int blk = (g0 + q * BIN_THREADS) / GSR_BLOCK + tid;
+      if (blk * GSR_BLOCK < P)
+        vw.block_sums[blk] = s_wave_sum[4 * tid] + s_wave_sum[4 * tid + 1] + s_wave_sum[4 * tid + 2] + s_wave_sum[4 * tid + 3];
+    }
+    __syncthreads();
+  }
+  if (!count) return;
+#pragma unroll
+  for (int q = 0; q < BIN_PER_THREAD; ++q) {
+    if (!po[q].tiles) continue;
+    const BinGauss b = bin_gauss(po[q].rc, po[q].tmask);
+    if (b.area > BIN_BIG_AREA) {
+      const uint32_t slot = atomicAdd(&s_nbig, 1u);
+      if (slot < BIN_BIG_MAX) { s_big[slot] = po[q].rc; continue; }
+    }
+    bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
+  }
+  __syncthreads();
+  const uint32_t nbig = min(s_nbig, (uint32_t)BIN_BIG_MAX);
+  for (uint32_t i = wv; i < nbig; i += BIN_THREADS / 64) {   // one wave per parked Gaussian, a lane per tile
+    const BinGauss b = bin_gauss(s_big[i], 0u);
+    for (uint32_t k = lane; k < b.area; k += 64) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
+  }
+  if (nbig) __syncthreads();
+  uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
+  for (int t = tid; t < Ts; t += BIN_THREADS) row[t] = t < T ? s_cnt[t] : 0u;      // (the padding columns of the row stay zero)
+}
+
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float* __restrict__ view,
                                                                  const float* __restrict__ means3D,
                                                                  uint8_t* __restrict__ present) {
@@ -292,17 +409,31 @@ using namespace gsr_preprocess_fwd;
 
 int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, hipStream_t st) {
+                          const float* shs, const float* cov3D_precomp, hipStream_t st, bool count_rows) {
   if (P <= 0 || tab.V <= 0) return 0;
   int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
   const char* ref_lists = getenv("GSR_REFERENCE_LISTS");
   const int tight = (ref_lists && ref_lists[0] == '1') ? 0 : 1;
   { GSR_PROF("preprocess_fwd", st);
+  if (count_rows)    // the counting form: one workgroup per GSR_BIN_G Gaussians, its tile counts go to its row of the view's matrix
+    hipLaunchKernelGGL(preprocess_fwd_count_kernel, dim3(gsr_bin_rows(P), tab.V), dim3(BIN_THREADS), sizeof(uint32_t) * (size_t)cam.T, st, tab, P,
+                       cam.W, cam.H, cam.gx, cam.gy, cam.scale_modifier, cam.sh_degree, cam.M, means3D, scales, rotations, opacities,
+                       colors_precomp, shs, cov3D_precomp, tight);
+  else
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks, tab.V), dim3(GSR_BLOCK), 0, st, tab, P, cam.W, cam.H, cam.gx,
                      cam.gy, cam.scale_modifier, cam.sh_degree, cam.M, means3D, scales, rotations, opacities,
                      colors_precomp, shs, cov3D_precomp, tight); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+// Static LDS of the counting form (the launch adds 4 T bytes of tile counters): gsr_fused_count_ok() compares with the device's limit.
+size_t gsr_preprocess_count_static_lds() {
+  static const size_t v = [] {
+    hipFuncAttributes a{};
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(preprocess_fwd_count_kernel)) == hipSuccess ? (size_t)a.sharedSizeBytes : (size_t)(12 << 10);
+  }();
+  return v;
 }
 
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st) {

@@ -93,13 +93,7 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
     const float dxlo = (float)x0 - mx, dxhi = (float)(x0 + GSR_QW - 1) - mx;
     const float dylo = (float)y0 - my, dyhi = (float)(y0 + GSR_QH - 1) - my;
     bool keep = dxlo <= 0.0f && dxhi >= 0.0f && dylo <= 0.0f && dyhi >= 0.0f;
-    if (!keep) {
-      float q = qmin_on_vertical_edge(A, B, C, invC, dxlo, dylo, dyhi);
-      q = fminf(q, qmin_on_vertical_edge(A, B, C, invC, dxhi, dylo, dyhi));
-      q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dylo, dxlo, dxhi));
-      q = fminf(q, qmin_on_horizontal_edge(A, B, C, invA, dyhi, dxlo, dxhi));
-      keep = q <= tau2;
-    }
+    if (!keep) keep = gsr_qmin_facing_edges(A, B, C, invA, invC, dxlo, dxhi, dylo, dyhi) <= tau2;   // the two edges that face the mean
     if (keep) m |= 1u << w;
   }
   return m;

@@ -931,7 +931,8 @@ def test_pair_fusion_and_static_launch_variants(dev, tmp_path):
     script = tmp_path / "variant.py"
     script.write_text(_VARIANT_SCRIPT)
     outs = {}
-    for name, env in (("default", {}), ("nopair", {"GSR_NO_PAIR_FUSION": "1"}), ("static", {"GSR_RENDER_STATIC": "1"})):
+    for name, env in (("default", {}), ("nopair", {"GSR_NO_PAIR_FUSION": "1"}), ("static", {"GSR_RENDER_STATIC": "1"}),
+                      ("counted", {"GSR_FUSED_COUNT": "1"})):      # the counting form of preprocess_fwd (round-4 A/B switch, off by default)
         e = dict(os.environ)
         e.update(env)
         out = tmp_path / (name + ".npz")
@@ -942,6 +943,7 @@ def test_pair_fusion_and_static_launch_variants(dev, tmp_path):
     d, n, st = outs["default"], outs["nopair"], outs["static"]
     for k in d.files:
         assert np.array_equal(d[k], st[k]), ("static", k)
+        assert np.array_equal(d[k], outs["counted"][k]), ("counted", k)   # same lists, same record slots: bit-identical
     assert np.array_equal(d["im"], n["im"]) and np.array_equal(d["dep"], n["dep"])
     assert float(np.abs(d["im"][1] - d["im"][0]).max()) > 0.1            # different colours and background
     for k in d.files:
