@@ -215,6 +215,8 @@ struct GsrRenderView {         // blend forward / backward
 struct GsrRenderViews {
   int V, W, H, gx, T; const uint4* order; uint32_t* queue;
   int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
+  int prio_len;         // backward (GSR_BWD_PRIO_LEN, experiment): tickets with at least this many entries run at base priority 1; 0 = off
+  int prio_frac16;      // ... or the longest prio_frac16 / 16 of the busy tickets (GSR_BWD_PRIO_FRAC16)
   GsrRenderView v[GSR_MAX_BATCH];
 };
 

@@ -102,6 +102,9 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
 #ifndef GSR_INDEX_AHEAD
 #define GSR_INDEX_AHEAD 1
 #endif
+#ifndef GSR_FWD_SIGNED_T
+#define GSR_FWD_SIGNED_T 1     // the forward keeps a pixel's stopped flag in the sign of T (0: the round-1..3 form with an SGPR mask, for A/B)
+#endif
 // Per-strip compacted entry lists of one staged batch (stable: list order is preserved).
 // PAIR: the tile pass also blends a partner view that shares this view's camera and differs only in its colours (the
 // segmentation render next to the colour render of get_loss, the mask render next to the colour render of predict.py):
@@ -140,10 +143,18 @@ __device__ __forceinline__ void fwd_tile(
   const float pxf = (float)px, pyf = (float)py;
   const int n = (int)(rg.y - rg.x);
 
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+#if GSR_FWD_SIGNED_T
+  float T = inside ? 1.0f : -1.0f;      // the sign of T is the stopped flag (see GSR_FWD_ENTRY)
+#define done (!(T > 0.0f))
+#else
+  float T = 1.0f;
+#endif
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
   float C3 = 0.f, C4 = 0.f, C5 = 0.f;   // PAIR: the partner's colour
   uint32_t last = 0;
+#if !GSR_FWD_SIGNED_T
   bool done = !inside;
+#endif
   GSR_T0();
 
   // Software-pipelined staging: the gathers of batch b+1 are issued before batch b is walked, so their
@@ -222,6 +233,29 @@ __device__ __forceinline__ void fwd_tile(
       const float2* __restrict__ wD = L.sD[wv];
       // One list entry: evaluate, then blend predicated.  (Skipping the blend arithmetic of a visit no pixel of the quad uses -- a
       // wave-uniform branch on __ballot(hit) -- was measured 9 % SLOWER: straight-line code lets the compiler overlap the visits.)
+#if GSR_FWD_SIGNED_T
+      /* Round 4 ("predicates in VALU registers"; measured: render_fwd 45.4 -> 43.5 us at one view, 103.8 -> 102.3 at four, 192.7 -> 189.9 at eight): the pixel's stopped flag lives in the SIGN of T (T > 0: live,
+         T = -|T at the stop|: stopped) instead of in an SGPR mask that every entry ANDs into its hit mask and ORs its stop mask into --
+         a stopped pixel has test_T < 0 < T_EPS, so `stop` holds for it by itself and `blend` is false: three SALU mask operations
+         per entry fewer, one v_cndmask more. */                                                                           \
+#define GSR_FWD_ENTRY(ea, eb, ec, ed)                                                               \
+      {                                                                                             \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
+        const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
+        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * __builtin_amdgcn_exp2f(power));             \
+        const bool hit = power <= 0.0f && alpha >= GSR_ALPHA_MIN;                                   \
+        const float test_T = T * (1.0f - alpha);                                                    \
+        const bool stop = hit && test_T < GSR_T_EPS;                                                \
+        const bool blend = hit != stop;                                                             \
+        const float w = blend ? alpha * T : 0.0f;                                                   \
+        C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                         \
+        C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                         \
+        if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
+        T = blend ? test_T : T;                                                                     \
+        T = stop ? -__builtin_fabsf(T) : T;                                                         \
+        last = blend ? __float_as_uint(ec.z) : last;                                                \
+      }
+#else
 #define GSR_FWD_ENTRY(ea, eb, ec, ed)                                                               \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
@@ -245,6 +279,7 @@ __device__ __forceinline__ void fwd_tile(
       // address computations and four scalar branches per trip: render_fwd 222 -> 201 us at 8 views, 58 -> 49 us at one view.  The
       // backward's visits branch on __ballot(hit), the loads cannot move across that, and there the hand-rotated prefetch is 3 %
       // faster than blocks.)
+#endif
       constexpr int UN = PAIR ? FWD_UNROLL_PAIR : FWD_UNROLL;
       int j = 0;
       for (; j + UN <= m; j += UN) {
@@ -269,6 +304,10 @@ __device__ __forceinline__ void fwd_tile(
     GSR_TP(5);
   }
   GSR_TP(1);
+#if GSR_FWD_SIGNED_T
+#undef done
+  T = __builtin_fabsf(T);
+#endif
   if (inside) {
     const int pix = py * W + px;
     const size_t N = (size_t)H * W;
@@ -346,7 +385,9 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
                            if (lane >= 48 && lane <= 53) L.sRed[wv][j][lane - 48] = z; }
 #endif
 #define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial6(p, e, r0, a, b)   // (36-byte stores instead: measured the same)
-template <bool PAIR, int NBB = GSR_BWD_BB(PAIR), bool COL = true>
+// BASE: the ticket's base wave priority (round-4 experiment, GSR_BWD_PRIO_LEN: tickets with at least that many entries run at base 1 --
+// the longest lists of a short queue get a larger share of their CU and finish with the pack instead of draining alone)
+template <bool PAIR, int NBB = GSR_BWD_BB(PAIR), bool COL = true, int BASE = 0>
 __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -362,6 +403,7 @@ __device__ __forceinline__ void bwd_tile(
   const float pxf = (float)px, pyf = (float)py;
   const int n = (int)(rg.y - rg.x);
   if (n == 0) return;  // uniform: nothing to differentiate in an empty tile
+  if (BASE) __builtin_amdgcn_s_setprio(BASE);
   const size_t N = (size_t)H * W;
   const int pix = py * W + px;
 
@@ -514,8 +556,8 @@ __device__ __forceinline__ void bwd_tile(
 #define GSR_PRIO_COMBINE 0    /* ... and while a batch's totals are combined and stored */
 #endif
 #if GSR_PRIO_VISIT
-#define GSR_BWD_PRIO_IN __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT);
-#define GSR_BWD_PRIO_OUT __builtin_amdgcn_s_setprio(0);
+#define GSR_BWD_PRIO_IN __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);
+#define GSR_BWD_PRIO_OUT __builtin_amdgcn_s_setprio(BASE);
 #else
 #define GSR_BWD_PRIO_IN
 #define GSR_BWD_PRIO_OUT
@@ -626,6 +668,7 @@ __device__ __forceinline__ void bwd_tile(
     __syncthreads();
     GSR_TP(7);
   }
+  if (BASE) __builtin_amdgcn_s_setprio(0);
   GSR_TFLUSH_B();
 }
 
@@ -756,6 +799,8 @@ __global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == 96) ? 5 : BWD_WAVES_PE
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
+    else if ((tab.prio_len > 0 && (int)(ord.z - ord.y) >= tab.prio_len) || ticket * 16u < n_busy * (uint32_t)tab.prio_frac16)
+      bwd_tile<false, NBB, COL, 1>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     else
       bwd_tile<false, NBB, COL>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
 #ifdef GSR_TRACE_TICKETS
@@ -842,8 +887,18 @@ int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
   return 0;
 }
 
-int gsr_launch_render_bwd(const GsrRenderViews& tab, hipStream_t st) {
-  if (tab.T <= 0 || tab.V <= 0) return 0;
+int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
+  if (tab_in.T <= 0 || tab_in.V <= 0) return 0;
+  GsrRenderViews tab = tab_in;
+  // Base wave priority of a ticket (round 4).  One view per launch -- the per-GPU share of a view-sharded step -- is ONE round of tickets
+  // on the resident workgroups followed by a drain in which they finish one by one: the longest 10/16 of the tickets (the order is
+  // longest-first: rank = ticket) run at base priority 1, so that a CU's long lists get a larger share of it and end with the pack:
+  // render_bwd 90.5 -> 87 us, the one-view step 213 -> 208.5 us (profiles/r04_small_blend_experiments.txt); nothing at 2+ views (off there).
+  // GSR_BWD_PRIO_FRAC16 = k overrides (0 = off) for launches of up to GSR_BWD_PRIO_MAXV views; GSR_BWD_PRIO_LEN = n: by list length instead.
+  static const int prio_len = env_int("GSR_BWD_PRIO_LEN", 0), prio_frac = env_int("GSR_BWD_PRIO_FRAC16", -1);
+  static const int prio_maxv = env_int("GSR_BWD_PRIO_MAXV", prio_frac >= 0 || prio_len > 0 ? 16 : 1);
+  tab.prio_len = tab.V <= prio_maxv ? prio_len : 0;
+  tab.prio_frac16 = tab.V <= prio_maxv ? (prio_frac >= 0 ? prio_frac : (prio_len > 0 ? 0 : 10)) : 0;
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
   static const int pair_wg_per_cu = env_int("GSR_BWD_PAIR_WG_PER_CU", 4);
