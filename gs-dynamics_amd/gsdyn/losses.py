@@ -287,6 +287,12 @@ def image_loss(pred, target, w_l1: float = 0.8, w_ssim: float = 0.2):
     HIP tensors take the fused kernels; CPU tensors (host-logic tests) evaluate the reference's own torch formula.
     ``pred`` / ``target`` [C,H,W] -> scalar, or a batch [N,C,H,W] -> [N] (one kernel launch for all images)."""
     if pred.is_cuda:
+        if pred.dim() == 3 and pred.dtype == torch.float32:
+            # ONE image: the views-loss kernels with a single row (no camera affine, weight 1) -- the loss scalar comes straight out of
+            # the finishing kernel.  The single-image kernels below return block sums that six small torch ops (+ their autograd nodes)
+            # turn into the loss: ~110 us of HOST time per call in the reference-shaped loop (two calls per camera; round 4,
+            # profiles/r04_dropin_host_profile.txt).  Same values; the target's window moments are cached by the views path as well.
+            return _FusedViewsLoss.apply(pred.unsqueeze(0), None, None, [target], [-1], [1.0], w_l1, w_ssim)[0]
         return _FusedImageLoss.apply(pred, target, w_l1, w_ssim)
     if pred.dim() == 4:
         return torch.stack([w_l1 * l1_loss_v1(p, t) + w_ssim * (1.0 - calc_ssim(p, t)) for p, t in zip(pred, target)])
