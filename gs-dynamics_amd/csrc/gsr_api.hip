@@ -375,8 +375,15 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
   GsrRange _range("gsr_forward_render");
   if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
   void* geom = const_cast<void*>(geom_state);
+  // round 4: the single-view entry points bin with the tile-row counting sort too (the matrix lives in the geometry state): one
+  // binning = bin_count + bin_colprefix + bin_scan + bin_emit (with the tile order) ~ 37 us at 100 k / 800^2 instead of emit_entries +
+  // radix_hist + 2 x radix_scatter + tile_order ~ 85 us.  Larger tile grids than GSR_BIN_MAX_T and GSR_RADIX_BINNING=1 keep the radix path.
+  GeomState g;
+  gsr_carve_geom(geom, P, &g);
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
-                nullptr, nullptr, (hipStream_t)stream);
+                nullptr, nullptr, (hipStream_t)stream, nullptr, (geom && P > 0 && gsr_rows_path_ok(cam.T)) ? g.tile_rows : nullptr);
 }
 
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,

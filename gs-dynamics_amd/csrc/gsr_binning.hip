@@ -1336,7 +1336,8 @@ static size_t bin_lds_static() {     // the larger static LDS block of the two w
 // static + dynamic LDS of the two walks against what a workgroup may have on THIS device (160 KiB on gfx950; a 64 KiB part would
 // fail the launch for T above ~3800): the radix path is the fallback, as for tile grids above GSR_BIN_MAX_T
 bool gsr_rows_path_ok(int T) {
-  static const bool radix_only = [] { const char* e = getenv("GSR_RADIX_BINNING"); return e && *e && atoi(e) != 0; }();
+  const char* e = getenv("GSR_RADIX_BINNING");        // (read per call: the tests pin the radix path inside one process)
+  const bool radix_only = e && *e && atoi(e) != 0;
   return !radix_only && T > 0 && T <= GSR_BIN_MAX_T && bin_lds_static() + sizeof(uint32_t) * (size_t)T <= bin_lds_limit();
 }
 bool gsr_fused_count_ok(int T) {     // GSR_FUSED_COUNT=1: the counting form of preprocess_fwd instead of the separate bin_count launch.  OFF by

@@ -25,6 +25,16 @@
 //              bits(tile mask: which tiles of a rect of <= 32 tiles are in the Gaussian's lists)}
 // The alpha-box is the int16 pixel box outside which alpha < 1/255.
 #define GSR_REC_F4 4
+// Tile-row binning (gsr_binning.hip): a workgroup of 1024 threads owns GSR_BIN_G consecutive Gaussians of a view.
+#ifndef GSR_BIN_G
+#define GSR_BIN_G 2048              // Gaussians per counting / emitting workgroup.  Measured (100 k Gaussians, step us at 1 / 2 / 4 / 8 views): 4096: 228 / 318 /
+                                    // 488 / 850, 2048: 220 / 306 / 479 / 850, 1024: 219 / 308 / 479; configs[4] frame: the same; 8192: worse everywhere
+#endif
+#define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS: 4 T dynamic bytes (40 KiB at the limit) next to the kernels' static
+                                    // arrays -- ~50 KiB in bin_emit_kernel since the tile-order builder moved into it (TileOrderLds 33.8 KiB, s_big /
+                                    // s_bigkey 8 KiB each): ~83 KiB at 1080p, ~90 KiB at the limit, i.e. gfx950's 160 KiB at one workgroup per CU.
+                                    // gsr_launch_binning checks static + dynamic bytes against the device's limit and takes the radix path
+                                    // otherwise (as larger tile grids do)
 struct GeomState {
   float4* rec;            // [4P]
   uint2* rect;            // {minx | miny<<16, maxx | maxy<<16} in tiles
@@ -38,6 +48,8 @@ struct GeomState {
                           //     instead of two 16-byte gathers from the 64-byte record)
   uint2* block_hash;      // [ceil(P/256)] 64-bit fingerprint per preprocess block of everything the tile lists depend on (single-view
                           //     entry points: lets a second render with the same geometry reuse the first one's lists)
+  uint32_t* tile_rows;    // [(ceil(P / GSR_BIN_G) + 1) x GSR_BIN_MAX_T] the (workgroups x tiles) matrix of the tile-row binning for the
+                          //     SINGLE-VIEW entry points (round 4; multi-view calls keep theirs in the batch state)
 };
 struct ImageState {
   float* final_T;         // [H*W]
@@ -76,6 +88,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->counters = (uint32_t*)take(64);
   g->ekey = (uint2*)take(Pn * 8);
   g->block_hash = (uint2*)take(nblk * 8);
+  g->tile_rows = (uint32_t*)take(((Pn + GSR_BIN_G - 1) / GSR_BIN_G + 1) * (size_t)GSR_BIN_MAX_T * 4);
   return off;
 }
 static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageState* im) {
@@ -222,15 +235,6 @@ struct GsrRenderViews {
 
 // Batch state (V > 1): the structures shared by the views of one call.
 // Tile-row binning (gsr_binning.hip): a workgroup of 1024 threads owns GSR_BIN_G consecutive Gaussians of a view.
-#ifndef GSR_BIN_G
-#define GSR_BIN_G 2048              // Gaussians per counting / emitting workgroup.  Measured (100 k Gaussians, step us at 1 / 2 / 4 / 8 views): 4096: 228 / 318 /
-                                    // 488 / 850, 2048: 220 / 306 / 479 / 850, 1024: 219 / 308 / 479; configs[4] frame: the same; 8192: worse everywhere
-#endif
-#define GSR_BIN_MAX_T 10240         // tile counters of a view live in LDS: 4 T dynamic bytes (40 KiB at the limit) next to the kernels' static
-                                    // arrays -- ~50 KiB in bin_emit_kernel since the tile-order builder moved into it (TileOrderLds 33.8 KiB, s_big /
-                                    // s_bigkey 8 KiB each): ~83 KiB at 1080p, ~90 KiB at the limit, i.e. gfx950's 160 KiB at one workgroup per CU.
-                                    // gsr_launch_binning checks static + dynamic bytes against the device's limit and takes the radix path
-                                    // otherwise (as larger tile grids do)
 static inline int gsr_bin_rows(int P) { return ((P > 0 ? P : 1) + GSR_BIN_G - 1) / GSR_BIN_G; }
 static inline __host__ __device__ int gsr_bin_stride(int T) { return (T + 3) & ~3; }   // row stride of the matrix: rows stay 16-byte aligned
 struct BatchState {

@@ -369,6 +369,33 @@ def test_random_scenes_vs_oracle(dev, P, W, H, seed):
                           tol_worst=ROW_TOL_WORST_P5000 if P == 5000 else ROW_TOL_WORST)
 
 
+def test_randomised_sweep_vs_oracle(dev):
+    """Round 4: 36 seeded random (scene, camera, image size) combinations against the oracle in one go -- sizes that are not multiples of
+    the tile, one- and few-Gaussian scenes, Gaussians far larger than a tile and far smaller than a pixel, cameras inside the cloud
+    (near-plane culls, frustum clamp), opaque and nearly transparent scenes -- with the full check of `_check_against_oracle` (radii and
+    lists bit-exact, images, all gradients norm-wise and row-wise)."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    for case in range(36):
+        P = int(rng.choice([1, 2, 3, 17, 64, 257, 900, 2500]))
+        W, H = int(rng.integers(9, 220)), int(rng.integers(9, 160))
+        lo = float(rng.choice([0.002, 0.02, 0.1]))
+        hi = lo * float(rng.choice([2.0, 10.0, 40.0]))
+        g = random_gaussians(P, seed=1000 + case, scale_lo=lo, scale_hi=hi, spread=float(rng.choice([0.3, 1.0, 2.5])))
+        shift = float(rng.choice([-3.0, 0.0, 2.5]))                     # opacity logits shifted: faint / as is / opaque scenes
+        g["opacities"] = (1.0 / (1.0 + np.exp(-(np.log(g["opacities"] / (1.0 - g["opacities"])) + shift)))).astype(np.float32)
+        cam = ring_camera(W, H, v=int(rng.integers(0, 7)), V=7, radius=float(rng.choice([0.6, 2.0, 4.0, 9.0])),
+                          height=float(rng.choice([-0.5, 0.8, 3.0])), bg=tuple(float(x) for x in rng.uniform(0, 1, 3)))
+        try:
+            _check_against_oracle(cam, g, dev, seed=case, min_ok=0.98, tol_worst=ROW_TOL_WORST_P5000)
+            done += 1
+        except AssertionError as e:
+            if "too many threshold-ambiguous pixels" in str(e):     # (a scene of a few huge faint Gaussians: nothing to compare tightly)
+                continue
+            raise AssertionError(f"case {case}: P={P} {W}x{H} scales {lo}..{hi}: {e}") from e
+    assert done >= 30, done
+
+
 def test_reference_list_mode_is_bit_identical(dev, monkeypatch, golden_dir):
     """GSR_REFERENCE_LISTS=1 keeps the reference's 3-sigma-rect duplicates: tiles_touched / offsets / point_list /
     ranges / n_contrib are then bit-identical to the oracle's, and -- because the pairs the default mode drops
@@ -439,12 +466,26 @@ def test_many_gaussians_take_the_scan_kernel_path(dev):
     _check_against_oracle(ring_camera(96, 64, v=1), g, dev, seed=9, nthreads=min(64, os.cpu_count() or 8))
 
 
+@pytest.mark.parametrize("P,W,H,seed", [(700, 130, 94, 3), (5000, 256, 192, 4), (540_000, 96, 64, 91)])
+def test_radix_binning_path_vs_oracle(dev, monkeypatch, P, W, H, seed):
+    """Round 4: the single-view entry points bin with the tile-row counting sort as well; the radix path (emit_entries -> radix_hist ->
+    radix_scatter x 2 -> tile_order) stays the fallback for tile grids above GSR_BIN_MAX_T and for devices whose LDS cannot hold a
+    view's tile counters.  GSR_RADIX_BINNING=1 pins it: the same oracle check (lists bit-exact), incl. the device-side block scan
+    above 512 Ki Gaussians."""
+    monkeypatch.setenv("GSR_RADIX_BINNING", "1")
+    big = P > 100_000
+    g = random_gaussians(P, seed=seed, scale_lo=0.004 if big else 0.02, scale_hi=0.02 if big else 0.25, spread=1.2 if big else 1.0)
+    _check_against_oracle(ring_camera(W, H, v=seed % 4, bg=(0.1, 0.3, 0.5)), g, dev, seed=seed, nthreads=min(64, os.cpu_count() or 8),
+                          tol_worst=ROW_TOL_WORST_P5000 if P == 5000 else ROW_TOL_WORST)
+
+
 @pytest.mark.parametrize("P", [524_033, 524_288])
-def test_last_host_scanned_block_count(dev, P):
+def test_last_host_scanned_block_count(dev, monkeypatch, P):
     """P in 524 033 .. 524 288 = exactly 2048 preprocess blocks, the most emit_entries prefixes in LDS itself: the total sits in
     slot 2048, one past the 256 x 8 slots the threads fill (it was never written).  Both the synchronous forward and
     the capacity-mode forward (entry count read on the device) against the oracle."""
     from diff_gaussian_rasterization import _hip
+    monkeypatch.setenv("GSR_RADIX_BINNING", "1")      # emit_entries is the radix path's kernel (the default is the tile-row binning now)
     g = random_gaussians(P, seed=92, scale_lo=0.004, scale_hi=0.02, spread=1.2)
     cam = ring_camera(96, 64, v=2)
     o2 = _check_against_oracle(cam, g, dev, seed=10, nthreads=min(64, os.cpu_count() or 8))
