@@ -211,7 +211,11 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         for k in grads:
             assert np.array_equal(grads[k], grads_s[k]), f"torch C++ layer vs ctypes: grad {k}"
     assert np.array_equal(radii, o2.radii), "radii differ"
-    if check_lists:
+    if check_lists and o2.num_rendered == 0:      # nothing visible: no binning ran (offsets[] / point_list are never written or read)
+        rg0 = views["ranges"].cpu().numpy()
+        assert np.array_equal(rg0[:, 0], rg0[:, 1]), "an empty scene must have empty tile ranges"
+        assert not views["n_contrib"].cpu().numpy().any()
+    elif check_lists:
         _check_lists(views, H, W, o2.point_list, o2.ranges, o2.n_contrib, ok, o2.means2D, o2.conic_opacity,
                      o2.tiles_touched, o2.offsets)
         assert mixed_err(views["final_T"].cpu().numpy()[ok], o2.final_T[ok]) < TOL
@@ -222,7 +226,7 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         assert np.abs(color[:, ~ok] - o2.color[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * cs, "colour on ambiguous pixels"
         assert np.abs(depth[:, ~ok] - o2.depth[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * max(1.0, float(o2.depth.max())), "depth on ambiguous pixels"
     rg = views["ranges"].cpu().numpy().astype(np.int64)
-    o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max())        # longest per-tile list the HIP path sorted
+    o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max()) if o2.num_rendered else 0        # longest per-tile list the HIP path sorted
     if not backward:
         return o2
     gr = o2.backward(dL)
@@ -387,7 +391,11 @@ def test_randomised_sweep_vs_oracle(dev):
         cam = ring_camera(W, H, v=int(rng.integers(0, 7)), V=7, radius=float(rng.choice([0.6, 2.0, 4.0, 9.0])),
                           height=float(rng.choice([-0.5, 0.8, 3.0])), bg=tuple(float(x) for x in rng.uniform(0, 1, 3)))
         try:
-            _check_against_oracle(cam, g, dev, seed=case, min_ok=0.98, tol_worst=ROW_TOL_WORST_P5000)
+            # Gaussians larger than the whole scene (scale up to 4 in a unit cloud) cover every pixel of every tile: their gradients are
+            # sums over ~25 000 pixels of terms that cancel, and BOTH fp32 evaluations sit up to ~1e-3 from the fp64 oracle row-wise
+            # (test_row_wise_error_against_the_fp64_oracle; measured here: 3.1e-4 between the two fp32 evaluations) -- the worst-row bound
+            # is 1e-3 for those cases; the norm-wise 1e-4 and the 99.9 % row bound of 1e-4 hold for all
+            _check_against_oracle(cam, g, dev, seed=case, min_ok=0.98, tol_worst=1e-3 if hi >= 1.0 else ROW_TOL_WORST_P5000)
             done += 1
         except AssertionError as e:
             if "too many threshold-ambiguous pixels" in str(e):     # (a scene of a few huge faint Gaussians: nothing to compare tightly)
