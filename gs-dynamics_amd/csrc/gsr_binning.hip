@@ -995,6 +995,7 @@ __device__ __forceinline__ uint32_t gsr_lane_xor(uint32_t v) {   // value of lan
   else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
   else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); // row_mirror
   else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  // (xor 4 as two bank-masked DPP moves instead of ds_swizzle: measured the same, 242 vs 244 us per configs[4] frame -- not kept)
   else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);          // bit mode: xor M
   else return (uint32_t)__shfl_xor((int)v, M, 64);
 }
@@ -1172,7 +1173,7 @@ __device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, in
 // NW: waves per workgroup (4; the MODE 1 launch of the RCAP = 4096 build runs 16: a long list is sorted by 1024 threads -- the LDS
 // block allows two such workgroups per CU either way, with 4 waves each that is 2 waves per SIMD working through 5 barriers per pass)
 #ifndef TS_W32_WAVES
-#define TS_W32_WAVES 4
+#define TS_W32_WAVES 5     // 32 keys per lane: 96 VGPRs (8 bytes of scratch) -> five waves per SIMD: tile_sort 252.5 -> 246 us per configs[4] frame (4: 97 VGPRs; 6: 268 us)
 #endif
 #ifndef TS_MIN_WAVES
 #define TS_MIN_WAVES 7   // wave-sorted lists: 7 waves per SIMD (72 VGPRs) measured 47.0 -> 44.9 us at 8 views; 8 (64 VGPRs, spills): 47.4
