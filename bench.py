@@ -100,6 +100,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     single_dev = os.environ.get("GSR_BENCH_SINGLE_DEVICE") == "1"   # smoke test of the N > 1 code path on a 1-GPU box
+    # GSR_BENCH_FORCE_DIST=1 with one rank: the `nccl` (= RCCL) process group is created all the same and the step runs its reduce leg --
+    # bucket packing, ONE RCCL all-reduce on the flat bucket, the all-reduce timing pass -- over a communicator of one: what a 1-GPU box can
+    # execute of the N > 1 path's RCCL calls (tests/test_multirank_gpu.py)
+    force_dist = os.environ.get("GSR_BENCH_FORCE_DIST") == "1" and world == 1
     if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -117,6 +121,18 @@ def main():
             dist.all_reduce = _host_all_reduce
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    rccl_ranks = None
+    if (world > 1 and not single_dev) or force_dist:      # one RCCL all-reduce of ones before anything is timed: the communicator exists and spans `world` ranks
+        ones = torch.ones((1,), device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, world)
+        _flush_c_stdio()                   # RCCL's banner leaves every rank's C stdout buffer now, not at exit behind the JSON line
+
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -129,13 +145,6 @@ def main():
     from gsdyn import initialize_optimizer, params2rendervar, synth_ring_cameras, synth_scene_params
     from gsdyn.dp import GradBucket, shard_views
     from gsdyn.step import params2rendervar_fused, render_step_views
-
-    rccl_ranks = None
-    if world > 1 and not single_dev:      # one RCCL all-reduce of ones before anything is timed: the communicator exists and spans `world` ranks
-        ones = torch.ones((1,), device=dev)
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, world)
 
     rng = np.random.default_rng(1234)
     GRAD_KEYS = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
@@ -174,7 +183,7 @@ def main():
         bucket = GradBucket(params)
         opt = initialize_optimizer(params, 4.0) if with_opt else None     # gsdyn.optim.FusedAdam: one launch for all groups
         m2 = torch.zeros((len(cams), P_GAUSS, 3), device=dev, requires_grad=True) if args.autograd else None
-        with_reduce = world > 1
+        with_reduce = world > 1 or force_dist
         grad_out = bucket.views() if with_reduce else None     # the backward writes straight into the all-reduce bucket (no packing copy)
         ar_ev = [None]           # (start, end) HIP events around the all-reduce of ONE step, set by the separate pass below
 
@@ -194,7 +203,10 @@ def main():
             if with_reduce:
                 if ar_ev[0] is not None:
                     ar_ev[0][0].record()
-                bucket.all_reduce()          # gradients already sit in the flat bucket: ONE all-reduce, .grad = bucket slices
+                if force_dist:               # (a communicator of one: GradBucket.all_reduce would skip the collective)
+                    dist.all_reduce(bucket.pack())
+                else:
+                    bucket.all_reduce()      # gradients already sit in the flat bucket: ONE all-reduce, .grad = bucket slices
                 if ar_ev[0] is not None:
                     ar_ev[0][1].record()
             if opt is not None:
@@ -240,7 +252,7 @@ def main():
             res["roofline"] = kernel_roofline(_hip, step, max(len(cams), 1), D, t_step, args.steps)
         return res
 
-    default_n1 = world == 1 and not args.weak and args.config == 4 and args.views is None and not args.no_optimizer
+    default_n1 = world == 1 and not force_dist and not args.weak and args.config == 4 and args.views is None and not args.no_optimizer
     if args.weak:
         vpr = args.views or 4
         total_views = vpr * world
@@ -302,9 +314,27 @@ def main():
             "allreduce_us": main_res["allreduce_us"],
             "scale_n1": scale_n1, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
         }
-        print(json.dumps(line))
-    if world > 1:
+        _emit(line)
+    if world > 1 or force_dist:
         dist.destroy_process_group()
+        _flush_c_stdio()
+
+
+def _flush_c_stdio():
+    """RCCL writes its version banner to the C stdout stream at communicator creation; behind a pipe that buffer is flushed at exit, i.e.
+    AFTER anything Python printed.  Flush it now so that the JSON line is the last thing on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def _emit(line):
+    """The ONE JSON line of the contract, as the last line of stdout."""
+    _flush_c_stdio()
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def kernel_roofline(_hip, step, vpl, D, t_step, steps):
@@ -466,7 +496,7 @@ def bench_config5(args, dev, rank, world):
     fwd_us = per_step_us.get("render_fwd", float("nan"))
     fwd_bytes = ab["render_fwd"] * cams_here
     if rank == 0:
-        print(json.dumps({
+        _emit(({
             "metric": "fwd Mpix/s, predict.py frame (colour + mask render per camera), 500k Gaussians, 1920x1080", "value": mpix, "unit": "Mpix/s",
             "n_gpus": world, "steps": frames, "warmup": args.warmup, "ms_per_step": dt / frames * 1e3, "higher_is_better": True,
             "ms_per_step_mask_blended": dt_blend / frames * 1e3, "ms_per_step_input_order": dt_input_order / frames * 1e3,
@@ -537,7 +567,7 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
     dt_overlap = float(to)
     if rank == 0:
         renders = 2 * CAMS * frames
-        print(json.dumps({
+        _emit(({
             "metric": "fwd Mpix/s, predict.py episode end to end (GNN rollout + colour + mask render per camera), 500k Gaussians, 1920x1080",
             "value": renders * W5 * H5 / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": frames, "warmup": 1, "ms_per_step": dt / frames * 1e3,
             "ms_per_step_overlapped": dt_overlap / frames * 1e3,

@@ -272,3 +272,21 @@ def test_frame_shards_on_the_real_kernels(tmp_path, world):
             for name, idx in (("im", 0), ("depth", 1), ("mask", 2)):
                 assert np.array_equal(z[f"{name}_{f}_{c}"], want[(f, c)][idx].cpu().numpy()), (r, f, c, name)
     assert seen == set(want)
+
+
+@pytest.mark.timeout(600)
+def test_bench_reduce_leg_over_rccl_with_one_rank(tmp_path):
+    """``bench.py`` with GSR_BENCH_FORCE_DIST=1: the ``nccl`` (= RCCL) process group on this box's one GPU, the step's reduce leg on the
+    flat bucket through RCCL, the all-reduce timing pass and the ``rccl_ranks`` probe -- every RCCL call of the N > 1 path, over a
+    communicator of one (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.update(GSR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--views", "2", "--steps", "3", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line is the LAST line of stdout (RCCL's banner is flushed before it)
+    assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["allreduce_us"] is not None and 0.0 < line["allreduce_us"] < 5000.0
+    assert line["value"] > 0 and line["config"]["views_total"] == 2
