@@ -118,7 +118,7 @@ void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, c
                       float* out_color, float* out_depth, const float* dL_dcolor, float4* partials) {
   o.point_list = bs.point_list; o.rec = g.rec; o.bg = cam.bg; o.final_T = im.final_T; o.n_contrib = im.n_contrib;
   o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
-  o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0; o.colors = nullptr;
+  o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0; o.colors = nullptr; o.contrib = bs.contrib;
 }
 
 // Fused pairs: the FIRST alias of a view (same camera, other colours) is blended inside its owner's tile pass instead of
@@ -146,7 +146,7 @@ void skippable_aliases(int V, const int32_t* geometry_of, const float* const* co
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
-  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_len = 0; t.prio_frac16 = 0;
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_len = 0; t.prio_frac16 = 0; t.track = 1;
 }
 
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).
@@ -336,6 +336,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     if (counts_dev && owner == v) bt.v[v].D_dev = g.offsets + P;
   }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
+  rt.track = (flags & GSR_FORWARD_ONLY) ? 0 : 1;
   return gsr_launch_render_fwd(rt, st);
 }
 }  // namespace
@@ -387,7 +388,7 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
 }
 
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
-                              const void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
+                              void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
                               float* out_depth, void* stream) {
   GsrRange _range("gsr_forward_render_shared");
   GsrCam cam;

@@ -64,6 +64,8 @@ struct BinningState {
   uint64_t* dg[2];        // [D] depth_bits << 32 | gaussian id
   uint32_t* point_list;   // [D] final per-tile depth-sorted Gaussian ids
   uint32_t* block_hist;   // [nblocks * 256] radix block histograms (block-major: hist[block][bin])
+  uint8_t* contrib;       // [D] per list entry: bit w = some pixel of quad w of the entry's tile blended it (written by the forward blend,
+                          //     read by the backward: its per-quad lists are exactly these bits)
 };
 
 static inline __host__ __device__ size_t gsr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -114,6 +116,7 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
   bs->dg[1] = (uint64_t*)take(Dn * 8);
   bs->point_list = (uint32_t*)take(Dn * 4);
   bs->block_hist = (uint32_t*)take(256 * (nb + 1) * 4);   // + one row: bin totals of the column-scanned form
+  bs->contrib = (uint8_t*)take(Dn);
   return off;
 }
 
@@ -222,6 +225,7 @@ struct GsrRenderView {         // blend forward / backward
   const float* dL_dcolor; const uint2* rect; const uint32_t* offsets; float4* partials;
   const uint2* ranges;
   const float* colors;   // != nullptr (fused alias of a forward-only call): this view's colours [P,3]; it has no records of its own
+  uint8_t* contrib;      // the lists' per-entry quad-contribution bytes (BinningState::contrib of the view that owns the lists)
   int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
   int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
 };
@@ -230,6 +234,7 @@ struct GsrRenderViews {
   int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
   int prio_len;         // backward (GSR_BWD_PRIO_LEN, experiment): tickets with at least this many entries run at base priority 1; 0 = off
   int prio_frac16;      // ... or the longest prio_frac16 / 16 of the busy tickets (GSR_BWD_PRIO_FRAC16)
+  int track;            // forward: 1 = record the contribution bytes (a backward may follow); 0 = forward-only call
   GsrRenderView v[GSR_MAX_BATCH];
 };
 

@@ -60,7 +60,8 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float* __restric
 __device__ __forceinline__ int sext16_(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
 // What the rest of a launch needs to know about one preprocessed Gaussian (everything else went to memory).
-struct PreOut { uint32_t tiles; uint2 rc; uint32_t tmask; uint32_t depth_bits; };
+struct PreOut { uint32_t tiles; uint2 rc; uint32_t tmask; uint32_t depth_bits;
+                uint64_t blend_bits; };   // hash of what the blend DECISIONS of its entries depend on: 2D mean, conic, opacity (0 without entries)
 
 // One Gaussian of one view: cull, project, covariance, conic, radius, rect / alpha box / tile mask, colour; every per-Gaussian output
 // stored.  `i` may be out of range (in_range = false: nothing loaded, nothing stored, an empty result).
@@ -277,6 +278,12 @@ __device__ __forceinline__ PreOut preprocess_gaussian(
   }
   PreOut o;
   o.tiles = tiles; o.rc = rc; o.tmask = tmask; o.depth_bits = __float_as_uint(c2.y);
+  {
+    uint64_t hb = (((uint64_t)__float_as_uint(a4.x) << 32) | __float_as_uint(a4.y)) * 0xD6E8FEB86659FD93ull;
+    hb = ((hb << 27) | (hb >> 37)) ^ ((((uint64_t)__float_as_uint(a4.z) << 32) | __float_as_uint(a4.w)) * 0xA0761D6478BD642Full);
+    hb = ((hb << 31) | (hb >> 33)) ^ ((((uint64_t)__float_as_uint(b4.x) << 32) | __float_as_uint(b4.y)) * 0xE7037ED1A0B428DBull);
+    o.blend_bits = tiles ? hb : 0ull;
+  }
   return o;
 }
 
@@ -301,11 +308,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   // Fingerprint of what the tile lists depend on -- tile rect, tile mask, depth bits and the Gaussian's index -- XOR-ed over the
   // block (the host XORs the blocks): two preprocess runs with equal fingerprints AND equal entry counts produce the same lists
   // (up to a 2^-64 coincidence), whatever tensors the inputs came from.  Only when asked for (single-view entry points).
+  // Round 4: it also covers what the blend decisions depend on (2D mean, conic, opacity of every Gaussian with entries): the forward
+  // leaves per-entry contribution bytes for the backward NEXT TO the lists (BinningState::contrib), so two forwards that share lists
+  // share those bytes, and they must then be the same bytes -- colours may differ, geometry and opacity may not.
   if (vw.block_hash) {
     uint64_t h = ((uint64_t)(uint32_t)i + 1ull) * 0x9E3779B97F4A7C15ull;
     h ^= (((uint64_t)rc.x << 32) | rc.y) * 0xC2B2AE3D27D4EB4Full;
     h = (h << 31) | (h >> 33);
     h ^= (((uint64_t)tmask << 32) | po.depth_bits) * 0x165667B19E3779F9ull;
+    h = ((h << 23) | (h >> 41)) ^ po.blend_bits;     // round 4: the sharer also shares the owner's per-quad contribution bytes (see below)
     h *= 0x9E3779B97F4A7C15ull;
     h ^= h >> 29;
     if (!in_range) h = 0;

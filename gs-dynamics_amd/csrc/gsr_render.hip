@@ -68,11 +68,52 @@ namespace gsr_render {
 #ifndef FWD_WAVES_PER_EU
 #define FWD_WAVES_PER_EU 1
 #endif
+#ifndef BWD_SMALL_BB
+// Batch of the long-queue backward build; its LDS decides the workgroups per CU.  Rounds 2-3: 96 entries (30 KB) at five per CU.  With the
+// exact per-quad lists of round 4 the build needs 80 VGPRs, so six fit: 80 entries (25 KB) at six per CU -- render_bwd 397 -> 389.5 us at
+// eight views, equal at four (profiles/r04_exact_lists.txt).
+#define BWD_SMALL_BB 80
+#define BWD_SMALL_WAVES 6
+#endif
+#ifndef FWD_TRACK_WAVES
+#define FWD_TRACK_WAVES 6    // the tracking build is bounded to the occupancy the plain one reaches by itself (75 VGPRs)
+#endif
 #ifndef BWD_WAVES_PER_EU
 #define BWD_WAVES_PER_EU 1
 #endif
 
 __device__ __forceinline__ int sext16(uint32_t v) { return (int)(short)(v & 0xffffu); }
+
+// Selects driven by an explicit 64-bit lane mask in a scalar register pair (what v_cndmask takes): the tracking forward keeps its predicates
+// as masks -- ballots of fresh compares fold into the compares' SGPR results, the combinations are scalar ANDs / XORs, and "did ANY pixel
+// blend this entry" is one scalar compare on the mask the selects use anyway.  (Written in C++ with bools, __ballot(blend) made the
+// compiler rebuild the predicate in a VGPR: +2 VALU per entry and 40 VGPRs of pressure.)
+__device__ __forceinline__ float gsr_sel(uint64_t m, float a, float b) {          // m ? a : b, per lane
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ float gsr_sel_or_zero(uint64_t m, float a) {           // m ? a : 0
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ float gsr_sel_neg_abs(uint64_t m, float a) {           // m ? -|a| : a
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, -|%1|, %2" : "=v"(r) : "v"(a), "s"(m));
+  return r;
+}
+// acc = 2 * acc + (the mask has a lane set): the any-pixel-blended bits of a walk shift into a scalar register, two SALU per entry
+// (the first entry of a group of 32 ends up in the top bit)
+__device__ __forceinline__ uint32_t gsr_shift_in_any(uint32_t acc, uint64_t m) {
+  asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(m) : "scc");
+  return acc;
+}
+__device__ __forceinline__ uint32_t gsr_sel_u(uint64_t m, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
 
 // Which of the tile's four per-wave pixel regions (8x8 quads) can this Gaussian reach with alpha >= 1/255?  (bit w = wave w)
 // Level 1: the integer pixel box from preprocess.  Level 2, for strips that pass: the exact minimum of the
@@ -102,6 +143,9 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
 #ifndef GSR_INDEX_AHEAD
 #define GSR_INDEX_AHEAD 1
 #endif
+#ifndef GSR_EXACT_LISTS
+#define GSR_EXACT_LISTS 1      // the backward's per-quad lists come from the forward's contribution bytes (fwd_tile<.., TRACK>): no rectangle tests, no
+#endif                         // visits without a contributing pixel; 0 = the round-1..3 form (conservative tests + a wave-uniform skip), for A/B
 #ifndef GSR_FWD_SIGNED_T
 #define GSR_FWD_SIGNED_T 1     // the forward keeps a pixel's stopped flag in the sign of T (0: the round-1..3 form with an SGPR mask, for A/B)
 #endif
@@ -117,6 +161,9 @@ struct FwdLdsT {
   float4 sC[4][FWD_BATCH + 1];   // b, depth, bits(1-based list position), partner r
   float2 sD[4][PAIR ? FWD_BATCH + 1 : 1];   // partner g, b
   uint32_t cnt[4][4];        // [staging wave][strip]
+  uint32_t cmask[4][4];      // TRACK: per wave and group of 32 entries of its compacted list, bit 31 - k = "some pixel of the quad blended entry k of the group"
+  uint32_t cpos[2][FWD_BATCH];  // TRACK: per staged entry, its position in each quad's compacted list (8 bits per quad, 0xff = not in that list);
+  //                               by batch parity: waves 2 and 3 turn the previous batch's into bytes while waves 0 and 1 stage the next one
 };
 
 // the partner's side of a fused pair (all nullptr / unused when !PAIR)
@@ -130,12 +177,37 @@ __device__ __forceinline__ float3 fwd_partner_colour(const FwdPartner& pt, uint3
   return make_float3(q1.z, q1.w, pt.rec[GSR_REC_F4 * g + 2].x);
 }
 
+// TRACK (round 4): the forward records, per list entry and quad, whether ANY pixel of the quad blended the entry -- one byte per entry
+// (bit w = quad w) in `contrib`, next to the tile lists.  The backward's hit test of a pixel (list position below its last contributor,
+// power <= 0, opacity * G >= 1/255, evaluated on the same LDS-staged values in the same order) is exactly the forward's `blend`, so these
+// bytes ARE the backward's per-quad lists: it stages an entry for a quad only when that quad used it -- 46 % of its quad visits evaluated
+// 64 pixels to find none (conservative rectangle tests, pixels that had terminated) -- and needs no rectangle test of its own.
+// Cost here: one scalar compare-select-or per visit and 128 byte stores per batch.  Forward-only calls (GSR_FORWARD_ONLY) run TRACK = false.
+// The contribution bytes of a batch are written by its staging threads once every wave's masks are in LDS, i.e. behind the next
+// barrier: the next batch's loop-top barrier, and for the last batch of a tile a barrier of the CALLER (fwd_tile returns the batch's
+// first list position, or -1; the persistent kernel stores behind the barrier of its ticket pop: no barrier is added per tile).
 template <bool PAIR>
-__device__ __forceinline__ void fwd_tile(
+__device__ __forceinline__ void fwd_store_contrib(const FwdLdsT<PAIR>& L, uint8_t* __restrict__ contrib, uint32_t list0, int n, int pend_base) {
+  static_assert(GSR_BLOCK == 2 * FWD_BATCH, "the upper half of the workgroup writes the bytes of the batch the lower half staged");
+  const int e = (int)threadIdx.x - FWD_BATCH, pidx = pend_base + e;   // waves 2 and 3: they stage nothing, so the bytes cost the staging waves no time
+  if (pend_base >= 0 && e >= 0 && pidx < n && contrib) {   // (contrib == nullptr: a view without lists -- it has no busy tile to get here with)
+    const uint32_t pc = L.cpos[(pend_base / FWD_BATCH) & 1][e];
+    uint32_t byte = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t pw = (pc >> (8 * w)) & 0xffu;
+      if (pw != 0xffu) byte |= ((L.cmask[w][pw >> 5] >> (31u - (pw & 31u))) & 1u) << w;
+    }
+    contrib[list0 + pidx] = (uint8_t)byte;
+  }
+}
+
+template <bool PAIR, bool TRACK = false>
+__device__ __forceinline__ int fwd_tile(
     const int tile, const uint2 rg, FwdLdsT<PAIR>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth, const FwdPartner pt) {
+    float* __restrict__ out_depth, const FwdPartner pt, uint8_t* __restrict__ contrib = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
   const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
@@ -174,8 +246,13 @@ __device__ __forceinline__ void fwd_tile(
     if (PAIR) np = fwd_partner_colour(pt, g);
   }
   GSR_TP(0);
+  int pend_base = -1;             // TRACK (wave-uniform): first list position of the batch whose contribution bytes are due -- they are written
+  //                                 by the staging threads once the waves' masks are in LDS (the positions of their entries in the four
+  //                                 compacted lists wait in L.cpos: no per-thread register lives across the blend loop for this)
   for (int base = 0; base < n; base += FWD_BATCH) {
-    if (__syncthreads_count(done) == GSR_BLOCK) break;  // also fences the previous batch's LDS reads
+    const bool all_done = __syncthreads_count(done) == GSR_BLOCK;  // also fences the previous batch's LDS reads (and publishes its cmask)
+    if (TRACK) { fwd_store_contrib<PAIR>(L, contrib, rg.x, n, pend_base); pend_base = -1; }
+    if (all_done) break;
     GSR_TP(1);
     // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
     const float4 a = na, b = nb;
@@ -204,6 +281,7 @@ __device__ __forceinline__ void fwd_tile(
     GSR_TP(2);
     __syncthreads();
     GSR_TP(3);
+    uint32_t cpos = 0xffffffffu;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if ((mask >> w) & 1u) {
@@ -214,8 +292,10 @@ __device__ __forceinline__ void fwd_tile(
         L.sB[w][pos] = make_float4(GSR_HALF_LOG2E * b.x, b.y, b.z, b.w);
         L.sC[w][pos] = c;
         if (PAIR) L.sD[w][pos] = d;
+        if (TRACK) cpos = (cpos & ~(0xffu << (8 * w))) | (pos << (8 * w));
       }
     }
+    if (TRACK) { if (tid < FWD_BATCH) L.cpos[(base / FWD_BATCH) & 1][tid] = cpos; pend_base = base; }
     // readfirstlane makes the trip count a scalar
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv] + L.cnt[2][wv] + L.cnt[3][wv]));
     __syncthreads();
@@ -223,6 +303,7 @@ __device__ __forceinline__ void fwd_tile(
     // ---- blend: wave wv walks only the entries that can reach its strip.  Straight-line body: the next
     // entry's record is fetched from LDS while this one is evaluated, and the blend itself is predicated
     // (w = 0 when the pair does not contribute) instead of branched, so consecutive iterations overlap.
+    if (TRACK && lane < 4) L.cmask[wv][lane] = 0u;   // groups the walk does not reach (same wave, in order: its later writes win)
     if (__ballot(!done) != 0ull) {
 #ifdef GSR_PRIO_FBLEND
       __builtin_amdgcn_s_setprio(GSR_PRIO_FBLEND);     // A/B hook: the blend walk of a batch at raised wave priority -- measured: no effect (203 us either way)
@@ -238,13 +319,26 @@ __device__ __forceinline__ void fwd_tile(
          T = -|T at the stop|: stopped) instead of in an SGPR mask that every entry ANDs into its hit mask and ORs its stop mask into --
          a stopped pixel has test_T < 0 < T_EPS, so `stop` holds for it by itself and `blend` is false: three SALU mask operations
          per entry fewer, one v_cndmask more. */                                                                           \
-#define GSR_FWD_ENTRY(ea, eb, ec, ed)                                                               \
+#define GSR_FWD_ENTRY(ea, eb, ec, ed, UBIT)                                                             \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
         const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
         const float alpha = fminf(GSR_ALPHA_MAX, eb.y * __builtin_amdgcn_exp2f(power));             \
-        const bool hit = power <= 0.0f && alpha >= GSR_ALPHA_MIN;                                   \
         const float test_T = T * (1.0f - alpha);                                                    \
+        if constexpr (TRACK) {                                                                      \
+          /* the same predicates as lane masks (see gsr_sel): hit = power <= 0 && alpha >= 1/255, stop = hit && test_T < eps, blend = hit ^ stop */ \
+          const uint64_t mh = __ballot(power <= 0.0f) & __ballot(alpha >= GSR_ALPHA_MIN);           \
+          const uint64_t ms = mh & __ballot(test_T < GSR_T_EPS);                                    \
+          const uint64_t mb = mh ^ ms;                                                              \
+          const float w = gsr_sel_or_zero(mb, alpha * T);                                           \
+          C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                       \
+          C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                       \
+          if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
+          T = gsr_sel_neg_abs(ms, gsr_sel(mb, test_T, T));                                          \
+          last = gsr_sel_u(mb, __float_as_uint(ec.z), last);                                        \
+          acc = gsr_shift_in_any(acc, mb);                /* some pixel of the quad blended this entry */ \
+        } else {                                                                                    \
+        const bool hit = power <= 0.0f && alpha >= GSR_ALPHA_MIN;                                   \
         const bool stop = hit && test_T < GSR_T_EPS;                                                \
         const bool blend = hit != stop;                                                             \
         const float w = blend ? alpha * T : 0.0f;                                                   \
@@ -254,9 +348,10 @@ __device__ __forceinline__ void fwd_tile(
         T = blend ? test_T : T;                                                                     \
         T = stop ? -__builtin_fabsf(T) : T;                                                         \
         last = blend ? __float_as_uint(ec.z) : last;                                                \
+        }                                                                                           \
       }
 #else
-#define GSR_FWD_ENTRY(ea, eb, ec, ed)                                                               \
+#define GSR_FWD_ENTRY(ea, eb, ec, ed, UBIT)                                                             \
       {                                                                                             \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
         const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
@@ -272,6 +367,9 @@ __device__ __forceinline__ void fwd_tile(
         if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
         T = blend ? test_T : T;                                                                     \
         last = blend ? __float_as_uint(ec.z) : last;                                                \
+        /* any pixel blended it <=> some lane's weight is non-zero (alpha >= 1/255 and T >= 1e-4 there).  The ballot of a FRESH compare \
+           folds into the compare's SGPR mask; __ballot(blend) made the compiler rebuild the bool in a VGPR (+2 VALU, +40 VGPRs of pressure) */ \
+        if constexpr (TRACK) acc = gsr_shift_in_any(acc, __ballot(w != 0.0f));                       \
       }
       // Blocks of FWD_UNROLL entries, fully unrolled: the LDS reads are immediate offsets off one running pointer, the compiler
       // places them ahead of their uses without register rotation, and the all-done check runs once per block.  (Round 1's form --
@@ -280,21 +378,67 @@ __device__ __forceinline__ void fwd_tile(
       // backward's visits branch on __ballot(hit), the loads cannot move across that, and there the hand-rotated prefetch is 3 %
       // faster than blocks.)
 #endif
-      constexpr int UN = PAIR ? FWD_UNROLL_PAIR : FWD_UNROLL;
-      int j = 0;
-      for (; j + UN <= m; j += UN) {
+#ifndef FWD_UNROLL_TRACK
+#define FWD_UNROLL_TRACK 8      // the tracking build: blocks of eight like the plain one (76 VGPRs, no spills, with the shift-register form of the bits)
+#endif
+#ifndef FWD_UNROLL_PAIR_TRACK
+#define FWD_UNROLL_PAIR_TRACK 2
+#endif
+      constexpr int UN = PAIR ? (TRACK ? FWD_UNROLL_PAIR_TRACK : FWD_UNROLL_PAIR) : (TRACK ? FWD_UNROLL_TRACK : FWD_UNROLL);
+      if constexpr (TRACK) {
+        // The any-pixel-blended bit of each entry shifts into a scalar register (gsr_shift_in_any).  The list is walked as groups of
+        // 32 entries, one register each; a group that ends early (list end, every pixel finished) is shifted up so that entry k of
+        // a group always sits at bit 31 - k.  (Round 4's first form -- static bit positions ORed per block and placed with a 64-bit
+        // shift and a three-way branch on the word -- cost a compare-select-or per entry plus four branches and six register copies
+        // per block.)
+        static_assert(32 % UN == 0, "a block of the tracking walk must not straddle two groups");
+        bool live = true;
+#pragma unroll 1
+        for (int g = 0; g < 4 && live; ++g) {
+          const int mm = min(m - 32 * g, 32);
+          if (mm <= 0) break;
+          const float4* __restrict__ hA = wA + 32 * g;
+          const float4* __restrict__ hB = wB + 32 * g;
+          const float4* __restrict__ hC = wC + 32 * g;
+          const float2* __restrict__ hD = wD + 32 * g;
+          uint32_t acc = 0u;
+          int j = 0;
+          for (; j + UN <= mm; j += UN) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const float4 ea = wA[j + u], eb = wB[j + u], ec = wC[j + u];
-          const float2 ed = PAIR ? wD[j + u] : make_float2(0.f, 0.f);
-          GSR_FWD_ENTRY(ea, eb, ec, ed)
+            for (int u = 0; u < UN; ++u) {
+              const float4 ea = hA[j + u], eb = hB[j + u], ec = hC[j + u];
+              const float2 ed = PAIR ? hD[j + u] : make_float2(0.f, 0.f);
+              GSR_FWD_ENTRY(ea, eb, ec, ed, u)
+            }
+            if (__ballot(!done) == 0ull) { j += UN; live = false; break; }
+          }
+          if (live)
+            for (; j < mm; ++j) {
+              const float4 ea = hA[j], eb = hB[j], ec = hC[j];
+              const float2 ed = PAIR ? hD[j] : make_float2(0.f, 0.f);
+              GSR_FWD_ENTRY(ea, eb, ec, ed, 0)
+            }
+          acc <<= (32 - j) & 31;                   // j = entries walked in this group (1..32)
+          if (lane == 0) L.cmask[wv][g] = acc;     // read by the staging threads behind the next barrier
         }
-        if (__ballot(!done) == 0ull) { j = m; break; }
-      }
-      for (; j < m; ++j) {
-        const float4 ea = wA[j], eb = wB[j], ec = wC[j];
-        const float2 ed = PAIR ? wD[j] : make_float2(0.f, 0.f);
-        GSR_FWD_ENTRY(ea, eb, ec, ed)
+      } else {
+        uint32_t acc = 0u;        // (unused: the entry body names it only under TRACK)
+        int j = 0;
+        for (; j + UN <= m; j += UN) {
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const float4 ea = wA[j + u], eb = wB[j + u], ec = wC[j + u];
+            const float2 ed = PAIR ? wD[j + u] : make_float2(0.f, 0.f);
+            GSR_FWD_ENTRY(ea, eb, ec, ed, u)
+          }
+          if (__ballot(!done) == 0ull) { j = m; break; }
+        }
+        for (; j < m; ++j) {
+          const float4 ea = wA[j], eb = wB[j], ec = wC[j];
+          const float2 ed = PAIR ? wD[j] : make_float2(0.f, 0.f);
+          GSR_FWD_ENTRY(ea, eb, ec, ed, 0)
+        }
+        (void)acc;
       }
 #undef GSR_FWD_ENTRY
 #ifdef GSR_PRIO_FBLEND
@@ -328,6 +472,7 @@ __device__ __forceinline__ void fwd_tile(
   }
   GSR_TP(6);
   GSR_TFLUSH();
+  return pend_base;     // TRACK: the last batch's contribution bytes are still due (fwd_store_contrib, behind a barrier of the caller)
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -366,6 +511,7 @@ struct BwdLdsT {
                                                // word count, so both the 9-lane write and the per-entry read are conflict-free)
   uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
   uint32_t sSlot[BB];                          // by batch index: the entry's record slot in the Gaussian-major scratch
+  uint8_t sQuads[BB];                          // by batch index: which quads staged the entry (= whose totals the combine adds up)
   uint32_t cnt[4][4];                          // [staging wave][strip]
   int sQuadLast[4];                            // per wave: the deepest list position any of its 64 pixels used
 };
@@ -392,7 +538,7 @@ __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    float4* __restrict__ partials, const BwdPartner pt) {
+    float4* __restrict__ partials, const uint8_t* __restrict__ contrib, const BwdPartner pt) {
   constexpr int BB = NBB;
   constexpr bool ROWS_PERM = !PAIR && NBB == BWD_BATCH;   // the short-queue build: see gsr_rows_sum
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -440,8 +586,10 @@ __device__ __forceinline__ void bwd_tile(
   uint32_t gz = 0;
   if (kz < n) gz = point_list[rg.x + kz];
   uint32_t ng = 0, ng_ahead = 0;                     // ng_ahead: list entry of batch b+2 (see fwd_tile)
+  uint32_t nquads = 0;                               // GSR_EXACT_LISTS: the entry's contribution byte (which quads blended it in the forward)
   if (tid < BB && tid < max_last) {
     ng = point_list[rg.x + (max_last - 1 - tid)];
+    if (GSR_EXACT_LISTS) nquads = contrib[rg.x + (max_last - 1 - tid)];
     if (GSR_INDEX_AHEAD && tid + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (tid + BB))];
   }
   const int red6 = lane >= 48 ? gsr_sum6_slot(lane) : -1;   // !COL (GSR_NOCOL_SUM6): where this lane's total of the six-value reduction goes
@@ -490,15 +638,21 @@ __device__ __forceinline__ void bwd_tile(
         L.sSlot[tid] = __float_as_uint(nslot.z) + gsr_tile_rank(__float_as_uint(nslot.w), (maxx - minx) * (maxy - miny),
                                                                 ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
       }
-      mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
-      // a quad whose pixels all stopped before this list position has nothing to add for it
-      const int pos = max_last - 1 - (base + tid);
-      mask &= (pos < ql0 ? 1u : 0u) | (pos < ql1 ? 2u : 0u) | (pos < ql2 ? 4u : 0u) | (pos < ql3 ? 8u : 0u);
+      if (GSR_EXACT_LISTS) {
+        mask = nquads;        // exactly the quads with a pixel that blended this entry (implies: below the quad's deepest contributor)
+        L.sQuads[tid] = (uint8_t)mask;
+      } else {
+        mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
+        // a quad whose pixels all stopped before this list position has nothing to add for it
+        const int pos = max_last - 1 - (base + tid);
+        mask &= (pos < ql0 ? 1u : 0u) | (pos < ql1 ? 2u : 0u) | (pos < ql2 ? 4u : 0u) | (pos < ql3 ? 8u : 0u);
+      }
     }
     {
       const int nj = base + BB + tid;
       if (tid < BB && nj < max_last) {
         ng = GSR_INDEX_AHEAD ? ng_ahead : point_list[rg.x + (max_last - 1 - nj)];
+        if (GSR_EXACT_LISTS) nquads = contrib[rg.x + (max_last - 1 - nj)];
         if (GSR_INDEX_AHEAD && nj + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (nj + BB))];
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
@@ -556,8 +710,8 @@ __device__ __forceinline__ void bwd_tile(
 #define GSR_PRIO_COMBINE 0    /* ... and while a batch's totals are combined and stored */
 #endif
 #if GSR_PRIO_VISIT
-#define GSR_BWD_PRIO_IN __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);
-#define GSR_BWD_PRIO_OUT __builtin_amdgcn_s_setprio(BASE);
+#define GSR_BWD_PRIO_IN if (!GSR_EXACT_LISTS) __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);   /* exact lists: every visit contributes -- */
+#define GSR_BWD_PRIO_OUT if (!GSR_EXACT_LISTS) __builtin_amdgcn_s_setprio(BASE);                  /* the whole replay loop is raised instead */
 #else
 #define GSR_BWD_PRIO_IN
 #define GSR_BWD_PRIO_OUT
@@ -571,7 +725,7 @@ __device__ __forceinline__ void bwd_tile(
       const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);        \
       const float G0 = __builtin_amdgcn_exp2f(power);  /* power is in log2 units (pre-scaled conic) */        \
       const bool hit = (pos < last) && power <= 0.0f && eb.y * G0 >= GSR_ALPHA_MIN; /* = min(0.99, .) >= 1/255 */ \
-      if (__ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add for this entry */                \
+      if (GSR_EXACT_LISTS || __ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add (exact lists: always something) */ \
         GSR_BWD_PRIO_IN                                                                                        \
         /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
            alpha = 0, 1/(1-alpha) = 1, T and the accumulated colour are unchanged (an alpha = 0 entry only flushes \
@@ -621,12 +775,13 @@ __device__ __forceinline__ void bwd_tile(
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         GSR_BWD_PARK9(v0, v1, v2, v3, v4, v5, v6, v7, v8)                                                     \
         }                                                                                                     \
-        GSR_MARK_ACTIVE(j)                                                                                    \
+        if (!GSR_EXACT_LISTS) GSR_MARK_ACTIVE(j)                                                             \
         GSR_BWD_PRIO_OUT                                                                                       \
       }                                                                                                       \
     }
     // two entries per trip on ping-pong registers: the record of entry j+1 (j+2) is fetched from LDS while entry j (j+1) is
     // evaluated, no copies to rotate the prefetch (unrolled blocks as in fwd_tile measured 3 % slower here)
+    if (GSR_EXACT_LISTS && GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);
     float4 ea = wA[0], eb = wB[0];
     float2 ec = wC[0];
     float4 ed = wD[0];
@@ -642,16 +797,18 @@ __device__ __forceinline__ void bwd_tile(
     }
     if (jj < m) GSR_BWD_ENTRY(ea, eb, ec, ed)
 #undef GSR_BWD_ENTRY
-    if (lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
+    if (GSR_EXACT_LISTS && GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(BASE);
+    if (!GSR_EXACT_LISTS && lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
     GSR_TP(4);
     __syncthreads();
     GSR_TP(5);
     if (GSR_PRIO_COMBINE) __builtin_amdgcn_s_setprio(GSR_PRIO_COMBINE);
     if (tid < m_all) {
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+      const uint32_t quads = GSR_EXACT_LISTS ? (uint32_t)L.sQuads[tid] : 0u;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        if ((L.sActive[w][tid >> 6] >> (tid & 63)) & 1ull) {
+        if (GSR_EXACT_LISTS ? ((quads >> w) & 1u) != 0u : ((L.sActive[w][tid >> 6] >> (tid & 63)) & 1ull) != 0ull) {
           const float* q = L.sRed[w][tid];
           r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
           r1.x += q[4]; r1.y += q[5];
@@ -677,7 +834,7 @@ __device__ __forceinline__ void bwd_tile(
 // view}; the view's pointers come from the kernarg table (uniform index: scalar loads).
 #define GSR_FWD_PASS(vw) tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).out_color, (vw).out_depth
 #define GSR_BWD_PASS(vw) \
-  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials
+  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials, (vw).contrib
 
 __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
   return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth, p.colors};
@@ -686,21 +843,30 @@ __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
 // PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the
 // plain path.  A call without pairs runs the PAIRS = false build (smaller LDS footprint: one more workgroup per CU).
 static_assert(sizeof(FwdLdsT<true>) >= sizeof(FwdLdsT<false>), "the pair build's LDS must hold the plain layout too");
-template <bool PAIRS>
+template <bool PAIRS, bool TRACK = false>
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
   __shared__ FwdLdsT<PAIRS> L;
   const GsrRenderView& vw = tab.v[blockIdx.y];
   if (vw.fused_alias) return;                       // rendered by its owner's workgroup
+  const uint2 rg = vw.ranges[blockIdx.x];
+  int pend;
   if (PAIRS && vw.partner >= 0)
-    fwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]));
+    pend = fwd_tile<PAIRS, TRACK>((int)blockIdx.x, rg, L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib);
   else
-    fwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{});
+    pend = fwd_tile<false, TRACK>((int)blockIdx.x, rg, reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib);
+  if (TRACK) {
+    __syncthreads();
+    if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, rg.x, (int)(rg.y - rg.x), pend);
+    else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, rg.x, (int)(rg.y - rg.x), pend);
+  }
 }
 
 // Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
 // (grid-stride over the tail of the order array), then pop busy tiles longest-first.
-template <bool PAIRS>
-__global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persistent(GsrRenderViews tab) {
+// Launch bounds = the residency the launch asks for (six workgroups per CU, five for the pair build): without them the allocator took
+// 112 - 121 VGPRs for the tracking build (four waves per SIMD) where the round-3 code happened to land on 75 / 94.
+template <bool PAIRS, bool TRACK = false>
+__global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : FWD_WAVES_PER_EU) void render_fwd_persistent(GsrRenderViews tab) {
   __shared__ FwdLdsT<PAIRS> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
@@ -736,16 +902,21 @@ __global__ __launch_bounds__(GSR_BLOCK, FWD_WAVES_PER_EU) void render_fwd_persis
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
+    int pend;
     if (PAIRS && vw.partner >= 0)
-      fwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]));
+      pend = fwd_tile<PAIRS, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib);
     else
-      fwd_tile<false>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{});
+      pend = fwd_tile<false, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib);
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[0], 1u);
     __syncthreads();
     ticket = s_ticket;
+    if (TRACK) {     // the tile's last contribution bytes: every wave's masks are in LDS behind the barrier above, and the one below keeps the next tile's staging off them
+      if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, ord.y, (int)(ord.z - ord.y), pend);
+      else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, ord.y, (int)(ord.z - ord.y), pend);
+    }
     __syncthreads();  // every wave has its copy before thread 0 overwrites the slot
 #ifdef GSR_TILE_TIMING
     if (threadIdx.x == 0) atomicAdd(&g_fwd_timing[7], __builtin_readcyclecounter() - tq0);
@@ -782,7 +953,7 @@ __device__ uint4 g_ticket_trace[GSR_TRACE_MAX];
 // of the no-colour-gradient build came out at 97 -- one register over, four waves per SIMD, the fifth workgroup of every CU waiting for
 // a slot: that was round 2's "six-value reduction is 17 % slower than nine values with zeros" (the nine-value build happened to need 96).
 template <bool PAIRS, int NBB = BWD_BATCH, bool COL = true>
-__global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == 96) ? 5 : BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
+__global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == BWD_SMALL_BB) ? BWD_SMALL_WAVES : BWD_WAVES_PER_EU) void render_bwd_persistent(GsrRenderViews tab) {
   __shared__ BwdLdsAny<PAIRS, NBB> L;
   __shared__ uint32_t s_ticket;
   const uint4* __restrict__ tile_order = tab.order;
@@ -871,16 +1042,21 @@ int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
   static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 6);
   const bool pairs = has_pairs(tab);
+  const bool track = GSR_EXACT_LISTS && tab.track != 0;                // record the per-quad contribution bytes for a backward (not in forward-only calls)
   { GSR_PROF("render_fwd", st);
     if (use_static) {
-      if (pairs) hipLaunchKernelGGL(render_fwd_static<true>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL(render_fwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      if (pairs && track) hipLaunchKernelGGL((render_fwd_static<true, true>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      else if (pairs) hipLaunchKernelGGL((render_fwd_static<true, false>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      else if (track) hipLaunchKernelGGL((render_fwd_static<false, true>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL((render_fwd_static<false, false>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
       const int tiles = tab.T * tab.V;
       const int per_cu = pairs ? (wg_per_cu < 5 ? wg_per_cu : 5) : wg_per_cu;   // the pair build's LDS fits 5 workgroups per CU
       const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
-      if (pairs) hipLaunchKernelGGL(render_fwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL(render_fwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      if (pairs && track) hipLaunchKernelGGL((render_fwd_persistent<true, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (pairs) hipLaunchKernelGGL((render_fwd_persistent<true, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (track) hipLaunchKernelGGL((render_fwd_persistent<false, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else hipLaunchKernelGGL((render_fwd_persistent<false, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }
   }
   GSR_HIP_CHECK(hipGetLastError());
@@ -912,12 +1088,12 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
       // long queue (>= 3 tiles per resident workgroup slot, counting the empty ones): the 96-entry build, five workgroups per CU
       static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 7500);
       const bool small = !pairs && tiles >= small_batch_from;
-      const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + 1 : wg_per_cu);
+      const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
       const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
       const bool col = !tab.no_colour_grad;
       if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (small && col) hipLaunchKernelGGL((render_bwd_persistent<false, 96>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, 96, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (small && col) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
       else if (col) hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
       else hipLaunchKernelGGL((render_bwd_persistent<false, BWD_BATCH, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
     }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 117 /* 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 118 /* 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -85,7 +85,9 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
  * then segmentation colours, /root/reference/src/tracking/train_utils.py:178,192; colours, then an all-ones mask,
  * /root/reference/src/predict.py:115-123 -- and hands the second call FRESH copies of the geometry tensors, so tensor identity cannot
  * key a cache).  gsr_forward_preprocess_fp is gsr_forward_preprocess that also returns a 64-bit fingerprint of everything the tile
- * lists depend on (per Gaussian: index, tile rect, tile mask, depth bits; 0 = not available: P > 512 Ki).  Two calls with the same
+ * lists and the blend decisions depend on (per Gaussian: index, tile rect, tile mask, depth bits, and -- since version 118 -- 2D mean,
+ * conic and opacity: the forward leaves the backward's per-quad contribution bytes in the binning state, next to the lists, so a
+ * sharer rewrites the owner's bytes with the same values; colours may differ; 0 = not available: P > 512 Ki).  Two calls with the same
  * (P, image size, num_rendered, fingerprint) have the same lists: the second one may then call gsr_forward_render_shared with the
  * first call's binning and image states instead of gsr_forward_render -- no duplicates are emitted or sorted, its own image state
  * receives a copy of the owner's ranges and tile order, and gsr_backward takes (own geom, OWNER's binning, own image) as usual.
@@ -95,7 +97,7 @@ int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* mea
                               const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
                               uint32_t* num_rendered_host, uint64_t* fingerprint_host, void* stream);
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
-                              const void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
+                              void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
                               float* out_depth, void* stream);
 
 /* ---- backward  (replaces `rasterize_gaussians_backward`).

@@ -2122,6 +2122,27 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
             im2_ref, _, _ = GaussianRasterizer(raster_settings=cams[2])(**moved)
         assert torch.equal(mask, mask_ref) and torch.equal(im2, im2_ref)
         assert float(mask.max()) <= 1.0 + 1e-5 and not torch.equal(im1, im2)
+
+        # Same geometry, OTHER OPACITIES, both forwards before either backward: the tile lists would be the same, but the forward leaves
+        # the backward's per-quad contribution bytes next to the lists (round 4) and those depend on the opacities -- the fingerprint
+        # covers them, so the second call bins for itself and the first call's backward still finds its own bytes.
+        def two_opacities(reuse):
+            C_.set_list_reuse(reuse)
+            h0 = C_.list_reuse_hits()
+            leaves = {k: params[k].detach().clone().requires_grad_(True) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors")}
+            thin = {k: (v - 1.5 if k == "logit_opacities" else v) for k, v in leaves.items()}
+            im_a, _, _ = GaussianRasterizer(raster_settings=cams[3])(**params2rendervar(leaves))
+            im_b, _, _ = GaussianRasterizer(raster_settings=cams[3])(**params2rendervar(thin))
+            (im_a * g1).sum().backward()
+            ga = {k: v.grad.clone() for k, v in leaves.items()}
+            (im_b * g2).sum().backward()
+            torch.cuda.synchronize()
+            return im_a.detach(), im_b.detach(), ga, {k: v.grad.clone() for k, v in leaves.items()}, C_.list_reuse_hits() - h0
+        ra, rb = two_opacities(True), two_opacities(False)
+        assert ra[4] == 0 and rb[4] == 0
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and not torch.equal(ra[0], ra[1])
+        for k in ra[2]:
+            assert torch.equal(ra[2][k], rb[2][k]) and torch.equal(ra[3][k], rb[3][k]), k
     finally:
         C_.set_list_reuse(True)
 
