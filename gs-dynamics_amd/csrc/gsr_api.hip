@@ -846,6 +846,82 @@ int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, con
                               (hipStream_t)stream);
 }
 
+int gsr_gnn_aggregate(int32_t n_rows, int32_t n_sum_rows, int32_t width, const float* rel_part, const float* node_parts, const int64_t* senders,
+                      const int64_t* row_start, float* agg, void* stream) {
+  GsrRange _range("gsr_gnn_aggregate");
+  if (n_rows <= 0 || n_sum_rows < 0 || n_sum_rows > n_rows || width <= 0 || (width & 3) || !rel_part || !node_parts || !senders || !row_start || !agg) {
+    gsr_set_error("gsr_gnn_aggregate: bad argument (width a multiple of 4)");
+    return -2;
+  }
+  return gsr_launch_gnn_aggregate(n_rows, n_sum_rows, width, rel_part, node_parts, (const long long*)senders, (const long long*)row_start, agg, (hipStream_t)stream);
+}
+int gsr_gnn_rel_inputs(int32_t n_rel, int32_t attr_dim, int32_t group_dim, int32_t state_cols, const float* rel_nodes, const int64_t* receivers,
+                       const int64_t* senders, float* out, void* stream) {
+  GsrRange _range("gsr_gnn_rel_inputs");
+  if (n_rel <= 0 || attr_dim < 0 || group_dim < 0 || state_cols < 0 || !rel_nodes || !receivers || !senders || !out) {
+    gsr_set_error("gsr_gnn_rel_inputs: bad argument");
+    return -2;
+  }
+  return gsr_launch_gnn_rel_inputs(n_rel, attr_dim, group_dim, state_cols, rel_nodes, (const long long*)receivers, (const long long*)senders, out,
+                                   (hipStream_t)stream);
+}
+
+static size_t gnn_carve(void* base, int32_t N, int32_t E, int32_t H, GsrGnnArgs* a) {
+  size_t off = 0;
+  char* b = (char*)base;
+  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
+  const size_t nh = (size_t)N * H * 4, eh = (size_t)E * H * 4;
+  a->xp0 = (float*)take(nh); a->xp1 = (float*)take(nh); a->pe = (float*)take(nh); a->pewp = (float*)take(nh);
+  a->eff0 = (float*)take(nh); a->eff1 = (float*)take(nh); a->a23 = (float*)take(2 * nh); a->agg = (float*)take(nh);
+  a->xr0 = (float*)take(eh); a->xr1 = (float*)take(eh); a->rew1 = (float*)take(eh);
+  a->row_start = (int*)take(((size_t)N + 1) * 4);
+  a->stamps = (unsigned long long*)take(256);
+  a->sync = (unsigned*)take(16);
+  return off - gsr_align(16) + 16;      // the barrier / error words are the LAST 16 bytes
+}
+int64_t gsr_gnn_workspace_bytes(int32_t n_rows, int32_t n_rel, int32_t width) {
+  if (n_rows <= 0 || n_rel <= 0 || width <= 0) return 0;
+  GsrGnnArgs a;
+  return (int64_t)gnn_carve(nullptr, n_rows, n_rel, width, &a);
+}
+int gsr_gnn_propagate(const gsr_gnn_model* m, int32_t n_rows, int32_t n_rel, const float* p_inputs, const float* rel_nodes,
+                      const int64_t* receivers, const int64_t* senders, const float* last_pos, int32_t last_pos_stride, void* workspace,
+                      float* pred_pos, float* pred_motion, void* stream) {
+  GsrRange _range("gsr_gnn_propagate");
+  if (!m || !p_inputs || !rel_nodes || !receivers || !senders || !last_pos || !workspace || !pred_pos || !pred_motion) {
+    gsr_set_error("gsr_gnn_propagate: NULL argument");
+    return -2;
+  }
+  if (n_rows <= 0 || n_rel <= 0 || (n_rows & 15) || (n_rel & 15) || m->width <= 0 || (m->width & 15) || m->particle_in < 1 || m->attr_dim < 0 ||
+      m->group_dim < 0 || m->state_cols < 0 || m->pstep < 0 || last_pos_stride < 3) {
+    gsr_set_error("gsr_gnn_propagate: n_rows, n_rel and width must be positive multiples of 16 (pad with a dummy row and dummy relations)");
+    return -2;
+  }
+  if (m->width > 512) { gsr_set_error("gsr_gnn_propagate: width <= 512 (a quarter of K per wave in one register set)"); return -2; }
+  const float* const* w = &m->pe_w0;
+  for (int i = 0; i < 22; ++i)
+    if (!w[i]) { gsr_set_error("gsr_gnn_propagate: weight pointer %d is NULL", i); return -2; }
+  GsrGnnArgs a;
+  gnn_carve(workspace, n_rows, n_rel, m->width, &a);
+  a.N = n_rows; a.E = n_rel; a.H = m->width; a.Dp = m->particle_in; a.A = m->attr_dim; a.G = m->group_dim; a.S = m->state_cols;
+  a.pstep = m->pstep; a.clamp = m->motion_clamp;
+  a.p_in = p_inputs; a.nodes = rel_nodes; a.recv = (const long long*)receivers; a.send = (const long long*)senders;
+  a.last_pos = last_pos; a.last_stride = last_pos_stride;
+  a.pe_w0 = m->pe_w0; a.pe_b0 = m->pe_b0; a.pe_w1 = m->pe_w1; a.pe_b1 = m->pe_b1; a.pe_w2 = m->pe_w2; a.pe_b2 = m->pe_b2;
+  a.re_w0 = m->re_w0; a.re_b0 = m->re_b0; a.re_w1 = m->re_w1; a.re_b1 = m->re_b1; a.re_w2 = m->re_w2; a.re_b2 = m->re_b2;
+  a.rp_w = m->rp_w; a.rp_b = m->rp_b; a.pp_w = m->pp_w; a.pp_b = m->pp_b;
+  a.h_w0 = m->h_w0; a.h_b0 = m->h_b0; a.h_w1 = m->h_w1; a.h_b1 = m->h_b1; a.h_w2 = m->h_w2; a.h_b2 = m->h_b2;
+  a.out_pos = pred_pos; a.out_mot = pred_motion;
+  // a persistent grid with device-wide barriers: every workgroup must be resident, so at most one per CU
+  static const int want = [] { const char* e = getenv("GSR_GNN_WORKGROUPS"); return (e && *e) ? atoi(e) : 128; }();
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    gsr_set_error("gsr_gnn_propagate: cannot query the device");
+    return -1;
+  }
+  return gsr_launch_gnn_propagate(a, want < cus ? (want < 1 ? 1 : want) : cus, (hipStream_t)stream);
+}
+
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {
   GsrRange _range("gsr_fps");
   if (N < 0 || npoints < 0 || (N > 0 && npoints > 0 && (!pos || !scratch || !out_idx))) { gsr_set_error("gsr_fps: bad argument"); return -2; }

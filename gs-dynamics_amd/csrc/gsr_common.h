@@ -130,6 +130,35 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
 #define GSR_HOST_SCAN_MAX_BLOCKS 2048
 static inline bool gsr_host_block_scan(int P) { return (P + GSR_BLOCK - 1) / GSR_BLOCK <= GSR_HOST_SCAN_MAX_BLOCKS; }
 
+// ---------------------------------------------------------------- propagation network in one launch (gsr_gnn.hip)
+struct GsrGnnArgs {
+  int N, E, H;               // node rows, relations (both multiples of 16), width (multiple of 16)
+  int Dp, A, G, S;           // particle input width; attribute / instance / state widths of `nodes`
+  int pstep;
+  float clamp;
+  const float* p_in;         // [N, Dp]
+  const float* nodes;        // [N, A + G + S]: attributes, instance columns, state history
+  const long long* recv;     // [E] ascending
+  const long long* send;     // [E]
+  const float* last_pos;     // [N, 3] with row stride last_stride: what the predicted motion is added to
+  int last_stride;
+  const float *pe_w0, *pe_b0, *pe_w1, *pe_b1, *pe_w2, *pe_b2;     // particle encoder  [H,Dp] [H,H] [H,H]
+  const float *re_w0, *re_b0, *re_w1, *re_b1, *re_w2, *re_b2;     // relation encoder  [H,Dr] [H,H] [H,H],  Dr = 2A + 1 + S
+  const float *rp_w, *rp_b;                                       // relation propagator [H, 3H]
+  const float *pp_w, *pp_b;                                       // particle propagator [H, 2H]
+  const float *h_w0, *h_b0, *h_w1, *h_b1, *h_w2, *h_b2;           // head [H,H] [H,H] [3,H]
+  float *xp0, *xp1, *pe, *pewp, *eff0, *eff1, *a23, *agg;         // [N,H] each, a23 [N,2H]
+  float *xr0, *xr1, *rew1;                                        // [E,H] each
+  int* row_start;                                                 // [N + 1]
+  unsigned long long* stamps;                                     // [32] 100 MHz time stamps of workgroup 0 after each stage (diagnostics)
+  unsigned* sync;                                                 // [0] arrivals, [1] exits, [2] error flag (relations not sorted)
+  float *out_pos, *out_mot;                                       // [N,3]
+};
+
+int gsr_launch_gnn_propagate(const GsrGnnArgs& a, int workgroups, hipStream_t st);
+int gsr_launch_gnn_aggregate(int N, int n_sum, int H, const float* rew1, const float* a23, const long long* send, const long long* row_start, float* agg, hipStream_t st);
+int gsr_launch_gnn_rel_inputs(int E, int A, int G, int S, const float* nodes, const long long* recv, const long long* send, float* out, hipStream_t st);
+
 // ---------------------------------------------------------------- error plumbing (gsr_api.hip)
 void gsr_set_error(const char* fmt, ...);
 #define GSR_HIP_CHECK(expr)                                                                   \

@@ -248,7 +248,10 @@ class DynamicsPredictor(nn.Module):
         g = torch.cat([p_instance[0], torch.zeros(N - n_p, p_instance.shape[2], dtype=a.dtype, device=a.device)], 0)
         act = action[0] if c["action_dim"] > 0 else torch.zeros((N, 0), dtype=a.dtype, device=a.device)
         if a.is_cuda and not torch.is_grad_enabled() and _GRAPH_ROLLOUT and state.shape[3] == 3:
-            pos, mot = self._propagate_graphed(state_t, a, g, act, receivers, senders)
+            if self._fused_ok(a, g):
+                pos, mot = self._propagate_fused_padded(state_t, a, g, act, receivers, senders)
+            else:
+                pos, mot = self._propagate_graphed(state_t, a, g, act, receivers, senders)
         else:
             pos, mot = self._propagate(state_t, a, g, act, receivers, senders)
         return pos[:n_p][None], mot[:n_p][None]
@@ -285,6 +288,122 @@ class DynamicsPredictor(nn.Module):
         pred_pos = state_t[:, -3:] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
         return pred_pos, pred_motion
 
+    # ---- the whole network in ONE launch (gsr_gnn_propagate, csrc/gsr_gnn.hip): persistent grid, f32 MFMA, device-wide barriers
+    def _fused_ok(self, a, g) -> bool:
+        c = self.model_config
+        H = c["nf_effect"]
+        return (_GNN_FUSED and a.is_cuda and not torch.is_grad_enabled() and c["nf_particle"] == H and c["nf_relation"] == H and H % 16 == 0 and H <= 512
+                and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["state_dim"] in (0, 1, 3)
+                and a.dtype == torch.float32)
+
+    def _particle_inputs(self, state_t, a, act):
+        c = self.model_config
+        N, n_his = a.shape[0], c["n_his"]
+        parts = [a]
+        if c["state_dim"] == 3:
+            parts.append(state_t)
+        elif c["state_dim"] == 1:
+            parts.append(state_t.view(N, n_his, 3)[..., 2])
+        if self.motion_dim > 0:
+            s4 = state_t.view(N, n_his, 3)
+            parts.append((s4[:, 1:] - s4[:, :-1]).reshape(N, (n_his - 1) * 3))
+        if c["action_dim"] > 0:
+            parts.append(act)
+        return torch.cat(parts, 1)
+
+    # ---- the default device path: the products through the GEMM library, with the propagators' concatenated products split
+    def _split_ok(self, a) -> bool:
+        c = self.model_config
+        return (_GNN_SPLIT and a.is_cuda and not torch.is_grad_enabled() and a.dtype == torch.float32 and c["nf_effect"] % 4 == 0
+                and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["state_dim"] in (0, 1, 3))
+
+    def _propagate_split(self, state_t, a, g, act, receivers, senders, dummy_last_row: bool = False):
+        """``_propagate`` for relations ASCENDING in the receiver, inference on a device.  The relation propagator's product
+        cat(relation_encode, effect[recv], effect[send]) @ [W1 | W2 | W3]^T is evaluated as relation_encode @ W1^T + b (once: it does not
+        change over the propagation steps) + (effect @ W2^T)[recv] + (effect @ W3^T)[send] -- products on the N nodes instead of the E
+        relations -- and the particle propagator's cat(particle_encode, agg) @ [Wp1 | Wp2]^T likewise; the ReLU of the relation effects
+        and their sum onto the receivers are one kernel (gsr_gnn_aggregate: a segmented sum in list order, deterministic, where
+        index_add's atomics are not), the relation encoder's input rows another (gsr_gnn_rel_inputs).  Per step 5 launches instead of
+        10, and an N x H x 2H product instead of an E x 3H x H one.  Exact in real arithmetic; in f32 a different summation order
+        (test_split_propagation_equals_eager: 2e-6 of the largest motion)."""
+        from diff_gaussian_rasterization import _hip
+        c = self.model_config
+        H, N = c["nf_effect"], int(a.shape[0])
+        p_in = self._particle_inputs(state_t, a, act)
+        nodes = torch.cat([a, g, state_t], 1)
+        rel_in = _hip.gnn_rel_inputs(nodes, receivers, senders, a.shape[1], g.shape[1])
+        pe = self.particle_encoder(p_in)
+        re = self.relation_encoder(rel_in)
+        Wr, Wp = self.relation_propagator.linear.weight, self.particle_propagator.linear.weight       # [H, 3H], [H, 2H]
+        key = (Wr.data_ptr(), Wr._version)
+        ent = self.__dict__.get("_split_w")
+        if ent is None or ent[0] != key:
+            ent = self.__dict__["_split_w"] = (key, torch.cat([Wr[:, H:2 * H].t(), Wr[:, 2 * H:].t()], 1).contiguous())   # [H, 2H]: effect @ . = (a2 | a3)
+        w23 = ent[1]
+        rew1 = torch.addmm(self.relation_propagator.linear.bias, re, Wr[:, :H].t())
+        pewp = torch.addmm(self.particle_propagator.linear.bias, pe, Wp[:, :H].t())
+        wp2t = Wp[:, H:].t()
+        row_start = torch.searchsorted(receivers, torch.arange(N + 1, device=a.device, dtype=receivers.dtype))
+        effect = pe
+        for _ in range(c["pstep"]):
+            a23 = torch.mm(effect, w23)
+            agg = _hip.gnn_aggregate(rew1, a23, senders, row_start, N - 1 if dummy_last_row else N)   # (the dummy row of a padded graph: nobody reads its effect)
+            effect = torch.relu_(torch.addmm(pewp + effect, agg, wp2t))
+        pred_motion = self.non_rigid_predictor(effect)
+        pred_pos = state_t[:, -3:] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
+        return pred_pos, pred_motion
+
+    def _gnn_struct(self, a, g, state_t, p_in_dim):
+        """gsr_gnn_model over THIS module's parameter storage (rebuilt when a parameter moves: load_state_dict copies in place, .to() does not)."""
+        from diff_gaussian_rasterization import _hip
+        ws = [self.particle_encoder.model[0], self.particle_encoder.model[2], self.particle_encoder.model[4],
+              self.relation_encoder.model[0], self.relation_encoder.model[2], self.relation_encoder.model[4],
+              self.relation_propagator.linear, self.particle_propagator.linear,
+              self.non_rigid_predictor.linear_0, self.non_rigid_predictor.linear_1, self.non_rigid_predictor.linear_2]
+        tensors = [t for lin in ws for t in (lin.weight, lin.bias)]
+        key = (tuple(t.data_ptr() for t in tensors), int(a.shape[1]), int(g.shape[1]), int(state_t.shape[1]), int(p_in_dim))
+        ent = self.__dict__.get("_gnn_model")
+        if ent is None or ent[0] != key:
+            for t in tensors:
+                if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
+                    raise RuntimeError("DynamicsPredictor: the one-launch propagation needs contiguous float32 parameters on the device")
+            m = _hip.GnnModel()
+            m.width, m.particle_in, m.attr_dim, m.group_dim, m.state_cols = self.model_config["nf_effect"], p_in_dim, a.shape[1], g.shape[1], state_t.shape[1]
+            m.pstep, m.motion_clamp = self.model_config["pstep"], self.motion_clamp
+            for name, t in zip(_hip.GnnModel._WEIGHTS, tensors):
+                setattr(m, name, t.data_ptr())
+            ent = self.__dict__["_gnn_model"] = (key, m)
+        return ent[1]
+
+    def _propagate_fused(self, state_t, a, g, act, receivers, senders, workspace=None):
+        """``_propagate`` as ONE launch.  Rows and relations already padded to multiples of 16 (dummy last row, dummy relations on it),
+        relations ascending in the receiver.  -> (predicted positions, motions) of all rows."""
+        from diff_gaussian_rasterization import _hip
+        p_in = self._particle_inputs(state_t, a, act)
+        nodes = torch.cat([a, g, state_t], 1)
+        m = self._gnn_struct(a, g, state_t, p_in.shape[1])
+        N, E = int(a.shape[0]), int(receivers.shape[0])
+        if workspace is None:
+            cache = self.__dict__.setdefault("_gnn_ws", {})
+            workspace = cache.get((N, E, str(a.device)))
+            if workspace is None:
+                if len(cache) >= 16:
+                    cache.clear()
+                workspace = cache[(N, E, str(a.device))] = _hip.gnn_workspace(N, E, m.width, a.device)
+        return _hip.gnn_propagate(m, p_in, nodes, receivers, senders, state_t[:, -3:], workspace)
+
+    def _propagate_fused_padded(self, state_t, a, g, act, receivers, senders):
+        """Pads one graph like ``_propagate_graphed`` does (N to a multiple of 32 with at least one dummy row, E to a multiple of 128 with
+        dummy relations from the last row to itself) and runs the one-launch propagation."""
+        N, E = int(a.shape[0]), int(receivers.shape[0])
+        n_cap, e_cap = ((N + 1 + 31) // 32) * 32, max(128, ((E + 127) // 128) * 128)
+        pad = lambda t: torch.cat([t, t.new_zeros((n_cap - N, t.shape[1]))], 0)  # noqa: E731
+        fill = receivers.new_full((e_cap - E,), n_cap - 1)
+        receivers, order = torch.sort(receivers, stable=True)                    # ascending receivers (the rollout's lists are already: row-major
+        senders = senders[order]                                                 # order of the adjacency matrix); no host round trip to find out
+        pos, mot = self._propagate_fused(pad(state_t), pad(a), pad(g), pad(act), torch.cat([receivers, fill]), torch.cat([senders, fill]))
+        return pos[:N], mot[:N]
+
     def _propagate_graphed(self, state_t, a, g, act, receivers, senders):
         """``_propagate`` replayed from a hipGraph.  The rollout is bound by how fast the host can issue ~45 small launches per step
         (0.63 ms eager at 100 bones); captured once per padded shape they cost one launch and ~0.26 ms of GPU time.  Shapes are padded
@@ -299,6 +418,9 @@ class DynamicsPredictor(nn.Module):
         cache = self.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         fin = torch.cat([state_t, a, g, act], 1)
+        if self._split_ok(a):          # the split path sums a receiver's relations as a segment of the list: ascending receivers (the dummies sort last)
+            receivers, order = torch.sort(receivers, stable=True)
+            senders = senders[order]
         if ent is None:
             if len(cache) >= 16:
                 cache.clear()
@@ -307,7 +429,10 @@ class DynamicsPredictor(nn.Module):
             fbuf[:N].copy_(fin)
             ibuf[0, :E].copy_(receivers); ibuf[1, :E].copy_(senders)
             o0, o1, o2 = widths[0], widths[0] + widths[1], widths[0] + widths[1] + widths[2]
-            run = lambda: self._propagate(fbuf[:, :o0], fbuf[:, o0:o1], fbuf[:, o1:o2], fbuf[:, o2:], ibuf[0], ibuf[1])  # noqa: E731
+            if self._split_ok(a):
+                run = lambda: self._propagate_split(fbuf[:, :o0], fbuf[:, o0:o1], fbuf[:, o1:o2], fbuf[:, o2:], ibuf[0], ibuf[1], dummy_last_row=True)  # noqa: E731
+            else:
+                run = lambda: self._propagate(fbuf[:, :o0], fbuf[:, o0:o1], fbuf[:, o1:o2], fbuf[:, o2:], ibuf[0], ibuf[1])  # noqa: E731
             side = torch.cuda.Stream(device=fin.device)
             side.wait_stream(torch.cuda.current_stream(fin.device))
             with torch.cuda.stream(side):
@@ -528,6 +653,12 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
 # ------------------------------------------------------------------------------------------ one rollout step
 _STEP_CONSTANTS: Dict = {}
 _GRAPH_ROLLOUT = os.environ.get("GSDYN_GRAPH_ROLLOUT", "1") != "0"     # 0: the GNN propagation of a rollout step runs eagerly (A/B, debugging)
+# 1: the propagation network as ONE launch (gsr_gnn_propagate: persistent grid, f32 MFMA, device-wide barriers).  Built and checked in
+# round 4 (1e-6 of the GEMM-library path), but measured SLOWER than the graph of library GEMMs it was meant to replace (379 us per call
+# against ~290 us: its tiles load 16 rows x 64 bytes per instruction straight into the MFMA operand layout, which the address unit
+# serves at ~6 bytes per clock per CU; profiles/r04_gnn_one_launch.txt) -- opt-in until its products are staged through LDS.
+_GNN_FUSED = os.environ.get("GSDYN_GNN_FUSED", "0") == "1"
+_GNN_SPLIT = os.environ.get("GSDYN_GNN_SPLIT", "1") != "0"              # 0: the propagators' concatenated products as the reference writes them (A/B)
 _GRAPH_ROLLOUT_STEP = os.environ.get("GSDYN_GRAPH_ROLLOUT_STEP", "1") != "0"   # 0: only the propagation is graphed, the rest of a step runs eagerly
 
 
@@ -594,6 +725,8 @@ class _GraphedStep:
         pad_rows = z(self.n_cap - N, n_his * 3)
         act_obj, act_pad = z(nb, 3), z(self.n_cap - N, 3)
 
+        self.gnn_ws = _hip.gnn_workspace(self.n_cap, self.e_cap, c["nf_effect"], dev) if model._fused_ok(a, g) else None
+
         def body():
             idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
             bones_hist = self.hist[:, idx1[thin]]                                             # [n_his, nb, 3]; rows >= cnt repeat a real particle
@@ -601,7 +734,12 @@ class _GraphedStep:
             recv, send, _ = _hip.construct_edges_padded(states[-1], cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1)
             state_t = torch.cat([states.transpose(0, 1).reshape(N, n_his * 3), pad_rows], 0)
             act = torch.cat([act_obj, self.eef_next - self.eef_hist[-1], act_pad], 0)
-            pos_all, _ = model._propagate(state_t, a, g, act, recv, send)
+            if model._fused_ok(a, g):
+                pos_all, _ = model._propagate_fused(state_t, a, g, act, recv, send, workspace=self.gnn_ws)   # one launch (rows / relations are padded already)
+            elif model._split_ok(a):
+                pos_all, _ = model._propagate_split(state_t, a, g, act, recv, send, dummy_last_row=True)   # (the padded lists are ascending in the receiver)
+            else:
+                pos_all, _ = model._propagate(state_t, a, g, act, recv, send)
             bones, pred = bones_hist[-1], pos_all[:nb]
             rel = torch.zeros((self.n_cap, self.n_cap), dtype=torch.long, device=dev)
             rel.view(-1).index_fill_(0, recv * self.n_cap + send, 1)                           # (rel[recv, send] = 1 sorts its indices: not capturable)

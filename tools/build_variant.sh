@@ -7,7 +7,7 @@ make -C $C -j8 >/dev/null
 EXTRA=""; [ "$F" = gsr_preprocess_fwd ] && EXTRA="-ffp-contract=off"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA $2 -c $C/$F.hip -o /tmp/${F}_$1.o
 OBJS=""
-for o in gsr_preprocess_fwd gsr_binning gsr_render gsr_preprocess_bwd gsr_loss gsr_dynamics gsr_rigidity gsr_step gsr_api; do
+for o in gsr_preprocess_fwd gsr_binning gsr_render gsr_preprocess_bwd gsr_loss gsr_dynamics gsr_gnn gsr_rigidity gsr_step gsr_api; do
   if [ $o = $F ]; then OBJS="$OBJS /tmp/${F}_$1.o"; else OBJS="$OBJS $C/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libgsr_$1.so $OBJS

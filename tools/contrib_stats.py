@@ -1,0 +1,44 @@
+"""How many tile-list entries does the forward blend at all?  Reads the per-entry contribution bytes (BinningState::contrib, bit w = some
+pixel of quad w blended the entry) that the forward leaves for the backward, for one view of the benchmark scene (100k Gaussians, 800^2)
+and of the 500k / 1080p frame.  Usage (GPU box): python tools/contrib_stats.py"""
+import os, sys
+import numpy as np, torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, "gs-dynamics_amd"))
+import diff_gaussian_rasterization as dgr
+from diff_gaussian_rasterization import GaussianRasterizer
+from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+
+def stats(P, W, H, **kw):
+    dev = torch.device("cuda:0")
+    params = synth_scene_params(P, device=dev, **kw)
+    cam = synth_ring_cameras(8, W, H, device=dev)[0]
+    with torch.no_grad():
+        rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+    C = dgr._C
+    out = C.rasterize_gaussians(cam.bg, rv["means3D"], rv["colors_precomp"], rv["opacities"], rv["scales"], rv["rotations"], cam.scale_modifier,
+                                torch.empty(0, device=dev), cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, cam.image_height,
+                                cam.image_width, torch.empty(0, device=dev), cam.sh_degree, cam.campos, cam.prefiltered)
+    D, binning = out[0], out[5]
+    torch.cuda.synchronize()
+    a = (D + 255) // 256 * 256
+    c = binning[binning.numel() - a:][:D].cpu().numpy()
+    image = out[6].cpu().numpy()
+    al = lambda x: (x + 255) // 256 * 256
+    N, T = H * W, ((H + 15) // 16) * ((W + 15) // 16)
+    ranges = image[2 * al(4 * N):][:8 * T].view(np.uint32).reshape(T, 2)
+    below = useless_below = 0
+    for lo, hi in ranges:
+        nz = np.flatnonzero(c[lo:hi])
+        if nz.size:
+            below += nz[-1] + 1
+            useless_below += nz[-1] + 1 - nz.size
+    print(f"   entries below their tile's deepest blended entry (what the backward walks): {below} = {below / D:.3f} of all; of those NOT blended "
+          f"by any quad: {useless_below / max(below, 1):.3f}")
+    pop = np.unpackbits(c[:, None], axis=1)[:, 4:].sum(1)
+    print(f"P={P} {W}x{H}: D={D} entries; no quad blended it: {np.mean(c == 0):.3f}; quads per entry (of entries with any): "
+          + " ".join(f"{k}:{np.mean(pop[c != 0] == k):.3f}" for k in (1, 2, 3, 4)) + f"; mean quads per entry {pop.mean():.3f}")
+
+if __name__ == "__main__":
+    stats(100_000, 800, 800)
+    stats(500_000, 1920, 1080)
