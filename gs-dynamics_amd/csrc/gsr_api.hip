@@ -832,7 +832,31 @@ int gsr_construct_edges(const float* positions, int32_t n_obj_cap, const int32_t
     return -2;
   }
   return gsr_launch_construct_edges(positions, n_obj_cap, (const int*)n_valid, thresh_sq, topk, (long long)dummy_index, e_cap, (long long*)receivers,
-                                    (long long*)senders, (int*)count, (hipStream_t)stream);
+                                    (long long*)senders, (int*)count, nullptr, 0, (hipStream_t)stream);
+}
+int gsr_construct_edges_dense(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                              int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, int64_t* relations, int32_t relations_n,
+                              void* stream) {
+  GsrRange _range("gsr_construct_edges");
+  if (!positions || !n_valid || !receivers || !senders || !count || !relations || n_obj_cap < 1 || n_obj_cap > 127 || topk < 1 || topk > 16 || e_cap < 1 ||
+      relations_n < n_obj_cap + 1) {
+    gsr_set_error("gsr_construct_edges_dense: bad argument (1 <= n_obj_cap <= 127, 1 <= topk <= 16, relations_n > n_obj_cap)");
+    return -2;
+  }
+  return gsr_launch_construct_edges(positions, n_obj_cap, (const int*)n_valid, thresh_sq, topk, (long long)dummy_index, e_cap, (long long*)receivers,
+                                    (long long*)senders, (int*)count, (long long*)relations, relations_n, (hipStream_t)stream);
+}
+int gsr_rollout_step_tail(int32_t n_track, int32_t n_his, int32_t n_bones, const float* all_pos, const int64_t* track, float* pos_track, float* hist,
+                          float* eef_hist, const float* eef_next, const float* pred_in, const int32_t* n_valid, const int32_t* code, float* pred_out,
+                          int32_t* n_valid_out, int64_t* bad, void* stream) {
+  GsrRange _range("gsr_rollout_step_tail");
+  if (n_track < 0 || n_his < 1 || n_bones < 0 || !all_pos || !track || !pos_track || !hist || !eef_hist || !eef_next || !pred_in || !n_valid || !code ||
+      !pred_out || !n_valid_out || !bad) {
+    gsr_set_error("gsr_rollout_step_tail: bad argument");
+    return -2;
+  }
+  return gsr_launch_rollout_tail(n_track, n_his, n_bones, all_pos, (const long long*)track, pos_track, hist, eef_hist, eef_next, pred_in,
+                                 (const int*)n_valid, (const int*)code, pred_out, (int*)n_valid_out, (long long*)bad, (hipStream_t)stream);
 }
 
 int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,

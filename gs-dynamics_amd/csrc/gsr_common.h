@@ -389,7 +389,10 @@ int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float r
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st, const int* nb_valid = nullptr);
 int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
-                               long long* recv, long long* send, int* count, hipStream_t st);
+                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st);
+int gsr_launch_rollout_tail(int n_track, int n_his, int nb, const float* all_pos, const long long* track, float* pos_track, float* hist,
+                            float* eef_hist, const float* eef_next, const float* pred_in, const int* cnt, const int* code, float* pred_out,
+                            int* n_valid_out, long long* bad, hipStream_t st);
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st);
 int gsr_run_selftest(hipStream_t st);
 int gsr_debug_fwd_timing(unsigned long long* out16);

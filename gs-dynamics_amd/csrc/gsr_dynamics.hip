@@ -188,7 +188,7 @@ __device__ __forceinline__ unsigned long long ce_wave_min(unsigned long long v) 
 __global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float* __restrict__ pos, int n_obj_cap, const int* __restrict__ n_valid_p,
                                                                    float thr2, int topk, long long dummy, int e_cap,
                                                                    long long* __restrict__ recv, long long* __restrict__ send,
-                                                                   int* __restrict__ count) {
+                                                                   int* __restrict__ count, long long* __restrict__ rel, int rel_n) {
   __shared__ float sp[3 * 128];
   __shared__ unsigned long long s_mask[128][2];      // row i: which senders it is related to
   __shared__ int s_base[128];
@@ -260,6 +260,12 @@ __global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float
   }
   if (tid == 0) *count = min(total, e_cap);
   for (int e = total + tid; e < e_cap; e += CE_THREADS) { recv[e] = dummy; send[e] = dummy; }
+  // the same relations as a dense rel_n x rel_n 0 / 1 matrix (what gsr_fit_bones reads): one launch less than scattering the lists into zeros
+  if (rel)
+    for (int o = tid; o < rel_n * rel_n; o += CE_THREADS) {
+      const int i = o / rel_n, j = o - i * rel_n;
+      rel[o] = (i < N && j < N) ? (long long)((s_mask[i][j >> 6] >> (j & 63)) & 1ull) : 0ll;
+    }
 }
 
 // ---------------------------------------------------------------- farthest point sampling, several workgroups
@@ -341,9 +347,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __res
 #define LBS_CHUNK 256   // bones staged per LDS round
 __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const float* __restrict__ bones,
                                                         const float* __restrict__ R, const float* __restrict__ t,
-                                                        const float* __restrict__ bq, const float* __restrict__ xyz,
-                                                        const float* __restrict__ quat, float* __restrict__ out_xyz,
-                                                        float* __restrict__ out_quat, const int* __restrict__ nb_valid) {
+                                                        const float* __restrict__ bq, const float* xyz,
+                                                        const float* quat, float* out_xyz,
+                                                        float* out_quat, const int* __restrict__ nb_valid) {   // out_* may BE xyz / quat (a thread reads its Gaussian, then writes it)
   __shared__ float sB[LBS_CHUNK][3], sR[LBS_CHUNK][9], sT[LBS_CHUNK][3], sQ[LBS_CHUNK][4];
   if (nb_valid) nb = min(nb, *nb_valid);      // fixed-shape callers: only the first *nb_valid bones are real
   const int p = blockIdx.x * GSR_BLOCK + threadIdx.x;
@@ -590,10 +596,61 @@ int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const floa
   return 0;
 }
 
+// ---------------------------------------------------------------- bookkeeping at the end of a graphed rollout step
+// After the skinning: the tracked particles' new positions gathered out of the cloud, the history windows shifted by one frame
+// (dynamics_module.py:150-165 of the reference does this with torch.cat per step), the predicted bones masked to the valid ones, the
+// count of bones the device could not resolve -- one launch instead of ~16 tiny ones.
+__global__ __launch_bounds__(GSR_BLOCK) void rollout_tail_kernel(int n_track, int n_his, int nb, const float* __restrict__ all_pos,
+                                                                const long long* __restrict__ track, float* __restrict__ pos_track,
+                                                                float* __restrict__ hist, float* __restrict__ eef_hist,
+                                                                const float* __restrict__ eef_next, const float* __restrict__ pred_in,
+                                                                const int* __restrict__ cnt, const int* __restrict__ code,
+                                                                float* __restrict__ pred_out, int* __restrict__ n_valid_out,
+                                                                long long* __restrict__ bad) {
+  const int t = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (t < n_track) {
+    const long long g = track[t];
+    const float x = all_pos[3 * g], y = all_pos[3 * g + 1], z = all_pos[3 * g + 2];
+    pos_track[3 * t] = x; pos_track[3 * t + 1] = y; pos_track[3 * t + 2] = z;
+    for (int h = 0; h + 1 < n_his; ++h)
+      for (int c = 0; c < 3; ++c) hist[((size_t)h * n_track + t) * 3 + c] = hist[((size_t)(h + 1) * n_track + t) * 3 + c];
+    float* last = hist + ((size_t)(n_his - 1) * n_track + t) * 3;
+    last[0] = x; last[1] = y; last[2] = z;
+  }
+  if (blockIdx.x == 0) {
+    const int n = min(*cnt, nb);
+    if (threadIdx.x < 3) {
+      for (int h = 0; h + 1 < n_his; ++h) eef_hist[3 * h + threadIdx.x] = eef_hist[3 * (h + 1) + threadIdx.x];
+      eef_hist[3 * (n_his - 1) + threadIdx.x] = eef_next[threadIdx.x];
+    }
+    int wrong = 0;
+    for (int b = threadIdx.x; b < nb; b += GSR_BLOCK) {
+      const bool valid = b < n;
+      for (int c = 0; c < 3; ++c) pred_out[3 * b + c] = valid ? pred_in[3 * b + c] : 0.f;     // the reference leaves the unused bone rows at zero
+      wrong += (valid && code[b] == 1) ? 1 : 0;
+    }
+    __shared__ int s_wrong;
+    if (threadIdx.x == 0) { s_wrong = 0; *n_valid_out = *cnt; }
+    __syncthreads();
+    if (wrong) atomicAdd(&s_wrong, wrong);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_wrong) *bad += s_wrong;
+  }
+}
+int gsr_launch_rollout_tail(int n_track, int n_his, int nb, const float* all_pos, const long long* track, float* pos_track, float* hist,
+                            float* eef_hist, const float* eef_next, const float* pred_in, const int* cnt, const int* code, float* pred_out,
+                            int* n_valid_out, long long* bad, hipStream_t st) {
+  { GSR_PROF("rollout_tail", st);
+    hipLaunchKernelGGL(rollout_tail_kernel, dim3((n_track + GSR_BLOCK - 1) / GSR_BLOCK > 0 ? (n_track + GSR_BLOCK - 1) / GSR_BLOCK : 1), dim3(GSR_BLOCK), 0, st,
+                       n_track, n_his, nb, all_pos, track, pos_track, hist, eef_hist, eef_next, pred_in, cnt, code, pred_out, n_valid_out, bad); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
-                               long long* recv, long long* send, int* count, hipStream_t st) {
+                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st) {
   { GSR_PROF("construct_edges", st);
-    hipLaunchKernelGGL(construct_edges_kernel, dim3(1), dim3(CE_THREADS), 0, st, pos, n_obj_cap, n_valid, thr2, topk, dummy, e_cap, recv, send, count); }
+    hipLaunchKernelGGL(construct_edges_kernel, dim3(1), dim3(CE_THREADS), 0, st, pos, n_obj_cap, n_valid, thr2, topk, dummy, e_cap, recv, send, count, rel, rel_n); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -76,7 +76,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping", "gsr_wait_counts",
-           "gsr_gnn_workspace_bytes", "gsr_gnn_propagate", "gsr_gnn_aggregate", "gsr_gnn_rel_inputs")
+           "gsr_gnn_workspace_bytes", "gsr_gnn_propagate", "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail")
 
 
 def load_library():
@@ -169,6 +169,10 @@ def load_library():
     lib.gsr_fps_scratch_bytes.argtypes = [i32, i32]
     lib.gsr_fit_rotations.restype = C.c_int
     lib.gsr_fit_rotations.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gsr_construct_edges_dense.restype = C.c_int
+    lib.gsr_construct_edges_dense.argtypes = [vp, i32, vp, C.c_float, i32, C.c_int64, i32, vp, vp, vp, vp, i32, vp]
+    lib.gsr_rollout_step_tail.restype = C.c_int
+    lib.gsr_rollout_step_tail.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_construct_edges.restype = C.c_int
     lib.gsr_construct_edges.argtypes = [vp, i32, vp, C.c_float, i32, C.c_int64, i32, vp, vp, vp, vp]
     lib.gsr_lbs_valid.restype = C.c_int
@@ -877,9 +881,10 @@ def fps_thin_padded(pos: torch.Tensor, npoints: int, radius: float, start_idx: i
     return out, thin, cnt
 
 
-def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: float, topk: int, e_cap: int, dummy: int):
+def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: float, topk: int, e_cap: int, dummy: int, dense_n: int = 0):
     """gsr_construct_edges: pos [n_obj_cap + 1, 3] (the tool last), n_valid [1] int32 on the device -> (receivers [e_cap], senders [e_cap]
-    int64 padded with ``dummy``, count [1] int32)."""
+    int64 padded with ``dummy``, count [1] int32); dense_n > 0: also the relations as a dense [dense_n, dense_n] int64 0 / 1 matrix
+    (gsr_construct_edges_dense) as a fourth result."""
     import numpy as np
     lib = load_library()
     _require_device(pos)
@@ -890,9 +895,24 @@ def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: flo
         send = torch.empty((e_cap,), dtype=torch.int64, device=dev)
         cnt = torch.empty((1,), dtype=torch.int32, device=dev)
         thr2 = float(np.float32(float(thresh) * float(thresh)))          # the scalar a float32 tensor is compared with
+        if dense_n:
+            rel = torch.empty((int(dense_n), int(dense_n)), dtype=torch.int64, device=dev)
+            _check(lib.gsr_construct_edges_dense(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
+                                                 _ptr(cnt), _ptr(rel), int(dense_n), _stream(dev)), "gsr_construct_edges_dense")
+            return recv, send, cnt, rel
         _check(lib.gsr_construct_edges(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
                                        _ptr(cnt), _stream(dev)), "gsr_construct_edges")
     return recv, send, cnt
+
+
+def rollout_step_tail(all_pos, track, pos_track, hist, eef_hist, eef_next, pred_in, n_valid, code, pred_out, n_valid_out, bad):
+    """gsr_rollout_step_tail: the in-place bookkeeping that ends a graphed rollout step (see include/gsr.h); every tensor on the device, contiguous."""
+    lib = load_library()
+    dev = all_pos.device
+    with _on(dev):
+        _check(lib.gsr_rollout_step_tail(int(track.shape[0]), int(hist.shape[0]), int(pred_out.shape[0]), _ptr(all_pos), _ptr(track), _ptr(pos_track),
+                                         _ptr(hist), _ptr(eef_hist), _ptr(eef_next), _ptr(pred_in), _ptr(n_valid), _ptr(code), _ptr(pred_out),
+                                         _ptr(n_valid_out), _ptr(bad), _stream(dev)), "gsr_rollout_step_tail")
 
 
 def fps_thin(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0, thin_start_idx: int = 0):
@@ -1002,9 +1022,9 @@ def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tenso
     return R, q, code
 
 
-def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat, n_valid=None):
+def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat, n_valid=None, in_place=False):
     """gsr_lbs: returns (xyz_new [P,3], quat_new [P,4] or None, None) -- the [P, n_bones] weight matrix of the reference is
-    never materialised."""
+    never materialised.  in_place: xyz / quat (float32, contiguous) are overwritten and returned."""
     lib = load_library()
     _require_device(xyz)
     dev = xyz.device
@@ -1012,8 +1032,13 @@ def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat,
     f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
     bones, rotations, translations, bone_quats = f(bones), f(rotations).reshape(nb, 9), f(translations), f(bone_quats)
     with _on(dev):
-        out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None
+        if in_place:
+            if not (xyz.is_contiguous() and xyz.dtype == torch.float32 and (quat is None or (quat.is_contiguous() and quat.dtype == torch.float32))):
+                raise ValueError("linear_blend_skinning(in_place=True): contiguous float32 tensors, please")
+            out_xyz, out_q = xyz, quat
+        else:
+            out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None
         if n_valid is not None:      # only the first n_valid[0] bones (device int32) are real: fixed-shape callers
             _check(lib.gsr_lbs_valid(P, nb, _ptr(n_valid), _ptr(bones), _ptr(rotations), _ptr(translations), _ptr(bone_quats), _ptr(xyz), _ptr(quat),
                                      _ptr(out_xyz), _ptr(out_q), _stream(dev)), "gsr_lbs_valid")

@@ -731,7 +731,7 @@ class _GraphedStep:
             idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
             bones_hist = self.hist[:, idx1[thin]]                                             # [n_his, nb, 3]; rows >= cnt repeat a real particle
             states = torch.cat([bones_hist, self.eef_hist], 1)                                 # tool at row nb
-            recv, send, _ = _hip.construct_edges_padded(states[-1], cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1)
+            recv, send, _, rel = _hip.construct_edges_padded(states[-1], cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1, dense_n=self.n_cap)
             state_t = torch.cat([states.transpose(0, 1).reshape(N, n_his * 3), pad_rows], 0)
             act = torch.cat([act_obj, self.eef_next - self.eef_hist[-1], act_pad], 0)
             if model._fused_ok(a, g):
@@ -741,19 +741,13 @@ class _GraphedStep:
             else:
                 pos_all, _ = model._propagate(state_t, a, g, act, recv, send)
             bones, pred = bones_hist[-1], pos_all[:nb]
-            rel = torch.zeros((self.n_cap, self.n_cap), dtype=torch.long, device=dev)
-            rel.view(-1).index_fill_(0, recv * self.n_cap + send, 1)                           # (rel[recv, send] = 1 sorts its indices: not capturable)
-            R, q, code = _hip.fit_bones(bones, pred - bones, rel[:nb, :nb])
-            xyz_new, quat_new, _ = _hip.linear_blend_skinning(bones, R, pred - bones, q, self.all_pos, self.all_rot, n_valid=cnt)
-            self.all_pos.copy_(xyz_new); self.all_rot.copy_(quat_new)                           # noqa: E702
-            new_track = xyz_new[self.track]
-            self.pos_track.copy_(new_track)
-            self.hist.copy_(torch.cat([self.hist[1:], new_track[None]], 0))
-            self.eef_hist.copy_(torch.cat([self.eef_hist[1:], self.eef_next[None]], 0))
-            valid = (torch.arange(nb, device=dev) < cnt)
-            self.pred.copy_(pred * valid[:, None])                                             # the reference leaves the unused bone rows at zero
-            self.n_valid.copy_(cnt)
-            self.bad.add_(((code == 1) & valid).sum())                                         # rank-1 bones the device could not resolve (none, normally)
+            motion = pred - bones
+            R, q, code = _hip.fit_bones(bones, motion, rel[:nb, :nb])
+            _hip.linear_blend_skinning(bones, R, motion, q, self.all_pos, self.all_rot, n_valid=cnt, in_place=True)
+            # the tracked particles' new positions, both history windows shifted, the bones masked to the valid ones, the count of bones
+            # the device could not resolve (rank 1: none, normally): one launch
+            _hip.rollout_step_tail(self.all_pos, self.track, self.pos_track, self.hist, self.eef_hist, self.eef_next, pred.contiguous(), cnt, code,
+                                   self.pred, self.n_valid, self.bad)
         self._body, self.graph = body, None
 
     def load(self, track, pos_track, hist, eef_hist, all_pos, all_rot):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 119 /* 0.1.19: + gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 119 /* 0.1.19: + gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -326,6 +326,18 @@ int gsr_fps_thin(int32_t N, const float* pos, int32_t npoints, int32_t start_idx
  * row-major order, padded with dummy_index, *count = the real ones; gsr_lbs_valid = gsr_lbs over the first *n_valid bones. */
 int gsr_construct_edges(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
                         int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, void* stream);
+/* gsr_construct_edges_dense (ABI 119) = gsr_construct_edges that also writes the relations as a dense relations_n x relations_n 0 / 1
+ * int64 matrix (what gsr_fit_bones reads; rows / columns beyond the tool are zero).  gsr_rollout_step_tail (ABI 119): the bookkeeping
+ * that ends a graphed rollout step, one launch -- pos_track[t] = all_pos[track[t]]; hist [n_his, n_track, 3] and eef_hist [n_his, 3] shifted
+ * by one frame with the new positions / eef_next appended (/root/reference/src/gnn/dynamics_module.py:150-165 does this with torch.cat);
+ * pred_out [n_bones, 3] = pred_in rows below *n_valid, zeros above; *n_valid_out = *n_valid; *bad += bones below *n_valid with code 1.
+ * gsr_lbs / gsr_lbs_valid: out_xyz / out_quat may be xyz / quat themselves (in place). */
+int gsr_construct_edges_dense(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                              int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, int64_t* relations, int32_t relations_n,
+                              void* stream);
+int gsr_rollout_step_tail(int32_t n_track, int32_t n_his, int32_t n_bones, const float* all_pos, const int64_t* track, float* pos_track, float* hist,
+                          float* eef_hist, const float* eef_next, const float* pred_in, const int32_t* n_valid, const int32_t* code, float* pred_out,
+                          int32_t* n_valid_out, int64_t* bad, void* stream);
 int gsr_lbs_valid(int32_t P, int32_t n_bones, const int32_t* n_valid, const float* bones, const float* rotations, const float* translations,
                   const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);
 /* gsr_fit_bones: the moment matrices, gsr_fit_rotations and the bones' unit quaternions in one launch -- what interpolate_motions
