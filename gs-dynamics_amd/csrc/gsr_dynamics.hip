@@ -163,6 +163,88 @@ __global__ __launch_bounds__(FT_THREADS) void fps_thin_small_kernel(const float*
   for (int i = kept + tid; i < npoints; i += FT_THREADS) thin_idx[i] = thin_start;   // padding: a valid position (fixed-shape consumers gather with it)
 }
 
+// The same in ONE wave (N <= 1024, npoints <= 128: the rollout's 100-of-1000): lane l owns the CONSECUTIVE points 16 l .. 16 l + 15 in
+// registers; a pick is the wave maximum (DPP), the first lane holding it (ballot + ffs) and that lane's first maximum (readlane) -- no
+// barrier, no LDS exchange, one LDS read for the pick's coordinates.  Four waves with a barrier per pick cost 0.65 us per pick, the
+// per-lane arithmetic was a quarter of it: 131 -> ~70 us per rollout step for the 100 picks + ~85 thinning rounds.  Same arithmetic,
+// same tie rule (first maximum), bit-identical picks (test_bones_sampling_and_thinning_in_one_launch).
+__global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restrict__ pos, int N, int npoints, int start, float radius,
+                                                           int thin_start, long long* __restrict__ out_idx,
+                                                           long long* __restrict__ thin_idx, int* __restrict__ thin_count) {
+  __shared__ float sp[3 * 128];           // the picked points, in pick order
+  __shared__ float sa[3 * 1024];          // the whole cloud (a pick's coordinates)
+  const int lane = threadIdx.x;
+  float px[16], py[16], pz[16], mind[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = 16 * lane + q;
+    const bool have = i < N;
+    px[q] = have ? pos[3 * i] : 0.f; py[q] = have ? pos[3 * i + 1] : 0.f; pz[q] = have ? pos[3 * i + 2] : 0.f;
+    sa[3 * i] = px[q]; sa[3 * i + 1] = py[q]; sa[3 * i + 2] = pz[q];
+    mind[q] = __builtin_inff();
+  }
+  __syncthreads();
+  int cur = start;
+  for (int k = 0; k < npoints; ++k) {
+    const float cx = sa[3 * cur], cy = sa[3 * cur + 1], cz = sa[3 * cur + 2];
+    if (lane == 0) { out_idx[k] = cur; sp[3 * k] = cx; sp[3 * k + 1] = cy; sp[3 * k + 2] = cz; }
+    float best = -1.0f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = 16 * lane + q;
+      if (i < N) {
+        const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        mind[q] = fminf(mind[q], d);
+        if (mind[q] > best) { best = mind[q]; besti = i; }      // ascending i: the lane's first maximum
+      }
+    }
+    float m = fmaxf(best, 0.0f);
+    m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
+    m = ft_dpp_max<0x142, 0xA>(m); m = ft_dpp_max<0x143, 0xC>(m);
+    const float wmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    const uint64_t who = __ballot(best == wmax && best >= 0.0f);
+    cur = who ? __builtin_amdgcn_readlane(besti, __ffsll((long long)who) - 1) : 0x7fffffff;
+    if (!who) break;                        // (N == 0: nothing to pick; the launcher does not get here)
+  }
+  __syncthreads();                          // sp[] complete (one wave: orders the LDS writes of lane 0 before the reads below)
+  float qx[2], qy[2], qz[2], dist[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = 2 * lane + q;
+    const bool mine = i < npoints;
+    qx[q] = mine ? sp[3 * i] : 0.f; qy[q] = mine ? sp[3 * i + 1] : 0.f; qz[q] = mine ? sp[3 * i + 2] : 0.f;
+    dist[q] = __builtin_inff();
+  }
+  int kept = 0, nxt = thin_start;
+  for (int it = 0; it < npoints; ++it) {
+    if (lane == 0) thin_idx[kept] = nxt;
+    ++kept;
+    const float nx = sp[3 * nxt], ny = sp[3 * nxt + 1], nz = sp[3 * nxt + 2];
+    float best = -1.0f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * lane + q;
+      if (i < npoints) {
+        const float dx = qx[q] - nx, dy = qy[q] - ny, dz = qz[q] - nz;
+        dist[q] = fminf(dist[q], __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))));
+        if (dist[q] > best) { best = dist[q]; besti = i; }
+      }
+    }
+    float m = fmaxf(best, 0.0f);
+    m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
+    m = ft_dpp_max<0x142, 0xA>(m); m = ft_dpp_max<0x143, 0xC>(m);
+    const float wmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    const uint64_t who = __ballot(best == wmax && best >= 0.0f);
+    if (!who || !(wmax > radius)) break;              // wave-uniform
+    nxt = __builtin_amdgcn_readlane(besti, __ffsll((long long)who) - 1);
+  }
+  if (lane == 0) *thin_count = kept;
+  for (int i = kept + lane; i < npoints; i += 64) thin_idx[i] = thin_start;   // padding: a valid position (fixed-shape consumers gather with it)
+}
+
 // ---------------------------------------------------------------- relations of a rollout step, fixed shapes
 // construct_edges (gsdyn.dynamics; /root/reference/src/data/dataset.py:88-147) for the rollout's graph -- object particles 0 .. n_obj_cap - 1
 // of which the first *n_valid are real, ONE tool particle at index n_obj_cap -- as one launch with padded outputs: receiver / sender
@@ -581,7 +663,11 @@ int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind,
 int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
                         int* thin_count, hipStream_t st) {
   { GSR_PROF("fps_thin", st);
-    hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(FT_THREADS), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }
+    static const bool four_waves = [] { const char* e = getenv("GSR_FPS_THIN_4WAVES"); return e && *e && atoi(e) != 0; }();    // A/B: round 3's form
+    if (N <= 1024 && npoints <= 128 && !four_waves)
+      hipLaunchKernelGGL(fps_thin_wave_kernel, dim3(1), dim3(64), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count);
+    else
+      hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(FT_THREADS), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
