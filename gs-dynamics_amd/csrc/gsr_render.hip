@@ -109,6 +109,13 @@ __device__ __forceinline__ uint32_t gsr_shift_in_any(uint32_t acc, uint64_t m) {
   asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(m) : "scc");
   return acc;
 }
+// blend = hit ^ stop (stop implies hit) AND the shift-in of "blend has a lane set" in one go: a scalar logical operation leaves
+// SCC = (result != 0), so the s_cmp of gsr_shift_in_any is the xor the masks need anyway
+__device__ __forceinline__ uint64_t gsr_xor_shift_in_any(uint64_t hit, uint64_t stop, uint32_t& acc) {
+  uint64_t blend;
+  asm("s_xor_b64 %0, %2, %3\n\ts_addc_u32 %1, %1, %1" : "=s"(blend), "+s"(acc) : "s"(hit), "s"(stop) : "scc");
+  return blend;
+}
 __device__ __forceinline__ uint32_t gsr_sel_u(uint64_t m, uint32_t a, uint32_t b) {
   uint32_t r;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
@@ -142,6 +149,9 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
 
 #ifndef GSR_INDEX_AHEAD
 #define GSR_INDEX_AHEAD 1
+#endif
+#ifndef GSR_TRACK_FUSED_SCC
+#define GSR_TRACK_FUSED_SCC 1     // the tracking bit rides on the SCC of the blend mask's own s_xor_b64: one SALU per entry instead of two
 #endif
 #ifndef GSR_EXACT_LISTS
 #define GSR_EXACT_LISTS 1      // the backward's per-quad lists come from the forward's contribution bytes (fwd_tile<.., TRACK>): no rectangle tests, no
@@ -329,14 +339,14 @@ __device__ __forceinline__ int fwd_tile(
           /* the same predicates as lane masks (see gsr_sel): hit = power <= 0 && alpha >= 1/255, stop = hit && test_T < eps, blend = hit ^ stop */ \
           const uint64_t mh = __ballot(power <= 0.0f) & __ballot(alpha >= GSR_ALPHA_MIN);           \
           const uint64_t ms = mh & __ballot(test_T < GSR_T_EPS);                                    \
-          const uint64_t mb = mh ^ ms;                                                              \
+          const uint64_t mb = GSR_TRACK_FUSED_SCC ? gsr_xor_shift_in_any(mh, ms, acc) : (mh ^ ms);  /* + some pixel of the quad blended this entry */ \
           const float w = gsr_sel_or_zero(mb, alpha * T);                                           \
           C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                       \
           C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                       \
           if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
           T = gsr_sel_neg_abs(ms, gsr_sel(mb, test_T, T));                                          \
           last = gsr_sel_u(mb, __float_as_uint(ec.z), last);                                        \
-          acc = gsr_shift_in_any(acc, mb);                /* some pixel of the quad blended this entry */ \
+          if (!GSR_TRACK_FUSED_SCC) acc = gsr_shift_in_any(acc, mb);                                \
         } else {                                                                                    \
         const bool hit = power <= 0.0f && alpha >= GSR_ALPHA_MIN;                                   \
         const bool stop = hit && test_T < GSR_T_EPS;                                                \
