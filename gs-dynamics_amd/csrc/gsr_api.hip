@@ -102,6 +102,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
   o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.skip = 0; o.tile_rows = nullptr;
+  o.used = g.used; o.tracked = g.counters + 1;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
@@ -119,6 +120,7 @@ void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, c
   o.point_list = bs.point_list; o.rec = g.rec; o.bg = cam.bg; o.final_T = im.final_T; o.n_contrib = im.n_contrib;
   o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
   o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0; o.colors = nullptr; o.contrib = bs.contrib;
+  o.used = g.used; o.tracked = g.counters + 1;
 }
 
 // Fused pairs: the FIRST alias of a view (same camera, other colours) is blended inside its owner's tile pass instead of
@@ -646,6 +648,9 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
+    static const bool no_used = [] { const char* e = getenv("GSR_NO_USED_FLAGS"); return e && *e && atoi(e) != 0; }();    // A/B: write / read every record as before
+    w.used = no_used ? nullptr : g.used; w.tracked = g.counters + 1;
+    if (no_used) rt.v[v].used = nullptr;     // (the blend backward's zero fill and the per-Gaussian backward must agree)
     w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
     w.dL_dcolors = dL_dcolors_views ? dL_dcolors_views[v] : nullptr;
     w.partner_dL_dmeans2D = partner[v] >= 0 ? dL_dmeans2D[partner[v]] : nullptr;

@@ -50,6 +50,8 @@ struct GeomState {
                           //     entry points: lets a second render with the same geometry reuse the first one's lists)
   uint32_t* tile_rows;    // [(ceil(P / GSR_BIN_G) + 1) x GSR_BIN_MAX_T] the (workgroups x tiles) matrix of the tile-row binning for the
                           //     SINGLE-VIEW entry points (round 4; multi-view calls keep theirs in the batch state)
+  uint8_t* used;          // [P] 1: some pixel of this view blended the Gaussian (set by the tracking forward, cleared by preprocess; valid when
+                          //     counters[1] != 0): the per-Gaussian backward skips the records of the others -- all zeros: 45 % of the entries
 };
 struct ImageState {
   float* final_T;         // [H*W]
@@ -91,6 +93,7 @@ static inline size_t gsr_carve_geom(void* base, int32_t P, GeomState* g) {
   g->ekey = (uint2*)take(Pn * 8);
   g->block_hash = (uint2*)take(nblk * 8);
   g->tile_rows = (uint32_t*)take(((Pn + GSR_BIN_G - 1) / GSR_BIN_G + 1) * (size_t)GSR_BIN_MAX_T * 4);
+  g->used = (uint8_t*)take(Pn);
   return off;
 }
 static inline size_t gsr_carve_image(void* base, int32_t H, int32_t W, ImageState* im) {
@@ -210,6 +213,7 @@ struct GsrPreView {            // preprocess
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
   uint2* ekey;
   uint2* block_hash;     // nullptr: no fingerprint wanted
+  uint8_t* used; uint32_t* tracked;   // GeomState::used, &GeomState::counters[1]: both cleared here, set by the tracking forward
   int skip;              // 1: nothing to preprocess for this view (forward-only fused alias: its owner's tile pass reads its colours
                          //    straight from its colour array, nobody reads a record of its own)
   uint32_t* tile_rows;   // counting form (preprocess_fwd_count_kernel): this view's (workgroups x tiles) matrix of the tile-row binning --
@@ -255,6 +259,7 @@ struct GsrRenderView {         // blend forward / backward
   const uint2* ranges;
   const float* colors;   // != nullptr (fused alias of a forward-only call): this view's colours [P,3]; it has no records of its own
   uint8_t* contrib;      // the lists' per-entry quad-contribution bytes (BinningState::contrib of the view that owns the lists)
+  uint8_t* used; uint32_t* tracked;   // this view's GeomState::used / &counters[1] (forward: written; see GeomState)
   int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
   int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
 };
@@ -317,6 +322,7 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
 struct GsrBwdView {
   const float *view, *proj;
   const int32_t* radii;
+  const uint8_t* used; const uint32_t* tracked;   // GeomState::used, valid when *tracked != 0 (nullptr: not available)
   const uint32_t* offsets;
   const float4* partials;
   float* dL_dmeans2D;

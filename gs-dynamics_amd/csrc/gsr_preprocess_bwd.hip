@@ -256,6 +256,13 @@ __device__ __forceinline__ void cov3_to_scale_rot(const Cov3& cv, float mod, con
   gq[3] = 2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]);
 }
 
+// The tracking forward marks the Gaussians some pixel of the view blended (GeomState::used; trusted when the view's `tracked` word is
+// set): the records of the others are all zeros -- 45 % of a benchmark view's entries -- and so is everything the chain rule would make
+// of them (exact zeros: every term carries a factor from the records): skipped.
+__device__ __forceinline__ bool gsr_view_used(const GsrBwdView& w, int i) {
+  return !w.used || !w.tracked || *w.tracked == 0u || w.used[i] != 0;
+}
+
 // ---- single view ------------------------------------------------------------------------------------
 template <bool USE_SH>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
@@ -266,12 +273,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ clamped,
     const float4* __restrict__ partials, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh) {
+    float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    const uint8_t* __restrict__ used, const uint32_t* __restrict__ tracked) {
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   if (i >= P) return;
   float gm3[3] = {0.f, 0.f, 0.f}, gm2[2] = {0.f, 0.f}, gcol[3] = {0.f, 0.f, 0.f}, gop = 0.f;
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool alive = radii[i] > 0;
+  const bool alive = radii[i] > 0 && (!used || !tracked || *tracked == 0u || used[i] != 0);   // (see gsr_view_used)
   if (USE_SH && !alive && dL_dsh) {
     for (int k = 0; k < M * 3; ++k) dL_dsh[(size_t)i * M * 3 + k] = 0.f;
   }
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
     if (w.fused_alias) continue;      // its owner's records carry it (fused pair): the owner writes its dL_dmeans2D too
     float gm2[2] = {0.f, 0.f}, gm2a[2] = {0.f, 0.f};
     const bool pair = w.partner_dL_dmeans2D != nullptr;
-    if (w.radii[i] > 0) {
+    if (w.radii[i] > 0 && gsr_view_used(w, i)) {
       any = true;
       const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap),
                                             pair || w.dL_dcolors != nullptr || dL_dcolors != nullptr);
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64 * GSR_MAX_BATCH, PBW_MIN_WAVES) void preprocess_
   if (live && v >= 0) {
     float gm2[2] = {0.f, 0.f}, gm2a[2] = {0.f, 0.f};
     const bool pair = w.partner_dL_dmeans2D != nullptr;
-    if (w.radii[i] > 0) {
+    if (w.radii[i] > 0 && gsr_view_used(w, i)) {
       seen = 1.f;
       const PartialSum ps = reduce_partials(w.partials, min(w.offsets[i], w.cap), min(w.offsets[i + 1], w.cap),
                                             pair || w.dL_dcolors != nullptr || dL_dcolors != nullptr);
@@ -484,7 +492,7 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
 #define GSR_PBWD_ARGS                                                                                              \
   P, cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,       \
       cam.campos, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g.offsets, g.clamped,  \
-      partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dsh
+      partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dsh, g.used, g.counters + 1
   if (shs) {
     if (!dL_dsh) { gsr_set_error("gsr_backward: shs given but dL_dsh is NULL"); return -2; }
     { GSR_PROF("preprocess_bwd", st);

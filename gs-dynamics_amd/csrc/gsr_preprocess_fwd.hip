@@ -275,6 +275,8 @@ __device__ __forceinline__ PreOut preprocess_gaussian(
     tiles_touched[i] = tiles;
     clamped_out[i] = clamp_bits;
     radii[i] = radius_i;
+    if (vw.used) vw.used[i] = 0;                  // set by the tracking forward when some pixel blends the Gaussian
+    if (i == 0 && vw.tracked) *vw.tracked = 0u;   // ... which also says so here (a forward-only call leaves 0: the flags are then ignored)
   }
   PreOut o;
   o.tiles = tiles; o.rc = rc; o.tmask = tmask; o.depth_bits = __float_as_uint(c2.y);

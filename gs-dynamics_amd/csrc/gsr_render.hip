@@ -180,6 +180,7 @@ struct FwdLdsT {
 struct FwdPartner {
   const float4* rec; const float* bg; float* final_T; uint32_t* n_contrib; float* out_color; float* out_depth;
   const float* colors;   // != nullptr: the partner's colours come from its [P,3] colour array (it has no records: forward-only calls)
+  uint8_t* used;         // TRACK: the partner's per-Gaussian used flags (same lists, same blend decisions: set together with the owner's)
 };
 __device__ __forceinline__ float3 fwd_partner_colour(const FwdPartner& pt, uint32_t g) {
   if (pt.colors) return make_float3(pt.colors[3 * (size_t)g], pt.colors[3 * (size_t)g + 1], pt.colors[3 * (size_t)g + 2]);
@@ -197,7 +198,8 @@ __device__ __forceinline__ float3 fwd_partner_colour(const FwdPartner& pt, uint3
 // barrier: the next batch's loop-top barrier, and for the last batch of a tile a barrier of the CALLER (fwd_tile returns the batch's
 // first list position, or -1; the persistent kernel stores behind the barrier of its ticket pop: no barrier is added per tile).
 template <bool PAIR>
-__device__ __forceinline__ void fwd_store_contrib(const FwdLdsT<PAIR>& L, uint8_t* __restrict__ contrib, uint32_t list0, int n, int pend_base) {
+__device__ __forceinline__ void fwd_store_contrib(const FwdLdsT<PAIR>& L, uint8_t* __restrict__ contrib, uint8_t* __restrict__ used,
+                                                  uint8_t* __restrict__ used_partner, uint32_t list0, int n, int pend_base, uint32_t pend_g) {
   static_assert(GSR_BLOCK == 2 * FWD_BATCH, "the upper half of the workgroup writes the bytes of the batch the lower half staged");
   const int e = (int)threadIdx.x - FWD_BATCH, pidx = pend_base + e;   // waves 2 and 3: they stage nothing, so the bytes cost the staging waves no time
   if (pend_base >= 0 && e >= 0 && pidx < n && contrib) {   // (contrib == nullptr: a view without lists -- it has no busy tile to get here with)
@@ -209,6 +211,10 @@ __device__ __forceinline__ void fwd_store_contrib(const FwdLdsT<PAIR>& L, uint8_
       if (pw != 0xffu) byte |= ((L.cmask[w][pw >> 5] >> (31u - (pw & 31u))) & 1u) << w;
     }
     contrib[list0 + pidx] = (uint8_t)byte;
+    if (byte && used) {            // the Gaussian is blended somewhere in this view (plain byte stores of the same value: no atomics needed)
+      used[pend_g] = 1;
+      if (PAIR && used_partner) used_partner[pend_g] = 1;
+    }
   }
 }
 
@@ -217,13 +223,14 @@ __device__ __forceinline__ int fwd_tile(
     const int tile, const uint2 rg, FwdLdsT<PAIR>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth, const FwdPartner pt, uint8_t* __restrict__ contrib = nullptr) {
+    float* __restrict__ out_depth, const FwdPartner pt, uint8_t* __restrict__ contrib, uint8_t* __restrict__ used, uint32_t& pend_g) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
   const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const int n = (int)(rg.y - rg.x);
+  pend_g = 0u;                // TRACK, waves 2 - 3: the Gaussian of the entry whose byte this thread writes next (loaded a batch ahead of its use)
 
 #if GSR_FWD_SIGNED_T
   float T = inside ? 1.0f : -1.0f;      // the sign of T is the stopped flag (see GSR_FWD_ENTRY)
@@ -261,7 +268,11 @@ __device__ __forceinline__ int fwd_tile(
   //                                 compacted lists wait in L.cpos: no per-thread register lives across the blend loop for this)
   for (int base = 0; base < n; base += FWD_BATCH) {
     const bool all_done = __syncthreads_count(done) == GSR_BLOCK;  // also fences the previous batch's LDS reads (and publishes its cmask)
-    if (TRACK) { fwd_store_contrib<PAIR>(L, contrib, rg.x, n, pend_base); pend_base = -1; }
+    if (TRACK) {
+      fwd_store_contrib<PAIR>(L, contrib, used, pt.used, rg.x, n, pend_base, pend_g);
+      pend_base = -1;
+      if (!all_done && used && tid >= FWD_BATCH && base + tid - FWD_BATCH < n) pend_g = point_list[rg.x + base + tid - FWD_BATCH];
+    }
     if (all_done) break;
     GSR_TP(1);
     // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
@@ -548,7 +559,7 @@ __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    float4* __restrict__ partials, const uint8_t* __restrict__ contrib, const BwdPartner pt) {
+    float4* __restrict__ partials, const uint8_t* __restrict__ contrib, const uint8_t* __restrict__ used, const BwdPartner pt) {
   constexpr int BB = NBB;
   constexpr bool ROWS_PERM = !PAIR && NBB == BWD_BATCH;   // the short-queue build: see gsr_rows_sum
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -612,7 +623,11 @@ __device__ __forceinline__ void bwd_tile(
   float4 np = na;      // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
   float4 slz = na;
-  if (kz < n) slz = rec[GSR_REC_F4 * gz + 3];   // rect bits, offsets[g]
+  // (round 4) a Gaussian no pixel of the view blended has no record anybody reads (the per-Gaussian backward skips it: GeomState::used):
+  // no zeros for it -- 97 % of the unreached entries
+  bool fill0 = kz < n;
+  if (fill0 && used) fill0 = used[gz] != 0;
+  if (fill0) slz = rec[GSR_REC_F4 * gz + 3];   // rect bits, offsets[g]
   if (tid < BB && tid < max_last) {
     { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
@@ -622,7 +637,11 @@ __device__ __forceinline__ void bwd_tile(
   // zero-fill of the unreached entries: the first 256 rode along with the loads above, the rest (rare) in a plain loop
   for (int k = kz; k < n; k += GSR_BLOCK) {
     float4 sl = slz;
-    if (k != kz) sl = rec[GSR_REC_F4 * point_list[rg.x + k] + 3];
+    if (k != kz) {
+      const uint32_t g2 = point_list[rg.x + k];
+      if (used && used[g2] == 0) continue;
+      sl = rec[GSR_REC_F4 * g2 + 3];
+    } else if (!fill0) continue;
     const uint32_t rx = __float_as_uint(sl.x), ry = __float_as_uint(sl.y);
     const uint32_t minx = rx & 0xffffu, miny = rx >> 16, maxx = ry & 0xffffu, maxy = ry >> 16;
     const uint32_t e = __float_as_uint(sl.z) + gsr_tile_rank(__float_as_uint(sl.w), (maxx - minx) * (maxy - miny),
@@ -843,11 +862,14 @@ __device__ __forceinline__ void bwd_tile(
 // One launch serves every view of the call: a ticket of the combined LPT order is {tile, list start, list end,
 // view}; the view's pointers come from the kernarg table (uniform index: scalar loads).
 #define GSR_FWD_PASS(vw) tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).out_color, (vw).out_depth
+// the per-Gaussian used flags are trusted by the backward only when the view's `tracked` word says a tracking forward wrote them
+#define GSR_FWD_MARK_TRACKED() if (TRACK) { if (threadIdx.x < (unsigned)tab.V && tab.v[threadIdx.x].tracked) *tab.v[threadIdx.x].tracked = 1u; }
 #define GSR_BWD_PASS(vw) \
-  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials, (vw).contrib
+  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials, (vw).contrib, \
+  ((vw).used && (vw).tracked && *(vw).tracked != 0u) ? (vw).used : nullptr
 
 __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
-  return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth, p.colors};
+  return FwdPartner{p.rec, p.bg, p.final_T, p.n_contrib, p.out_color, p.out_depth, p.colors, p.used};
 }
 
 // PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the
@@ -859,15 +881,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews ta
   const GsrRenderView& vw = tab.v[blockIdx.y];
   if (vw.fused_alias) return;                       // rendered by its owner's workgroup
   const uint2 rg = vw.ranges[blockIdx.x];
+  if (blockIdx.x == 0 && blockIdx.y == 0) GSR_FWD_MARK_TRACKED()
   int pend;
+  uint32_t pend_g;
   if (PAIRS && vw.partner >= 0)
-    pend = fwd_tile<PAIRS, TRACK>((int)blockIdx.x, rg, L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib);
+    pend = fwd_tile<PAIRS, TRACK>((int)blockIdx.x, rg, L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib, vw.used, pend_g);
   else
-    pend = fwd_tile<false, TRACK>((int)blockIdx.x, rg, reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib);
+    pend = fwd_tile<false, TRACK>((int)blockIdx.x, rg, reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib, vw.used, pend_g);
   if (TRACK) {
     __syncthreads();
-    if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, rg.x, (int)(rg.y - rg.x), pend);
-    else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, rg.x, (int)(rg.y - rg.x), pend);
+    if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, vw.used, tab.v[vw.partner].used, rg.x, (int)(rg.y - rg.x), pend, pend_g);
+    else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, vw.used, nullptr, rg.x, (int)(rg.y - rg.x), pend, pend_g);
   }
 }
 
@@ -908,15 +932,17 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
       }
     }
   }
+  if (blockIdx.x == 0) GSR_FWD_MARK_TRACKED()
   uint32_t ticket = blockIdx.x;
   while (ticket < n_busy) {
     const uint4 ord = tile_order[ticket];
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     int pend;
+    uint32_t pend_g;
     if (PAIRS && vw.partner >= 0)
-      pend = fwd_tile<PAIRS, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib);
+      pend = fwd_tile<PAIRS, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib, vw.used, pend_g);
     else
-      pend = fwd_tile<false, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib);
+      pend = fwd_tile<false, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib, vw.used, pend_g);
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
@@ -924,8 +950,8 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
     __syncthreads();
     ticket = s_ticket;
     if (TRACK) {     // the tile's last contribution bytes: every wave's masks are in LDS behind the barrier above, and the one below keeps the next tile's staging off them
-      if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, ord.y, (int)(ord.z - ord.y), pend);
-      else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, ord.y, (int)(ord.z - ord.y), pend);
+      if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, vw.used, tab.v[vw.partner].used, ord.y, (int)(ord.z - ord.y), pend, pend_g);
+      else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, vw.used, nullptr, ord.y, (int)(ord.z - ord.y), pend, pend_g);
     }
     __syncthreads();  // every wave has its copy before thread 0 overwrites the slot
 #ifdef GSR_TILE_TIMING

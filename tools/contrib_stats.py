@@ -35,6 +35,14 @@ def stats(P, W, H, **kw):
             useless_below += nz[-1] + 1 - nz.size
     print(f"   entries below their tile's deepest blended entry (what the backward walks): {below} = {below / D:.3f} of all; of those NOT blended "
           f"by any quad: {useless_below / max(below, 1):.3f}")
+    al256 = lambda x: (x + 255) // 256 * 256
+    pl_off = 2 * al256(4 * D) + 2 * al256(8 * D)
+    pl = binning[pl_off:pl_off + 4 * D].view(torch.int32).cpu().numpy()
+    used = np.zeros(P, dtype=bool)
+    np.logical_or.at(used, pl[c != 0], True)
+    cnt_g = np.bincount(pl, minlength=P)
+    print(f"   Gaussians with list entries: {int((cnt_g > 0).sum())}; of them blended somewhere: {int(used.sum())}; entries that belong to Gaussians "
+          f"blended NOWHERE: {cnt_g[~used].sum() / D:.3f} of all entries")
     pop = np.unpackbits(c[:, None], axis=1)[:, 4:].sum(1)
     print(f"P={P} {W}x{H}: D={D} entries; no quad blended it: {np.mean(c == 0):.3f}; quads per entry (of entries with any): "
           + " ".join(f"{k}:{np.mean(pop[c != 0] == k):.3f}" for k in (1, 2, 3, 4)) + f"; mean quads per entry {pop.mean():.3f}")
