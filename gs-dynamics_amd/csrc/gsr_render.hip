@@ -610,7 +610,7 @@ __device__ __forceinline__ void bwd_tile(
   uint32_t nquads = 0;                               // GSR_EXACT_LISTS: the entry's contribution byte (which quads blended it in the forward)
   if (tid < BB && tid < max_last) {
     ng = point_list[rg.x + (max_last - 1 - tid)];
-    if (GSR_EXACT_LISTS) nquads = contrib[rg.x + (max_last - 1 - tid)];
+    if (GSR_EXACT_LISTS) nquads = contrib ? contrib[rg.x + (max_last - 1 - tid)] : 0xfu;
     if (GSR_INDEX_AHEAD && tid + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (tid + BB))];
   }
   const int red6 = lane >= 48 ? gsr_sum6_slot(lane) : -1;   // !COL (GSR_NOCOL_SUM6): where this lane's total of the six-value reduction goes
@@ -681,7 +681,7 @@ __device__ __forceinline__ void bwd_tile(
       const int nj = base + BB + tid;
       if (tid < BB && nj < max_last) {
         ng = GSR_INDEX_AHEAD ? ng_ahead : point_list[rg.x + (max_last - 1 - nj)];
-        if (GSR_EXACT_LISTS) nquads = contrib[rg.x + (max_last - 1 - nj)];
+        if (GSR_EXACT_LISTS) nquads = contrib ? contrib[rg.x + (max_last - 1 - nj)] : 0xfu;
         if (GSR_INDEX_AHEAD && nj + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (nj + BB))];
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
@@ -865,7 +865,10 @@ __device__ __forceinline__ void bwd_tile(
 // the per-Gaussian used flags are trusted by the backward only when the view's `tracked` word says a tracking forward wrote them
 #define GSR_FWD_MARK_TRACKED() if (TRACK) { if (threadIdx.x < (unsigned)tab.V && tab.v[threadIdx.x].tracked) *tab.v[threadIdx.x].tracked = 1u; }
 #define GSR_BWD_PASS(vw) \
-  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials, (vw).contrib, \
+  tab.W, tab.H, tab.gx, (vw).point_list, (vw).rec, (vw).bg, (vw).final_T, (vw).n_contrib, (vw).dL_dcolor, (vw).partials,                 \
+  /* a forward that did not track (GSR_FORWARD_ONLY -- against the contract, but cheap to survive) left neither contribution bytes nor   \
+     used flags: every quad then stages every entry below the tile's deepest contributor (the per-pixel hit test keeps the result exact) */ \
+  (!(vw).tracked || *(vw).tracked != 0u) ? (vw).contrib : nullptr,                                                                        \
   ((vw).used && (vw).tracked && *(vw).tracked != 0u) ? (vw).used : nullptr
 
 __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
