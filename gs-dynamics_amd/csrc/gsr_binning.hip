@@ -727,6 +727,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   if (nbig) __syncthreads();
   uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
   for (int t = tid; t < Ts; t += BIN_THREADS) row[t] = t < T ? s_cnt[t] : 0u;      // (the padding columns of the row stay zero)
+  if (blockIdx.x == 0 && tid < 64) vw.block_hist[tid] = 0u;                        // the chained scan's words (bin_colprefix_scan_kernel)
 }
 
 // More than BIN_DIRECT_ROWS workgroups per view: one thread per tile column turns the counts into exclusive prefixes over the
@@ -748,6 +749,63 @@ __global__ __launch_bounds__(GSR_BLOCK) void bin_colprefix_kernel(GsrBinViews ta
   }
   for (; r < rows; ++r) { const uint32_t v = m[(size_t)r * Ts + t]; m[(size_t)r * Ts + t] = run; run += v; }
   m[(size_t)rows * Ts + t] = run;
+}
+
+// The same + the exclusive scan of the tile totals -> ranges, i.e. what bin_scan did in a launch of its own (6.5 us of a step for a
+// scan of T numbers): a chained scan over the view's few workgroups (<= 40).  A workgroup publishes its total as ONE word (bit 31 = valid)
+// with an agent-scope relaxed store and sums its predecessors' words as they appear -- the data is its own flag, so no fence and no
+// cache maintenance is involved (round 3's "last workgroup does the scan" needed both and was slower).  The words live in the view's
+// radix histogram block (unused on this path), zeroed by bin_count's first workgroup.  All workgroups of the launch are resident
+// together (<= 640 of 256 threads) and a workgroup only ever waits for lower-numbered ones.
+__global__ __launch_bounds__(GSR_BLOCK) void bin_colprefix_scan_kernel(GsrBinViews tab) {
+  const GsrBinView& vw = tab.v[blockIdx.y];
+  if (vw.shares_lists) return;
+  __shared__ uint32_t s_w[GSR_BLOCK / 64];
+  __shared__ uint32_t s_base;
+  const int T = tab.T, Ts = gsr_bin_stride(T), rows = tab.rows, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = blockIdx.x * GSR_BLOCK + tid;
+  uint32_t* __restrict__ m = vw.tile_rows;
+  uint32_t run = 0;
+  if (t < Ts) {
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = m[(size_t)(r + u) * Ts + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { m[(size_t)(r + u) * Ts + t] = run; run += v[u]; }
+    }
+    for (; r < rows; ++r) { const uint32_t v = m[(size_t)r * Ts + t]; m[(size_t)r * Ts + t] = run; run += v; }
+    m[(size_t)rows * Ts + t] = run;
+  }
+  // inclusive scan of the 256 column totals
+  uint32_t inc = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < GSR_BLOCK / 64; ++w) { if (w < wv) before += s_w[w]; total += s_w[w]; }
+  uint32_t* __restrict__ words = vw.block_hist;
+  if (tid == 0) __hip_atomic_store(&words[blockIdx.x], 0x80000000u | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wv == 0) {            // predecessors' totals (at most 40 workgroups per view: one lane each)
+    uint32_t mine = 0;
+    if (lane < (int)blockIdx.x) {
+      uint32_t w;
+      do { w = __hip_atomic_load(&words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w & 0x80000000u));
+      mine = w & 0x7fffffffu;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mine += __shfl_xor(mine, k, 64);
+    if (lane == 0) s_base = mine;
+  }
+  __syncthreads();
+  const uint32_t start = s_base + before + inc - run, cap = vw.D;
+  if (t < T) vw.ranges[t] = make_uint2(min(start, cap), min(start + run, cap));
 }
 
 // One view: (column prefix over the workgroups, unless bin_colprefix ran) + exclusive scan of the tile totals -> ranges.  A thread
@@ -1397,9 +1455,17 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     }
     GSR_HIP_CHECK(hipGetLastError());
     const int prefixed = tab.rows > BIN_DIRECT_ROWS ? 1 : 0;
-    if (prefixed) {
+    // the column prefix also scans the tile totals into the ranges (one launch less) unless the rows were counted by the preprocess launch
+    // (bin_scan then also leaves the view's entry count) or GSR_BIN_CHAINED_SCAN=0 (A/B)
+    static const bool chained_on = [] { const char* e = getenv("GSR_BIN_CHAINED_SCAN"); return !(e && *e && atoi(e) == 0); }();
+    const int col_wgs = (gsr_bin_stride(tab.T) + GSR_BLOCK - 1) / GSR_BLOCK;
+    const bool chained = prefixed && chained_on && !tab.counted && col_wgs <= 64;
+    if (chained) {
       GSR_PROF("bin_colprefix", st);
-      hipLaunchKernelGGL(bin_colprefix_kernel, dim3((gsr_bin_stride(tab.T) + GSR_BLOCK - 1) / GSR_BLOCK, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+      hipLaunchKernelGGL(bin_colprefix_scan_kernel, dim3(col_wgs, tab.V), dim3(GSR_BLOCK), 0, st, tab);
+    } else if (prefixed) {
+      GSR_PROF("bin_colprefix", st);
+      hipLaunchKernelGGL(bin_colprefix_kernel, dim3(col_wgs, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     }
     GSR_HIP_CHECK(hipGetLastError());
     const int n_items = tab.V * ((tab.T + 1023) / 1024);
@@ -1410,7 +1476,7 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
       GSR_PROF("bin_scan_order", st);
       hipLaunchKernelGGL(bin_scan_order_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tab, prefixed, n_items);
       order_done = true;
-    } else {
+    } else if (!chained) {
       GSR_PROF("bin_scan", st);
       hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed);
     }
