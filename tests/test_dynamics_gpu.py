@@ -403,6 +403,59 @@ def test_fixed_shape_relations_kernel(dev):
         got = torch.stack([recv[:m], send[:m]], 1).cpu()
         assert m == want.shape[0] and torch.equal(got, want), (n_valid, thr, k, m, want.shape[0])
         assert bool((recv[m:] == 127).all()) and bool((send[m:] == 127).all())
+        # gsr_construct_edges_dense: the same lists + the relations as the dense 0 / 1 matrix gsr_fit_bones reads
+        recv2, send2, cnt2, rel = _hip.construct_edges_padded(pos.to(dev), torch.tensor([n_valid], dtype=torch.int32, device=dev), thr, k, 1024, 127, dense_n=128)
+        assert torch.equal(recv2, recv) and torch.equal(send2, send) and int(cnt2.item()) == m
+        dense = torch.zeros((128, 128), dtype=torch.int64)
+        dense[want[:, 0], want[:, 1]] = 1
+        assert rel.dtype == torch.int64 and torch.equal(rel.cpu(), dense), (n_valid, thr, k)
+
+
+def test_rollout_step_tail_and_in_place_skinning(dev):
+    """gsr_rollout_step_tail (the bookkeeping that ends a graphed rollout step, one launch) against the torch statements it replaced
+    (gather of the tracked particles, torch.cat shifts of both history windows, the masked bone predictions, the count of unresolved
+    bones), and gsr_lbs_valid writing over its inputs against the out-of-place call."""
+    from diff_gaussian_rasterization import _hip
+    g = torch.Generator().manual_seed(21)
+    P, n_track, n_his, nb = 5000, 1000, 3, 100
+    all_pos = torch.rand(P, 3, generator=g).to(dev)
+    track = torch.randperm(P, generator=g)[:n_track].to(dev)
+    hist = torch.rand(n_his, n_track, 3, generator=g).to(dev)
+    eef_hist = torch.rand(n_his, 1, 3, generator=g).to(dev)
+    eef_next = torch.rand(1, 3, generator=g).to(dev)
+    pred_in = torch.rand(nb, 3, generator=g).to(dev)
+    code = torch.randint(0, 3, (nb,), generator=g).to(torch.int32).to(dev)
+    for n_valid in (100, 85, 1, 0):
+        cnt = torch.tensor([n_valid], dtype=torch.int32, device=dev)
+        new_track = all_pos[track]
+        want_hist = torch.cat([hist[1:], new_track[None]], 0)
+        want_eef = torch.cat([eef_hist[1:], eef_next[None]], 0)
+        valid = torch.arange(nb, device=dev) < n_valid
+        want_pred = pred_in * valid[:, None]
+        want_bad = 7 + int(((code == 1) & valid).sum())
+        h, e = hist.clone(), eef_hist.clone()
+        pos_track = torch.zeros(n_track, 3, device=dev)
+        pred_out = torch.full((nb, 3), -1.0, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        bad = torch.tensor([7], dtype=torch.int64, device=dev)
+        _hip.rollout_step_tail(all_pos, track, pos_track, h, e, eef_next, pred_in, cnt, code, pred_out, n_out, bad)
+        torch.cuda.synchronize()
+        assert torch.equal(pos_track, new_track) and torch.equal(h, want_hist) and torch.equal(e, want_eef)
+        assert torch.equal(pred_out, want_pred) and int(n_out) == n_valid and int(bad) == want_bad, (n_valid, int(bad), want_bad)
+    # skinning in place
+    bones = torch.rand(nb, 3, generator=g).to(dev)
+    R = torch.linalg.qr(torch.randn(nb, 3, 3, generator=g))[0].to(dev)
+    q = torch.nn.functional.normalize(torch.randn(nb, 4, generator=g)).to(dev)
+    mot = (torch.rand(nb, 3, generator=g) * 0.05).to(dev)
+    xyz = torch.rand(P, 3, generator=g).to(dev)
+    quat = torch.nn.functional.normalize(torch.randn(P, 4, generator=g)).to(dev)
+    cnt = torch.tensor([85], dtype=torch.int32, device=dev)
+    want_x, want_q, _ = _hip.linear_blend_skinning(bones, R, mot, q, xyz, quat, n_valid=cnt)
+    x2, q2 = xyz.clone(), quat.clone()
+    got_x, got_q, _ = _hip.linear_blend_skinning(bones, R, mot, q, x2, q2, n_valid=cnt, in_place=True)
+    torch.cuda.synchronize()
+    assert got_x.data_ptr() == x2.data_ptr() and got_q.data_ptr() == q2.data_ptr()
+    assert torch.equal(x2, want_x) and torch.equal(q2, want_q) and not torch.equal(x2, xyz)
 
 
 def test_whole_step_graph_equals_eager_rollout(dev, golden_dir):
