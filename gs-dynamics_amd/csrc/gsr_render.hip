@@ -882,9 +882,9 @@ template <bool PAIRS, bool TRACK = false>
 __global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
   __shared__ FwdLdsT<PAIRS> L;
   const GsrRenderView& vw = tab.v[blockIdx.y];
+  if (blockIdx.x == 0 && blockIdx.y == 0) GSR_FWD_MARK_TRACKED()
   if (vw.fused_alias) return;                       // rendered by its owner's workgroup
   const uint2 rg = vw.ranges[blockIdx.x];
-  if (blockIdx.x == 0 && blockIdx.y == 0) GSR_FWD_MARK_TRACKED()
   int pend;
   uint32_t pend_g;
   if (PAIRS && vw.partner >= 0)
