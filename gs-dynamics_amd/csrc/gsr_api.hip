@@ -375,6 +375,10 @@ int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* mea
 
 int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state,
                        void* binning_state, void* image_state, float* out_color, float* out_depth, void* stream) {
+  return gsr_forward_render_ex(s, P, num_rendered, geom_state, binning_state, image_state, out_color, out_depth, 0u, stream);
+}
+int gsr_forward_render_ex(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state, void* binning_state,
+                          void* image_state, float* out_color, float* out_depth, uint32_t flags, void* stream) {
   GsrRange _range("gsr_forward_render");
   if (!s) { gsr_set_error("gsr: settings is NULL"); return -2; }
   void* geom = const_cast<void*>(geom_state);
@@ -386,12 +390,19 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
-                nullptr, nullptr, (hipStream_t)stream, nullptr, (geom && P > 0 && gsr_rows_path_ok(cam.T)) ? g.tile_rows : nullptr);
+                nullptr, nullptr, (hipStream_t)stream, nullptr, (geom && P > 0 && gsr_rows_path_ok(cam.T)) ? g.tile_rows : nullptr,
+                (int)(flags & GSR_FORWARD_ONLY));
 }
 
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
                               void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
                               float* out_depth, void* stream) {
+  return gsr_forward_render_shared_ex(s, P, num_rendered, geom_state, owner_binning_state, owner_image_state, image_state, out_color, out_depth,
+                                      0u, stream);
+}
+int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state, void* owner_binning_state,
+                                 const void* owner_image_state, void* image_state, float* out_color, float* out_depth, uint32_t flags,
+                                 void* stream) {
   GsrRange _range("gsr_forward_render_shared");
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
@@ -414,6 +425,7 @@ int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_ren
     return rc;
   GsrRenderViews rt;
   render_header(rt, 1, cam, im.tile_order, im.queue);
+  rt.track = (flags & GSR_FORWARD_ONLY) ? 0 : 1;
   fill_render_view(rt.v[0], cam, g, bs, im, out_color, out_depth, nullptr, nullptr);
   return gsr_launch_render_fwd(rt, st);
 }

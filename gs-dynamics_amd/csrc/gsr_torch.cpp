@@ -90,7 +90,8 @@ std::tuple<int64_t, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, 
 rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
                     const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
                     const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
-                    int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered) {
+                    int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
+                    bool will_backward) {     // extension over upstream (default true): false = no input requires a gradient -- the blend records nothing for a backward
   TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build) runs on a HIP device only; there is no CPU fallback");
   const c10::Device dev = means3D.device();
@@ -116,17 +117,18 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   uint64_t fp = 0;
   check(gsr_forward_preprocess_fp(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
                                   radii.data_ptr<int32_t>(), &D, g_reuse ? &fp : nullptr, stream), "gsr_forward_preprocess");
+  const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
   ListCache& lc = g_lists;
   if (g_reuse && fp != 0 && D > 0 && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.D == D && lc.fp == fp && lc.stream == stream) {
     // same geometry, same camera as the previous forward: its lists are this render's lists
-    check(gsr_forward_render_shared(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
-                                    color.data_ptr<float>(), depth.data_ptr<float>(), stream), "gsr_forward_render_shared");
+    check(gsr_forward_render_shared_ex(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
+                                       color.data_ptr<float>(), depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render_shared");
     ++g_reuse_hits;
     return std::make_tuple((int64_t)D, color, depth, radii, geom, lc.binning, image);
   }
   torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
-  check(gsr_forward_render(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
-                           depth.data_ptr<float>(), stream), "gsr_forward_render");
+  check(gsr_forward_render_ex(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
+                              depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render");
   if (g_reuse && fp != 0 && D > 0) {
     lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.fp = fp; lc.stream = stream; lc.binning = binning; lc.image = image;
   } else {
@@ -206,7 +208,15 @@ torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& vi
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "MI355X rasterizer: torch layer over libgsr_hip.so (rasterize_gaussians / rasterize_gaussians_backward / mark_visible)";
-  m.def("rasterize_gaussians", &rasterize_gaussians);
+  m.def("rasterize_gaussians", &rasterize_gaussians);                      // 19 arguments: upstream's 18 + will_backward
+  m.def("rasterize_gaussians", [](const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                                  const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier,
+                                  const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+                                  double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh,
+                                  int64_t degree, const torch::Tensor& campos, bool prefiltered) {        // upstream's exact argument list
+    return rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                               tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, true);
+  });
   {
     namespace py = pybind11;
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),

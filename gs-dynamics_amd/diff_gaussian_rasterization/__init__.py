@@ -97,7 +97,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             col_, sh_, sc_, rot_, cov_ = t(colors_precomp), t(sh), t(scales), t(rotations), t(cov3Ds_precomp)
             D, color, depth, radii, geom, binning, image = native.rasterize_gaussians(
                 rs.bg, m3, col_, opacities, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
-                float(rs.tanfovy), int(rs.image_height), int(rs.image_width), sh_, int(rs.sh_degree), rs.campos, bool(rs.prefiltered))
+                float(rs.tanfovy), int(rs.image_height), int(rs.image_width), sh_, int(rs.sh_degree), rs.campos, bool(rs.prefiltered),
+                bool(any(ctx.needs_input_grad)))       # False (torch.no_grad(), detached inputs): the blend records nothing for a backward
             ctx.native, ctx.rs, ctx.num_rendered = native, rs, int(D)
             ctx.has = (sh_.numel() > 0, col_.numel() > 0, sc_.numel() > 0, cov_.numel() > 0)
             ctx.save_for_backward(m3, radii, col_, sh_, sc_, rot_, cov_, geom, binning, image)

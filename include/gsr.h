@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 119 /* 0.1.19: + gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 119 /* 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -92,6 +92,14 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
  * first call's binning and image states instead of gsr_forward_render -- no duplicates are emitted or sorted, its own image state
  * receives a copy of the owner's ranges and tile order, and gsr_backward takes (own geom, OWNER's binning, own image) as usual.
  * Results are bit-identical to gsr_forward_render. */
+/* gsr_forward_render_ex / gsr_forward_render_shared_ex (ABI 119): the same with `flags` -- GSR_FORWARD_ONLY (defined below): the caller
+ * will not run gsr_backward on these states, so the blend skips recording what only a backward reads (the per-entry contribution bytes
+ * and the per-Gaussian used flags: 7 % of a forward).  The torch layer passes it when no input of the call requires a gradient. */
+int gsr_forward_render_ex(const gsr_settings* s, int32_t P, uint32_t num_rendered, const void* geom_state, void* binning_state,
+                          void* image_state, float* out_color, float* out_depth, uint32_t flags, void* stream);
+int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state, void* owner_binning_state,
+                                 const void* owner_image_state, void* image_state, float* out_color, float* out_depth, uint32_t flags,
+                                 void* stream);
 int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                               const float* rotations, const float* opacities, const float* colors_precomp,
                               const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
