@@ -9,5 +9,5 @@ $B -c $C/gsr_binning.hip -o $O/gsr_binning.o &
 $B -fno-slp-vectorize -c $C/gsr_render.hip -o $O/gsr_render.o &
 $B -c $C/gsr_api.hip -o $O/gsr_api.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libgsr_$1.so $C/gsr_preprocess_fwd.o $O/gsr_binning.o $O/gsr_render.o $C/gsr_preprocess_bwd.o $C/gsr_loss.o $C/gsr_dynamics.o $C/gsr_rigidity.o $C/gsr_step.o $O/gsr_api.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libgsr_$1.so $C/gsr_preprocess_fwd.o $O/gsr_binning.o $O/gsr_render.o $C/gsr_preprocess_bwd.o $C/gsr_loss.o $C/gsr_dynamics.o $C/gsr_gnn.o $C/gsr_rigidity.o $C/gsr_step.o $O/gsr_api.o
 echo built libgsr_$1.so
