@@ -554,6 +554,49 @@ def test_early_termination_dense_scene(dev):
     _check_against_oracle(ring_camera(120, 88, bg=(1, 1, 1)), g, dev, seed=7)
 
 
+@pytest.mark.parametrize("case", ["sparse", "dense", "wide"])
+def test_exact_lists_and_used_flags_equal_the_conservative_backward(dev, case):
+    """Round 4: the tracking forward leaves per-entry contribution bytes (which of a tile's quads blended the entry) and per-Gaussian
+    used flags; the blend backward builds its per-quad lists from the bytes and skips the zero fill of unmarked Gaussians, the
+    per-Gaussian backward skips their records.  The geometry state's `tracked` word says whether to trust them: cleared (here: by
+    hand, between forward and backward), every quad stages every entry below the tile's deepest contributor and every record is
+    written and read -- the conservative evaluation.  Every gradient of the two must be EQUAL (the bytes and flags only remove visits
+    and records whose contributions are exact zeros): this pins both against the per-pixel hit test itself."""
+    from diff_gaussian_rasterization import _hip
+    if case == "sparse":
+        g, cam = random_gaussians(4000, seed=51), ring_camera(200, 136, bg=(0.1, 0.2, 0.3))
+    elif case == "dense":
+        g, cam = random_gaussians(3000, seed=52, scale_lo=0.1, scale_hi=0.5, spread=0.6), ring_camera(120, 88, bg=(1, 1, 1))
+        g["opacities"][:] = 0.95
+    else:
+        g, cam = random_gaussians(300, seed=53, scale_lo=0.5, scale_hi=2.0), ring_camera(96, 64, bg=(0, 0, 0))
+    rs = _settings(cam, dev)
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    P = t["means3D"].shape[0]
+    dL = torch.tensor(np.random.default_rng(9).uniform(-1, 1, (3, cam.image_height, cam.image_width)).astype(np.float32), device=dev)
+    outs = []
+    for conservative in (False, True):
+        color, radii, depth, st = _hip.rasterize_forward(rs, t["means3D"], t["opacities"], t["colors_precomp"], None, t["scales"], t["rotations"], None)
+        # the geometry state's counters: behind rec (64 P), rect (8 P), tiles_touched (4 P), offsets (4 (P + 1)), block sums / offsets, clamped (4 P)
+        al = lambda x: (x + 255) // 256 * 256      # noqa: E731
+        nblk = (P + 255) // 256
+        off = al(64 * P) + al(8 * P) + al(4 * P) + al(4 * (P + 1)) + al(4 * nblk) + al(4 * (nblk + 1)) + al(4 * P)
+        words = st.geom[off:off + 8].view(torch.int32)
+        assert int(words[1]) == 1, words.tolist()       # [1] = tracked ([0]: the entry count when the device scans the block sums)
+        used_off = off + al(64) + al(8 * P) + al(8 * nblk) + al(((P + 2047) // 2048 + 1) * 10240 * 4)
+        used = st.geom[used_off:used_off + P]
+        assert 0 < int(used.sum()) <= int((radii > 0).sum()) and int(used.max()) == 1
+        if conservative:
+            words[1] = 0
+        grads = _hip.rasterize_backward(st, dL, t["means3D"], radii, t["colors_precomp"], None, t["scales"], t["rotations"], None)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in grads if x is not None and x.numel()])
+    assert len(outs[0]) == len(outs[1]) >= 5
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), (case, float((a - b).abs().max()))
+    assert float(outs[0][0].abs().max()) > 0
+
+
 def test_edge_cases(dev):
     from diff_gaussian_rasterization import GaussianRasterizer
     cam = ring_camera(40, 24, bg=(0.3, 0.6, 0.9))
