@@ -1124,8 +1124,9 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
       else hipLaunchKernelGGL(render_bwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
     } else {
       const int tiles = tab.T * tab.V;
-      // long queue (>= 3 tiles per resident workgroup slot, counting the empty ones): the 96-entry build, five workgroups per CU
-      static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 7500);
+      // long queue (>= 2 tiles per resident workgroup slot, counting the empty ones): the small-batch build, more workgroups per CU
+      // (round 4, with the exact lists: 80 entries at six per CU; two views -- 5000 tiles -- gain too: render_bwd 132 -> 127 us; one view loses: 81 -> 87)
+      static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 4000);
       const bool small = !pairs && tiles >= small_batch_from;
       const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
       const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
