@@ -1024,7 +1024,8 @@ def test_pair_fusion_and_static_launch_variants(dev, tmp_path):
     script.write_text(_VARIANT_SCRIPT)
     outs = {}
     for name, env in (("default", {}), ("nopair", {"GSR_NO_PAIR_FUSION": "1"}), ("static", {"GSR_RENDER_STATIC": "1"}),
-                      ("counted", {"GSR_FUSED_COUNT": "1"})):      # the counting form of preprocess_fwd (round-4 A/B switch, off by default)
+                      ("counted", {"GSR_FUSED_COUNT": "1"}),       # the counting form of preprocess_fwd (round-4 A/B switch, off by default)
+                      ("no_used", {"GSR_NO_USED_FLAGS": "1"})):    # every record written and read (the per-Gaussian used flags ignored)
         e = dict(os.environ)
         e.update(env)
         out = tmp_path / (name + ".npz")
@@ -1036,6 +1037,7 @@ def test_pair_fusion_and_static_launch_variants(dev, tmp_path):
     for k in d.files:
         assert np.array_equal(d[k], st[k]), ("static", k)
         assert np.array_equal(d[k], outs["counted"][k]), ("counted", k)   # same lists, same record slots: bit-identical
+        assert np.array_equal(d[k], outs["no_used"][k]), ("no_used", k)   # the flags only remove records that are all zeros
     assert np.array_equal(d["im"], n["im"]) and np.array_equal(d["dep"], n["dep"])
     assert float(np.abs(d["im"][1] - d["im"][0]).max()) > 0.1            # different colours and background
     for k in d.files:
