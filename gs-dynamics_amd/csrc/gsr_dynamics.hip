@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
     const bool have = i < N;
     px[q] = have ? pos[3 * i] : 0.f; py[q] = have ? pos[3 * i + 1] : 0.f; pz[q] = have ? pos[3 * i + 2] : 0.f;
     sa[3 * i] = px[q]; sa[3 * i + 1] = py[q]; sa[3 * i + 2] = pz[q];
-    mind[q] = __builtin_inff();
+    mind[q] = have ? __builtin_inff() : -1.0f;      // a slot beyond N never beats `best` (>= -1): the pick loop needs no bounds test
   }
   __syncthreads();
   int cur = start;
@@ -192,13 +192,10 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
     int besti = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int i = 16 * lane + q;
-      if (i < N) {
-        const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        mind[q] = fminf(mind[q], d);
-        if (mind[q] > best) { best = mind[q]; besti = i; }      // ascending i: the lane's first maximum
-      }
+      const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      mind[q] = fminf(mind[q], d);
+      if (mind[q] > best) { best = mind[q]; besti = 16 * lane + q; }      // ascending index: the lane's first maximum
     }
     float m = fmaxf(best, 0.0f);
     m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
     const int i = 2 * lane + q;
     const bool mine = i < npoints;
     qx[q] = mine ? sp[3 * i] : 0.f; qy[q] = mine ? sp[3 * i + 1] : 0.f; qz[q] = mine ? sp[3 * i + 2] : 0.f;
-    dist[q] = __builtin_inff();
+    dist[q] = mine ? __builtin_inff() : -1.0f;       // (as above)
   }
   int kept = 0, nxt = thin_start;
   for (int it = 0; it < npoints; ++it) {
@@ -226,12 +223,9 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
     int besti = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int i = 2 * lane + q;
-      if (i < npoints) {
-        const float dx = qx[q] - nx, dy = qy[q] - ny, dz = qz[q] - nz;
-        dist[q] = fminf(dist[q], __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))));
-        if (dist[q] > best) { best = dist[q]; besti = i; }
-      }
+      const float dx = qx[q] - nx, dy = qy[q] - ny, dz = qz[q] - nz;
+      dist[q] = fminf(dist[q], __fsqrt_rn(__fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)))));
+      if (dist[q] > best) { best = dist[q]; besti = 2 * lane + q; }
     }
     float m = fmaxf(best, 0.0f);
     m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
@@ -427,18 +421,27 @@ __global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __res
 
 // ---------------------------------------------------------------- linear blend skinning of the Gaussians
 #define LBS_CHUNK 256   // bones staged per LDS round
+// Round 4: two Gaussians per thread (every broadcast LDS read of a bone serves both) and the inverse distance from v_rsq_f32 (<= 1 ulp;
+// the reference's cdist + division are not bit-defined either) instead of a correctly rounded sqrt and a correctly rounded division,
+// which were 20 of the ~45 instructions per (Gaussian, bone) pair: 65 -> 45 us for 500 k Gaussians x 85 bones.
+#define LBS_PER_THREAD 2
 __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const float* __restrict__ bones,
                                                         const float* __restrict__ R, const float* __restrict__ t,
                                                         const float* __restrict__ bq, const float* xyz,
                                                         const float* quat, float* out_xyz,
-                                                        float* out_quat, const int* __restrict__ nb_valid) {   // out_* may BE xyz / quat (a thread reads its Gaussian, then writes it)
+                                                        float* out_quat, const int* __restrict__ nb_valid) {   // out_* may BE xyz / quat (a thread reads its Gaussians, then writes them)
   __shared__ float sB[LBS_CHUNK][3], sR[LBS_CHUNK][9], sT[LBS_CHUNK][3], sQ[LBS_CHUNK][4];
   if (nb_valid) nb = min(nb, *nb_valid);      // fixed-shape callers: only the first *nb_valid bones are real
-  const int p = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  const bool live = p < P;
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (live) { x = xyz[3 * p]; y = xyz[3 * p + 1]; z = xyz[3 * p + 2]; }
-  float ws = 0.f, ax = 0.f, ay = 0.f, az = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  const int p0 = blockIdx.x * (GSR_BLOCK * LBS_PER_THREAD) + threadIdx.x;      // Gaussians p0 and p0 + GSR_BLOCK: coalesced either way
+  float x[LBS_PER_THREAD], y[LBS_PER_THREAD], z[LBS_PER_THREAD];
+  float ws[LBS_PER_THREAD], ax[LBS_PER_THREAD], ay[LBS_PER_THREAD], az[LBS_PER_THREAD], q0[LBS_PER_THREAD], q1[LBS_PER_THREAD], q2[LBS_PER_THREAD], q3[LBS_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < LBS_PER_THREAD; ++u) {
+    const int p = p0 + u * GSR_BLOCK;
+    const bool live = p < P;
+    x[u] = live ? xyz[3 * p] : 0.f; y[u] = live ? xyz[3 * p + 1] : 0.f; z[u] = live ? xyz[3 * p + 2] : 0.f;
+    ws[u] = ax[u] = ay[u] = az[u] = q0[u] = q1[u] = q2[u] = q3[u] = 0.f;
+  }
   for (int b0 = 0; b0 < nb; b0 += LBS_CHUNK) {
     const int n = min(LBS_CHUNK, nb - b0);
     __syncthreads();
@@ -447,26 +450,37 @@ __global__ __launch_bounds__(GSR_BLOCK) void lbs_kernel(int P, int nb, const flo
     for (int i = threadIdx.x; i < n * 4; i += GSR_BLOCK) (&sQ[0][0])[i] = bq[4 * b0 + i];
     __syncthreads();
     for (int b = 0; b < n; ++b) {   // every lane reads the same LDS address: broadcast, conflict-free
-      const float dx = x - sB[b][0], dy = y - sB[b][1], dz = z - sB[b][2];
-      const float w = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-4f);
-      ws += w;
-      ax += w * (sR[b][0] * dx + sR[b][1] * dy + sR[b][2] * dz + sT[b][0] + sB[b][0]);
-      ay += w * (sR[b][3] * dx + sR[b][4] * dy + sR[b][5] * dz + sT[b][1] + sB[b][1]);
-      az += w * (sR[b][6] * dx + sR[b][7] * dy + sR[b][8] * dz + sT[b][2] + sB[b][2]);
-      q0 += w * sQ[b][0]; q1 += w * sQ[b][1]; q2 += w * sQ[b][2]; q3 += w * sQ[b][3];
+      const float bx = sB[b][0], by = sB[b][1], bz = sB[b][2];
+      const float r0 = sR[b][0], r1 = sR[b][1], r2 = sR[b][2], r3 = sR[b][3], r4 = sR[b][4], r5 = sR[b][5], r6 = sR[b][6], r7 = sR[b][7], r8 = sR[b][8];
+      const float tx = sT[b][0], ty = sT[b][1], tz = sT[b][2];
+      const float c0 = sQ[b][0], c1 = sQ[b][1], c2 = sQ[b][2], c3 = sQ[b][3];
+#pragma unroll
+      for (int u = 0; u < LBS_PER_THREAD; ++u) {
+        const float dx = x[u] - bx, dy = y[u] - by, dz = z[u] - bz;
+        const float w = fminf(__builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz), 1e4f);      // = 1 / max(distance, 1e-4)
+        ws[u] += w;
+        ax[u] += w * (r0 * dx + r1 * dy + r2 * dz + tx + bx);
+        ay[u] += w * (r3 * dx + r4 * dy + r5 * dz + ty + by);
+        az[u] += w * (r6 * dx + r7 * dy + r8 * dz + tz + bz);
+        q0[u] += w * c0; q1[u] += w * c1; q2[u] += w * c2; q3[u] += w * c3;
+      }
     }
   }
-  if (!live) return;
-  const float inv = 1.0f / ws;
-  out_xyz[3 * p] = ax * inv; out_xyz[3 * p + 1] = ay * inv; out_xyz[3 * p + 2] = az * inv;
-  if (quat && out_quat) {
-    const float qn = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);   // F.normalize's eps
-    const float a0 = q0 / qn, a1 = q1 / qn, a2 = q2 / qn, a3 = q3 / qn;
-    const float b0 = quat[4 * p], b1 = quat[4 * p + 1], b2 = quat[4 * p + 2], b3 = quat[4 * p + 3];
-    out_quat[4 * p + 0] = a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3;
-    out_quat[4 * p + 1] = a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2;
-    out_quat[4 * p + 2] = a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1;
-    out_quat[4 * p + 3] = a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0;
+#pragma unroll
+  for (int u = 0; u < LBS_PER_THREAD; ++u) {
+    const int p = p0 + u * GSR_BLOCK;
+    if (p >= P) continue;
+    const float inv = 1.0f / ws[u];
+    out_xyz[3 * p] = ax[u] * inv; out_xyz[3 * p + 1] = ay[u] * inv; out_xyz[3 * p + 2] = az[u] * inv;
+    if (quat && out_quat) {
+      const float qn = fmaxf(sqrtf(q0[u] * q0[u] + q1[u] * q1[u] + q2[u] * q2[u] + q3[u] * q3[u]), 1e-12f);   // F.normalize's eps
+      const float a0 = q0[u] / qn, a1 = q1[u] / qn, a2 = q2[u] / qn, a3 = q3[u] / qn;
+      const float b0 = quat[4 * p], b1 = quat[4 * p + 1], b2 = quat[4 * p + 2], b3 = quat[4 * p + 3];
+      out_quat[4 * p + 0] = a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3;
+      out_quat[4 * p + 1] = a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2;
+      out_quat[4 * p + 2] = a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1;
+      out_quat[4 * p + 3] = a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0;
+    }
   }
 }
 
@@ -676,7 +690,7 @@ int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const floa
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st, const int* nb_valid) {
   if (P <= 0) return 0;
   { GSR_PROF("lbs", st);
-    hipLaunchKernelGGL(lbs_kernel, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, nb, bones, R, t, bq, xyz, quat,
+    hipLaunchKernelGGL(lbs_kernel, dim3((P + GSR_BLOCK * LBS_PER_THREAD - 1) / (GSR_BLOCK * LBS_PER_THREAD)), dim3(GSR_BLOCK), 0, st, P, nb, bones, R, t, bq, xyz, quat,
                        out_xyz, out_quat, nb_valid); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
