@@ -253,13 +253,21 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
 // issued ~30 k instructions from two waves: 96 us of the 0.8 ms rollout step; this one 6 us.)
 #define CE_THREADS 1024
 #define CE_MAXK 16
+// wave minimum of 64-bit keys, the same value in every lane: six DPP steps (both halves moved with the same control; lanes a step does
+// not reach read the identity ~0) leave it in lane 63, two readlanes broadcast it -- the butterfly of 64-bit __shfl_xor it replaces was
+// twelve ds_bpermute round trips per minimum, five minima per receiver.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned long long ce_dpp_min(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o < v ? o : v;
+}
 __device__ __forceinline__ unsigned long long ce_wave_min(unsigned long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const unsigned long long o = __shfl_xor(v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+  v = ce_dpp_min<0xB1>(v); v = ce_dpp_min<0x4E>(v); v = ce_dpp_min<0x141>(v); v = ce_dpp_min<0x140>(v);
+  v = ce_dpp_min<0x142, 0xA>(v); v = ce_dpp_min<0x143, 0xC>(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 __global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float* __restrict__ pos, int n_obj_cap, const int* __restrict__ n_valid_p,
                                                                    float thr2, int topk, long long dummy, int e_cap,
@@ -613,12 +621,55 @@ __device__ __forceinline__ void mat2quat_unit(const float* m, float* q) {
 __global__ __launch_bounds__(64) void fit_bones_kernel(int nb, const float* __restrict__ bones, const float* __restrict__ motions,
                                                        const long long* __restrict__ rel, long long rel_stride,
                                                        float* __restrict__ R, float* __restrict__ quat, int* __restrict__ code) {
+  // Round 4: the wave first turns its 64 rows of the relation matrix into bit masks with COALESCED loads (lane = column, a ballot per
+  // row half) and keeps the bones' positions in LDS; a thread then walks only its bone's set bits, in ascending order -- the same
+  // sums in the same order as the row walk it replaces (100 dependent 8-byte loads per thread at a row stride: 32 us for 100 bones).
+  __shared__ unsigned long long s_rel[64][2];
+  __shared__ float s_bone[128 * 3], s_mot[128 * 3];
+  const bool masks = nb <= 128;
+  if (masks) {
+    const int lane = threadIdx.x, b0 = blockIdx.x * 64;
+    for (int i = lane; i < nb * 3; i += 64) { s_bone[i] = bones[i]; s_mot[i] = motions[i]; }
+    const int c0 = min(lane, nb - 1), c1 = min(lane + 64, nb - 1);       // (clamped: every load is in range, the ballots mask the rest)
+    for (int r0 = 0; r0 < 64; r0 += 8) {        // eight rows' loads in flight, then their ballots
+      long long v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t row = (size_t)min(b0 + r0 + u, nb - 1) * rel_stride;
+        v0[u] = rel[row + c0]; v1[u] = rel[row + c1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool in = b0 + r0 + u < nb;
+        const unsigned long long m0 = __ballot(in && lane < nb && v0[u] != 0), m1 = __ballot(in && lane + 64 < nb && v1[u] != 0);
+        if (lane == 0) { s_rel[r0 + u][0] = m0; s_rel[r0 + u][1] = m1; }
+      }
+    }
+    __syncthreads();
+  }
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nb) return;
   const float bx = bones[3 * b], by = bones[3 * b + 1], bz = bones[3 * b + 2];
   const float nx = __fadd_rn(bx, motions[3 * b]), ny = __fadd_rn(by, motions[3 * b + 1]), nz = __fadd_rn(bz, motions[3 * b + 2]);
   float F[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int n = 0;
+  if (masks) {
+    for (int h = 0; h < 2; ++h) {
+      unsigned long long m = s_rel[threadIdx.x][h];
+      while (m) {
+        const int j = 64 * h + __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        ++n;
+        const float jx = s_bone[3 * j], jy = s_bone[3 * j + 1], jz = s_bone[3 * j + 2];
+        const float ox = __fsub_rn(jx, bx), oy = __fsub_rn(jy, by), oz = __fsub_rn(jz, bz);
+        const float wx = __fsub_rn(__fadd_rn(jx, s_mot[3 * j]), nx), wy = __fsub_rn(__fadd_rn(jy, s_mot[3 * j + 1]), ny),
+                    wz = __fsub_rn(__fadd_rn(jz, s_mot[3 * j + 2]), nz);
+        F[0] = __fadd_rn(F[0], __fmul_rn(wx, ox)); F[1] = __fadd_rn(F[1], __fmul_rn(wx, oy)); F[2] = __fadd_rn(F[2], __fmul_rn(wx, oz));
+        F[3] = __fadd_rn(F[3], __fmul_rn(wy, ox)); F[4] = __fadd_rn(F[4], __fmul_rn(wy, oy)); F[5] = __fadd_rn(F[5], __fmul_rn(wy, oz));
+        F[6] = __fadd_rn(F[6], __fmul_rn(wz, ox)); F[7] = __fadd_rn(F[7], __fmul_rn(wz, oy)); F[8] = __fadd_rn(F[8], __fmul_rn(wz, oz));
+      }
+    }
+  } else
   for (int j = 0; j < nb; ++j) {
     if (rel[(size_t)b * rel_stride + j] == 0) continue;
     ++n;

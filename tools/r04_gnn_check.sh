@@ -1,6 +1,6 @@
 #!/bin/bash
 # the one-launch propagation network: dynamics GPU tests, then the rollout step traced per kernel with and without it
-O=$PWD/gpurun_out/r04t; mkdir -p $O
+O=$PWD/gpurun_out/r04z; mkdir -p $O
 ( timeout 900 python -m pytest tests/test_dynamics_gpu.py -m gpu -x -q -s 2>&1 | tail -15 ) > $O/pytest.log 2>&1; cat $O/pytest.log
 for cfg in "GSDYN_GNN_SPLIT=1" "GSDYN_GNN_SPLIT=0" "GSDYN_GNN_FUSED=1" "GSDYN_GNN_SPLIT=1"; do
   echo "$cfg: $(env $cfg timeout 300 python tools/rollout_graph_loop.py 2>&1 | tail -1)"
