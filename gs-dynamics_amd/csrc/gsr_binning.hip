@@ -1102,6 +1102,7 @@ __device__ __forceinline__ void wave_sort_step(uint64_t (&x)[NR], int lane) {
 }
 template <int LK, int NR>
 __device__ __forceinline__ void wave_sort_stage(uint64_t (&x)[NR], int lane) {   // merge size k = 2^LK
+  static_assert(LK <= 11, "the half-cleaner steps below stop at stride 512");
   wave_sort_step<(1 << LK) - 1, NR>(x, lane);
   if constexpr (LK >= 11) wave_sort_step<512, NR>(x, lane);
   if constexpr (LK >= 10) wave_sort_step<256, NR>(x, lane);
@@ -1226,7 +1227,7 @@ __device__ __forceinline__ int tile_radix_sort(TileSortLds<RCAP, NW>& L, uint32_
 // RCAP = 4096 build.  So that build launches twice: MODE 2 = the wave tickets alone in a kernel WITHOUT any LDS (6 waves per SIMD, the
 // register limit), MODE 1 = the long tickets alone.
 template <int RCAP, int NW>
-__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur);
+__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur, uint32_t ticket);
 
 // NW: waves per workgroup (4; the MODE 1 launch of the RCAP = 4096 build runs 16: a long list is sorted by 1024 threads -- the LDS
 // block allows two such workgroups per CU either way, with 4 waves each that is 2 waves per SIMD working through 5 barriers per pass)
@@ -1273,18 +1274,26 @@ __global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES
     else wave_sort_tile<16>(seg, out, n, tid & 63);
     return;
   }
-  if constexpr (MODE != 2) {
-    if (blockIdx.x >= n_long) return;            // MODE 1: the wave tickets have their own launch
-    tile_sort_long_ticket<RCAP, NW>(tab, cur);
+  if constexpr (MODE == 1) {
+    // the wave tickets have their own launch; this one STRIDES over the long tickets with a grid that fits the chip once (round 4: it
+    // used to be one workgroup per tile of the call -- 32 640 workgroups of 36 KiB of LDS for a configs[4] frame, four resident per
+    // CU, nearly all of them returning at once: 110 - 600 us of dispatch for a handful of lists)
+    for (uint32_t ticket = blockIdx.x; ticket < n_long; ticket += gridDim.x) {
+      tile_sort_long_ticket<RCAP, NW>(tab, cur, ticket);
+      __syncthreads();                           // the LDS block is the next ticket's
+    }
+  } else if constexpr (MODE != 2) {
+    if (blockIdx.x >= n_long) return;
+    tile_sort_long_ticket<RCAP, NW>(tab, cur, blockIdx.x);
   }
 }
 
 template <int RCAP, int NW>
-__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur) {
+__device__ __forceinline__ void tile_sort_long_ticket(const GsrBinViews& tab, int cur, uint32_t ticket) {
   __shared__ TileSortLds<RCAP, NW> L;
   constexpr uint32_t NT = 64 * NW;
   const int tid = threadIdx.x;
-  const uint4 ord = tab.order[blockIdx.x];     // longest lists are dispatched first
+  const uint4 ord = tab.order[ticket];         // longest lists are dispatched first
   const GsrBinView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];
   if (vw.shares_lists) return;
   uint64_t* __restrict__ dg = vw.dg[cur];
@@ -1537,13 +1546,23 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     if (big) {  // long lists on average: the big-LDS build for the long tickets, the wave tickets in a launch of their own
       hipLaunchKernelGGL((tile_sort_kernel<2048, 2>), dim3((tab.V * tab.T + 3) / 4), dim3(GSR_BLOCK), 0, st, tab, cur);
       if (tab.wave_cap == 2048) hipLaunchKernelGGL((tile_sort_kernel<2048, 3>), dim3((tab.V * tab.T + 3) / 4), dim3(GSR_BLOCK), 0, st, tab, cur);
-      // Long tickets: measured at configs[4] size (500 k Gaussians, 1080p x 4 cameras; tile_sort us per frame, same box): 4096-entry LDS
-      // block with 4 / 8 / 16 waves per workgroup 507 / 429 / 733, 2048-entry block with 4 / 8 waves 309 / 349 -- workgroups per CU
-      // (36 KiB: four) count for more than lists of 2049 .. 4096 entries taking the LDS network instead of the radix sort.
+      // Long tickets (lists above 2032 entries).  Round 4: (i) the launch STRIDES over them with a grid that fits the chip once -- it used to
+      // be one workgroup per tile of the call (32 640 workgroups of 36 - 68 KiB of LDS for a configs[4] frame, nearly all returning at
+      // once), and that dispatch, not the sorting, was what made the 4096-entry block look slow in round 3 (507 vs 309 us); (ii) the
+      // 4096-entry block is the default: radix sort in LDS up to 4096 entries, 64-bit network in LDS up to 8192.  A deforming configs[4]
+      // episode has thousands of lists of 2033 .. 7000 entries per frame; with the 2048-entry block those ran the LDS network (<= 4096)
+      // or the network in GLOBAL memory (above): tile_sort 1040 us per frame of the episode, now ~450; its renders 1.67 -> 1.14 ms per
+      // frame.  GSR_LONG_SORT=2048 keeps the small block.  (One wave per list with 64 keys per lane -- 192 VGPRs, 116 us per list -- was
+      // measured too: slower than either.)
       const char* ls = getenv("GSR_LONG_SORT");      // (read per call: the tests switch builds inside one process)
-      const bool old_long = ls && ls[0] == '4';
-      if (old_long) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(tab.V * tab.T), dim3(256), 0, st, tab, cur);
-      else hipLaunchKernelGGL((tile_sort_kernel<2048, 1, 4>), dim3(tab.V * tab.T), dim3(256), 0, st, tab, cur);
+      const bool small_block = ls && ls[0] == '2';
+      if (small_block) {
+        const int g1 = tab.V * tab.T < 1024 ? tab.V * tab.T : 1024;      // four workgroups of the 36 KiB block per CU
+        hipLaunchKernelGGL((tile_sort_kernel<2048, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
+      } else {
+        const int g1 = tab.V * tab.T < 512 ? tab.V * tab.T : 512;        // two of the 68 KiB block
+        hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
+      }
     } else
       {
         // ordinary scenes: the 1024-entry LDS block (20 KiB: eight workgroups per CU -- the wave-sorted lists are the bulk of the work

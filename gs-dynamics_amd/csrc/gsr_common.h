@@ -245,7 +245,7 @@ struct GsrBinView {            // emit .. tile_sort
 struct GsrBinViews {
   int V, T, gx; uint4* order; uint32_t* queue;
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
-  int wave_cap;                  // tile_sort: lists up to this length (512 / 1024) are sorted by one wave each (set by gsr_launch_binning)
+  int wave_cap;                  // tile_sort: lists up to this length (512 / 1024 / 2048) are sorted by one wave each (set by gsr_launch_binning)
   int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
   int counted;                   // 1: the rows were counted by the preprocess launch (preprocess_fwd_count_kernel): no bin_count launch;
                                  //    bin_scan publishes the views' entry counts (offsets[P]) and bin_emit scans tiles_touched into offsets[]

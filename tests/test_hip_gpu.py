@@ -244,10 +244,10 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
 def _pin_tile_sort_build(monkeypatch, rcap):
     """The builds of tile_sort (gsr_launch_binning): "1024" = the default for ordinary scenes (one launch, 20 KiB LDS block), "2048" = the
     36 KiB block, "4096" = the dense-scene form (wave tickets in a launch without LDS + long tickets with the 2048-entry block),
-    "4096L" = the same with the long tickets on the 4096-entry block."""
+    "4096L" = the same with the long tickets on the 4096-entry block (the default of the dense-scene form since round 4)."""
     monkeypatch.setenv("GSR_TILE_SORT_RCAP", {"1024": "1", "2048": "2048", "4096": "4096", "4096L": "4096"}[rcap])
-    if rcap == "4096L":
-        monkeypatch.setenv("GSR_LONG_SORT", "4096")
+    if rcap == "4096":
+        monkeypatch.setenv("GSR_LONG_SORT", "2048")       # the 2048-entry block for the long tickets (the default until round 4)
     else:
         monkeypatch.delenv("GSR_LONG_SORT", raising=False)
 
