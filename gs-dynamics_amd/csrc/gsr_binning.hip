@@ -1561,7 +1561,10 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
         hipLaunchKernelGGL((tile_sort_kernel<2048, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
       } else {
         const int g1 = tab.V * tab.T < 512 ? tab.V * tab.T : 512;        // two of the 68 KiB block
-        hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
+        static const int lw = [] { const char* e = getenv("GSR_LONG_SORT_WAVES"); return e ? atoi(e) : 8; }();     // waves per workgroup: render of the configs[4] episode 1.12 (4) / 1.00 (8) / 1.11 (16) ms per frame
+        if (lw == 8) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 8>), dim3(g1), dim3(512), 0, st, tab, cur);
+        else if (lw == 16) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 16>), dim3(g1), dim3(1024), 0, st, tab, cur);
+        else hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
       }
     } else
       {
