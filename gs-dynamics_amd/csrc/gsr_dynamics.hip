@@ -392,11 +392,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __res
     }
     // distances are >= 0, so their bit patterns order like the values; ~index makes the smaller index the larger key
     unsigned long long key = best < 0.0f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)(~(uint32_t)besti));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const unsigned long long o = (unsigned long long)__shfl_xor((long long)key, off, 64);
-      key = o > key ? o : key;
-    }
+    key = ~ce_wave_min(~key);        // wave maximum on DPP (six steps + two readlanes; the 64-bit shuffle butterfly was twelve ds_bpermute trips)
     if (lane == 0) s_key[wv] = key;
     __syncthreads();
     if (wv == 0) {
@@ -415,11 +411,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __res
         } while (__ballot(v == 0ull) != 0ull);
         if (mine) win = v > win ? v : win;
       }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long o = (unsigned long long)__shfl_xor((long long)win, off, 64);
-        win = o > win ? o : win;
-      }
+      win = ~ce_wave_min(~win);
       if (lane == 0) s_cur = (int)(~(uint32_t)win);
     }
     __syncthreads();
