@@ -335,11 +335,10 @@ class DynamicsPredictor(nn.Module):
         pe = self.particle_encoder(p_in)
         re = self.relation_encoder(rel_in)
         Wr, Wp = self.relation_propagator.linear.weight, self.particle_propagator.linear.weight       # [H, 3H], [H, 2H]
-        key = (Wr.data_ptr(), Wr._version)
-        ent = self.__dict__.get("_split_w")
-        if ent is None or ent[0] != key:
-            ent = self.__dict__["_split_w"] = (key, torch.cat([Wr[:, H:2 * H].t(), Wr[:, 2 * H:].t()], 1).contiguous())   # [H, 2H]: effect @ . = (a2 | a3)
-        w23 = ent[1]
+        # [H, 2H]: effect @ . = (a2 | a3).  Re-materialised from the LIVE weight on every call (one small kernel): a cached copy would be
+        # baked into a captured graph and survive an in-place weight update (load_state_dict, an optimiser step) that the graph's other
+        # products pick up -- ADVICE r04.
+        w23 = torch.cat([Wr[:, H:2 * H].t(), Wr[:, 2 * H:].t()], 1)
         rew1 = torch.addmm(self.relation_propagator.linear.bias, re, Wr[:, :H].t())
         pewp = torch.addmm(self.particle_propagator.linear.bias, pe, Wp[:, :H].t())
         wp2t = Wp[:, H:].t()
