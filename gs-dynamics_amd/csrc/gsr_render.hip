@@ -1040,43 +1040,45 @@ __global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == BWD_SMALL_BB) ? BWD_SM
 
 
 // ------------------------------------------------------------------------------------------ backward, producer / consumer form (round 5)
-// What the ablation builds of round 5 showed (profiles/r05_ablation.txt, 4 views): render_bwd 213 us; with the replay loop walking
-// NOTHING 94 us; with the wave reduction replaced by eight adds 150 us.  The staging / barrier / combine skeleton of bwd_tile costs as
-// much as the visits' arithmetic, and the four waves of a workgroup meet at four barriers per batch with unequal quad lists.
+// What round 5 measured first (profiles/r05_ablation.txt, r05_visit_peak.txt; 4 views): render_bwd 213 us; with the replay loop walking
+// NOTHING 94 us; the visit body alone (LDS-resident entries, no staging, no barriers) peaks at 98 - 104 ns per visit per SIMD with 6 - 8
+// waves, i.e. ~140 us for this launch's 1.39 M visits.  The staging / barrier / combine skeleton of bwd_tile and the four-barriers-per-batch
+// lockstep of unequal quad lists cost the difference.
 //
-// Here the roles are split between the waves of one workgroup:
-//   waves 0 - 3        CONSUMERS: wave q replays quad q of every tile the workgroup works on; it only ever waits for a published batch
-//                                 (and loads the next tile's per-pixel values while it still replays the current one)
-//   waves 4 .. 3 + K   STAGERS:   a tile's list is walked back to front in chunks of 64 positions; chunk G (counted over the workgroup's
-//                                 whole run) belongs to stager G mod K, which loads its contribution bytes, keeps the entries some quad
-//                                 blended (the useful-entry compaction of item 1a), gathers their records ONCE per tile -- K chunks'
-//                                 dependent memory trips in flight -- and then, when it is chunk G's TURN, appends them + four per-quad
-//                                 offset lists to a ring of batches in LDS.  (With one stager the consumers waited for batches 65 % of
-//                                 their time: profiles/r05_pc_phase_timing.txt.)  Stager 0 also pops the tickets, one tile ahead.
-//   last wave          COMBINER:  when all four consumers are through a batch, adds the per-quad totals of every entry and stores its
-//                                 record; in its idle time it zero-fills the records of unreached entries of used Gaussians
-// Hand-offs are sequence counters in LDS polled with s_sleep: no workgroup barrier anywhere.  A consumer runs up to PC_R batches ahead of
-// the slowest quad, across tile boundaries, so quad imbalance averages over the ring instead of being paid per batch.  Per visit the
-// arithmetic and its order are bwd_tile's, and so is the order in which the combine adds the quads: records bit-identical to the barrier form's.
+// Here the roles are split between the five waves of a 320-thread workgroup:
+//   waves 0 - 3  CONSUMERS: wave q replays quad q of every tile the workgroup works on; it only ever waits for a published batch, and
+//                           loads the next tile's per-pixel values while it still replays the current one.  The consumer that arrives LAST
+//                           at the end of a batch (an LDS counter) adds the per-quad totals of the batch's entries and stores their records.
+//   wave 4       STAGER:    pops the tickets, walks a tile's list back to front in chunks of 64 positions (the next chunk's list words are
+//                           in flight while this one's records are gathered), keeps the entries some quad blended (the forward's
+//                           contribution bytes: the useful-entry compaction of item 1a), gathers their records ONCE per tile, appends them
+//                           + four per-quad offset lists to a ring of batches in LDS, and zero-fills the records of unreached entries of
+//                           used Gaussians while the next ticket's atomic is in flight
+// Hand-offs are words in LDS polled with s_sleep: no workgroup barrier anywhere.  A consumer runs up to PC_R batches ahead of the slowest
+// quad, across tile boundaries, so quad imbalance averages over the ring instead of being paid per batch.  24.9 KB of LDS and 5 waves per
+// workgroup: SIX workgroups per CU = 24 replaying waves.  Per visit the arithmetic and its order are bwd_tile's, and so is the order in
+// which the combine adds the quads: the records are bit-identical to the barrier form's (tools/r05_pc_check.sh).
 #ifndef PC_BB
-#define PC_BB 64          // entries per batch (one per stager lane)
+#define PC_BB 40          // entries per batch
 #endif
 #ifndef PC_R
 #define PC_R 3            // batches in the ring
 #endif
-#ifndef PC_K
-#define PC_K 3            // stager waves
-#endif
-#define PC_WAVES (4 + PC_K + 1)
+#define PC_WAVES 5
 #define PC_THREADS (64 * PC_WAVES)
 #define PC_ENT_BYTES 48
 #define PC_FLAG_FIRST 1u
 #define PC_FLAG_EXIT 2u
-#ifndef PC_POLL_SLEEP
-#define PC_POLL_SLEEP 4
+#ifndef PC_CONS_PRIO
+#define PC_CONS_PRIO 1
 #endif
-#define PC_TK 8           // ring of known tickets (stager 0 runs at most PC_TK - 2 tiles ahead of the slowest stager)
-#define PC_ZF 8           // ring of tiles whose unreached entries await their zeros
+#ifndef PC_POP_EARLY
+#define PC_POP_EARLY 0
+#endif
+#ifndef PC_POLL_SLEEP
+#define PC_POLL_SLEEP 2   // x 64 clocks between two polls of a hand-off word
+#endif
+static_assert(PC_BB >= 32 && PC_BB <= 64, "a half chunk (32 entries) must fit one batch; the combine is one lane per entry");
 struct alignas(16) PcSlot {
   float4 ent[PC_BB][3];              // {mx, my, A', B'} {C', opacity, r, g} {b, bits(list position), bits(byte offset of the entry's totals: 36 j), 0}
   float red[4][PC_BB][9];            // per quad and batch index: the nine wave totals
@@ -1091,45 +1093,41 @@ struct alignas(16) PcLds {
   uint32_t flags[PC_R];              //   PC_FLAG_*,
   uint32_t tile[PC_R];               //   tile id and
   uint32_t view[PC_R];               //   view index of the batch's tile
-  // ---- control words (zeroed at kernel start: ctl0 .. ctl_end)
+  // ---- control words (zeroed at kernel start: prod_seq .. ctl_end)
   uint32_t prod_seq;                 // batches published (= number of the open batch)
-  uint32_t cons_seq[4];              // batches finished by consumer q
-  uint32_t comb_seq;                 // batches retired by the combiner (their ring slot is free)
+  uint32_t arrive[PC_R];             // consumers through the batch in this slot: the fourth one combines it
+  uint32_t retired[PC_R];            // number + 1 of the last batch retired from this slot (its records are on their way: the slot is free)
   uint32_t abort;                    // a wait timed out (protocol bug): everybody leaves
-  uint32_t turn;                     // the chunk (global index) that may append to the stream
-  uint32_t st_fill, st_first;        // stream state, owned by the turn holder: entries in the open batch, "the open batch starts a tile"
-  uint32_t st_cq[4];                 //   and its per-quad list lengths
-  uint32_t tk_seq;                   // tickets known: tk[i % PC_TK] is the ticket of the workgroup's i-th tile for i < tk_seq
-  uint32_t sg_tile[PC_K];            // tile index each stager works on
-  uint32_t zf_tail, zf_head;         // zero-fill jobs written / done
   uint32_t ctl_end;
-  uint32_t tk[PC_TK];
-  uint32_t zf[PC_ZF][5];             // {list start, entries, first unreached position, view, tile}
 };
 
 __device__ uint32_t g_pc_error;     // != 0: some wait of the producer / consumer backward ran out of patience (see pc_wait_gt); read by gsr_debug_pc_error
 __device__ __forceinline__ uint32_t pc_peek(const uint32_t* p) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
-// Until *p > v (an LDS word written by another wave of the workgroup).  BOUNDED: a wait that outlasts ~2^21 polls (tens of milliseconds;
-// a batch takes microseconds) can only be a protocol bug -- it raises the workgroup's abort word, which ends every other wait at once,
-// and the device error word; the kernel then drains instead of hanging the GPU.  -> false: aborted
+// Until *p > v (an LDS word written by another wave of the workgroup).  A poll costs the SIMD a handful of issue slots: the wave sleeps
+// PC_POLL_SLEEP x 64 clocks between polls, at priority 0, so that waiting waves stay out of the replaying waves' way.  BOUNDED: a wait that
+// outlasts ~2^19 polls (tens of milliseconds; a batch takes microseconds) can only be a protocol bug -- it raises the workgroup's abort
+// word, which ends every other wait at once, and the device error word; the kernel then drains instead of hanging the GPU.  -> false: aborted
+template <int PRIO_AFTER>
 __device__ __forceinline__ bool pc_wait_gt(const uint32_t* p, uint32_t v, uint32_t* abort_word) {
+  if (pc_peek(p) > v) { asm volatile("" ::: "memory"); return true; }
+  if (PRIO_AFTER) __builtin_amdgcn_s_setprio(0);
   uint32_t spins = 0;
+  bool ok = true;
   while (pc_peek(p) <= v) {
-    // a poll costs the SIMD a handful of issue slots: sleep long enough that a workgroup's waiting waves stay out of the replaying
-    // waves' way (PC_POLL_SLEEP x 64 clocks; a batch lasts thousands)
     __builtin_amdgcn_s_sleep(PC_POLL_SLEEP);
     if ((++spins & 255u) == 0u) {
-      if (pc_peek(abort_word) != 0u) return false;
+      if (pc_peek(abort_word) != 0u) { ok = false; break; }
       if (spins >= (1u << 19)) {
         if (gsr_lane() == 0) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicExch(&g_pc_error, 1u); }
-        return false;
+        ok = false; break;
       }
     }
   }
+  if (PRIO_AFTER) __builtin_amdgcn_s_setprio(PRIO_AFTER);
   asm volatile("" ::: "memory");
-  return true;
+  return ok;
 }
 // LDS operations of one wave are performed in order: once this wave's earlier DS operations are done (lgkmcnt 0), a flag store is seen
 // by the other waves after them
@@ -1139,13 +1137,13 @@ __device__ __forceinline__ void pc_publish(uint32_t* p, uint32_t v) {
 }
 #ifdef GSR_TILE_TIMING
 __device__ unsigned long long g_pc_start[2048];
-// phase clocks of the producer / consumer backward (debug build): g_bwd_timing[0..3] consumer 0 {waiting for a batch, tile head, visits, -},
-// [4..7] stager 0 {waiting (tickets, turn, ring slot), tile start chain, chunk loads + gathers, appending}, [8..10] combiner {waiting, combining, zero fill}
-// (wall_clock64: the constant 100 MHz counter -- the sums are in units of 10 ns whatever the shader clock does)
-// accumulated in registers, flushed once per wave at its exit (an atomic per phase clock would queue in front of every later load)
-#define PC_T0() unsigned long long _pt = wall_clock64(), _pa[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// phase clocks of the producer / consumer backward (debug build, wall_clock64: the constant 100 MHz counter -- sums in units of 10 ns):
+// g_bwd_timing[0..3] consumer 0 {waiting for a batch, tile head, visits, combining}, [4..8] stager {waiting for a ring slot, tile start chain,
+// chunk loads + gathers, appending, ticket + zero fill}.  Accumulated in registers, flushed once per wave at its exit (an atomic per
+// phase clock would queue in front of every later load).
+#define PC_T0() unsigned long long _pt = wall_clock64(), _pa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PC_TP(i) do { const unsigned long long _n = wall_clock64(); _pa[i] += _n - _pt; _pt = _n; } while (0)
-#define PC_TFLUSH() do { if (gsr_lane() == 0) for (int _i = 0; _i < 13; ++_i) if (_pa[_i]) atomicAdd(&g_bwd_timing[_i], _pa[_i]); } while (0)
+#define PC_TFLUSH() do { if (gsr_lane() == 0) for (int _i = 0; _i < 9; ++_i) if (_pa[_i]) atomicAdd(&g_bwd_timing[_i], _pa[_i]); } while (0)
 #else
 #define PC_T0() do {} while (0)
 #define PC_TP(i) do {} while (0)
@@ -1169,24 +1167,20 @@ __device__ __forceinline__ const uint8_t* pc_contrib(const GsrRenderView& vw) { 
 __device__ __forceinline__ const uint8_t* pc_used(const GsrRenderView& vw) { return (vw.used && vw.tracked && *vw.tracked != 0u) ? vw.used : nullptr; }
 
 template <bool COL>
-__device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab, const int k) {
+__device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab) {
   const int lane = gsr_lane();
   const uint4* __restrict__ tile_order = tab.order;
   uint32_t* __restrict__ queue = tab.queue;
   const uint32_t n_busy = queue[4];
   const int W = tab.W, H = tab.H, gx = tab.gx;
-  uint32_t gbase = 0;                        // global index of the current tile's first chunk
+  uint32_t seq = 0;                          // number of the open batch (= batches published)
+  uint32_t ticket = blockIdx.x;              // the first ticket is implicit (see render_bwd_persistent)
+  __builtin_amdgcn_s_setprio(3);             // light and on everybody's critical path (its waits drop to 0)
   PC_T0();
-  for (uint32_t ti = 0;; ++ti) {
-    if (!pc_wait_gt(&L.tk_seq, ti, &L.abort)) return;
-    const uint32_t ticket = pc_peek(&L.tk[ti % PC_TK]);
-    if (ticket >= n_busy) break;             // every stager reads the same tickets: they all leave here
-    if (k == 0) PC_TP(4);
-    const uint4 ord = tile_order[ticket];
-    uint32_t next = 0;
-    if (k == 0 && lane == 0) next = gridDim.x + atomicAdd(&queue[1], 1u);     // the next ticket, one tile ahead: its latency rides along
+  uint4 ord = make_uint4(0u, 0u, 0u, 0u);
+  if (ticket < n_busy) ord = tile_order[ticket];
+  while (ticket < n_busy) {
     const int vi = __builtin_amdgcn_readfirstlane((int)ord.w);
-    if (k == 0) PC_TP(11);
     const GsrRenderView& vw = tab.v[vi];
     const int tile = __builtin_amdgcn_readfirstlane((int)ord.x);
     const uint32_t list0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ord.y);
@@ -1210,34 +1204,44 @@ __device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab, c
       for (int msk = 32; msk >= 1; msk >>= 1) ml = max(ml, __shfl_xor(ml, msk, 64));
       max_last = __builtin_amdgcn_readfirstlane(ml);
     }
-    if (k == 0) PC_TP(12);
-    if (k == 0) {
-      // the next ticket for everybody; bounded run-ahead (a stager still on tile ti + 2 - PC_TK must not lose its ring entry)
-      if (ti + 2u >= PC_TK)
-        for (int j = 1; j < PC_K; ++j)
-          if (!pc_wait_gt(&L.sg_tile[j], ti + 2u - PC_TK, &L.abort)) return;
-      const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-      if (lane == 0) L.tk[(ti + 1u) % PC_TK] = nx;
-      pc_publish(&L.tk_seq, ti + 2u);
-      // the tile's unreached entries: a job for the combiner's idle time
-      if (max_last < n) {
-        const uint32_t zt = pc_peek(&L.zf_tail);
-        if (zt >= PC_ZF && !pc_wait_gt(&L.zf_head, zt - PC_ZF, &L.abort)) return;
-        if (lane == 0) { uint32_t* z = L.zf[zt % PC_ZF]; z[0] = list0; z[1] = (uint32_t)n; z[2] = (uint32_t)max_last; z[3] = (uint32_t)vi; z[4] = (uint32_t)tile; }
-        pc_publish(&L.zf_tail, zt + 1u);
+    // (Popping the NEXT ticket here, so that the atomic and the order entry it leads to travel while this tile is staged, was measured
+    // 15 % SLOWER (render_bwd 208 -> 241 us, 4 views): a workgroup then commits to a tile while it is still busy with another, and the
+    // launch's tail loses its balance -- what round 3 saw in the forward.)
+    uint32_t next = 0;
+#if PC_POP_EARLY
+    if (lane == 0) next = gridDim.x + atomicAdd(&queue[1], 1u);
+#endif
+    PC_TP(5);
+    int fill = 0;                            // entries in the open batch
+    uint32_t cqa[4] = {0u, 0u, 0u, 0u};      // its per-quad list lengths
+    bool first = true, aborted = false;
+    auto publish_open = [&](int nent) {      // the open batch (number seq) holds nent entries: header, sentinels, sequence counter
+      PcSlot& S = L.s[seq % PC_R];
+      const int sl = (int)(seq % PC_R);
+      if (lane < 4) {
+        const uint32_t cc = lane == 0 ? cqa[0] : lane == 1 ? cqa[1] : lane == 2 ? cqa[2] : cqa[3];
+        S.idx[lane][cc] = 0; S.idx[lane][cc + 1] = 0;
+        L.cnt[sl][lane] = cc;
       }
-    } else {
-      if (lane == 0) __hip_atomic_store(&L.sg_tile[k], ti + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) { L.n[sl] = (uint32_t)nent; L.flags[sl] = first ? PC_FLAG_FIRST : 0u; L.tile[sl] = (uint32_t)tile; L.view[sl] = (uint32_t)vi; }
+      pc_publish(&L.prod_seq, seq + 1u);
+      ++seq; first = false;
+    };
+    // ---- the walked part, back to front, 64 list positions per chunk; the entries some quad blended are appended to the batch stream
+    const int C = (max_last + 63) >> 6;
+    uint32_t ng = 0, nbyte = 0;              // list word and contribution byte of the NEXT chunk's position (in flight during this chunk's gathers)
+    if (C > 0) {
+      const int pos0 = max_last - 1 - lane;
+      if (pos0 >= 0) { ng = point_list[list0 + pos0]; nbyte = contrib ? (uint32_t)contrib[list0 + pos0] : 0xfu; }
     }
-    if (k == 0) PC_TP(5);
-    const int C = (max_last + 63) >> 6;      // chunks of the tile
-    for (int c = 0; c < C; ++c) {
-      const uint32_t G = gbase + (uint32_t)c;
-      if ((int)(G % PC_K) != k) continue;
+    for (int c = 0; c < C && !aborted; ++c) {
       const int pos = max_last - 1 - 64 * c - lane;
       const bool valid = pos >= 0;
-      uint32_t g = 0, byte = 0;
-      if (valid) { g = point_list[list0 + pos]; byte = contrib ? (uint32_t)contrib[list0 + pos] : 0xfu; }
+      const uint32_t g = ng, byte = valid ? nbyte : 0u;
+      {
+        const int npos = pos - 64;
+        if (c + 1 < C && npos >= 0) { ng = point_list[list0 + npos]; nbyte = contrib ? (uint32_t)contrib[list0 + npos] : 0xfu; }
+      }
       const bool useful = byte != 0u;
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
       bool zf = valid && !useful;            // walked, but blended by no quad: a zero record when the view uses the Gaussian anywhere
@@ -1246,44 +1250,28 @@ __device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab, c
       if (useful) { r0 = rec[GSR_REC_F4 * g]; r1 = rec[GSR_REC_F4 * g + 1]; r2 = rec[GSR_REC_F4 * g + 2]; }
       const uint32_t e = pc_slot_of(r3, tx, ty);
       if (zf) pc_zero_record<COL>(partials, e);
-      const uint64_t bu = __ballot(useful);
-      const int nu = __popcll(bu);
-      const int pre = (int)__popcll(bu & gsr_lanemask_lt());
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (timing builds: the loads' latency is booked here, not under the turn)
-      if (k == 0) PC_TP(6);
-      // ---- this chunk's turn: append to the stream
-      if (G > 0u && !pc_wait_gt(&L.turn, G - 1u, &L.abort)) return;
-      uint32_t seq = pc_peek(&L.prod_seq);
-      int fill = (int)pc_peek(&L.st_fill);
-      uint32_t cqa[4], cqb[4] = {0u, 0u, 0u, 0u};
+#ifdef GSR_TILE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      PC_TP(6);
+      // appended in two halves of 32 lanes: a half never spans more than two batches
 #pragma unroll
-      for (int w = 0; w < 4; ++w) cqa[w] = pc_peek(&L.st_cq[w]);
-      bool first = pc_peek(&L.st_first) != 0u;
-      if (k == 0) PC_TP(4);
-      auto publish_open = [&](int nent) {    // the open batch (number seq) holds nent entries: header, sentinels, sequence counter
-        PcSlot& S = L.s[seq % PC_R];
-        const int sl = (int)(seq % PC_R);
-        if (lane < 4) {
-          const uint32_t cc = lane == 0 ? cqa[0] : lane == 1 ? cqa[1] : lane == 2 ? cqa[2] : cqa[3];
-          S.idx[lane][cc] = 0; S.idx[lane][cc + 1] = 0;
-          L.cnt[sl][lane] = cc;
-        }
-        if (lane == 0) { L.n[sl] = (uint32_t)nent; L.flags[sl] = first ? PC_FLAG_FIRST : 0u; L.tile[sl] = (uint32_t)tile; L.view[sl] = (uint32_t)vi; }
-        pc_publish(&L.prod_seq, seq + 1u);
-        ++seq; first = false;
-      };
-      if (nu > 0) {
-        const int tgt = fill + pre;
+      for (int h = 0; h < 2; ++h) {
+        const bool u = useful && (lane >> 5) == h;
+        const uint64_t bu = __ballot(u);
+        const int nu = __popcll(bu);
+        if (nu == 0) continue;
+        const int tgt = fill + (int)__popcll(bu & gsr_lanemask_lt());
         const bool straddle = fill + nu > PC_BB;
-        // the ring slots this chunk writes must have been retired
-        if (seq >= PC_R && !pc_wait_gt(&L.comb_seq, seq - PC_R, &L.abort)) return;
-        if (straddle && seq + 1u >= PC_R && !pc_wait_gt(&L.comb_seq, seq + 1u - PC_R, &L.abort)) return;
-        if (k == 0) PC_TP(4);
+        // the ring slots this half writes must have been retired
+        if (seq >= PC_R && !pc_wait_gt<3>(&L.retired[seq % PC_R], seq - PC_R, &L.abort)) { aborted = true; break; }
+        if (straddle && seq + 1u >= PC_R && !pc_wait_gt<3>(&L.retired[(seq + 1u) % PC_R], seq + 1u - PC_R, &L.abort)) { aborted = true; break; }
+        PC_TP(4);
         const bool inA = tgt < PC_BB;
         const int j = inA ? tgt : tgt - PC_BB;
         PcSlot& SA = L.s[seq % PC_R];
         PcSlot& SB = L.s[(seq + 1u) % PC_R];
-        if (useful) {
+        if (u) {
           PcSlot& S = inA ? SA : SB;
           S.ent[j][0] = make_float4(r0.x, r0.y, GSR_HALF_LOG2E * r0.z, GSR_NEG_LOG2E * r0.w);   // (-A/2, -B) * log2(e), see fwd_tile
           S.ent[j][1] = make_float4(GSR_HALF_LOG2E * r1.x, r1.y, r1.z, r1.w);                   // -C/2 * log2(e)
@@ -1291,9 +1279,10 @@ __device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab, c
           S.slot[j] = e;
           S.quads[j] = (uint8_t)byte;
         }
+        uint32_t cqb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          const bool has = useful && ((byte >> w) & 1u);
+          const bool has = u && ((byte >> w) & 1u);
           const uint64_t balA = __ballot(has && inA), balB = __ballot(has && !inA);
           if (has) {
             if (inA) SA.idx[w][cqa[w] + (uint32_t)__popcll(balA & gsr_lanemask_lt())] = (uint16_t)(PC_ENT_BYTES * j);
@@ -1311,130 +1300,53 @@ __device__ __forceinline__ void pc_stager(PcLds& L, const GsrRenderViews& tab, c
           fill += nu;
         }
       }
-      if (c == C - 1) {                      // the tile ends here: its last batch goes out short, the next tile opens a fresh one
-        if (fill > 0) publish_open(fill);
-        fill = 0; first = true;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) cqa[w] = 0u;
-      }
-      if (lane == 0) {
-        L.st_fill = (uint32_t)fill; L.st_first = first ? 1u : 0u;
-        L.st_cq[0] = cqa[0]; L.st_cq[1] = cqa[1]; L.st_cq[2] = cqa[2]; L.st_cq[3] = cqa[3];
-      }
-      pc_publish(&L.turn, G + 1u);
-      if (k == 0) PC_TP(7);
+      PC_TP(7);
     }
-    gbase += (uint32_t)C;
+    if (aborted) return;
+    if (fill > 0) {
+      if (seq >= PC_R && !pc_wait_gt<3>(&L.retired[seq % PC_R], seq - PC_R, &L.abort)) return;   // (free already: the entries are in it)
+      publish_open(fill);
+    }
+    PC_TP(7);
+    // the next tile's order entry is requested before this tile's zero fill: zeros for the entries nobody reached (they still own a
+    // record in the Gaussian-major scratch; only those of Gaussians the view uses somewhere are ever read)
+#if PC_POP_EARLY
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    if (ticket < n_busy) ord = tile_order[ticket];
+#else
+    if (lane == 0) next = gridDim.x + atomicAdd(&queue[1], 1u);      // the next ticket: its latency hides behind the zero fill
+#endif
+    for (int base = max_last; base < n; base += 256) {
+      uint32_t gz[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int kk = base + lane + 64 * u; on[u] = kk < n; gz[u] = on[u] ? point_list[list0 + kk] : 0u; }
+      if (used) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (on[u]) on[u] = used[gz[u]] != 0;
+      }
+      float4 w3[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (on[u]) w3[u] = rec[GSR_REC_F4 * gz[u] + 3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (on[u]) pc_zero_record<COL>(partials, pc_slot_of(w3[u], tx, ty));
+    }
+#if !PC_POP_EARLY
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    if (ticket < n_busy) ord = tile_order[ticket];
+#endif
+    PC_TP(8);
   }
-  if (k == 0) PC_TFLUSH();
-  if (k != 0) return;
-  // exit marker for the consumers and the combiner, behind every chunk of the run
-  if (gbase > 0u && !pc_wait_gt(&L.turn, gbase - 1u, &L.abort)) return;
-  const uint32_t seq = pc_peek(&L.prod_seq);
-  if (seq >= PC_R && !pc_wait_gt(&L.comb_seq, seq - PC_R, &L.abort)) return;
+  // exit marker for the consumers
+  if (seq >= PC_R && !pc_wait_gt<3>(&L.retired[seq % PC_R], seq - PC_R, &L.abort)) return;
   if (lane == 0) L.flags[seq % PC_R] = PC_FLAG_EXIT;
   pc_publish(&L.prod_seq, seq + 1u);
+  PC_TFLUSH();
   // The last workgroup to leave re-arms the queue for a possible second backward over the same state (see render_bwd_persistent)
   if (lane == 0 && atomicAdd(&queue[5], 1u) == gridDim.x - 1u) {
     atomicExch(&queue[1], 0u);
     atomicExch(&queue[5], 0u);
   }
-}
-
-// One slab (up to 256 list positions) of a zero-fill job; -> true when the job is finished.  Entries nobody reached still own a record
-// in the Gaussian-major scratch: zeros for those of Gaussians the view uses somewhere (the others' records are never read).
-template <bool COL>
-__device__ __forceinline__ bool pc_zero_fill_slab(PcLds& L, const GsrRenderViews& tab, uint32_t job, int& done_upto) {
-  const int lane = gsr_lane();
-  const uint32_t* z = L.zf[job % PC_ZF];
-  const uint32_t list0 = pc_peek(&z[0]);
-  const int n = (int)pc_peek(&z[1]), ml = (int)pc_peek(&z[2]);
-  const GsrRenderView& vw = tab.v[pc_peek(&z[3])];
-  const int tile = (int)pc_peek(&z[4]);
-  const int tx = tile % tab.gx, ty = tile / tab.gx;
-  const uint8_t* __restrict__ used = pc_used(vw);
-  if (done_upto < ml) done_upto = ml;
-  const int base = done_upto;
-  uint32_t g[4];
-  bool on[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const int kk = base + lane + 64 * u; on[u] = kk < n; g[u] = on[u] ? vw.point_list[list0 + kk] : 0u; }
-  if (used) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (on[u]) on[u] = used[g[u]] != 0;
-  }
-  float4 w3[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) if (on[u]) w3[u] = vw.rec[GSR_REC_F4 * g[u] + 3];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) if (on[u]) pc_zero_record<COL>(vw.partials, pc_slot_of(w3[u], tx, ty));
-  done_upto = base + 256;
-  return done_upto >= n;
-}
-
-template <bool COL>
-__device__ __forceinline__ void pc_combiner(PcLds& L, const GsrRenderViews& tab) {
-  const int lane = gsr_lane();
-  uint32_t zjob = 0;       // zero-fill jobs finished
-  int zdone = 0;           // progress inside the current one
-  PC_T0();
-  for (uint32_t seq = 0;; ++seq) {
-    // wait for the batch to be published and replayed by all four consumers; zero-fill jobs fill the idle time
-    uint32_t spins = 0;
-    for (;;) {
-      if (pc_peek(&L.prod_seq) > seq) {
-        const int sl0 = (int)(seq % PC_R);
-        if (pc_peek(&L.flags[sl0]) & PC_FLAG_EXIT) break;
-        if (pc_peek(&L.cons_seq[0]) > seq && pc_peek(&L.cons_seq[1]) > seq && pc_peek(&L.cons_seq[2]) > seq && pc_peek(&L.cons_seq[3]) > seq) break;
-      }
-      if (pc_peek(&L.zf_tail) > zjob) {
-        PC_TP(8);
-        if (pc_zero_fill_slab<COL>(L, tab, zjob, zdone)) { ++zjob; zdone = 0; pc_publish(&L.zf_head, zjob); }
-        PC_TP(10);
-        continue;
-      }
-      __builtin_amdgcn_s_sleep(PC_POLL_SLEEP);
-      if ((++spins & 255u) == 0u) {
-        if (pc_peek(&L.abort) != 0u) return;
-        if (spins >= (1u << 19)) {
-          if (lane == 0) { __hip_atomic_store(&L.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicExch(&g_pc_error, 2u); }
-          return;
-        }
-      }
-    }
-    asm volatile("" ::: "memory");
-    const int sl = (int)(seq % PC_R);
-    if (pc_peek(&L.flags[sl]) & PC_FLAG_EXIT) break;
-    const int n = (int)pc_peek(&L.n[sl]);
-    float4* __restrict__ partials = tab.v[pc_peek(&L.view[sl])].partials;
-    PC_TP(8);
-    const PcSlot& S = L.s[sl];
-    if (lane < n) {
-      float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-      float r2x = 0.f;
-      const uint32_t quads = (uint32_t)S.quads[lane];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if ((quads >> w) & 1u) {
-          const float* q = S.red[w][lane];
-          r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
-          r1.x += q[4]; r1.y += q[5];
-          if (COL) { r1.z += q[6]; r1.w += q[7]; r2x += q[8]; }
-        }
-      }
-      const uint32_t e = S.slot[lane];
-      if (COL) gsr_store_partial(partials, e, r0, r1, r2x);
-      else gsr_store_partial6(partials, e, r0, r1.x, r1.y);
-    }
-    PC_TP(9);
-    pc_publish(&L.comb_seq, seq + 1u);     // the slot's LDS reads are done (the record stores may still be in flight: they hold their data)
-  }
-  // the zero-fill jobs still queued (stager 0 wrote the last one before it published the exit marker)
-  while (pc_peek(&L.zf_tail) > zjob) {
-    if (pc_zero_fill_slab<COL>(L, tab, zjob, zdone)) { ++zjob; zdone = 0; pc_publish(&L.zf_head, zjob); }
-  }
-  PC_TP(10);
-  PC_TFLUSH();
 }
 
 template <bool COL>
@@ -1461,9 +1373,10 @@ __device__ __forceinline__ void pc_consumer(PcLds& L, const GsrRenderViews& tab,
       a_ = vw.dL_dcolor[pix]; b_ = vw.dL_dcolor[N + pix]; c_ = vw.dL_dcolor[2 * N + pix];
     }
   };
+  __builtin_amdgcn_s_setprio(PC_CONS_PRIO);  // (its waits drop to 0)
   PC_T0();
   for (uint32_t seq = 0;; ++seq) {
-    if (!pc_wait_gt(&L.prod_seq, seq, &L.abort)) return;
+    if (!pc_wait_gt<PC_CONS_PRIO>(&L.prod_seq, seq, &L.abort)) return;
     if (wv == 0) PC_TP(0);
     const int sl = (int)(seq % PC_R);
     const uint32_t flags = pc_peek(&L.flags[sl]);
@@ -1527,7 +1440,6 @@ __device__ __forceinline__ void pc_consumer(PcLds& L, const GsrRenderViews& tab,
           if (red6 >= 0) *rp_ = z;                                                                              \
         }                                                                                                       \
       }
-      __builtin_amdgcn_s_setprio(1);
       uint32_t o0 = ip[0], o1 = ip[1];
       float4 ea, eb, ec, xa, xb, xc;
       PC_LOAD(o0, ea, eb, ec)
@@ -1540,37 +1452,60 @@ __device__ __forceinline__ void pc_consumer(PcLds& L, const GsrRenderViews& tab,
         PC_VISIT(xa, xb, xc)
       }
       if (p < m) PC_VISIT(ea, eb, ec)
-      __builtin_amdgcn_s_setprio(0);
 #undef PC_VISIT
 #undef PC_LOAD
     }
-    pc_publish(&L.cons_seq[wv], seq + 1u);
     if (wv == 0) PC_TP(2);
+    // through with the batch.  The consumer that arrives last adds up the quads' totals of every entry and stores its record
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's totals are in LDS before it counts itself in
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&L.arrive[sl], 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == 3u) {
+      const int n = (int)pc_peek(&L.n[sl]);
+      float4* __restrict__ partials = tab.v[pc_peek(&L.view[sl])].partials;
+      if (lane == 0) L.arrive[sl] = 0u;
+      if (lane < n) {
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        float r2x = 0.f;
+        const uint32_t quads = (uint32_t)S.quads[lane];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if ((quads >> w) & 1u) {
+            const float* q = S.red[w][lane];
+            r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
+            r1.x += q[4]; r1.y += q[5];
+            if (COL) { r1.z += q[6]; r1.w += q[7]; r2x += q[8]; }
+          }
+        }
+        const uint32_t e = S.slot[lane];
+        if (COL) gsr_store_partial(partials, e, r0, r1, r2x);
+        else gsr_store_partial6(partials, e, r0, r1.x, r1.y);
+      }
+      pc_publish(&L.retired[sl], seq + 1u);    // the slot's LDS reads are done (the record stores may still be in flight: they hold their data)
+      if (wv == 0) PC_TP(3);
+    }
   }
   if (wv == 0) PC_TFLUSH();
 }
 
 #ifndef PC_WAVES_PER_EU
-#define PC_WAVES_PER_EU 6
+#define PC_WAVES_PER_EU 8
 #endif
-#ifdef PC_NUM_SGPR
-#define PC_SGPR_ATTR __attribute__((amdgpu_num_sgpr(PC_NUM_SGPR)))
-#else
-#define PC_SGPR_ATTR
+#ifndef PC_NUM_SGPR
+#define PC_NUM_SGPR 80       // eight waves per SIMD need <= 80 SGPRs per wave (MI355X_MICROARCH: residency by .sgpr_count)
 #endif
 template <bool COL>
-__global__ __launch_bounds__(PC_THREADS, PC_WAVES_PER_EU) PC_SGPR_ATTR void render_bwd_pc(GsrRenderViews tab) {
+__global__ __launch_bounds__(PC_THREADS, PC_WAVES_PER_EU) __attribute__((amdgpu_num_sgpr(PC_NUM_SGPR))) void render_bwd_pc(GsrRenderViews tab) {
   __shared__ PcLds L;
 #ifdef GSR_TILE_TIMING
   if (threadIdx.x == 0 && blockIdx.x < 2048) g_pc_start[blockIdx.x] = wall_clock64();     // residency census: do all workgroups start together?
 #endif
   for (uint32_t* w = &L.prod_seq + threadIdx.x; w < &L.ctl_end; w += PC_THREADS) *w = 0u;
-  if (threadIdx.x == 0) { L.tk[0] = blockIdx.x; L.tk_seq = 1u; L.st_first = 1u; }     // the first ticket is implicit (see render_bwd_persistent)
   __syncthreads();
   const int wv = (int)(threadIdx.x >> 6);
   if (wv < 4) pc_consumer<COL>(L, tab, wv);
-  else if (wv < 4 + PC_K) pc_stager<COL>(L, tab, wv - 4);
-  else pc_combiner<COL>(L, tab);
+  else pc_stager<COL>(L, tab);
 }
 
 }  // namespace gsr_render
@@ -1603,6 +1538,11 @@ extern "C" int gsr_debug_pc_starts(unsigned long long* out2048) {   // timing bu
   return 0;
 }
 #endif
+extern "C" int gsr_debug_pc_occupancy() {   // workgroups of render_bwd_pc per CU according to the runtime (the hardware may admit one fewer: MI355X_MICROARCH)
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_bwd_pc<true>, PC_THREADS, 0) != hipSuccess) return -1;
+  return nb;
+}
 extern "C" int gsr_debug_pc_error(uint32_t* out) {   // 0: no wait of render_bwd_pc ever timed out (tests read it; not part of include/gsr.h)
   GSR_HIP_CHECK(hipDeviceSynchronize());
   GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_error), sizeof(uint32_t)));
@@ -1689,7 +1629,7 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
       const bool col = !tab.no_colour_grad;
       static const int use_pc = env_int("GSR_BWD_PC", 0);   // the producer / consumer form (round 5) for calls without fused pairs
       if (!pairs && use_pc) {
-        static const int pc_per_cu = env_int("GSR_BWD_PC_WG_PER_CU", 3);
+        static const int pc_per_cu = env_int("GSR_BWD_PC_WG_PER_CU", 6);
         const int pgrid = tiles < 256 * pc_per_cu ? tiles : 256 * pc_per_cu;
         if (col) hipLaunchKernelGGL(render_bwd_pc<true>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);
         else hipLaunchKernelGGL(render_bwd_pc<false>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);

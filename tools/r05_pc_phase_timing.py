@@ -37,8 +37,8 @@ N = 10
 for _ in range(N):
     run()
 lib.gsr_debug_phase_timing(buf)
-names = ["consumer0: waiting for a batch", "consumer0: tile head (pixel loads)", "consumer0: visits + publish", "-", "stager0: waiting (tickets, turn, ring slot)", "stager0: tile start chain (ord, n_contrib, max, zf job)", "stager0: chunk loads + gathers", "stager0: appending + publishing", "combiner: waiting", "combiner: combine + stores", "combiner: zero fill", "stager0: ord load (one coalesced trip, incl. tracked flags)", "stager0: ticket atomic + n_contrib loads + wave max"]
-tot = sum(buf[i] for i in range(13))
+names = ["consumer0: waiting for a batch", "consumer0: tile head (pixel loads)", "consumer0: visits", "consumer0: combining (when last to arrive)", "stager: waiting for a ring slot", "stager: tile start chain (n_contrib, max)", "stager: chunk loads + gathers", "stager: appending + publishing", "stager: next ticket + zero fill + order entry"]
+tot = sum(buf[i] for i in range(9))
 print("tiles per launch", buf[15] / N)
 for i, n in enumerate(names):
     print(f"{n:50s} {buf[i] / N / 1e3:10.2f} x10us  {100.0 * buf[i] / max(tot, 1):5.1f} %")
@@ -51,3 +51,7 @@ try:
     err = C.c_uint32(0); lib.gsr_debug_pc_error(C.byref(err)); print("pc error word", err.value)
 except Exception as e:
     print("no start census:", e)
+try:
+    print("occupancy API: workgroups per CU =", lib.gsr_debug_pc_occupancy())
+except Exception as e:
+    print("no occupancy export:", e)
