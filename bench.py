@@ -675,6 +675,46 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                              "fused = loss_and_grads_views + gsdyn.optim.FusedAdam"}
     except Exception as e:  # noqa: BLE001
         out["train_iteration_one_camera"] = {"error": repr(e)}
+    try:   # the REFERENCE's own workload shapes: 1280x720 with 4 cameras (/root/reference/src/tracking/utils/metadata.py:96-97,
+        #    src/render/renderer.py:13-14), one random camera per iteration (src/tracking/train_utils.py:82-86), ~9 k - 50 k Gaussians
+        #    (assets/demo/gs_orig.splat holds 8 957; the demo fit runs at 640x480)
+        from gsdyn import initialize_optimizer
+        shapes = {}
+        for label, (Pn, Wn, Hn) in (("1280x720_50k_4cams", (50_000, 1280, 720)), ("640x480_9k_4cams", (8_957, 640, 480))):
+            im_n, seg_n = synth_targets(Wn, Hn, device=dev)
+            cams_n = synth_ring_cameras(4, Wn, Hn, device=dev)
+            res = {}
+            for mode in ("reference_shape", "fused"):
+                pn = synth_scene_params(Pn, seed=0, device=dev)
+                vn = init_variables(Pn, dev)
+                vn.update(make_rigidity_variables(pn, num_knn=20))
+                views_n = [dict(cam=c, im=im_n, seg=seg_n, id=i) for i, c in enumerate(cams_n)]
+                if mode == "fused":
+                    opt = initialize_optimizer(pn, 4.0)
+                else:
+                    lrs = {g["name"]: g["lr"] for g in initialize_optimizer(pn, 4.0).param_groups}
+                    opt = torch.optim.Adam([{"params": [v], "name": k, "lr": lrs[k]} for k, v in pn.items()], lr=0.0, eps=1e-15)
+                it = [0]
+
+                def iteration():
+                    d = views_n[it[0] % 4]
+                    it[0] += 1
+                    if mode == "fused":
+                        loss_and_grads_views(pn, [d], vn, False, w)
+                    else:
+                        loss, _ = get_loss(pn, d, vn, False, w)
+                        loss.backward()
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                ms = _time_ms(iteration, 20, 5)
+                res[mode] = {"ms_per_iteration": ms, "iterations_per_s": 1e3 / ms}
+            shapes[label] = res
+        out["reference_shapes"] = {**shapes, "what": "train_gs.py iteration at the reference's own sizes (t > 0: colour + seg render of ONE camera, "
+                                   "0.8 L1 + 0.2 (1 - SSIM) on both, rigid / rot / iso / floor / bg terms, backward, Adam), 4 ring cameras taken in turn; "
+                                   "reference_shape = gsdyn.get_loss as train_utils.py writes it (two GaussianRasterizer calls through the C++ autograd node, "
+                                   "torch loss ops) + torch.optim.Adam; fused = loss_and_grads_views + FusedAdam"}
+    except Exception as e:  # noqa: BLE001
+        out["reference_shapes"] = {"error": repr(e)}
     try:
         p2 = synth_scene_params(50_000, seed=0, device=dev)
         with torch.no_grad():

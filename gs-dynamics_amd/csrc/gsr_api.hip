@@ -101,7 +101,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.skip = 0; o.tile_rows = nullptr;
+  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.cmp_rec = nullptr; o.cmp_rect = nullptr; o.cmp_ekey = nullptr; o.cmp_tiles = nullptr; o.skip = 0; o.tile_rows = nullptr;
   o.used = g.used; o.tracked = g.counters + 1;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
@@ -183,8 +183,8 @@ int check_inputs(const char* who, const float* means3D, const float* opacities, 
 int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
-           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, uint64_t* fingerprint_host = nullptr,
-           const int* skip = nullptr, const int32_t* geometry_of = nullptr, uint32_t* tile_rows = nullptr) {
+           uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, int32_t* same_host = nullptr,
+           const int* skip = nullptr, const int32_t* geometry_of = nullptr, uint32_t* tile_rows = nullptr, const void* prev_geom = nullptr) {
   // tile_rows != nullptr (multi-view entry points): the batch state's matrix of the tile-row binning -- when the call's tile grid takes
   // that path with the first walk fused (gsr_fused_count_ok) the preprocess launch counts the rows itself
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
@@ -222,7 +222,12 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     GeomState g;
     gsr_carve_geom(geom_states[v], P, &g);
     fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
-    if (fingerprint_host && V == 1 && gsr_host_block_scan(P)) tab.v[v].block_hash = g.block_hash;
+    if (same_host && prev_geom && V == 1 && gsr_host_block_scan(P)) {      // compare mode: this forward against an earlier one's geometry state
+      GeomState pg;
+      gsr_carve_geom(const_cast<void*>(prev_geom), P, &pg);
+      tab.v[v].block_hash = g.block_hash;
+      tab.v[v].cmp_rec = pg.rec; tab.v[v].cmp_rect = pg.rect; tab.v[v].cmp_ekey = pg.ekey; tab.v[v].cmp_tiles = pg.tiles_touched;
+    }
     if (skip && skip[v]) tab.v[v].skip = 1;
   }
   const bool count_rows = tile_rows != nullptr && gsr_fused_count_ok(cam0.T);
@@ -243,16 +248,16 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
   }
   uint32_t* host = pinned_sums();
   if (!host) { gsr_set_error("gsr forward: pinned host allocation failed"); return -1; }
-  if (fingerprint_host) *fingerprint_host = 0;
+  if (same_host) *same_host = 0;
   if (gsr_host_block_scan(P)) {
     GSR_HIP_CHECK(hipMemcpyAsync(host, sums, sizeof(uint32_t) * nblk * V, hipMemcpyDeviceToHost, st));
     uint32_t* hash_host = host + (size_t)GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS;      // behind the counts (see pinned_sums)
     if (tab.v[0].block_hash) GSR_HIP_CHECK(hipMemcpyAsync(hash_host, tab.v[0].block_hash, sizeof(uint2) * nblk, hipMemcpyDeviceToHost, st));
     GSR_HIP_CHECK(hipStreamSynchronize(st));
     if (tab.v[0].block_hash) {
-      uint64_t fp = 0x243F6A8885A308D3ull ^ (uint64_t)P;
-      for (uint32_t b = 0; b < nblk; ++b) fp ^= ((uint64_t)hash_host[2 * b + 1] << 32) | hash_host[2 * b];
-      *fingerprint_host = fp ? fp : 1ull;        // 0 = "no fingerprint"
+      uint32_t any = 0;
+      for (uint32_t b = 0; b < nblk; ++b) any |= hash_host[2 * b];
+      *same_host = any ? 0 : 1;
     }
     for (int v = 0; v < V; ++v) {
       uint64_t tot = 0;
@@ -348,26 +353,27 @@ int gsr_forward_preprocess(const gsr_settings* s, int32_t P, const float* means3
                            const float* rotations, const float* opacities, const float* colors_precomp,
                            const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
                            uint32_t* num_rendered_host, void* stream) {
-  return gsr_forward_preprocess_fp(s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_state, radii,
-                                   num_rendered_host, nullptr, stream);
+  return gsr_forward_preprocess_same(s, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, geom_state, radii,
+                                     num_rendered_host, nullptr, nullptr, stream);
 }
 
-int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                              const float* rotations, const float* opacities, const float* colors_precomp,
-                              const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
-                              uint32_t* num_rendered_host, uint64_t* fingerprint_host, void* stream) {
+int gsr_forward_preprocess_same(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                const float* rotations, const float* opacities, const float* colors_precomp,
+                                const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
+                                uint32_t* num_rendered_host, const void* prev_geom_state, int32_t* same_host, void* stream) {
   GsrRange _range("gsr_forward_preprocess");
-  if (fingerprint_host) *fingerprint_host = 0;
+  if (same_host) *same_host = 0;
   GsrCam cam;
   if (int rc = make_cam(s, &cam)) return rc;
   if (num_rendered_host) *num_rendered_host = 0;
   if (P <= 0) return 0;
   if (!geom_state || !radii) { gsr_set_error("gsr_forward_preprocess: NULL argument"); return -2; }
+  if (prev_geom_state == geom_state) { gsr_set_error("gsr_forward_preprocess_same: a forward cannot be compared with the state it writes"); return -2; }
   GeomState g;
   gsr_carve_geom(geom_state, P, &g);
   uint32_t D = 0;
   if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, nullptr, shs, cov3D_precomp, &geom_state,
-                      &radii, g.block_sums, &D, (hipStream_t)stream, nullptr, fingerprint_host))
+                      &radii, g.block_sums, &D, (hipStream_t)stream, nullptr, same_host, nullptr, nullptr, nullptr, prev_geom_state))
     return rc;
   if (num_rendered_host) *num_rendered_host = D;
   return 0;

@@ -46,8 +46,9 @@ struct GeomState {
   uint32_t* counters;     // [0] = num_rendered
   uint2* ekey;            // [P] {depth bits, tile mask}: what the tile-row binning reads per Gaussian next to rect[] (coalesced 8 + 8 bytes
                           //     instead of two 16-byte gathers from the 64-byte record)
-  uint2* block_hash;      // [ceil(P/256)] 64-bit fingerprint per preprocess block of everything the tile lists depend on (single-view
-                          //     entry points: lets a second render with the same geometry reuse the first one's lists)
+  uint2* block_hash;      // [ceil(P/256)] per preprocess block: .x = 1 when a Gaussian of the block differs from the geometry state the
+                          //     forward was asked to compare itself with (single-view entry points: a second render with the same
+                          //     geometry reuses the first one's lists)
   uint32_t* tile_rows;    // [(ceil(P / GSR_BIN_G) + 1) x GSR_BIN_MAX_T] the (workgroups x tiles) matrix of the tile-row binning for the
                           //     SINGLE-VIEW entry points (round 4; multi-view calls keep theirs in the batch state)
   uint8_t* used;          // [P] 1: some pixel of this view blended the Gaussian (set by the tracking forward, cleared by preprocess; valid when
@@ -212,7 +213,8 @@ struct GsrPreView {            // preprocess
   float tanfovx, tanfovy;
   float4* rec; uint2* rect; uint32_t* tiles_touched; uint32_t* clamped; int32_t* radii; uint32_t* block_sums;
   uint2* ekey;
-  uint2* block_hash;     // nullptr: no fingerprint wanted
+  uint2* block_hash;     // != nullptr (compare mode): per preprocess block, .x = 1 when a Gaussian of the block differs from the compared state
+  const float4* cmp_rec; const uint2* cmp_rect; const uint2* cmp_ekey; const uint32_t* cmp_tiles;   // the compared (earlier) geometry state, or nullptr
   uint8_t* used; uint32_t* tracked;   // GeomState::used, &GeomState::counters[1]: both cleared here, set by the tracking forward
   int skip;              // 1: nothing to preprocess for this view (forward-only fused alias: its owner's tile pass reads its colours
                          //    straight from its colour array, nobody reads a record of its own)

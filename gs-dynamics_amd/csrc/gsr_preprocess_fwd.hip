@@ -61,7 +61,8 @@ __device__ __forceinline__ int sext16_(uint32_t v) { return (int)(int16_t)(v & 0
 
 // What the rest of a launch needs to know about one preprocessed Gaussian (everything else went to memory).
 struct PreOut { uint32_t tiles; uint2 rc; uint32_t tmask; uint32_t depth_bits;
-                uint64_t blend_bits; };   // hash of what the blend DECISIONS of its entries depend on: 2D mean, conic, opacity (0 without entries)
+                bool differs; };          // compare mode (GsrPreView::cmp_rec): something the tile lists or the blend decisions depend on is not
+                                          // bit-equal to the compared geometry state's (entry count, tile rect, tile mask, depth bits, 2D mean, conic, opacity)
 
 // One Gaussian of one view: cull, project, covariance, conic, radius, rect / alpha box / tile mask, colour; every per-Gaussian output
 // stored.  `i` may be out of range (in_range = false: nothing loaded, nothing stored, an empty result).
@@ -280,11 +281,18 @@ __device__ __forceinline__ PreOut preprocess_gaussian(
   }
   PreOut o;
   o.tiles = tiles; o.rc = rc; o.tmask = tmask; o.depth_bits = __float_as_uint(c2.y);
-  {
-    uint64_t hb = (((uint64_t)__float_as_uint(a4.x) << 32) | __float_as_uint(a4.y)) * 0xD6E8FEB86659FD93ull;
-    hb = ((hb << 27) | (hb >> 37)) ^ ((((uint64_t)__float_as_uint(a4.z) << 32) | __float_as_uint(a4.w)) * 0xA0761D6478BD642Full);
-    hb = ((hb << 31) | (hb >> 33)) ^ ((((uint64_t)__float_as_uint(b4.x) << 32) | __float_as_uint(b4.y)) * 0xE7037ED1A0B428DBull);
-    o.blend_bits = tiles ? hb : 0ull;
+  o.differs = false;
+  if (in_range && vw.cmp_rec) {      // exact comparison with an earlier forward's geometry state (same P, same image size: the caller's business)
+    bool d = vw.cmp_tiles[i] != tiles;
+    if (!d && tiles) {
+      const uint2 pr = vw.cmp_rect[i], pk = vw.cmp_ekey[i];
+      const float4 pa = vw.cmp_rec[GSR_REC_F4 * (size_t)i], pb = vw.cmp_rec[GSR_REC_F4 * (size_t)i + 1];
+      d = pr.x != rc.x || pr.y != rc.y || pk.x != __float_as_uint(c2.y) || pk.y != tmask ||
+          __float_as_uint(pa.x) != __float_as_uint(a4.x) || __float_as_uint(pa.y) != __float_as_uint(a4.y) ||
+          __float_as_uint(pa.z) != __float_as_uint(a4.z) || __float_as_uint(pa.w) != __float_as_uint(a4.w) ||
+          __float_as_uint(pb.x) != __float_as_uint(b4.x) || __float_as_uint(pb.y) != __float_as_uint(b4.y);
+    }
+    o.differs = d;
   }
   return o;
 }
@@ -307,29 +315,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
                                         opacities, colors_precomp, shs, cov3D_precomp, tight_lists);
   const uint32_t tiles = po.tiles, tmask = po.tmask;
   const uint2 rc = po.rc;
-  // Fingerprint of what the tile lists depend on -- tile rect, tile mask, depth bits and the Gaussian's index -- XOR-ed over the
-  // block (the host XORs the blocks): two preprocess runs with equal fingerprints AND equal entry counts produce the same lists
-  // (up to a 2^-64 coincidence), whatever tensors the inputs came from.  Only when asked for (single-view entry points).
-  // Round 4: it also covers what the blend decisions depend on (2D mean, conic, opacity of every Gaussian with entries): the forward
-  // leaves per-entry contribution bytes for the backward NEXT TO the lists (BinningState::contrib), so two forwards that share lists
-  // share those bytes, and they must then be the same bytes -- colours may differ, geometry and opacity may not.
+  // Compare mode (single-view entry points, list reuse): is everything the tile lists and the blend decisions depend on bit-equal to an
+  // earlier forward's geometry state?  One word per block for the host (it rides in the copy that brings the entry counts): 0 = equal.
+  // (Rounds 3 - 4 compared a 64-bit fingerprint instead -- "identical up to a 2^-64 coincidence"; the bar for integer work is bit-exact.)
   if (vw.block_hash) {
-    uint64_t h = ((uint64_t)(uint32_t)i + 1ull) * 0x9E3779B97F4A7C15ull;
-    h ^= (((uint64_t)rc.x << 32) | rc.y) * 0xC2B2AE3D27D4EB4Full;
-    h = (h << 31) | (h >> 33);
-    h ^= (((uint64_t)tmask << 32) | po.depth_bits) * 0x165667B19E3779F9ull;
-    h = ((h << 23) | (h >> 41)) ^ po.blend_bits;     // round 4: the sharer also shares the owner's per-quad contribution bytes (see below)
-    h *= 0x9E3779B97F4A7C15ull;
-    h ^= h >> 29;
-    if (!in_range) h = 0;
-    uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { hl ^= (uint32_t)__shfl_xor((int)hl, m, 64); hh ^= (uint32_t)__shfl_xor((int)hh, m, 64); }
-    __shared__ uint2 s_hash[GSR_BLOCK / GSR_WAVE];
-    if ((threadIdx.x & 63) == 0) s_hash[threadIdx.x >> 6] = make_uint2(hl, hh);
-    __syncthreads();
-    if (threadIdx.x == 0)
-      vw.block_hash[blockIdx.x] = make_uint2(s_hash[0].x ^ s_hash[1].x ^ s_hash[2].x ^ s_hash[3].x, s_hash[0].y ^ s_hash[1].y ^ s_hash[2].y ^ s_hash[3].y);
+    const int any = __syncthreads_or(po.differs ? 1 : 0);
+    if (threadIdx.x == 0) vw.block_hash[blockIdx.x] = make_uint2(any ? 1u : 0u, 0u);
   }
   // per-block total of tiles_touched: feeds the two-level offsets scan (no full-length scan kernel)
   uint32_t wsum = tiles;

@@ -63,21 +63,22 @@ Settings make_settings(const torch::Tensor& bg, const torch::Tensor& viewmatrix,
   return o;
 }
 
-// Tile-list reuse (include/gsr.h: gsr_forward_preprocess_fp / gsr_forward_render_shared).  The reference renders every camera twice with
+// Tile-list reuse (include/gsr.h: gsr_forward_preprocess_same / gsr_forward_render_shared).  The reference renders every camera twice with
 // the same geometry and other colours -- get_loss: colours then segmentation colours (/root/reference/src/tracking/train_utils.py:178,192),
 // predict.py: colours then an all-ones mask (:115-123) -- through two separate GaussianRasterizer calls whose geometry tensors are fresh
-// copies.  The layer remembers the LAST forward's lists (binning + image state tensors) with the fingerprint of what they depend on; a
-// forward whose preprocess yields the same (P, H, W, num_rendered, fingerprint) blends from those lists instead of emitting and sorting
-// its own: bit-identical outputs, ~55 us of GPU time less per second render at 100k / 800^2.  One entry per host thread; the tensors it
-// holds (~20 MB at that size) are released when another geometry replaces them.  GSR_NO_LIST_REUSE=1 / set_list_reuse(false) switch it off.
+// copies.  The layer remembers the LAST forward's states (geometry + binning + image tensors); the next forward of the same (P, H, W,
+// stream) has its preprocess COMPARE itself with that geometry state on the device, bit for bit (entry counts, tile rects and masks, depth
+// bits, 2D means, conics, opacities: everything the lists and the blend decisions depend on), and when nothing differs it blends from those
+// lists instead of emitting and sorting its own: bit-identical outputs, ~55 us of GPU time less per second render at 100k / 800^2, and no
+// "up to a hash coincidence" (rounds 3 - 4 compared a 64-bit fingerprint).  One entry per host thread; the tensors it holds (~30 MB at
+// that size) are released when another geometry replaces them.  GSR_NO_LIST_REUSE=1 / set_list_reuse(false) switch it off.
 struct ListCache {
   bool valid = false;
   int dev = -1;
   int64_t P = 0, H = 0, W = 0;
   uint32_t D = 0;
-  uint64_t fp = 0;
   void* stream = nullptr;   // the stream the lists were produced on: a forward on ANOTHER stream is not ordered behind their writes -- it bins its own
-  torch::Tensor binning, image;
+  torch::Tensor geom, binning, image;
 };
 thread_local ListCache g_lists;
 bool g_reuse = [] { const char* e = getenv("GSR_NO_LIST_REUSE"); return !(e && *e && atoi(e) != 0); }();
@@ -114,13 +115,15 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   torch::Tensor image = torch::empty({(int64_t)gsr_image_bytes((int32_t)H, (int32_t)W)}, u8);
   void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
   uint32_t D = 0;
-  uint64_t fp = 0;
-  check(gsr_forward_preprocess_fp(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
-                                  radii.data_ptr<int32_t>(), &D, g_reuse ? &fp : nullptr, stream), "gsr_forward_preprocess");
-  const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
+  int32_t same = 0;
   ListCache& lc = g_lists;
-  if (g_reuse && fp != 0 && D > 0 && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.D == D && lc.fp == fp && lc.stream == stream) {
-    // same geometry, same camera as the previous forward: its lists are this render's lists
+  const bool candidate = g_reuse && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.stream == stream;
+  check(gsr_forward_preprocess_same(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
+                                    radii.data_ptr<int32_t>(), &D, candidate ? lc.geom.data_ptr() : nullptr, candidate ? &same : nullptr, stream),
+        "gsr_forward_preprocess");
+  const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
+  if (candidate && same && D > 0 && lc.D == D) {
+    // same geometry, same camera as the previous forward (compared on the device, bit for bit): its lists are this render's lists
     check(gsr_forward_render_shared_ex(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
                                        color.data_ptr<float>(), depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render_shared");
     ++g_reuse_hits;
@@ -129,8 +132,8 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
   check(gsr_forward_render_ex(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
                               depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render");
-  if (g_reuse && fp != 0 && D > 0) {
-    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.fp = fp; lc.stream = stream; lc.binning = binning; lc.image = image;
+  if (g_reuse && D > 0) {
+    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.stream = stream; lc.geom = geom; lc.binning = binning; lc.image = image;
   } else {
     lc = ListCache();
   }
@@ -189,6 +192,77 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
   return std::make_tuple(d_means2D, d_colors, d_opacity, d_means3D, d_cov, d_sh, d_scales, d_rot);
 }
 
+// ---- the autograd node of one GaussianRasterizer call, in C++ (round 5).  The Python wrapper used to be a
+// torch.autograd.Function whose forward / backward each crossed into this layer once and spent ~0.12 ms per camera in the interpreter
+// (profiles/r04_dropin_host_profile.txt); here the whole call is ONE crossing: GaussianRasterizer.forward -> _C.rasterize -> this node.
+// Inputs in the order of upstream's Python _RasterizeGaussians.apply (means3D, means2D, sh, colors_precomp, opacities, scales,
+// rotations, cov3Ds_precomp) followed by the settings record's fields; outputs (color, radii, depth).  means2D is the gradient holder
+// the reference reads back (`rendervar['means2D'].grad`, /root/reference/src/tracking/external.py:139-140): its values are ignored.
+struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D,
+                                                torch::Tensor sh, torch::Tensor colors, torch::Tensor opacities, torch::Tensor scales,
+                                                torch::Tensor rotations, torch::Tensor cov3D, torch::Tensor bg, torch::Tensor viewmatrix,
+                                                torch::Tensor projmatrix, torch::Tensor campos, double tanfovx, double tanfovy, int64_t H,
+                                                int64_t W, double scale_modifier, int64_t degree, bool prefiltered, bool will_backward) {
+    (void)means2D;
+    ctx->set_materialize_grads(false);        // grad_depth is ignored: do not let autograd fill a zero image for it
+    auto r = rasterize_gaussians(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix, tanfovx,
+                                 tanfovy, H, W, sh, degree, campos, prefiltered, will_backward);
+    torch::Tensor color = std::get<1>(r), depth = std::get<2>(r), radii = std::get<3>(r);
+    ctx->saved_data["R"] = std::get<0>(r);
+    ctx->saved_data["tanfovx"] = tanfovx; ctx->saved_data["tanfovy"] = tanfovy; ctx->saved_data["scale_modifier"] = scale_modifier;
+    ctx->saved_data["degree"] = degree; ctx->saved_data["H"] = H; ctx->saved_data["W"] = W;
+    ctx->saved_data["has_sh"] = sh.numel() > 0; ctx->saved_data["has_col"] = colors.numel() > 0;
+    ctx->saved_data["has_sc"] = scales.numel() > 0; ctx->saved_data["has_cov"] = cov3D.numel() > 0;
+    ctx->saved_data["empty"] = means3D.size(0) == 0;
+    ctx->save_for_backward({means3D, radii, colors, sh, scales, rotations, cov3D, std::get<4>(r), std::get<5>(r), std::get<6>(r), bg, viewmatrix,
+                            projmatrix, campos});
+    ctx->mark_non_differentiable({radii});
+    return {color, radii, depth};
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    torch::autograd::variable_list out(20);       // one slot per forward argument; undefined = no gradient
+    if (ctx->saved_data["empty"].toBool()) return out;
+    const auto sv = ctx->get_saved_variables();
+    const torch::Tensor &m3 = sv[0], &radii = sv[1], &col = sv[2], &sh = sv[3], &sc = sv[4], &rot = sv[5], &cov = sv[6], &geom = sv[7],
+                        &binning = sv[8], &image = sv[9], &bg = sv[10], &view = sv[11], &proj = sv[12], &campos = sv[13];
+    const int64_t H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+    torch::Tensor g = grads[0];                   // grads[1] (radii), grads[2] (depth): accepted, ignored -- no reference call site differentiates them
+    if (!g.defined()) g = torch::zeros({3, H, W}, m3.options().dtype(torch::kFloat32));
+    const bool has_sh = ctx->saved_data["has_sh"].toBool(), has_col = ctx->saved_data["has_col"].toBool(),
+               has_sc = ctx->saved_data["has_sc"].toBool(), has_cov = ctx->saved_data["has_cov"].toBool();
+    const bool want_col = has_col && ctx->needs_input_grad(3);      // frozen colours (the reference's training): the six-sum backward
+    auto r = rasterize_gaussians_backward(bg, m3, radii, col, sc, rot, ctx->saved_data["scale_modifier"].toDouble(), cov, view, proj,
+                                          ctx->saved_data["tanfovx"].toDouble(), ctx->saved_data["tanfovy"].toDouble(), g, sh,
+                                          ctx->saved_data["degree"].toInt(), campos, geom, ctx->saved_data["R"].toInt(), binning, image, want_col);
+    out[0] = std::get<3>(r);                      // means3D
+    out[1] = std::get<0>(r);                      // means2D (x, y in NDC units, z = 0)
+    if (has_sh) out[2] = std::get<5>(r);
+    if (want_col) out[3] = std::get<1>(r);
+    out[4] = std::get<2>(r);                      // opacities
+    if (has_sc) { out[5] = std::get<6>(r); out[6] = std::get<7>(r); }
+    if (has_cov) out[7] = std::get<4>(r);
+    return out;
+  }
+};
+
+// GaussianRasterizer.forward in one call.  Whether a backward can follow is decided HERE, before the node is built: inside a node's
+// forward the grad mode is always off and needs_input_grad reports requires_grad flags even under torch.no_grad() --
+// evaluation renders of trainable parameters under no_grad take the untracked forward (GSR_FORWARD_ONLY).
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize(const torch::Tensor& means3D, const torch::Tensor& means2D, const torch::Tensor& sh, const torch::Tensor& colors,
+          const torch::Tensor& opacities, const torch::Tensor& scales, const torch::Tensor& rotations, const torch::Tensor& cov3D,
+          const torch::Tensor& bg, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const torch::Tensor& campos,
+          double tanfovx, double tanfovy, int64_t H, int64_t W, double scale_modifier, int64_t degree, bool prefiltered) {
+  bool will_backward = false;
+  if (at::GradMode::is_enabled())
+    for (const torch::Tensor* t : {&means3D, &means2D, &sh, &colors, &opacities, &scales, &rotations, &cov3D})
+      will_backward = will_backward || (t->defined() && t->requires_grad());
+  auto o = RasterizeFn::apply(means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, bg, viewmatrix, projmatrix, campos, tanfovx,
+                              tanfovy, H, W, scale_modifier, degree, prefiltered, will_backward);
+  return std::make_tuple(o[0], o[1], o[2]);
+}
+
 // upstream: markVisible(means3D, viewmatrix, projmatrix) -> bool[P]
 torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix) {
   (void)projmatrix;   // the test is the near-plane cull in view space, as upstream's
@@ -225,6 +299,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
           py::arg("want_color_grad") = true);
   }
+  m.def("rasterize", &rasterize);      // one GaussianRasterizer call: forward + the autograd node (C++)
   m.def("mark_visible", &mark_visible);
   m.def("set_list_reuse", [](bool on) { g_reuse = on; g_lists = ListCache(); });
   m.def("list_reuse_hits", []() { return g_reuse_hits; });

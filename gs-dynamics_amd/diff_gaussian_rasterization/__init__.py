@@ -98,7 +98,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             D, color, depth, radii, geom, binning, image = native.rasterize_gaussians(
                 rs.bg, m3, col_, opacities, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
                 float(rs.tanfovy), int(rs.image_height), int(rs.image_width), sh_, int(rs.sh_degree), rs.campos, bool(rs.prefiltered),
-                bool(any(ctx.needs_input_grad)))       # False (torch.no_grad(), detached inputs): the blend records nothing for a backward
+                bool(any(ctx.needs_input_grad)))       # (only reached through the Python node: test doubles; under torch.no_grad() this still says True -- the C++ node decides before it is built)
             ctx.native, ctx.rs, ctx.num_rendered = native, rs, int(D)
             ctx.has = (sh_.numel() > 0, col_.numel() > 0, sc_.numel() > 0, cov_.numel() > 0)
             ctx.save_for_backward(m3, radii, col_, sh_, sc_, rot_, cov_, geom, binning, image)
@@ -219,6 +219,13 @@ def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=No
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    native = _native() if (means3D is not None and means3D.is_cuda) else None
+    if native is not None and hasattr(native, "rasterize"):
+        # one crossing into the torch C++ layer: forward and the autograd node live there (csrc/gsr_torch.cpp: RasterizeFn)
+        rs = raster_settings
+        return native.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg, rs.viewmatrix,
+                                rs.projmatrix, rs.campos, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height), int(rs.image_width),
+                                float(rs.scale_modifier), int(rs.sh_degree), bool(rs.prefiltered))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

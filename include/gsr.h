@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 119 /* 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 120 /* 0.1.20: gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -84,13 +84,16 @@ int gsr_forward_render(const gsr_settings* s, int32_t P, uint32_t num_rendered, 
 /* ---- tile-list reuse between two single-view forwards (the reference renders every camera twice with the same geometry: colours,
  * then segmentation colours, /root/reference/src/tracking/train_utils.py:178,192; colours, then an all-ones mask,
  * /root/reference/src/predict.py:115-123 -- and hands the second call FRESH copies of the geometry tensors, so tensor identity cannot
- * key a cache).  gsr_forward_preprocess_fp is gsr_forward_preprocess that also returns a 64-bit fingerprint of everything the tile
- * lists and the blend decisions depend on (per Gaussian: index, tile rect, tile mask, depth bits, and -- since version 118 -- 2D mean,
- * conic and opacity: the forward leaves the backward's per-quad contribution bytes in the binning state, next to the lists, so a
- * sharer rewrites the owner's bytes with the same values; colours may differ; 0 = not available: P > 512 Ki).  Two calls with the same
- * (P, image size, num_rendered, fingerprint) have the same lists: the second one may then call gsr_forward_render_shared with the
- * first call's binning and image states instead of gsr_forward_render -- no duplicates are emitted or sorted, its own image state
+ * key a cache).  gsr_forward_preprocess_same is gsr_forward_preprocess that also COMPARES its outputs, on the device and bit for bit, with
+ * the geometry state of an earlier forward of the same P and image size (prev_geom_state; it must outlive the call): per Gaussian the entry
+ * count, tile rect, tile mask, depth bits and -- because the forward leaves the backward's per-quad contribution bytes in the binning
+ * state, next to the lists, so a sharer rewrites the owner's bytes and they must be the same bytes -- 2D mean, conic and opacity; colours
+ * may differ.  *same_host = 1: everything equal (then num_rendered is equal too) -- the second forward may call gsr_forward_render_shared
+ * with the first call's binning and image states instead of gsr_forward_render: no duplicates are emitted or sorted, its own image state
  * receives a copy of the owner's ranges and tile order, and gsr_backward takes (own geom, OWNER's binning, own image) as usual.
+ * 0: something differs, or no comparison was made (prev_geom_state NULL, P > 512 Ki).  The verdict rides in the copy that brings the entry
+ * count back: no extra synchronisation; the comparison reads 84 bytes per Gaussian (~3 us at 100 k).  (ABI <= 119 compared a 64-bit
+ * fingerprint: equal "up to a 2^-64 coincidence"; the bar for integer work is bit-exact.)
  * Results are bit-identical to gsr_forward_render. */
 /* gsr_forward_render_ex / gsr_forward_render_shared_ex (ABI 119): the same with `flags` -- GSR_FORWARD_ONLY (defined below): the caller
  * will not run gsr_backward on these states, so the blend skips recording what only a backward reads (the per-entry contribution bytes
@@ -100,10 +103,10 @@ int gsr_forward_render_ex(const gsr_settings* s, int32_t P, uint32_t num_rendere
 int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state, void* owner_binning_state,
                                  const void* owner_image_state, void* image_state, float* out_color, float* out_depth, uint32_t flags,
                                  void* stream);
-int gsr_forward_preprocess_fp(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
-                              const float* rotations, const float* opacities, const float* colors_precomp,
-                              const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
-                              uint32_t* num_rendered_host, uint64_t* fingerprint_host, void* stream);
+int gsr_forward_preprocess_same(const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
+                                const float* rotations, const float* opacities, const float* colors_precomp,
+                                const float* shs, const float* cov3D_precomp, void* geom_state, int32_t* radii,
+                                uint32_t* num_rendered_host, const void* prev_geom_state, int32_t* same_host, void* stream);
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
                               void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
                               float* out_depth, void* stream);

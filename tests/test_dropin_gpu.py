@@ -1,0 +1,206 @@
+"""Row (b): the unchanged caller -- the reference's call pattern through GaussianRasterizer, the torch C++ layer against the ctypes binding, tile-list reuse.
+(split out of the former tests/test_hip_gpu.py; shared machinery: tests/hipcheck.py, fixtures: tests/conftest.py)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hipcheck import *  # noqa: F401,F403
+from hipcheck import _check_against_oracle, _check_lists, _margin, _pin_tile_sort_build, _row_check, _run_hip, _settings  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_call_pattern_get_loss(dev):
+    """The literal call sequence of /root/reference/src/tracking/train_utils.py:174-192, 243-245 and
+    /root/reference/src/tracking/external.py:138-142 runs against the HIP backend."""
+    from gsdyn import get_loss, LossWeights, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    W, H, P = 160, 128, 3000
+    params = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, W, H, device=dev)[0]
+    im, seg = synth_targets(W, H, device=dev)
+    variables = init_variables(P, dev)
+    loss, variables = get_loss(params, dict(cam=cam, im=im, seg=seg, id=0), variables, True, LossWeights())
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "seg_colors", "cam_m", "cam_c"):
+        assert params[k].grad is not None and torch.isfinite(params[k].grad).all(), k
+    g2 = variables["means2D"].grad
+    assert g2.shape == (P, 3) and torch.all(g2[:, 2] == 0)
+    seen = variables["seen"]
+    accum = torch.norm(g2[seen, :2], dim=-1)
+    assert seen.any() and torch.isfinite(accum).all()
+
+
+def test_torch_extension_path_equals_ctypes_path(dev):
+    """The torch C++ layer (_C.so: upstream's rasterize_gaussians / rasterize_gaussians_backward / mark_visible over the C-ABI) and
+    the ctypes binding drive the same kernels: images, radii, depth and every gradient are bit-identical; SH colours and
+    cov3D_precomp inputs, P = 0 and markVisible go through it too."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip
+    assert dgr._C is not None and dgr._native() is dgr._C, "the torch C++ layer must be built (and used) on a GPU box"
+    cam = ring_camera(144, 104, v=1, bg=(0.2, 0.4, 0.1), sh_degree=1)
+    rs = _settings(cam, dev)
+    for variant in ("colors", "shs", "cov3d"):
+        g = random_gaussians(900, seed=5, scale_lo=0.03, scale_hi=0.3, sh_M=4 if variant == "shs" else 0)
+        if variant == "shs":
+            del g["colors_precomp"]
+        if variant == "cov3d":
+            probe = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"], rotations=g["rotations"])
+            g = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=g["colors_precomp"], cov3D_precomp=probe.cov3D)
+        dL = torch.tensor(np.random.default_rng(2).uniform(-1, 1, (3, 104, 144)).astype(np.float32), device=dev)
+        outs = []
+        for use_ext in (True, False):
+            saved = dgr._C
+            if not use_ext:
+                dgr._C = None
+            try:
+                assert (dgr._native() is not None) == use_ext
+                t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+                m2 = torch.zeros((900, 3), device=dev, requires_grad=True)
+                im, radii, depth = GaussianRasterizer(raster_settings=rs)(
+                    means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
+                    scales=t.get("scales"), rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
+                im.backward(gradient=dL)
+                outs.append((im.detach(), radii, depth.detach(), m2.grad, {k: v.grad for k, v in t.items()}))
+            finally:
+                dgr._C = saved
+        a, b = outs
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), variant
+        for k in a[4]:
+            assert (a[4][k] is None) == (b[4][k] is None) and (a[4][k] is None or torch.equal(a[4][k], b[4][k])), (variant, k)
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    color, radii, depth = GaussianRasterizer(raster_settings=rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3),
+                                                                 scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, 104, 144) and radii.numel() == 0 and float(color.abs().max()) == 0.0
+    pts = torch.tensor(np.random.default_rng(0).uniform(-6, 6, (500, 3)).astype(np.float32), device=dev)
+    assert torch.equal(GaussianRasterizer(raster_settings=rs).markVisible(pts), _hip.mark_visible(pts, rs.viewmatrix))
+
+
+def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
+    """The reference's own call pattern -- two separate ``GaussianRasterizer`` calls per camera with the same geometry and other colours,
+    the second one fed FRESH copies of the geometry tensors (/root/reference/src/tracking/train_utils.py:174-192: ``params2rendervar`` is
+    evaluated twice; /root/reference/src/predict.py:115-123: ``copy.deepcopy``) -- through the unchanged drop-in API: the torch C++ layer
+    recognises the second call by the fingerprint of its preprocess outputs and blends from the first call's tile lists.  Images and
+    every gradient must equal the non-reusing path bit for bit; a changed Gaussian or another camera must NOT reuse."""
+    import copy
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    C_ = dgr._C
+    assert C_ is not None, "the torch C++ layer must be built on a GPU box"
+    P, W, H = 40_000, 400, 304
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.05)
+    cams = synth_ring_cameras(4, W, H, device=dev)
+    rng = np.random.default_rng(3)
+    g1, g2 = (torch.tensor(rng.uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev) for _ in range(2))
+    keys = ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors", "seg_colors")
+
+    def get_loss_pair(reuse, cam):
+        C_.set_list_reuse(reuse)
+        h0 = C_.list_reuse_hits()
+        for k in keys:
+            params[k].grad = None
+        params["rgb_colors"].requires_grad_(True)
+        rv = params2rendervar(params)
+        rv["means2D"].retain_grad()
+        im, radius, depth = GaussianRasterizer(raster_settings=cam)(**rv)
+        seg_rv = params2rendervar(params, colors_key="seg_colors")          # fresh rotations / opacities / scales tensors
+        seg_rv["means2D"].retain_grad()
+        seg, radius2, _ = GaussianRasterizer(raster_settings=cam)(**seg_rv)
+        ((im * g1).sum() + (seg * g2).sum()).backward()
+        torch.cuda.synchronize()
+        out = dict(im=im.detach(), seg=seg.detach(), depth=depth.detach(), radius=radius, radius2=radius2, m2=rv["means2D"].grad, m2s=seg_rv["means2D"].grad)
+        out.update({k: params[k].grad.clone() for k in keys})
+        return out, C_.list_reuse_hits() - h0
+
+    try:
+        a, hits_a = get_loss_pair(True, cams[0])
+        b, hits_b = get_loss_pair(False, cams[0])
+        assert hits_a == 1 and hits_b == 0, (hits_a, hits_b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        # another camera, then a moved Gaussian: new lists each time
+        C_.set_list_reuse(True)
+        with torch.no_grad():
+            rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+            h0 = C_.list_reuse_hits()
+            im0, _, _ = GaussianRasterizer(raster_settings=cams[1])(**rv)
+            im1, _, _ = GaussianRasterizer(raster_settings=cams[2])(**rv)                    # other camera
+            assert C_.list_reuse_hits() == h0
+            moved = dict(rv)
+            moved["means3D"] = rv["means3D"].clone()
+            moved["means3D"][123, 0] += 0.05
+            im2, _, _ = GaussianRasterizer(raster_settings=cams[2])(**moved)                 # same camera, one Gaussian moved
+            assert C_.list_reuse_hits() == h0
+            # predict.py's mask render: deep copy of the frame's data with colours = 1
+            ones = copy.deepcopy(moved)
+            ones["colors_precomp"] = torch.ones_like(moved["colors_precomp"])
+            mask, _, _ = GaussianRasterizer(raster_settings=cams[2])(**ones)
+            assert C_.list_reuse_hits() == h0 + 1
+            C_.set_list_reuse(False)
+            mask_ref, _, _ = GaussianRasterizer(raster_settings=cams[2])(**ones)
+            im2_ref, _, _ = GaussianRasterizer(raster_settings=cams[2])(**moved)
+        assert torch.equal(mask, mask_ref) and torch.equal(im2, im2_ref)
+        assert float(mask.max()) <= 1.0 + 1e-5 and not torch.equal(im1, im2)
+
+        # Same geometry, OTHER OPACITIES, both forwards before either backward: the tile lists would be the same, but the forward leaves
+        # the backward's per-quad contribution bytes next to the lists (round 4) and those depend on the opacities -- the fingerprint
+        # covers them, so the second call bins for itself and the first call's backward still finds its own bytes.
+        def two_opacities(reuse):
+            C_.set_list_reuse(reuse)
+            h0 = C_.list_reuse_hits()
+            leaves = {k: params[k].detach().clone().requires_grad_(True) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors")}
+            thin = {k: (v - 1.5 if k == "logit_opacities" else v) for k, v in leaves.items()}
+            im_a, _, _ = GaussianRasterizer(raster_settings=cams[3])(**params2rendervar(leaves))
+            im_b, _, _ = GaussianRasterizer(raster_settings=cams[3])(**params2rendervar(thin))
+            (im_a * g1).sum().backward()
+            ga = {k: v.grad.clone() for k, v in leaves.items()}
+            (im_b * g2).sum().backward()
+            torch.cuda.synchronize()
+            return im_a.detach(), im_b.detach(), ga, {k: v.grad.clone() for k, v in leaves.items()}, C_.list_reuse_hits() - h0
+        ra, rb = two_opacities(True), two_opacities(False)
+        assert ra[4] == 0 and rb[4] == 0
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and not torch.equal(ra[0], ra[1])
+        for k in ra[2]:
+            assert torch.equal(ra[2][k], rb[2][k]) and torch.equal(ra[3][k], rb[3][k]), k
+    finally:
+        C_.set_list_reuse(True)
+
+
+@pytest.mark.parametrize("P,W,H", [(50_000, 1280, 720), (8_957, 640, 480)])
+def test_reference_workload_shapes_vs_oracle(dev, P, W, H):
+    """The reference's own sizes (VERDICT r04 'missing' 3): 1280x720 (80 x 45 tiles; /root/reference/src/tracking/utils/metadata.py:96-97,
+    src/render/renderer.py:13-14) and the demo's 640x480 with the Gaussian count of assets/demo/gs_orig.splat -- one ring camera,
+    forward + backward through the drop-in module (the C++ autograd node) against the oracle, lists bit-exact."""
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    params = synth_scene_params(P, device=dev)
+    cam = synth_ring_cameras(4, W, H, device=dev)[1]
+    with torch.no_grad():
+        rv = {k: v.detach().cpu().numpy() for k, v in params2rendervar(params).items()}
+    ocam = OracleCamera(H, W, cam.tanfovx, cam.tanfovy, cam.bg.cpu().numpy(), 1.0, cam.viewmatrix.cpu().numpy().reshape(-1),
+                        cam.projmatrix.cpu().numpy().reshape(-1), 0, cam.campos.cpu().numpy())
+    g = dict(means3D=rv["means3D"], scales=rv["scales"], rotations=rv["rotations"], opacities=rv["opacities"], colors_precomp=rv["colors_precomp"])
+    o2 = _check_against_oracle(ocam, g, dev, seed=21, nthreads=os.cpu_count() or 8, backward=True)
+    print("num_rendered", o2.num_rendered)
+
+
+def test_no_grad_render_of_trainable_parameters_is_forward_only_and_equal(dev):
+    """an evaluation render under torch.no_grad() with parameters that require gradients must take the untracked forward
+    (decided before the autograd node is built) and give the same image as the tracked one; a render with gradients enabled still
+    differentiates."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    params = synth_scene_params(3000, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, 160, 96, device=dev)[0]
+    rv = params2rendervar(params)
+    assert any(v.requires_grad for v in rv.values())
+    im_t, rad_t, dep_t = GaussianRasterizer(raster_settings=cam)(**rv)
+    with torch.no_grad():
+        im_n, rad_n, dep_n = GaussianRasterizer(raster_settings=cam)(**params2rendervar(params))
+    assert not im_n.requires_grad and im_t.requires_grad
+    assert torch.equal(im_t.detach(), im_n) and torch.equal(rad_t, rad_n) and torch.equal(dep_t.detach(), dep_n)
+    im_t.sum().backward()
+    assert params["means3D"].grad is not None and torch.isfinite(params["means3D"].grad).all()
