@@ -261,7 +261,7 @@ def main():
         total_views = args.views or 8
         my_ids = shard_views(total_views, rank, world)
 
-    scale_n1 = frozen = extras = cpu_baseline = None
+    scale_n1 = weak_n1 = frozen = extras = cpu_baseline = None
     if default_n1:
         # ONE GPU, no flags: the top-level line is the configuration BASELINE.json's metric is quoted on (configs[2]: 4 x 800^2, fwd + bwd,
         # all gradients, no optimiser); the 8-view + Adam step of configs[3] -- what `--gpus N` times on N > 1 -- rides along as `scale_n1`
@@ -269,6 +269,12 @@ def main():
         scale_n1 = measure(8, list(range(8)), True, args.frozen_colours)
         scale_n1["workload"] = ("configs[3] on ONE GPU: the fixed 8-view step (8x800^2, 100k Gaussians) fwd+bwd + Adam, all 8 views on this rank -- "
                                 "the N = 1 point of the strong-scaling curve `bench.py --gpus N` measures (N > 1: views r, r+N, ... per rank + 1 RCCL all-reduce)")
+        # ... and the per-GPU work of a WEAK-scaling run (`--weak`: 4 views per rank + Adam; N ranks render a 4N-camera ring) as `weak_n1`:
+        # the N = 1 point of the curve whose per-GPU work does not shrink with N
+        weak_n1 = measure(4, list(range(4)), True, args.frozen_colours, want_roofline=False)
+        weak_n1["workload"] = ("`bench.py --weak --gpus N` at N = 1: 4 views per GPU (4x800^2, 100k Gaussians) fwd+bwd + Adam; N > 1: every rank renders its own 4 "
+                               "cameras of a 4N-camera ring, then 1 RCCL all-reduce of the gradient bucket.  Strong scaling of the fixed 8-view step (scale_n1) is "
+                               "predicted at 3.1 - 3.5x on 8 GPUs (DESIGN.md section 7: one view's dependent kernel chain + the all-reduce are floor terms)")
         total_views, my_ids, with_opt = 4, list(range(4)), False
     else:
         with_opt = not args.no_optimizer
@@ -312,7 +318,7 @@ def main():
             "roofline": main_res.get("roofline"),
             "rccl_ranks": rccl_ranks, "rank_step_ms_min": main_res["rank_step_ms_min"], "rank_step_ms_max": main_res["rank_step_ms_max"],
             "allreduce_us": main_res["allreduce_us"],
-            "scale_n1": scale_n1, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
+            "scale_n1": scale_n1, "weak_n1": weak_n1, "frozen_colours": frozen, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         _emit(line)
     if world > 1 or force_dist:
@@ -577,6 +583,14 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
                        "frames": frames, "gnn": "DynamicsPredictor width 512, pstep 3, random weights, 100 bones"},
             "rollout_ms_total": roll_ms, "rollout_ms_per_frame": roll_ms / max(frames - 1, 1), "render_ms_total": rend_ms,
             "render_ms_per_frame_this_rank": rend_ms / frames, "render_only_Mpix_per_s": renders * W5 * H5 / (rend_ms * 1e-3) / 1e6,
+            # the rollout is replicated on every rank (autoregressive), only the renders shard: predicted episode time per frame on N GPUs from
+            # THIS run's parts (world = 1 only: render_ms is then the whole episode's renders); `overlapped` = the renders on a second
+            # stream behind the rollout (predict_episode(overlap=True)): max of the two parts instead of their sum
+            "predicted_ms_per_frame_by_gpus": None if world > 1 else {
+                str(n): {"sequential": roll_ms / max(frames - 1, 1) + rend_ms / frames / n,
+                         "overlapped": max(roll_ms / max(frames - 1, 1), rend_ms / frames / n),
+                         "speedup_vs_1": (roll_ms / max(frames - 1, 1) + rend_ms / frames) / (roll_ms / max(frames - 1, 1) + rend_ms / frames / n)}
+                for n in (1, 2, 4, 8)},
             "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()

@@ -32,6 +32,7 @@ if os.environ.get("GSR_NO_TORCH_EXT") != "1" and "GSR_HIP_LIB" not in os.environ
     except ImportError:
         _C = None
 _CTYPES_FORWARD, _CTYPES_BACKWARD = _hip.rasterize_forward, _hip.rasterize_backward
+_PY_NODE = os.environ.get("GSR_PY_AUTOGRAD") == "1"   # A/B: the autograd node as a Python torch.autograd.Function (rounds 1 - 4) instead of _C.rasterize
 
 
 def _native():
@@ -220,7 +221,7 @@ def rasterize_gaussians_views(settings_list, means3D, means2D, opacities, shs=No
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     native = _native() if (means3D is not None and means3D.is_cuda) else None
-    if native is not None and hasattr(native, "rasterize"):
+    if native is not None and hasattr(native, "rasterize") and not _PY_NODE:
         # one crossing into the torch C++ layer: forward and the autograd node live there (csrc/gsr_torch.cpp: RasterizeFn)
         rs = raster_settings
         return native.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg, rs.viewmatrix,

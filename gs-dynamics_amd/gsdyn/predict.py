@@ -7,7 +7,10 @@ cam`` goes to rank ``(frame * n_cams + cam) mod world`` -- and a rank renders al
 each) in ONE multi-view rasterizer call (``Renderer.render_cameras_with_mask``: the two renders of a camera share their tile
 lists and are blended in one tile pass).  There is NO collective on the render path; ``gather_frames`` optionally brings
 the images to one rank afterwards.  The scene data of a frame (the GNN rollout's output) is the same on every rank: the rollout
-is deterministic and cheap next to the renders, so every rank runs it.
+is deterministic and autoregressive (/root/reference/src/render/dynamics_module.py:53-172: step t + 1 needs step t), so every rank runs
+it.  It is NOT cheap next to the renders any more (round 4: 0.75 ms per frame against 0.9 - 1.0 ms of renders on one GPU at 500 k /
+1080p): with the renders sharded over N ranks the episode costs about rollout + render / N per frame -- an Amdahl term that caps 8 GPUs at
+~2x (``bench.py --config 5 --with-rollout`` prints the prediction from its measured parts).
 
 ``predict_episode`` composes the whole of /root/reference/src/predict.py:74-164 for one episode -- ``collect_scene_data``
 (/root/reference/src/render/dynamics_module.py:174-257: activations, low-opacity and outlier filtering, the autoregressive GNN

@@ -33,6 +33,7 @@ def test_reference_list_mode_is_bit_identical(dev, monkeypatch, golden_dir):
     assert np.array_equal(tight[0], ref[0]) and np.array_equal(tight[1], ref[1]) and np.array_equal(tight[2], ref[2])
     for k in ref[3]:
         assert np.array_equal(tight[3][k], ref[3][k]), k
+    from test_forward_backward_gpu import test_committed_goldens
     test_committed_goldens(dev, golden_dir)
 
 
