@@ -101,7 +101,7 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.colors = colors;
   o.view = cam.view; o.proj = cam.proj; o.campos = cam.campos; o.tanfovx = cam.tanfovx; o.tanfovy = cam.tanfovy;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.clamped = g.clamped; o.radii = radii;
-  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.cmp_rec = nullptr; o.cmp_rect = nullptr; o.cmp_ekey = nullptr; o.cmp_tiles = nullptr; o.skip = 0; o.tile_rows = nullptr;
+  o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.cmp_rec = nullptr; o.cmp_rect = nullptr; o.cmp_ekey = nullptr; o.cmp_tiles = nullptr; o.skip = 0;
   o.used = g.used; o.tracked = g.counters + 1;
 }
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
@@ -138,17 +138,16 @@ void pair_up(int V, const int32_t* geometry_of, const uint32_t* num_rendered, in
 // preprocess and no records -- decided before the entry counts exist.
 void skippable_aliases(int V, const int32_t* geometry_of, const float* const* colors_views, int flags, int skip[GSR_MAX_BATCH]) {
   static const bool off = [] { const char* e = getenv("GSR_NO_PAIR_FUSION"); return e && *e && atoi(e) != 0; }();
-  static const bool no_skip = [] { const char* e = getenv("GSR_NO_ALIAS_SKIP"); return e && *e && atoi(e) != 0; }();
   int taken[GSR_MAX_BATCH];
   for (int v = 0; v < V; ++v) { skip[v] = 0; taken[v] = 0; }
-  if (!geometry_of || !colors_views || off || no_skip || !(flags & GSR_FORWARD_ONLY)) return;
+  if (!geometry_of || !colors_views || off || !(flags & GSR_FORWARD_ONLY)) return;
   for (int v = 0; v < V; ++v) {
     const int u = geometry_of[v];
     if (u != v && !taken[u]) { taken[u] = 1; skip[v] = 1; }
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
-  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_len = 0; t.prio_frac16 = 0; t.track = 1;
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac16 = 0; t.track = 1;
 }
 
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).
@@ -184,9 +183,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
            uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, int32_t* same_host = nullptr,
-           const int* skip = nullptr, const int32_t* geometry_of = nullptr, uint32_t* tile_rows = nullptr, const void* prev_geom = nullptr) {
-  // tile_rows != nullptr (multi-view entry points): the batch state's matrix of the tile-row binning -- when the call's tile grid takes
-  // that path with the first walk fused (gsr_fused_count_ok) the preprocess launch counts the rows itself
+           const int* skip = nullptr, const int32_t* geometry_of = nullptr, const void* prev_geom = nullptr) {
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -230,12 +227,7 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     }
     if (skip && skip[v]) tab.v[v].skip = 1;
   }
-  const bool count_rows = tile_rows != nullptr && gsr_fused_count_ok(cam0.T);
-  if (count_rows)
-    for (int v = 0; v < V; ++v)
-      if (!geometry_of || geometry_of[v] == v)    // (a view that shares another view's lists has nothing to count)
-        tab.v[v].tile_rows = tile_rows + (size_t)v * (gsr_bin_rows(P) + 1) * (size_t)gsr_bin_stride(cam0.T);
-  if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st, count_rows))
+  if (int rc = gsr_launch_preprocess(tab, cam0, P, means3D, scales, rotations, opacities, colors_precomp, shs, cov3D_precomp, st))
     return rc;
   if (!num_rendered_host) {   // capacity mode: the counts stay on the device (emit_entries adds the block sums up itself)
     if (!gsr_host_block_scan(P))
@@ -317,7 +309,6 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     if (v == 0) {
       bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = counts_dev; bt.P = P;
       bt.rows = tile_rows ? gsr_bin_rows(P) : 0;
-      bt.counted = (tile_rows && P > 0 && gsr_fused_count_ok(cam.T)) ? 1 : 0;     // stage1 took the same decision
       bt.forward_only = (flags & GSR_FORWARD_ONLY) ? 1 : 0;
       bt.order = order ? order : im.tile_order;
       bt.queue = queue ? queue : im.queue;
@@ -373,7 +364,7 @@ int gsr_forward_preprocess_same(const gsr_settings* s, int32_t P, const float* m
   gsr_carve_geom(geom_state, P, &g);
   uint32_t D = 0;
   if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, nullptr, shs, cov3D_precomp, &geom_state,
-                      &radii, g.block_sums, &D, (hipStream_t)stream, nullptr, same_host, nullptr, nullptr, nullptr, prev_geom_state))
+                      &radii, g.block_sums, &D, (hipStream_t)stream, nullptr, same_host, nullptr, nullptr, prev_geom_state))
     return rc;
   if (num_rendered_host) *num_rendered_host = D;
   return 0;
@@ -423,7 +414,7 @@ int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_
   gsr_carve_image(const_cast<void*>(owner_image_state), cam.H, cam.W, &im_owner);
   gsr_carve_binning(const_cast<void*>(owner_binning_state), num_rendered, &bs);
   GsrBinViews bt;
-  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.counted = 0; bt.forward_only = 0; bt.wave_cap = 512;
+  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512;
   bt.order = im.tile_order; bt.queue = im.queue;
   fill_bin_view(bt.v[0], P, num_rendered, g, bs, im, g.block_sums);
   if (int rc = gsr_launch_shared_lists(bt, P, num_rendered, im_owner.ranges, im_owner.tile_order, im_owner.queue, im.ranges, im.tile_order,
@@ -497,7 +488,7 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   // (no geometry_of at this entry point: every view counts its rows -- a view that turns out to share lists leaves its rows unused)
   return stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp, geom_states,
-                radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, b.tile_rows);
+                radii, b.sums, num_rendered_host, (hipStream_t)stream);
 }
 
 int gsr_forward_render_batch(int32_t V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered,
@@ -537,7 +528,7 @@ int gsr_forward_batch(int32_t V, const gsr_settings* s, int32_t P, const float* 
   int skip[GSR_MAX_BATCH];
   skippable_aliases(V, geometry_of, colors_views, flags, skip);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, skip, geometry_of, b.tile_rows))
+                      geom_states, radii, b.sums, num_rendered_host, (hipStream_t)stream, nullptr, nullptr, skip, geometry_of))
     return rc;
   bool fits = binning_states != nullptr && binning_bytes != nullptr;
   for (int v = 0; fits && v < V; ++v) {
@@ -584,7 +575,7 @@ int gsr_forward_batch_capacity_raw(int32_t V, const gsr_settings* s, int32_t P, 
   BatchState b;
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   if (int rc = stage1(V, s, P, means3D, scales, rotations, opacities, colors_precomp, colors_views, shs, cov3D_precomp,
-                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw, nullptr, nullptr, geometry_of, b.tile_rows))
+                      geom_states, radii, b.sums, nullptr, (hipStream_t)stream, raw, nullptr, nullptr, geometry_of))
     return rc;
   return stage2(V, s, P, capacity_entries, geom_states, binning_states, image_states, out_color, out_depth, b.sums, b.order,
                 b.queue, geometry_of, (hipStream_t)stream, counts_dev, b.tile_rows);
@@ -661,14 +652,12 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     fill_render_view(rt.v[v], cam, g, bs, im, nullptr, nullptr, dL_dcolor[v], (float4*)scratch[v]);
     rt.v[v].ranges = im_owner.ranges;
     rt.v[v].partner = partner[v]; rt.v[v].fused_alias = fused[v];
-    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; bt.counted = 0; bt.forward_only = 0; }
+    if (v == 0) { bt.V = V; bt.T = cam.T; bt.gx = cam.gx; bt.order = b.order; bt.queue = b.queue; bt.counts_out = nullptr; bt.P = P; bt.wave_cap = 512; bt.rows = 0; bt.forward_only = 0; }
     bt.v[v].ranges = im_owner.ranges; bt.v[v].fused_alias = (uint32_t)fused[v]; bt.v[v].shares_lists = owner != v;
     any = any || num_rendered[v] > 0;
     GsrBwdView& w = vw.v[v];
     w.view = cam.view; w.proj = cam.proj; w.radii = radii[v]; w.offsets = g.offsets;
-    static const bool no_used = [] { const char* e = getenv("GSR_NO_USED_FLAGS"); return e && *e && atoi(e) != 0; }();    // A/B: write / read every record as before
-    w.used = no_used ? nullptr : g.used; w.tracked = g.counters + 1;
-    if (no_used) rt.v[v].used = nullptr;     // (the blend backward's zero fill and the per-Gaussian backward must agree)
+    w.used = g.used; w.tracked = g.counters + 1;
     w.partials = (const float4*)scratch[v]; w.dL_dmeans2D = dL_dmeans2D[v];
     w.dL_dcolors = dL_dcolors_views ? dL_dcolors_views[v] : nullptr;
     w.partner_dL_dmeans2D = partner[v] >= 0 ? dL_dmeans2D[partner[v]] : nullptr;
@@ -911,62 +900,6 @@ int gsr_gnn_rel_inputs(int32_t n_rel, int32_t attr_dim, int32_t group_dim, int32
   }
   return gsr_launch_gnn_rel_inputs(n_rel, attr_dim, group_dim, state_cols, rel_nodes, (const long long*)receivers, (const long long*)senders, out,
                                    (hipStream_t)stream);
-}
-
-static size_t gnn_carve(void* base, int32_t N, int32_t E, int32_t H, GsrGnnArgs* a) {
-  size_t off = 0;
-  char* b = (char*)base;
-  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += gsr_align(bytes); return p; };
-  const size_t nh = (size_t)N * H * 4, eh = (size_t)E * H * 4;
-  a->xp0 = (float*)take(nh); a->xp1 = (float*)take(nh); a->pe = (float*)take(nh); a->pewp = (float*)take(nh);
-  a->eff0 = (float*)take(nh); a->eff1 = (float*)take(nh); a->a23 = (float*)take(2 * nh); a->agg = (float*)take(nh);
-  a->xr0 = (float*)take(eh); a->xr1 = (float*)take(eh); a->rew1 = (float*)take(eh);
-  a->row_start = (int*)take(((size_t)N + 1) * 4);
-  a->stamps = (unsigned long long*)take(256);
-  a->sync = (unsigned*)take(16);
-  return off - gsr_align(16) + 16;      // the barrier / error words are the LAST 16 bytes
-}
-int64_t gsr_gnn_workspace_bytes(int32_t n_rows, int32_t n_rel, int32_t width) {
-  if (n_rows <= 0 || n_rel <= 0 || width <= 0) return 0;
-  GsrGnnArgs a;
-  return (int64_t)gnn_carve(nullptr, n_rows, n_rel, width, &a);
-}
-int gsr_gnn_propagate(const gsr_gnn_model* m, int32_t n_rows, int32_t n_rel, const float* p_inputs, const float* rel_nodes,
-                      const int64_t* receivers, const int64_t* senders, const float* last_pos, int32_t last_pos_stride, void* workspace,
-                      float* pred_pos, float* pred_motion, void* stream) {
-  GsrRange _range("gsr_gnn_propagate");
-  if (!m || !p_inputs || !rel_nodes || !receivers || !senders || !last_pos || !workspace || !pred_pos || !pred_motion) {
-    gsr_set_error("gsr_gnn_propagate: NULL argument");
-    return -2;
-  }
-  if (n_rows <= 0 || n_rel <= 0 || (n_rows & 15) || (n_rel & 15) || m->width <= 0 || (m->width & 15) || m->particle_in < 1 || m->attr_dim < 0 ||
-      m->group_dim < 0 || m->state_cols < 0 || m->pstep < 0 || last_pos_stride < 3) {
-    gsr_set_error("gsr_gnn_propagate: n_rows, n_rel and width must be positive multiples of 16 (pad with a dummy row and dummy relations)");
-    return -2;
-  }
-  if (m->width > 512) { gsr_set_error("gsr_gnn_propagate: width <= 512 (a quarter of K per wave in one register set)"); return -2; }
-  const float* const* w = &m->pe_w0;
-  for (int i = 0; i < 22; ++i)
-    if (!w[i]) { gsr_set_error("gsr_gnn_propagate: weight pointer %d is NULL", i); return -2; }
-  GsrGnnArgs a;
-  gnn_carve(workspace, n_rows, n_rel, m->width, &a);
-  a.N = n_rows; a.E = n_rel; a.H = m->width; a.Dp = m->particle_in; a.A = m->attr_dim; a.G = m->group_dim; a.S = m->state_cols;
-  a.pstep = m->pstep; a.clamp = m->motion_clamp;
-  a.p_in = p_inputs; a.nodes = rel_nodes; a.recv = (const long long*)receivers; a.send = (const long long*)senders;
-  a.last_pos = last_pos; a.last_stride = last_pos_stride;
-  a.pe_w0 = m->pe_w0; a.pe_b0 = m->pe_b0; a.pe_w1 = m->pe_w1; a.pe_b1 = m->pe_b1; a.pe_w2 = m->pe_w2; a.pe_b2 = m->pe_b2;
-  a.re_w0 = m->re_w0; a.re_b0 = m->re_b0; a.re_w1 = m->re_w1; a.re_b1 = m->re_b1; a.re_w2 = m->re_w2; a.re_b2 = m->re_b2;
-  a.rp_w = m->rp_w; a.rp_b = m->rp_b; a.pp_w = m->pp_w; a.pp_b = m->pp_b;
-  a.h_w0 = m->h_w0; a.h_b0 = m->h_b0; a.h_w1 = m->h_w1; a.h_b1 = m->h_b1; a.h_w2 = m->h_w2; a.h_b2 = m->h_b2;
-  a.out_pos = pred_pos; a.out_mot = pred_motion;
-  // a persistent grid with device-wide barriers: every workgroup must be resident, so at most one per CU
-  static const int want = [] { const char* e = getenv("GSR_GNN_WORKGROUPS"); return (e && *e) ? atoi(e) : 128; }();
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-    gsr_set_error("gsr_gnn_propagate: cannot query the device");
-    return -1;
-  }
-  return gsr_launch_gnn_propagate(a, want < cus ? (want < 1 ? 1 : want) : cus, (hipStream_t)stream);
 }
 
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream) {

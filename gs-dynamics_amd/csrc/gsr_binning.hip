@@ -498,7 +498,7 @@ struct TileOrderLds {
   uint32_t empty_before_s, n_busy_s, n_long_s, n_empty_s;
 };
 // `bid`: the workgroup's index among those building the order (blockIdx.x of tile_order_kernel; 0 when another kernel builds the
-// whole order with one workgroup, see bin_scan_order_kernel)
+// whole order)
 __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int items_per_wg, int bid, TileOrderLds& L) {
   auto& h_before = L.h_before; auto& h_rest = L.h_rest; auto& start = L.start;
   uint32_t& empty_before_s = L.empty_before_s; uint32_t& n_busy_s = L.n_busy_s; uint32_t& n_long_s = L.n_long_s; uint32_t& n_empty_s = L.n_empty_s;
@@ -513,9 +513,7 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
     // capacity mode: the counts for the host.  counts_out may be PINNED HOST memory (the caller then needs no copy on the stream --
     // a 4 us blit plus a 6 us bubble between the forward and the backward): a system-scope store, visible once this kernel has ended
     if (tab.counts_out && tid < tab.V)
-      // (counted rows: a view that shares lists gets its offsets[P] from the emitting workgroups of THIS launch -- its owner's, from
-      //  bin_scan, is the same number: same camera, same tiles_touched)
-      __hip_atomic_store(&tab.counts_out[tid], tab.v[tab.counted ? tab.v[tid].owner : tid].offsets[tab.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&tab.counts_out[tid], tab.v[tid].offsets[tab.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // Work items = (view, 1024-tile slice) pairs, ORD_CHUNK of them at a time: all loads of a chunk are issued before
@@ -573,6 +571,7 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
 #pragma unroll
     for (int q = 0; q < 4; ++q) { st4[q] = run; run += c4[q]; }
     if (lane == 63) n_busy_s = run;   // buckets 0..254 only: bucket 255 (empty tiles) is never counted in the histograms
+    if (bid == 0 && lane == 0) queue[2] = c4[0];     // lists of more than 2032 entries (bucket 0): the order's first tickets
     // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
     if (tab.wave_cap == 2048) {      // lists of more than 2032 entries share bucket 0: they are the workgroup tickets; queue[3] = where the lists
       if (lane == 0) n_long_s = st4[0] + c4[0];                                   // of at most 1024 entries start (bucket 127)
@@ -862,9 +861,6 @@ __device__ __forceinline__ void bin_scan_view(const GsrBinViews& tab, const GsrB
     if (tid == BIN_THREADS - 1) *s_carry = start + mine;
     __syncthreads();
   }
-  // the view's entry count (all tiles' totals, unclamped): bin_count_kernel knew it from its offsets scan; with the rows counted by the
-  // preprocess launch (tab.counted) nobody else has it before the tile-order workgroups of the emit launch read it
-  if (tab.counted && tid == 0) vw.offsets[tab.P] = *s_carry;
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, int prefixed) {   // grid: V
@@ -873,20 +869,6 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(GsrBinViews tab, 
   const GsrBinView& vw = tab.v[blockIdx.x];
   if (vw.shares_lists) return;
   bin_scan_view(tab, vw, prefixed, s_wave, &s_carry);
-}
-
-// Few tiles in the whole call (V * ceil(T / 1024) <= 4: e.g. ONE 800 x 800 view, the per-GPU share of a view-sharded step): a single
-// workgroup scans every view and then builds the longest-first tile order itself -- one launch instead of bin_scan + tile_order,
-// and one memory round trip less on the critical path of a short step.
-__global__ __launch_bounds__(BIN_THREADS) void bin_scan_order_kernel(GsrBinViews tab, int prefixed, int n_items) {
-  __shared__ uint32_t s_wave[BIN_THREADS / 64];
-  __shared__ uint32_t s_carry;
-  __shared__ TileOrderLds L;
-  for (int v = 0; v < tab.V; ++v)
-    if (!tab.v[v].shares_lists) bin_scan_view(tab, tab.v[v], prefixed, s_wave, &s_carry);
-  __threadfence_block();      // the ranges written above are read back below (by other threads of this workgroup)
-  __syncthreads();
-  tile_order_body(tab, n_items, 0, L);
 }
 
 // `order_wgs` > 0: the launch carries the tile-order builder as well -- workgroups tab.rows .. tab.rows + order_wgs - 1 of grid row 0
@@ -906,50 +888,6 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
   const GsrBinView& vw = tab.v[blockIdx.y];
   const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
-  if (tab.counted && !tab.forward_only) {
-    // The rows were counted by the preprocess launch: the scan of tiles_touched into offsets[] (the Gaussian-major slots of the backward's
-    // records, + the offset word of the 64-byte records) that rode in bin_count_kernel happens here -- also for a view that shares
-    // another view's lists (its own backward pass addresses its own records).
-    __shared__ uint32_t s_red[BIN_THREADS / 64];
-    __shared__ uint32_t s_wsum[BIN_THREADS / 64];
-    uint32_t tt[BIN_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < BIN_PER_THREAD; ++q) {
-      const int g = g0 + tid * BIN_PER_THREAD + q;
-      tt[q] = g < P ? vw.tiles_touched[g] : 0u;
-    }
-    const int jb = g0 / GSR_BLOCK;
-    uint32_t part = 0;
-    if (vw.block_offsets) { if (tid == 0) part = vw.block_offsets[jb]; }
-    else for (int j = tid; j < jb; j += BIN_THREADS) part += vw.block_sums[j];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int q = 0; q < BIN_PER_THREAD; ++q) sum += tt[q];
-    uint32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
-    if (lane == 63) s_wsum[wv] = inc;
-    if (lane == 0) s_red[wv] = part;
-    __syncthreads();
-    uint32_t run = inc - sum;
-#pragma unroll
-    for (int w = 0; w < BIN_THREADS / 64; ++w) { run += s_red[w]; if (w < wv) run += s_wsum[w]; }
-#pragma unroll
-    for (int q = 0; q < BIN_PER_THREAD; ++q) {
-      const int g = g0 + tid * BIN_PER_THREAD + q;
-      if (g < P) {
-        vw.offsets[g] = run;
-        reinterpret_cast<uint32_t*>(vw.rec_w + GSR_REC_F4 * (size_t)g + 3)[2] = run;   // the blend backward reads it from the record
-      }
-      run += tt[q];
-    }
-    if (vw.shares_lists && g0 + GSR_BIN_G >= P && tid == BIN_THREADS - 1) vw.offsets[P] = run;   // (an owner's count came from bin_scan)
-  }
   if (vw.shares_lists) return;
   const uint32_t cap = vw.D;
   const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
@@ -1278,12 +1216,18 @@ __global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES
     // the wave tickets have their own launch; this one STRIDES over the long tickets with a grid that fits the chip once (round 4: it
     // used to be one workgroup per tile of the call -- 32 640 workgroups of 36 KiB of LDS for a configs[4] frame, four resident per
     // CU, nearly all of them returning at once: 110 - 600 us of dispatch for a handful of lists)
-    for (uint32_t ticket = blockIdx.x; ticket < n_long; ticket += gridDim.x) {
+    // (ordinary scenes, wave_cap 512: only the lists of more than 2032 entries -- queue[2] of them -- come here; the one-launch build takes the rest)
+    const uint32_t n_mine = tab.wave_cap == 512 ? tab.queue[2] : n_long;
+    for (uint32_t ticket = blockIdx.x; ticket < n_mine; ticket += gridDim.x) {
       tile_sort_long_ticket<RCAP, NW>(tab, cur, ticket);
       __syncthreads();                           // the LDS block is the next ticket's
     }
   } else if constexpr (MODE != 2) {
     if (blockIdx.x >= n_long) return;
+    // An ordinary scene's few VERY long lists (> 2032 entries: close-ups, a cluster behind one tile) would sort in global memory here
+    // (~160 us for one list); they belong to the strided launch of the 4096-entry block that follows (round 5: the build is chosen per
+    // ticket, not per scene)
+    if (RCAP <= 1024 && blockIdx.x < tab.queue[2]) return;
     tile_sort_long_ticket<RCAP, NW>(tab, cur, blockIdx.x);
   }
 }
@@ -1438,12 +1382,6 @@ bool gsr_rows_path_ok(int T) {
   const bool radix_only = e && *e && atoi(e) != 0;
   return !radix_only && T > 0 && T <= GSR_BIN_MAX_T && bin_lds_static() + sizeof(uint32_t) * (size_t)T <= bin_lds_limit();
 }
-bool gsr_fused_count_ok(int T) {     // GSR_FUSED_COUNT=1: the counting form of preprocess_fwd instead of the separate bin_count launch.  OFF by
-  // default: measured no faster (profiles/r04_rejected_fused_count.txt)
-  static const bool on = [] { const char* e = getenv("GSR_FUSED_COUNT"); return e && *e && atoi(e) != 0; }();
-  return on && gsr_rows_path_ok(T) && gsr_preprocess_count_static_lds() + sizeof(uint32_t) * (size_t)T <= bin_lds_limit();
-}
-
 int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   if (tab_in.V <= 0 || tab_in.T <= 0) return 0;
   GsrBinViews tab = tab_in;
@@ -1451,24 +1389,20 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   for (int v = 0; v < tab.V; ++v) { maxD = tab.v[v].D > maxD ? tab.v[v].D : maxD; maxblk = tab.v[v].nblocks > maxblk ? tab.v[v].nblocks : maxblk; }
   const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
-  static const bool wave32_off = [] { const char* e = getenv("GSR_WAVE_SORT_2048"); return e && *e && atoi(e) == 0; }();
-  tab.wave_cap = big ? (wave32_off ? 1024 : 2048) : 512;
+  tab.wave_cap = big ? 2048 : 512;
   int cur = 0;
   bool order_done = false;
   const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
   const bool rows_path = tab.rows > 0 && gsr_rows_path_ok(tab.T) && maxD > 0 && P > 0;
   if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
-    if (!tab.counted) {          // (counted: the preprocess launch stored the rows -- preprocess_fwd_count_kernel)
-      GSR_PROF("bin_count", st);
+    { GSR_PROF("bin_count", st);
       hipLaunchKernelGGL(bin_count_kernel, dim3(tab.rows, tab.V), dim3(BIN_THREADS), lds, st, P, tab);
     }
     GSR_HIP_CHECK(hipGetLastError());
     const int prefixed = tab.rows > BIN_DIRECT_ROWS ? 1 : 0;
-    // the column prefix also scans the tile totals into the ranges (one launch less) unless the rows were counted by the preprocess launch
-    // (bin_scan then also leaves the view's entry count) or GSR_BIN_CHAINED_SCAN=0 (A/B)
-    static const bool chained_on = [] { const char* e = getenv("GSR_BIN_CHAINED_SCAN"); return !(e && *e && atoi(e) == 0); }();
+    // the column prefix also scans the tile totals into the ranges (one launch less: bin_colprefix + bin_scan 13.9 -> 8.9 us per step)
     const int col_wgs = (gsr_bin_stride(tab.T) + GSR_BLOCK - 1) / GSR_BLOCK;
-    const bool chained = prefixed && chained_on && !tab.counted && col_wgs <= 64;
+    const bool chained = prefixed && col_wgs <= 64;
     if (chained) {
       GSR_PROF("bin_colprefix", st);
       hipLaunchKernelGGL(bin_colprefix_scan_kernel, dim3(col_wgs, tab.V), dim3(GSR_BLOCK), 0, st, tab);
@@ -1478,20 +1412,15 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
     }
     GSR_HIP_CHECK(hipGetLastError());
     const int n_items = tab.V * ((tab.T + 1023) / 1024);
-    // GSR_BIN_ORDER: 0 (default) = the tile order is built INSIDE the emit launch by extra workgroups; 1 = small calls scan and order in
-    // one workgroup (bin_scan_order; round-3 first form); 2 = a tile_order launch of its own behind the emit
-    static const int order_mode = [] { const char* e = getenv("GSR_BIN_ORDER"); return e ? atoi(e) : 0; }();
-    if (order_mode == 1 && n_items <= 4) {
-      GSR_PROF("bin_scan_order", st);
-      hipLaunchKernelGGL(bin_scan_order_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tab, prefixed, n_items);
-      order_done = true;
-    } else if (!chained) {
+    // the tile order is built INSIDE the emit launch by extra workgroups (a launch of its own behind the emit, or scan + order in one
+    // workgroup for small calls, were measured no better)
+    if (!chained) {
       GSR_PROF("bin_scan", st);
       hipLaunchKernelGGL(bin_scan_kernel, dim3(tab.V), dim3(BIN_THREADS), 0, st, tab, prefixed);
     }
     GSR_HIP_CHECK(hipGetLastError());
     int order_wgs = 0, per_wg = 1;
-    if (!order_done && order_mode == 0) {
+    {
       order_wgs = n_items < ORD_MAX_WG ? n_items : ORD_MAX_WG;
       if (order_wgs < 1) order_wgs = 1;
       per_wg = (n_items + order_wgs - 1) / order_wgs;
@@ -1552,27 +1481,21 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
       // 4096-entry block is the default: radix sort in LDS up to 4096 entries, 64-bit network in LDS up to 8192.  A deforming configs[4]
       // episode has thousands of lists of 2033 .. 7000 entries per frame; with the 2048-entry block those ran the LDS network (<= 4096)
       // or the network in GLOBAL memory (above): tile_sort 1040 us per frame of the episode, now ~450; its renders 1.67 -> 1.14 ms per
-      // frame.  GSR_LONG_SORT=2048 keeps the small block.  (One wave per list with 64 keys per lane -- 192 VGPRs, 116 us per list -- was
+      // frame.  (One wave per list with 64 keys per lane -- 192 VGPRs, 116 us per list -- was
       // measured too: slower than either.)
-      const char* ls = getenv("GSR_LONG_SORT");      // (read per call: the tests switch builds inside one process)
-      const bool small_block = ls && ls[0] == '2';
-      if (small_block) {
-        const int g1 = tab.V * tab.T < 1024 ? tab.V * tab.T : 1024;      // four workgroups of the 36 KiB block per CU
-        hipLaunchKernelGGL((tile_sort_kernel<2048, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
-      } else {
-        const int g1 = tab.V * tab.T < 512 ? tab.V * tab.T : 512;        // two of the 68 KiB block
-        static const int lw = [] { const char* e = getenv("GSR_LONG_SORT_WAVES"); return e ? atoi(e) : 8; }();     // waves per workgroup: render of the configs[4] episode 1.12 (4) / 1.00 (8) / 1.11 (16) ms per frame
-        if (lw == 8) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 8>), dim3(g1), dim3(512), 0, st, tab, cur);
-        else if (lw == 16) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 16>), dim3(g1), dim3(1024), 0, st, tab, cur);
-        else hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 4>), dim3(g1), dim3(256), 0, st, tab, cur);
-      }
+      const int g1 = tab.V * tab.T < 512 ? tab.V * tab.T : 512;        // two workgroups of the 68 KiB block per CU, eight waves each
+      hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 8>), dim3(g1), dim3(512), 0, st, tab, cur);     // (4 / 16 waves: render of the configs[4] episode 1.12 / 1.11 ms per frame against 1.00)
     } else
       {
         // ordinary scenes: the 1024-entry LDS block (20 KiB: eight workgroups per CU -- the wave-sorted lists are the bulk of the work
         // and want the occupancy); GSR_TILE_SORT_RCAP=2048 keeps the 36 KiB build
         const bool small_lds = !(force && force[0] == '2');
-        if (small_lds) hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
-        else hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
+        if (small_lds) {
+          hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
+          // ... and the scene's few lists of more than 2032 entries (queue[2]: normally none -- the workgroups read the count and leave)
+          // on the 4096-entry block: LDS radix sort up to 4096 entries, LDS network up to 8192 (was: the network in GLOBAL memory)
+          hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 8>), dim3(64), dim3(512), 0, st, tab, cur);
+        } else hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
       } }
     GSR_HIP_CHECK(hipGetLastError());
   }

@@ -134,32 +134,7 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
 #define GSR_HOST_SCAN_MAX_BLOCKS 2048
 static inline bool gsr_host_block_scan(int P) { return (P + GSR_BLOCK - 1) / GSR_BLOCK <= GSR_HOST_SCAN_MAX_BLOCKS; }
 
-// ---------------------------------------------------------------- propagation network in one launch (gsr_gnn.hip)
-struct GsrGnnArgs {
-  int N, E, H;               // node rows, relations (both multiples of 16), width (multiple of 16)
-  int Dp, A, G, S;           // particle input width; attribute / instance / state widths of `nodes`
-  int pstep;
-  float clamp;
-  const float* p_in;         // [N, Dp]
-  const float* nodes;        // [N, A + G + S]: attributes, instance columns, state history
-  const long long* recv;     // [E] ascending
-  const long long* send;     // [E]
-  const float* last_pos;     // [N, 3] with row stride last_stride: what the predicted motion is added to
-  int last_stride;
-  const float *pe_w0, *pe_b0, *pe_w1, *pe_b1, *pe_w2, *pe_b2;     // particle encoder  [H,Dp] [H,H] [H,H]
-  const float *re_w0, *re_b0, *re_w1, *re_b1, *re_w2, *re_b2;     // relation encoder  [H,Dr] [H,H] [H,H],  Dr = 2A + 1 + S
-  const float *rp_w, *rp_b;                                       // relation propagator [H, 3H]
-  const float *pp_w, *pp_b;                                       // particle propagator [H, 2H]
-  const float *h_w0, *h_b0, *h_w1, *h_b1, *h_w2, *h_b2;           // head [H,H] [H,H] [3,H]
-  float *xp0, *xp1, *pe, *pewp, *eff0, *eff1, *a23, *agg;         // [N,H] each, a23 [N,2H]
-  float *xr0, *xr1, *rew1;                                        // [E,H] each
-  int* row_start;                                                 // [N + 1]
-  unsigned long long* stamps;                                     // [32] 100 MHz time stamps of workgroup 0 after each stage (diagnostics)
-  unsigned* sync;                                                 // [0] arrivals, [1] exits, [2] error flag (relations not sorted)
-  float *out_pos, *out_mot;                                       // [N,3]
-};
-
-int gsr_launch_gnn_propagate(const GsrGnnArgs& a, int workgroups, hipStream_t st);
+// ---------------------------------------------------------------- propagation network pieces (gsr_gnn.hip)
 int gsr_launch_gnn_aggregate(int N, int n_sum, int H, const float* rew1, const float* a23, const long long* send, const long long* row_start, float* agg, hipStream_t st);
 int gsr_launch_gnn_rel_inputs(int E, int A, int G, int S, const float* nodes, const long long* recv, const long long* send, float* out, hipStream_t st);
 
@@ -218,9 +193,6 @@ struct GsrPreView {            // preprocess
   uint8_t* used; uint32_t* tracked;   // GeomState::used, &GeomState::counters[1]: both cleared here, set by the tracking forward
   int skip;              // 1: nothing to preprocess for this view (forward-only fused alias: its owner's tile pass reads its colours
                          //    straight from its colour array, nobody reads a record of its own)
-  uint32_t* tile_rows;   // counting form (preprocess_fwd_count_kernel): this view's (workgroups x tiles) matrix of the tile-row binning --
-                         //    the workgroup's per-tile entry counts go to its row (what bin_count_kernel does in a launch of its own);
-                         //    nullptr: the view shares another view's lists, nothing to count
 };
 struct GsrPreViews {
   int V;
@@ -249,8 +221,6 @@ struct GsrBinViews {
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
   int wave_cap;                  // tile_sort: lists up to this length (512 / 1024 / 2048) are sorted by one wave each (set by gsr_launch_binning)
   int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
-  int counted;                   // 1: the rows were counted by the preprocess launch (preprocess_fwd_count_kernel): no bin_count launch;
-                                 //    bin_scan publishes the views' entry counts (offsets[P]) and bin_emit scans tiles_touched into offsets[]
   int forward_only;              // GSR_FORWARD_ONLY: no backward will read these states (the record-slot offsets are not produced)
   GsrBinView v[GSR_MAX_BATCH];
 };
@@ -268,8 +238,7 @@ struct GsrRenderView {         // blend forward / backward
 struct GsrRenderViews {
   int V, W, H, gx, T; const uint4* order; uint32_t* queue;
   int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
-  int prio_len;         // backward (GSR_BWD_PRIO_LEN, experiment): tickets with at least this many entries run at base priority 1; 0 = off
-  int prio_frac16;      // ... or the longest prio_frac16 / 16 of the busy tickets (GSR_BWD_PRIO_FRAC16)
+  int prio_frac16;      // backward: the longest prio_frac16 / 16 of the busy tickets run at base wave priority 1 (one-view launches; 0 = off)
   int track;            // forward: 1 = record the contribution bytes (a backward may follow); 0 = forward-only call
   GsrRenderView v[GSR_MAX_BATCH];
 };
@@ -300,12 +269,9 @@ static inline size_t gsr_carve_batch(void* base, int V, int32_t P, int32_t H, in
 
 int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, hipStream_t st, bool count_rows = false);
-size_t gsr_preprocess_count_static_lds();
-// Will a multi-view call of this tile grid take the tile-row binning, with its first walk (the per-workgroup tile counts) fused into the
-// preprocess launch?  Decided from (T, device, environment) alone, so the preprocess stage and the render stage of a call agree.
+                          const float* shs, const float* cov3D_precomp, hipStream_t st);
+// Will a call of this tile grid take the tile-row binning?  Decided from (T, device, environment) alone.
 bool gsr_rows_path_ok(int T);
-bool gsr_fused_count_ok(int T);
 int gsr_launch_scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out, hipStream_t st);
 int gsr_launch_binning(const GsrBinViews& tab, int P, hipStream_t st);
 int gsr_launch_tile_order(const GsrBinViews& tab, hipStream_t st);
@@ -494,24 +460,6 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
                                                       float v6, float v7, float v8) {
   const int lane = gsr_lane();
   const bool b0 = lane & 1, b1 = lane & 2;
-#ifdef GSR_SUM_CNDMASK   // every level as two selects + one exchange-add (34 VALU issues): kept for A/B builds
-  const bool b2 = lane & 4, b3 = lane & 8;
-  // xor 1 (quad_perm [1,0,3,2]): 9 -> 5
-  const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
-  const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
-  const float r45 = (b0 ? v5 : v4) + gsr_dpp_get<0xB1>(b0 ? v4 : v5);
-  const float r67 = (b0 ? v7 : v6) + gsr_dpp_get<0xB1>(b0 ? v6 : v7);
-  const float r8 = v8 + gsr_dpp_get<0xB1>(v8);
-  // xor 2 (quad_perm [2,3,0,1]): 5 -> 3   (lane & 3 now indexes v0..v3 / v4..v7)
-  const float q03 = (b1 ? r23 : r01) + gsr_dpp_get<0x4E>(b1 ? r01 : r23);
-  const float q47 = (b1 ? r67 : r45) + gsr_dpp_get<0x4E>(b1 ? r45 : r67);
-  const float q8 = r8 + gsr_dpp_get<0x4E>(r8);
-  // xor 4 (ds_swizzle): 3 -> 2   (lane & 7 indexes v0..v7)
-  const float p07 = (b2 ? q47 : q03) + gsr_swz_xor4(b2 ? q03 : q47);
-  const float p8 = q8 + gsr_swz_xor4(q8);
-  // xor 8 (row_ror:8): 2 -> 1   (lanes with bit 3 clear: v_(lane&7); bit 3 set: v8)
-  float z = (b3 ? p8 : p07) + gsr_dpp_get<0x128>(b3 ? p07 : p8);
-#else
   // A level of the packed butterfly keeps "x_self + x_partner" of value a in the lanes whose selector bit is clear and of value
   // b in the others.  Where the selector is a DPP write-mask group -- lane bits 2 and 3 are the four-lane "banks" of a 16-lane
   // row -- the select folds into the add: one DPP add per half with bank_mask, two issues per pair instead of two v_cndmask +
@@ -546,48 +494,12 @@ __device__ __forceinline__ float gsr_wave_sum9_packed(float v0, float v1, float 
       "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
       "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
       : "=&v"(z) : "v"(p07), "v"(p8));
-#endif
   // rows: the packed layout differs per lane, so the row levels must be lane-wise exchanges (row_bcast would
   // broadcast a single lane), see gsr_rows_sum.  Every lane ends up with the total of "its" value: lane & 15 in 0..7 ->
   // v_(lane & 7), lane & 8 set -> v8.
   return gsr_rows_sum<PERM>(z);
 }
 
-// The nine sums WITHOUT the two row levels and without any LDS-crossbar step: after the in-row levels every 16-lane ROW holds its
-// own partial totals -- lanes with (lane & 15) = i < 8 the row's sum of v_i, lanes 8 .. 15 the row's sum of v8.  The caller adds the
-// four rows up with ONE ds_add_f32 per visit (36 active lanes, fire and forget) instead of ds_swizzle + wait + add + ds_bpermute +
-// wait + add + ds_write: the per-visit dependency chain then contains no LDS round trip at all.  (v8's xor-4 level is two masked
-// DPP adds here instead of the ds_swizzle of gsr_wave_sum9_packed.)
-__device__ __forceinline__ float gsr_wave_sum9_rows(float v0, float v1, float v2, float v3, float v4, float v5,
-                                                    float v6, float v7, float v8) {
-  const int lane = gsr_lane();
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float r01, r23, r45, r67, r8;
-  asm("s_nop 4\n\t"
-      "v_add_f32_dpp %0, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %1, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %2, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %4, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %0, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %1, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %3, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %4, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa"
-      : "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67), "=&v"(r8)
-      : "v"(v0), "v"(v4), "v"(v1), "v"(v5), "v"(v2), "v"(v6), "v"(v3), "v"(v7), "v"(v8));
-  const float q03 = (b0 ? r23 : r01) + gsr_dpp_get<0xB1>(b0 ? r01 : r23);
-  const float q47 = (b0 ? r67 : r45) + gsr_dpp_get<0xB1>(b0 ? r45 : r67);
-  const float q8 = r8 + gsr_dpp_get<0xB1>(r8);
-  const float p07 = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
-  const float p8 = q8 + gsr_dpp_get<0x4E>(q8);
-  float z;
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
-      : "=&v"(z) : "v"(p07), "v"(p8));
-  return z;
-}
 
 // Eight values (fused pair backward without colour gradients): 8 -> 4 -> 2 -> 1 registers, 20 VALU issues (see above).
 // Result z (in every lane): lane with (lane & 7) = i holds the wave total of v_i.
@@ -595,16 +507,6 @@ __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float 
                                                       float v6, float v7) {
   const int lane = gsr_lane();
   const bool b0 = lane & 1, b1 = lane & 2;
-#ifdef GSR_SUM_CNDMASK
-  const bool b2 = lane & 4;
-  const float r01 = (b0 ? v1 : v0) + gsr_dpp_get<0xB1>(b0 ? v0 : v1);
-  const float r23 = (b0 ? v3 : v2) + gsr_dpp_get<0xB1>(b0 ? v2 : v3);
-  const float r45 = (b0 ? v5 : v4) + gsr_dpp_get<0xB1>(b0 ? v4 : v5);
-  const float r67 = (b0 ? v7 : v6) + gsr_dpp_get<0xB1>(b0 ? v6 : v7);
-  const float q03 = (b1 ? r23 : r01) + gsr_dpp_get<0x4E>(b1 ? r01 : r23);
-  const float q47 = (b1 ? r67 : r45) + gsr_dpp_get<0x4E>(b1 ? r45 : r67);
-  float z = (b2 ? q47 : q03) + gsr_swz_xor4(b2 ? q03 : q47);
-#else
   float r01, r23, r45, r67;
   asm("s_nop 4\n\t"
       "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
@@ -620,7 +522,6 @@ __device__ __forceinline__ float gsr_wave_sum8_packed(float v0, float v1, float 
   const float q03 = (b0 ? r23 : r01) + gsr_dpp_get<0xB1>(b0 ? r01 : r23);
   const float q47 = (b0 ? r67 : r45) + gsr_dpp_get<0xB1>(b0 ? r45 : r67);
   float z = (b1 ? q47 : q03) + gsr_dpp_get<0x4E>(b1 ? q03 : q47);
-#endif
   z += gsr_dpp_get<0x128>(z);                                                        // xor 8 (row_ror:8)
   return gsr_rows_sum<false>(z);                                                     // xor 16, xor 32
 }

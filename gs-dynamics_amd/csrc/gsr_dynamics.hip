@@ -720,8 +720,7 @@ int gsr_launch_fps(int N, const float* pos, int npoints, int start, float* mind,
 int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float radius, int thin_start, long long* out_idx, long long* thin_idx,
                         int* thin_count, hipStream_t st) {
   { GSR_PROF("fps_thin", st);
-    static const bool four_waves = [] { const char* e = getenv("GSR_FPS_THIN_4WAVES"); return e && *e && atoi(e) != 0; }();    // A/B: round 3's form
-    if (N <= 1024 && npoints <= 128 && !four_waves)
+    if (N <= 1024 && npoints <= 128)       // one wave, 16 points per lane in registers (round 4); larger inputs: the four-wave form
       hipLaunchKernelGGL(fps_thin_wave_kernel, dim3(1), dim3(64), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count);
     else
       hipLaunchKernelGGL(fps_thin_small_kernel, dim3(1), dim3(FT_THREADS), 0, st, pos, N, npoints, start, radius, thin_start, out_idx, thin_idx, thin_count); }

@@ -513,8 +513,7 @@ int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_mo
   if (P <= 0) return 0;
   int nact = 0;
   for (int v = 0; v < vw.V; ++v) nact += vw.v[v].fused_alias ? 0 : 1;
-  static const bool loop_only = [] { const char* e = getenv("GSR_BWD_VIEWS_LOOP"); return e && *e && atoi(e) != 0; }();
-  if (nact >= 2 && !loop_only) {      // one wave per view
+  if (nact >= 2) {      // one wave per view
     { GSR_PROF("preprocess_bwd_views", st);
       hipLaunchKernelGGL(preprocess_bwd_views_waves_kernel, dim3((P + 63) / 64), dim3(64 * nact), sizeof(float) * (size_t)nact * (PBW_VALUES + 1) * 64,
                          st, vw, P, scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity,

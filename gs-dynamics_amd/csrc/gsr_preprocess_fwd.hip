@@ -331,74 +331,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
 }
 
-// The counting form (round 4): preprocess + the first walk of the tile-row binning in ONE launch.  A workgroup of BIN_THREADS threads owns
-// GSR_BIN_G consecutive Gaussians of a view (thread t: Gaussians g0 + t, g0 + t + BIN_THREADS, ... -- coalesced), preprocesses them and,
-// with their tile rects and masks still in registers, counts the entries per tile in LDS and stores the counters as ITS ROW of the
-// view's (workgroups x tiles) matrix -- what bin_count_kernel (gsr_binning.hip) did in a launch of its own after re-reading rect / ekey /
-// tiles_touched: one dependent launch and one pass over 20 bytes per Gaussian fewer in front of the blend.  The offsets[] scan that
-// rode in bin_count_kernel moves to bin_emit_kernel, the view's entry count (offsets[P]) to bin_scan.
-#ifndef GSR_PRECOUNT_WPE
-#define GSR_PRECOUNT_WPE 4      // waves per SIMD the register allocation is bounded for: 4 = one 1024-thread workgroup per CU (79 VGPRs, no spill);
-#endif                          // 8 = two per CU (64 VGPRs, 60 bytes of scratch per lane)
-__global__ __launch_bounds__(BIN_THREADS, GSR_PRECOUNT_WPE) void preprocess_fwd_count_kernel(
-    GsrPreViews tab, int P, int W, int H, int gx, int gy, float mod, int sh_degree, int M,
-    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ opacities, const float* __restrict__ colors_precomp,
-    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, int tight_lists) {
-  extern __shared__ uint32_t s_cnt[];                 // [T] tile counters
-  __shared__ uint32_t s_wave_sum[BIN_THREADS / GSR_WAVE];
-  __shared__ float4 s_rec[BIN_THREADS / GSR_WAVE][256];
-  __shared__ uint2 s_big[BIN_BIG_MAX];                // rects walked by a whole wave (see bin_count_kernel)
-  __shared__ uint32_t s_nbig;
-  const GsrPreView& vw = tab.v[blockIdx.y];
-  if (vw.skip) return;
-  if (vw.colors) colors_precomp = vw.colors;
-  const int T = gx * gy, Ts = gsr_bin_stride(T), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g0 = (int)blockIdx.x * GSR_BIN_G;
-  const bool count = vw.tile_rows != nullptr;
-  if (count) for (int t = tid; t < T; t += BIN_THREADS) s_cnt[t] = 0;
-  if (tid == 0) s_nbig = 0;
-  PreOut po[BIN_PER_THREAD];
-#pragma unroll
-  for (int q = 0; q < BIN_PER_THREAD; ++q) {          // (fully unrolled: po[] stays in registers)
-    const int i = g0 + q * BIN_THREADS + tid;
-    po[q] = preprocess_gaussian(tab, vw, i, P, s_rec[wv], blockIdx.y == 0, W, H, gx, gy, mod, sh_degree, M, means3D, scales, rotations, opacities,
-                                colors_precomp, shs, cov3D_precomp, tight_lists);
-    // per-256-Gaussian totals of tiles_touched, as the 256-thread form writes them (the host's entry count, the offsets scan of bin_emit)
-    uint32_t wsum = po[q].tiles;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m, 64);
-    if (lane == 0) s_wave_sum[wv] = wsum;
-    __syncthreads();                                    // (also orders the zeroing of s_cnt before the first count below)
-    if (tid < BIN_THREADS / GSR_BLOCK) {
-      const int blk = (g0 + q * BIN_THREADS) / GSR_BLOCK + tid;
-      if (blk * GSR_BLOCK < P)
-        vw.block_sums[blk] = s_wave_sum[4 * tid] + s_wave_sum[4 * tid + 1] + s_wave_sum[4 * tid + 2] + s_wave_sum[4 * tid + 3];
-    }
-    __syncthreads();
-  }
-  if (!count) return;
-#pragma unroll
-  for (int q = 0; q < BIN_PER_THREAD; ++q) {
-    if (!po[q].tiles) continue;
-    const BinGauss b = bin_gauss(po[q].rc, po[q].tmask);
-    if (b.area > BIN_BIG_AREA) {
-      const uint32_t slot = atomicAdd(&s_nbig, 1u);
-      if (slot < BIN_BIG_MAX) { s_big[slot] = po[q].rc; continue; }
-    }
-    bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
-  }
-  __syncthreads();
-  const uint32_t nbig = min(s_nbig, (uint32_t)BIN_BIG_MAX);
-  for (uint32_t i = wv; i < nbig; i += BIN_THREADS / 64) {   // one wave per parked Gaussian, a lane per tile
-    const BinGauss b = bin_gauss(s_big[i], 0u);
-    for (uint32_t k = lane; k < b.area; k += 64) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
-  }
-  if (nbig) __syncthreads();
-  uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
-  for (int t = tid; t < Ts; t += BIN_THREADS) row[t] = t < T ? s_cnt[t] : 0u;      // (the padding columns of the row stay zero)
-}
-
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float* __restrict__ view,
                                                                  const float* __restrict__ means3D,
                                                                  uint8_t* __restrict__ present) {
@@ -413,31 +345,17 @@ using namespace gsr_preprocess_fwd;
 
 int gsr_launch_preprocess(const GsrPreViews& tab, const GsrCam& cam, int P, const float* means3D, const float* scales,
                           const float* rotations, const float* opacities, const float* colors_precomp,
-                          const float* shs, const float* cov3D_precomp, hipStream_t st, bool count_rows) {
+                          const float* shs, const float* cov3D_precomp, hipStream_t st) {
   if (P <= 0 || tab.V <= 0) return 0;
   int blocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
   const char* ref_lists = getenv("GSR_REFERENCE_LISTS");
   const int tight = (ref_lists && ref_lists[0] == '1') ? 0 : 1;
   { GSR_PROF("preprocess_fwd", st);
-  if (count_rows)    // the counting form: one workgroup per GSR_BIN_G Gaussians, its tile counts go to its row of the view's matrix
-    hipLaunchKernelGGL(preprocess_fwd_count_kernel, dim3(gsr_bin_rows(P), tab.V), dim3(BIN_THREADS), sizeof(uint32_t) * (size_t)cam.T, st, tab, P,
-                       cam.W, cam.H, cam.gx, cam.gy, cam.scale_modifier, cam.sh_degree, cam.M, means3D, scales, rotations, opacities,
-                       colors_precomp, shs, cov3D_precomp, tight);
-  else
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks, tab.V), dim3(GSR_BLOCK), 0, st, tab, P, cam.W, cam.H, cam.gx,
                      cam.gy, cam.scale_modifier, cam.sh_degree, cam.M, means3D, scales, rotations, opacities,
                      colors_precomp, shs, cov3D_precomp, tight); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
-}
-
-// Static LDS of the counting form (the launch adds 4 T bytes of tile counters): gsr_fused_count_ok() compares with the device's limit.
-size_t gsr_preprocess_count_static_lds() {
-  static const size_t v = [] {
-    hipFuncAttributes a{};
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(preprocess_fwd_count_kernel)) == hipSuccess ? (size_t)a.sharedSizeBytes : (size_t)(12 << 10);
-  }();
-  return v;
 }
 
 int gsr_launch_mark_visible(const float* view, int P, const float* means3D, uint8_t* present, hipStream_t st) {

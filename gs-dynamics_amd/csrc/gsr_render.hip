@@ -28,7 +28,6 @@
 // grid of PERSISTENT workgroups pops tickets (one device-scope atomicAdd per tile) from a queue of tiles
 // sorted longest-first (tile_order_kernel in gsr_binning.hip): greedy longest-processing-time scheduling,
 // so every CU stays occupied until the queue drains and the tail consists of the cheapest tiles.
-// GSR_RENDER_STATIC=1 selects the plain one-workgroup-per-tile launch for A/B.
 #include <stdlib.h>
 #include "gsr_common.h"
 
@@ -103,12 +102,8 @@ __device__ __forceinline__ float gsr_sel_neg_abs(uint64_t m, float a) {         
   asm("v_cndmask_b32_e64 %0, %1, -|%1|, %2" : "=v"(r) : "v"(a), "s"(m));
   return r;
 }
-// acc = 2 * acc + (the mask has a lane set): the any-pixel-blended bits of a walk shift into a scalar register, two SALU per entry
-// (the first entry of a group of 32 ends up in the top bit)
-__device__ __forceinline__ uint32_t gsr_shift_in_any(uint32_t acc, uint64_t m) {
-  asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(acc) : "s"(m) : "scc");
-  return acc;
-}
+// The any-pixel-blended bits of a walk shift into a scalar register, acc = 2 * acc + (the mask has a lane set); the first entry of a group
+// of 32 ends up in the top bit.
 // blend = hit ^ stop (stop implies hit) AND the shift-in of "blend has a lane set" in one go: a scalar logical operation leaves
 // SCC = (result != 0), so the s_cmp of gsr_shift_in_any is the xor the masks need anyway
 __device__ __forceinline__ uint64_t gsr_xor_shift_in_any(uint64_t hit, uint64_t stop, uint32_t& acc) {
@@ -147,18 +142,6 @@ __device__ __forceinline__ uint32_t strip_mask(uint2 box, float4 a, float conicC
   return m;
 }
 
-#ifndef GSR_INDEX_AHEAD
-#define GSR_INDEX_AHEAD 1
-#endif
-#ifndef GSR_TRACK_FUSED_SCC
-#define GSR_TRACK_FUSED_SCC 1     // the tracking bit rides on the SCC of the blend mask's own s_xor_b64: one SALU per entry instead of two
-#endif
-#ifndef GSR_EXACT_LISTS
-#define GSR_EXACT_LISTS 1      // the backward's per-quad lists come from the forward's contribution bytes (fwd_tile<.., TRACK>): no rectangle tests, no
-#endif                         // visits without a contributing pixel; 0 = the round-1..3 form (conservative tests + a wave-uniform skip), for A/B
-#ifndef GSR_FWD_SIGNED_T
-#define GSR_FWD_SIGNED_T 1     // the forward keeps a pixel's stopped flag in the sign of T (0: the round-1..3 form with an SGPR mask, for A/B)
-#endif
 // Per-strip compacted entry lists of one staged batch (stable: list order is preserved).
 // PAIR: the tile pass also blends a partner view that shares this view's camera and differs only in its colours (the
 // segmentation render next to the colour render of get_loss, the mask render next to the colour render of predict.py):
@@ -232,18 +215,11 @@ __device__ __forceinline__ int fwd_tile(
   const int n = (int)(rg.y - rg.x);
   pend_g = 0u;                // TRACK, waves 2 - 3: the Gaussian of the entry whose byte this thread writes next (loaded a batch ahead of its use)
 
-#if GSR_FWD_SIGNED_T
   float T = inside ? 1.0f : -1.0f;      // the sign of T is the stopped flag (see GSR_FWD_ENTRY)
 #define done (!(T > 0.0f))
-#else
-  float T = 1.0f;
-#endif
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
   float C3 = 0.f, C4 = 0.f, C5 = 0.f;   // PAIR: the partner's colour
   uint32_t last = 0;
-#if !GSR_FWD_SIGNED_T
-  bool done = !inside;
-#endif
   GSR_T0();
 
   // Software-pipelined staging: the gathers of batch b+1 are issued before batch b is walked, so their
@@ -253,11 +229,11 @@ __device__ __forceinline__ int fwd_tile(
   float3 np = make_float3(0.f, 0.f, 0.f);   // PAIR: partner colour
   uint2 nbox = make_uint2(1u, 1u);
   // The gather is two dependent trips (list entry -> record).  The list entry of batch b+2 is fetched while batch b is walked,
-  // so the record loads of batch b+1 issue without waiting for an index (GSR_INDEX_AHEAD=0: index and record in one go).
+  // so the record loads of batch b+1 issue without waiting for an index.
   uint32_t g_ahead = 0;
   if (tid < FWD_BATCH && tid < n) {
     const uint32_t g = point_list[rg.x + tid];
-    if (GSR_INDEX_AHEAD && tid + FWD_BATCH < n) g_ahead = point_list[rg.x + tid + FWD_BATCH];
+    if (tid + FWD_BATCH < n) g_ahead = point_list[rg.x + tid + FWD_BATCH];
     { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
     if (PAIR) np = fwd_partner_colour(pt, g);
@@ -285,8 +261,8 @@ __device__ __forceinline__ int fwd_tile(
     {
       const int nidx = idx + FWD_BATCH;
       if (tid < FWD_BATCH && nidx < n) {
-        const uint32_t g = GSR_INDEX_AHEAD ? g_ahead : point_list[rg.x + nidx];
-        if (GSR_INDEX_AHEAD && nidx + FWD_BATCH < n) g_ahead = point_list[rg.x + nidx + FWD_BATCH];
+        const uint32_t g = g_ahead;
+        if (nidx + FWD_BATCH < n) g_ahead = point_list[rg.x + nidx + FWD_BATCH];
         { const float4 t2 = rec[GSR_REC_F4 * g + 2]; na = rec[GSR_REC_F4 * g]; nb = rec[GSR_REC_F4 * g + 1]; nc = make_float2(t2.x, t2.y);
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
         if (PAIR) np = fwd_partner_colour(pt, g);
@@ -326,16 +302,12 @@ __device__ __forceinline__ int fwd_tile(
     // (w = 0 when the pair does not contribute) instead of branched, so consecutive iterations overlap.
     if (TRACK && lane < 4) L.cmask[wv][lane] = 0u;   // groups the walk does not reach (same wave, in order: its later writes win)
     if (__ballot(!done) != 0ull) {
-#ifdef GSR_PRIO_FBLEND
-      __builtin_amdgcn_s_setprio(GSR_PRIO_FBLEND);     // A/B hook: the blend walk of a batch at raised wave priority -- measured: no effect (203 us either way)
-#endif
       const float4* __restrict__ wA = L.sA[wv];
       const float4* __restrict__ wB = L.sB[wv];
       const float4* __restrict__ wC = L.sC[wv];
       const float2* __restrict__ wD = L.sD[wv];
       // One list entry: evaluate, then blend predicated.  (Skipping the blend arithmetic of a visit no pixel of the quad uses -- a
       // wave-uniform branch on __ballot(hit) -- was measured 9 % SLOWER: straight-line code lets the compiler overlap the visits.)
-#if GSR_FWD_SIGNED_T
       /* Round 4 ("predicates in VALU registers"; measured: render_fwd 45.4 -> 43.5 us at one view, 103.8 -> 102.3 at four, 192.7 -> 189.9 at eight): the pixel's stopped flag lives in the SIGN of T (T > 0: live,
          T = -|T at the stop|: stopped) instead of in an SGPR mask that every entry ANDs into its hit mask and ORs its stop mask into --
          a stopped pixel has test_T < 0 < T_EPS, so `stop` holds for it by itself and `blend` is false: three SALU mask operations
@@ -350,14 +322,13 @@ __device__ __forceinline__ int fwd_tile(
           /* the same predicates as lane masks (see gsr_sel): hit = power <= 0 && alpha >= 1/255, stop = hit && test_T < eps, blend = hit ^ stop */ \
           const uint64_t mh = __ballot(power <= 0.0f) & __ballot(alpha >= GSR_ALPHA_MIN);           \
           const uint64_t ms = mh & __ballot(test_T < GSR_T_EPS);                                    \
-          const uint64_t mb = GSR_TRACK_FUSED_SCC ? gsr_xor_shift_in_any(mh, ms, acc) : (mh ^ ms);  /* + some pixel of the quad blended this entry */ \
+          const uint64_t mb = gsr_xor_shift_in_any(mh, ms, acc);  /* blend = hit ^ stop, + "some pixel of the quad blended this entry" */ \
           const float w = gsr_sel_or_zero(mb, alpha * T);                                           \
           C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                       \
           C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                       \
           if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
           T = gsr_sel_neg_abs(ms, gsr_sel(mb, test_T, T));                                          \
           last = gsr_sel_u(mb, __float_as_uint(ec.z), last);                                        \
-          if (!GSR_TRACK_FUSED_SCC) acc = gsr_shift_in_any(acc, mb);                                \
         } else {                                                                                    \
         const bool hit = power <= 0.0f && alpha >= GSR_ALPHA_MIN;                                   \
         const bool stop = hit && test_T < GSR_T_EPS;                                                \
@@ -371,34 +342,12 @@ __device__ __forceinline__ int fwd_tile(
         last = blend ? __float_as_uint(ec.z) : last;                                                \
         }                                                                                           \
       }
-#else
-#define GSR_FWD_ENTRY(ea, eb, ec, ed, UBIT)                                                             \
-      {                                                                                             \
-        const float dx = ea.x - pxf, dy = ea.y - pyf;                                               \
-        const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);   \
-        const float alpha = fminf(GSR_ALPHA_MAX, eb.y * __builtin_amdgcn_exp2f(power));  /* power is in log2 units */ \
-        const bool hit = !done && power <= 0.0f && alpha >= GSR_ALPHA_MIN;                          \
-        const float test_T = T * (1.0f - alpha);                                                    \
-        const bool stop = hit && test_T < GSR_T_EPS;                                                \
-        const bool blend = hit != stop;  /* = hit && !stop, from the ONE compare above (a second v_cmp otherwise) */ \
-        done = done || stop;                                                                        \
-        const float w = blend ? alpha * T : 0.0f;                                                   \
-        C0 = __builtin_fmaf(eb.z, w, C0); C1 = __builtin_fmaf(eb.w, w, C1);                         \
-        C2 = __builtin_fmaf(ec.x, w, C2); Dp = __builtin_fmaf(ec.y, w, Dp);                         \
-        if (PAIR) { C3 = __builtin_fmaf(ec.w, w, C3); C4 = __builtin_fmaf(ed.x, w, C4); C5 = __builtin_fmaf(ed.y, w, C5); } \
-        T = blend ? test_T : T;                                                                     \
-        last = blend ? __float_as_uint(ec.z) : last;                                                \
-        /* any pixel blended it <=> some lane's weight is non-zero (alpha >= 1/255 and T >= 1e-4 there).  The ballot of a FRESH compare \
-           folds into the compare's SGPR mask; __ballot(blend) made the compiler rebuild the bool in a VGPR (+2 VALU, +40 VGPRs of pressure) */ \
-        if constexpr (TRACK) acc = gsr_shift_in_any(acc, __ballot(w != 0.0f));                       \
-      }
       // Blocks of FWD_UNROLL entries, fully unrolled: the LDS reads are immediate offsets off one running pointer, the compiler
       // places them ahead of their uses without register rotation, and the all-done check runs once per block.  (Round 1's form --
       // two entries per trip on ping-pong registers with the check folded into the trip -- compiled to five register copies, two
       // address computations and four scalar branches per trip: render_fwd 222 -> 201 us at 8 views, 58 -> 49 us at one view.  The
       // backward's visits branch on __ballot(hit), the loads cannot move across that, and there the hand-rotated prefetch is 3 %
       // faster than blocks.)
-#endif
 #ifndef FWD_UNROLL_TRACK
 #define FWD_UNROLL_TRACK 8      // the tracking build: blocks of eight like the plain one (76 VGPRs, no spills, with the shift-register form of the bits)
 #endif
@@ -462,17 +411,12 @@ __device__ __forceinline__ int fwd_tile(
         (void)acc;
       }
 #undef GSR_FWD_ENTRY
-#ifdef GSR_PRIO_FBLEND
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
     GSR_TP(5);
   }
   GSR_TP(1);
-#if GSR_FWD_SIGNED_T
 #undef done
   T = __builtin_fabsf(T);
-#endif
   if (inside) {
     const int pix = py * W + px;
     const size_t N = (size_t)H * W;
@@ -507,18 +451,12 @@ __device__ __forceinline__ int fwd_tile(
 // Plain passes come in two batch sizes: 128 entries (39.7 KB of LDS, four workgroups per CU) for launches with few busy tiles --
 // there a tile's critical path sets the kernel's time, and it grows with the number of batches -- and 96 entries (29.9 KB, five per
 // CU) when the queue is long and latency hiding is what counts: -4 % kernel time at 4 views x 2500 tiles, +3 % at one view.
-// How the nine per-entry wave totals of a visit reach LDS.  Default: finish the reduction in the wave (two LDS-crossbar row levels),
-// nine lanes store.  GSR_BWD_LDS_ACCUM: stop after the in-row levels and let ONE ds_add_f32 (36 lanes: nine per 16-lane row) add the
-// four rows into the wave's slot -- no LDS round trip left in the visit's dependency chain; the slots are zeroed per batch.  Rows of
-// one instruction that hit the same address are added in lane order: deterministic.
-#ifdef GSR_ABL_NOREDUCE   // ablation build: the nine partials are added up per lane (8 adds keep them alive) instead of reduced over the wave (24 issues)
+// The nine per-entry wave totals of a visit: the packed reduction finishes in the wave, nine lanes store.  (Round 3 measured the alternative --
+// stop after the in-row levels and let one ds_add_f32 add the four rows -- slower: profiles/r03_rejected_lds_accumulate.txt.)
+#ifdef GSR_ABL_NOREDUCE   // ablation build (tools/r05_ablation.sh): the nine partials are added up per lane (8 adds keep them alive) instead of reduced over the wave (24 issues)
 #define GSR_BWD_PARK9(a0, a1, a2, a3, a4, a5, a6, a7, a8)                                            \
         { const float z = (((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7))) + a8;                  \
           if (lane >= 48 && lane <= 56) L.sRed[wv][j][lane - 48] = z; }
-#elif defined(GSR_BWD_LDS_ACCUM)
-#define GSR_BWD_PARK9(a0, a1, a2, a3, a4, a5, a6, a7, a8)                                            \
-        { const float z = gsr_wave_sum9_rows(a0, a1, a2, a3, a4, a5, a6, a7, a8);                    \
-          if ((lane & 15) <= 8) atomicAdd(&L.sRed[wv][j][lane & 15], z); }
 #else
 #define GSR_BWD_PARK9(a0, a1, a2, a3, a4, a5, a6, a7, a8)                                            \
         { const float z = gsr_wave_sum9_packed<ROWS_PERM>(a0, a1, a2, a3, a4, a5, a6, a7, a8);       \
@@ -534,7 +472,6 @@ struct BwdLdsT {
   float4 sD[4][PAIR ? BB + 1 : 1];      // partner r, g, b, -
   float sRed[4][BB][9];                        // per-wave totals of the 9 partials, by batch index (36 B stride: odd
                                                // word count, so both the 9-lane write and the per-entry read are conflict-free)
-  uint64_t sActive[4][2];                      // which (wave, entry) totals are valid (bit j of word j / 64)
   uint32_t sSlot[BB];                          // by batch index: the entry's record slot in the Gaussian-major scratch
   uint8_t sQuads[BB];                          // by batch index: which quads staged the entry (= whose totals the combine adds up)
   uint32_t cnt[4][4];                          // [staging wave][strip]
@@ -545,19 +482,13 @@ struct BwdPartner { const float4* rec; const float* bg; const float* dL_dcolor; 
 
 // COL = false (plain passes only): the caller wants no colour gradient -- six sums per entry instead of nine (15 instead of 24
 // VALU issues of reduction, four multiplies less) and 24-byte records.
-// The no-colour reduction is the six-value one (gsr_wave_sum6_packed).  Round 2 measured it 17 % SLOWER than the nine-value form
-// fed three zeros and kept the latter; the cause was the register count, not the chain of DPP adds (see render_bwd_persistent's
-// launch bounds): 433 -> 397 us per 8-view launch once the build fits five waves per SIMD.  GSR_NOCOL_SUM9 restores nine-with-zeros.
-#ifndef GSR_NOCOL_SUM9
+// The no-colour reduction is the six-value one (gsr_wave_sum6_packed; its build must stay within the launch's register budget: round 2's
+// "six values are slower than nine with zeros" was a 97th VGPR, see render_bwd_persistent's launch bounds).
 #define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum6_packed(tx, ty, tx * dx, tx * dy, ty * dy, v5); \
                            if (red6 >= 0) L.sRed[wv][j][red6] = z; }
-#else
-#define GSR_NOCOL_REDUCE { const float z = gsr_wave_sum9_packed<ROWS_PERM>(tx, ty, tx * dx, tx * dy, ty * dy, v5, 0.f, 0.f, 0.f); \
-                           if (lane >= 48 && lane <= 53) L.sRed[wv][j][lane - 48] = z; }
-#endif
 #define GSR_NOCOL_STORE6(p, e, r0, a, b) gsr_store_partial6(p, e, r0, a, b)   // (36-byte stores instead: measured the same)
-// BASE: the ticket's base wave priority (round-4 experiment, GSR_BWD_PRIO_LEN: tickets with at least that many entries run at base 1 --
-// the longest lists of a short queue get a larger share of their CU and finish with the pack instead of draining alone)
+// BASE: the ticket's base wave priority (one-view launches: the longest tickets run at base 1 -- the longest lists of a short queue get a
+// larger share of their CU and finish with the pack instead of draining alone; see gsr_launch_render_bwd)
 template <bool PAIR, int NBB = GSR_BWD_BB(PAIR), bool COL = true, int BASE = 0>
 __device__ __forceinline__ void bwd_tile(
     const int tile, const uint2 rg, BwdLdsT<PAIR, NBB>& L, int W, int H, int gx,
@@ -611,11 +542,11 @@ __device__ __forceinline__ void bwd_tile(
   uint32_t gz = 0;
   if (kz < n) gz = point_list[rg.x + kz];
   uint32_t ng = 0, ng_ahead = 0;                     // ng_ahead: list entry of batch b+2 (see fwd_tile)
-  uint32_t nquads = 0;                               // GSR_EXACT_LISTS: the entry's contribution byte (which quads blended it in the forward)
+  uint32_t nquads = 0;                               // the entry's contribution byte (which quads blended it in the forward)
   if (tid < BB && tid < max_last) {
     ng = point_list[rg.x + (max_last - 1 - tid)];
-    if (GSR_EXACT_LISTS) nquads = contrib ? contrib[rg.x + (max_last - 1 - tid)] : 0xfu;
-    if (GSR_INDEX_AHEAD && tid + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (tid + BB))];
+    nquads = contrib ? contrib[rg.x + (max_last - 1 - tid)] : 0xfu;
+    if (tid + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (tid + BB))];
   }
   const int red6 = lane >= 48 ? gsr_sum6_slot(lane) : -1;   // !COL (GSR_NOCOL_SUM6): where this lane's total of the six-value reduction goes
   (void)red6;
@@ -656,9 +587,6 @@ __device__ __forceinline__ void bwd_tile(
   }
   GSR_TP(0);
   for (int base = 0; base < max_last; base += BB) {
-#ifdef GSR_PRIO_STAGE
-    __builtin_amdgcn_s_setprio(GSR_PRIO_STAGE);      // A/B: classification + staging of a batch (gates the barrier) at raised priority
-#endif
     // batch entry j (0 = deepest still unprocessed) is list position pos = max_last - 1 - (base + j)
     const int m_all = min(BB, max_last - base);
     const float4 a = na, b = nb, d = np;
@@ -671,22 +599,15 @@ __device__ __forceinline__ void bwd_tile(
         L.sSlot[tid] = __float_as_uint(nslot.z) + gsr_tile_rank(__float_as_uint(nslot.w), (maxx - minx) * (maxy - miny),
                                                                 ((uint32_t)ty - miny) * (maxx - minx) + ((uint32_t)tx - minx));
       }
-      if (GSR_EXACT_LISTS) {
-        mask = nquads;        // exactly the quads with a pixel that blended this entry (implies: below the quad's deepest contributor)
-        L.sQuads[tid] = (uint8_t)mask;
-      } else {
-        mask = strip_mask(nbox, a, b.x, b.y, tx0, ty0);
-        // a quad whose pixels all stopped before this list position has nothing to add for it
-        const int pos = max_last - 1 - (base + tid);
-        mask &= (pos < ql0 ? 1u : 0u) | (pos < ql1 ? 2u : 0u) | (pos < ql2 ? 4u : 0u) | (pos < ql3 ? 8u : 0u);
-      }
+      mask = nquads;          // exactly the quads with a pixel that blended this entry (the forward's contribution byte; a forward that did
+      L.sQuads[tid] = (uint8_t)mask;   // not track hands 0xf: every quad then replays the entry and the per-pixel hit test keeps the result exact)
     }
     {
       const int nj = base + BB + tid;
       if (tid < BB && nj < max_last) {
-        ng = GSR_INDEX_AHEAD ? ng_ahead : point_list[rg.x + (max_last - 1 - nj)];
-        if (GSR_EXACT_LISTS) nquads = contrib ? contrib[rg.x + (max_last - 1 - nj)] : 0xfu;
-        if (GSR_INDEX_AHEAD && nj + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (nj + BB))];
+        ng = ng_ahead;
+        nquads = contrib ? contrib[rg.x + (max_last - 1 - nj)] : 0xfu;
+        if (nj + BB < max_last) ng_ahead = point_list[rg.x + (max_last - 1 - (nj + BB))];
         { const float4 t2 = rec[GSR_REC_F4 * ng + 2]; na = rec[GSR_REC_F4 * ng]; nb = rec[GSR_REC_F4 * ng + 1]; nblue = t2.x;
       nslot = rec[GSR_REC_F4 * ng + 3];
       nbox = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)); }
@@ -700,12 +621,6 @@ __device__ __forceinline__ void bwd_tile(
 #pragma unroll
       for (int w = 0; w < 4; ++w) L.cnt[wv][w] = (uint32_t)__popcll(bal[w]);
     }
-#ifdef GSR_BWD_LDS_ACCUM
-    if (!PAIR && COL) {      // this batch's slots start from zero (the previous batch's combine is behind the barrier that ended it)
-      float4* z4 = reinterpret_cast<float4*>(&L.sRed[0][0][0]);
-      for (int i = tid; i < 4 * BB * 9 / 4; i += GSR_BLOCK) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#endif
     GSR_TP(1);
     __syncthreads();
     GSR_TP(2);
@@ -725,14 +640,8 @@ __device__ __forceinline__ void bwd_tile(
 #else
     const int m = __builtin_amdgcn_readfirstlane((int)(L.cnt[0][wv] + L.cnt[1][wv]));
 #endif
-#ifdef GSR_PRIO_STAGE
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __syncthreads();
     GSR_TP(3);
-    uint64_t active_lo = 0ull, active_hi = 0ull;
-    // branch-free scalar form (an if / else on j < 64 becomes two scalar branches per visit: +0.5 % at 8 views, +1.5 % at one)
-#define GSR_MARK_ACTIVE(j) { const uint64_t bit_ = 1ull << (j & 63); active_lo |= j < 64 ? bit_ : 0ull; active_hi |= j < 64 ? 0ull : bit_; }
     const float4* __restrict__ wA = L.sA[wv];
     const float4* __restrict__ wB = L.sB[wv];
     const float2* __restrict__ wC = L.sC[wv];
@@ -740,18 +649,8 @@ __device__ __forceinline__ void bwd_tile(
     // One list entry: re-evaluate alpha; when some pixel of the quad used the entry, back out T, form the nine partials,
     // reduce them over the wave and park the totals.
 #ifndef GSR_PRIO_VISIT
-#define GSR_PRIO_VISIT 1      /* wave priority (s_setprio) inside a contributing visit; 0 = leave it alone.  Measured, 8 views, one box, 3 rounds each:
+#define GSR_PRIO_VISIT 1      /* wave priority (s_setprio) of the replay loop; 0 = leave it alone.  Measured, 8 views, one box, 3 rounds each:
                                  0: 441.7 us, 1 / 2 / 3: 433.6 / 431.9 / 431.9 us per launch; raising the staging phase as well or instead: 437.8 / 448 */
-#endif
-#ifndef GSR_PRIO_COMBINE
-#define GSR_PRIO_COMBINE 0    /* ... and while a batch's totals are combined and stored */
-#endif
-#if GSR_PRIO_VISIT
-#define GSR_BWD_PRIO_IN if (!GSR_EXACT_LISTS) __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);   /* exact lists: every visit contributes -- */
-#define GSR_BWD_PRIO_OUT if (!GSR_EXACT_LISTS) __builtin_amdgcn_s_setprio(BASE);                  /* the whole replay loop is raised instead */
-#else
-#define GSR_BWD_PRIO_IN
-#define GSR_BWD_PRIO_OUT
 #endif
 #define GSR_BWD_ENTRY(ea, eb, ec, ed)                                                                           \
     {                                                                                                         \
@@ -762,8 +661,7 @@ __device__ __forceinline__ void bwd_tile(
       const float power = __builtin_fmaf(__builtin_fmaf(ea.w, dy, ea.z * dx), dx, (eb.x * dy) * dy);        \
       const float G0 = __builtin_amdgcn_exp2f(power);  /* power is in log2 units (pre-scaled conic) */        \
       const bool hit = (pos < last) && power <= 0.0f && eb.y * G0 >= GSR_ALPHA_MIN; /* = min(0.99, .) >= 1/255 */ \
-      if (GSR_EXACT_LISTS || __ballot(hit) != 0ull) { /* wave-uniform: otherwise nothing to add (exact lists: always something) */ \
-        GSR_BWD_PRIO_IN                                                                                        \
+      { /* every staged visit contributes (exact lists) */                                                    \
         /* No exec-masked region: a lane that does not use the entry runs the same arithmetic with G = 0.  Then  \
            alpha = 0, 1/(1-alpha) = 1, T and the accumulated colour are unchanged (an alpha = 0 entry only flushes \
            the pending (last_alpha, last colour) pair, which the next real entry would have done with the same    \
@@ -812,13 +710,11 @@ __device__ __forceinline__ void bwd_tile(
         const float v6 = w * dL0, v7 = w * dL1, v8 = w * dL2;                                                 \
         GSR_BWD_PARK9(v0, v1, v2, v3, v4, v5, v6, v7, v8)                                                     \
         }                                                                                                     \
-        if (!GSR_EXACT_LISTS) GSR_MARK_ACTIVE(j)                                                             \
-        GSR_BWD_PRIO_OUT                                                                                       \
       }                                                                                                       \
     }
     // two entries per trip on ping-pong registers: the record of entry j+1 (j+2) is fetched from LDS while entry j (j+1) is
     // evaluated, no copies to rotate the prefetch (unrolled blocks as in fwd_tile measured 3 % slower here)
-    if (GSR_EXACT_LISTS && GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);
+    if (GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(GSR_PRIO_VISIT + BASE);
     float4 ea = wA[0], eb = wB[0];
     float2 ec = wC[0];
     float4 ed = wD[0];
@@ -834,18 +730,16 @@ __device__ __forceinline__ void bwd_tile(
     }
     if (jj < m) GSR_BWD_ENTRY(ea, eb, ec, ed)
 #undef GSR_BWD_ENTRY
-    if (GSR_EXACT_LISTS && GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(BASE);
-    if (!GSR_EXACT_LISTS && lane == 0) { L.sActive[wv][0] = active_lo; L.sActive[wv][1] = active_hi; }
+    if (GSR_PRIO_VISIT) __builtin_amdgcn_s_setprio(BASE);
     GSR_TP(4);
     __syncthreads();
     GSR_TP(5);
-    if (GSR_PRIO_COMBINE) __builtin_amdgcn_s_setprio(GSR_PRIO_COMBINE);
     if (tid < m_all) {
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-      const uint32_t quads = GSR_EXACT_LISTS ? (uint32_t)L.sQuads[tid] : 0u;
+      const uint32_t quads = (uint32_t)L.sQuads[tid];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        if (GSR_EXACT_LISTS ? ((quads >> w) & 1u) != 0u : ((L.sActive[w][tid >> 6] >> (tid & 63)) & 1ull) != 0ull) {
+        if ((quads >> w) & 1u) {
           const float* q = L.sRed[w][tid];
           r0.x += q[0]; r0.y += q[1]; r0.z += q[2]; r0.w += q[3];
           r1.x += q[4]; r1.y += q[5];
@@ -857,7 +751,6 @@ __device__ __forceinline__ void bwd_tile(
       if (PAIR || COL) gsr_store_partial(partials, e, r0, r1, r2.x);
       else GSR_NOCOL_STORE6(partials, e, r0, r1.x, r1.y);
     }
-    if (GSR_PRIO_COMBINE) __builtin_amdgcn_s_setprio(0);
     GSR_TP(6);
     __syncthreads();
     GSR_TP(7);
@@ -886,26 +779,6 @@ __device__ __forceinline__ FwdPartner fwd_partner(const GsrRenderView& p) {
 // PAIRS: the call holds fused pairs (GsrRenderView::partner): tickets of such views blend both; the other tickets take the
 // plain path.  A call without pairs runs the PAIRS = false build (smaller LDS footprint: one more workgroup per CU).
 static_assert(sizeof(FwdLdsT<true>) >= sizeof(FwdLdsT<false>), "the pair build's LDS must hold the plain layout too");
-template <bool PAIRS, bool TRACK = false>
-__global__ __launch_bounds__(GSR_BLOCK) void render_fwd_static(GsrRenderViews tab) {   // grid (T, V)
-  __shared__ FwdLdsT<PAIRS> L;
-  const GsrRenderView& vw = tab.v[blockIdx.y];
-  if (blockIdx.x == 0 && blockIdx.y == 0) GSR_FWD_MARK_TRACKED()
-  if (vw.fused_alias) return;                       // rendered by its owner's workgroup
-  const uint2 rg = vw.ranges[blockIdx.x];
-  int pend;
-  uint32_t pend_g;
-  if (PAIRS && vw.partner >= 0)
-    pend = fwd_tile<PAIRS, TRACK>((int)blockIdx.x, rg, L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib, vw.used, pend_g);
-  else
-    pend = fwd_tile<false, TRACK>((int)blockIdx.x, rg, reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib, vw.used, pend_g);
-  if (TRACK) {
-    __syncthreads();
-    if (PAIRS && vw.partner >= 0) fwd_store_contrib<PAIRS>(L, vw.contrib, vw.used, tab.v[vw.partner].used, rg.x, (int)(rg.y - rg.x), pend, pend_g);
-    else fwd_store_contrib<false>(reinterpret_cast<FwdLdsT<false>&>(L), vw.contrib, vw.used, nullptr, rg.x, (int)(rg.y - rg.x), pend, pend_g);
-  }
-}
-
 // Persistent forward.  Empty tiles never enter the queue: the workgroups first paint their background
 // (grid-stride over the tail of the order array), then pop busy tiles longest-first.
 // Launch bounds = the residency the launch asks for (six workgroups per CU, five for the pair build): without them the allocator took
@@ -980,17 +853,6 @@ struct BwdLdsAny {
   alignas(16) unsigned char raw[BYTES];
 };
 
-template <bool PAIRS>
-__global__ __launch_bounds__(GSR_BLOCK) void render_bwd_static(GsrRenderViews tab) {   // grid (T, V)
-  __shared__ BwdLdsAny<PAIRS> L;
-  const GsrRenderView& vw = tab.v[blockIdx.y];
-  if (vw.fused_alias) return;
-  if (PAIRS && vw.partner >= 0)
-    bwd_tile<PAIRS>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
-  else
-    bwd_tile<false>((int)blockIdx.x, vw.ranges[blockIdx.x], reinterpret_cast<BwdLdsT<false>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
-}
-
 #ifdef GSR_TRACE_TICKETS
 // Debug build (tools/ticket_trace.py): per backward ticket {start, end (s_memrealtime, 100 MHz), workgroup, list length}
 #define GSR_TRACE_MAX 65536
@@ -1017,7 +879,7 @@ __global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == BWD_SMALL_BB) ? BWD_SM
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
-    else if ((tab.prio_len > 0 && (int)(ord.z - ord.y) >= tab.prio_len) || ticket * 16u < n_busy * (uint32_t)tab.prio_frac16)
+    else if (ticket * 16u < n_busy * (uint32_t)tab.prio_frac16)
       bwd_tile<false, NBB, COL, 1>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     else
       bwd_tile<false, NBB, COL>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
@@ -1492,6 +1354,8 @@ __device__ __forceinline__ void pc_consumer(PcLds& L, const GsrRenderViews& tab,
 #ifndef PC_WAVES_PER_EU
 #define PC_WAVES_PER_EU 8
 #endif
+#define PC_WG_PER_CU 5        // what the hardware admits (hipOccupancyMaxActiveBlocksPerMultiprocessor says 6: the sixth never becomes resident, and its
+                             // implicit first tickets would run at the very end -- tools/r05_pc_phase_timing.py counts the late starters)
 #ifndef PC_NUM_SGPR
 #define PC_NUM_SGPR 80       // eight waves per SIMD need <= 80 SGPRs per wave (MI355X_MICROARCH: residency by .sgpr_count)
 #endif
@@ -1557,10 +1421,6 @@ extern "C" int gsr_debug_ticket_trace(uint32_t* out4, int n) {   // debug builds
 }
 #endif
 
-static bool env_flag(const char* name) {
-  const char* v = getenv(name);
-  return v && *v && atoi(v) != 0;
-}
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -1572,27 +1432,22 @@ static bool has_pairs(const GsrRenderViews& tab) {
   return false;
 }
 
+// Launch parameters: workgroups per CU of the two blend kernels and the queue length from which the backward takes its small-batch build.
+// The defaults are the optimum of the round-5 sweep (tools/autotune.py -> profiles/r05_autotune.json: V = 1 .. 8 views x three densities);
+// the switches exist for that sweep.
 int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
   if (tab.T <= 0 || tab.V <= 0) return 0;
-  static const bool use_static = env_flag("GSR_RENDER_STATIC");
   static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 6);
   const bool pairs = has_pairs(tab);
-  const bool track = GSR_EXACT_LISTS && tab.track != 0;                // record the per-quad contribution bytes for a backward (not in forward-only calls)
+  const bool track = tab.track != 0;                // record the per-quad contribution bytes for a backward (not in forward-only calls)
   { GSR_PROF("render_fwd", st);
-    if (use_static) {
-      if (pairs && track) hipLaunchKernelGGL((render_fwd_static<true, true>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-      else if (pairs) hipLaunchKernelGGL((render_fwd_static<true, false>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-      else if (track) hipLaunchKernelGGL((render_fwd_static<false, true>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL((render_fwd_static<false, false>), dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-    } else {
-      const int tiles = tab.T * tab.V;
-      const int per_cu = pairs ? (wg_per_cu < 5 ? wg_per_cu : 5) : wg_per_cu;   // the pair build's LDS fits 5 workgroups per CU
-      const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
-      if (pairs && track) hipLaunchKernelGGL((render_fwd_persistent<true, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (pairs) hipLaunchKernelGGL((render_fwd_persistent<true, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (track) hipLaunchKernelGGL((render_fwd_persistent<false, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL((render_fwd_persistent<false, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-    }
+    const int tiles = tab.T * tab.V;
+    const int per_cu = pairs ? (wg_per_cu < 5 ? wg_per_cu : 5) : wg_per_cu;   // the pair build's LDS fits 5 workgroups per CU
+    const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    if (pairs && track) hipLaunchKernelGGL((render_fwd_persistent<true, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else if (pairs) hipLaunchKernelGGL((render_fwd_persistent<true, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else if (track) hipLaunchKernelGGL((render_fwd_persistent<false, true>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else hipLaunchKernelGGL((render_fwd_persistent<false, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
   }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1605,41 +1460,29 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
   // on the resident workgroups followed by a drain in which they finish one by one: the longest 10/16 of the tickets (the order is
   // longest-first: rank = ticket) run at base priority 1, so that a CU's long lists get a larger share of it and end with the pack:
   // render_bwd 90.5 -> 87 us, the one-view step 213 -> 208.5 us (profiles/r04_small_blend_experiments.txt); nothing at 2+ views (off there).
-  // GSR_BWD_PRIO_FRAC16 = k overrides (0 = off) for launches of up to GSR_BWD_PRIO_MAXV views; GSR_BWD_PRIO_LEN = n: by list length instead.
-  static const int prio_len = env_int("GSR_BWD_PRIO_LEN", 0), prio_frac = env_int("GSR_BWD_PRIO_FRAC16", -1);
-  static const int prio_maxv = env_int("GSR_BWD_PRIO_MAXV", prio_frac >= 0 || prio_len > 0 ? 16 : 1);
-  tab.prio_len = tab.V <= prio_maxv ? prio_len : 0;
-  tab.prio_frac16 = tab.V <= prio_maxv ? (prio_frac >= 0 ? prio_frac : (prio_len > 0 ? 0 : 10)) : 0;
-  static const bool use_static = env_flag("GSR_RENDER_STATIC");
+  tab.prio_frac16 = tab.V <= 1 ? 10 : 0;
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
-  static const int pair_wg_per_cu = env_int("GSR_BWD_PAIR_WG_PER_CU", 4);
   const bool pairs = has_pairs(tab);
   { GSR_PROF("render_bwd", st);
-    if (use_static) {
-      if (pairs) hipLaunchKernelGGL(render_bwd_static<true>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL(render_bwd_static<false>, dim3(tab.T, tab.V), dim3(GSR_BLOCK), 0, st, tab);
-    } else {
-      const int tiles = tab.T * tab.V;
-      // long queue (>= 2 tiles per resident workgroup slot, counting the empty ones): the small-batch build, more workgroups per CU
-      // (round 4, with the exact lists: 80 entries at six per CU; two views -- 5000 tiles -- gain too: render_bwd 132 -> 127 us; one view loses: 81 -> 87)
-      static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 4000);
-      const bool small = !pairs && tiles >= small_batch_from;
-      const int per_cu = pairs ? pair_wg_per_cu : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
-      const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
-      const bool col = !tab.no_colour_grad;
-      static const int use_pc = env_int("GSR_BWD_PC", 0);   // the producer / consumer form (round 5) for calls without fused pairs
-      if (!pairs && use_pc) {
-        static const int pc_per_cu = env_int("GSR_BWD_PC_WG_PER_CU", 6);
-        const int pgrid = tiles < 256 * pc_per_cu ? tiles : 256 * pc_per_cu;
-        if (col) hipLaunchKernelGGL(render_bwd_pc<true>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);
-        else hipLaunchKernelGGL(render_bwd_pc<false>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);
-      } else
-      if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (small && col) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else if (col) hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
-      else hipLaunchKernelGGL((render_bwd_persistent<false, BWD_BATCH, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    const int tiles = tab.T * tab.V;
+    // long queue (>= 2 tiles per resident workgroup slot, counting the empty ones): the small-batch build, more workgroups per CU
+    // (round 4, with the exact lists: 80 entries at six per CU; two views -- 5000 tiles -- gain too: render_bwd 132 -> 127 us; one view loses: 81 -> 87)
+    static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 4000);
+    const bool small = !pairs && tiles >= small_batch_from;
+    const int per_cu = pairs ? 4 : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
+    const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    const bool col = !tab.no_colour_grad;
+    static const int use_pc = env_int("GSR_BWD_PC", 0);   // the producer / consumer form (round 5, opt-in: it ties the barrier form) for calls without fused pairs
+    if (!pairs && use_pc) {
+      const int pgrid = tiles < 256 * PC_WG_PER_CU ? tiles : 256 * PC_WG_PER_CU;
+      if (col) hipLaunchKernelGGL(render_bwd_pc<true>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);
+      else hipLaunchKernelGGL(render_bwd_pc<false>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);
     }
+    else if (pairs) hipLaunchKernelGGL(render_bwd_persistent<true>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else if (small && col) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else if (small) hipLaunchKernelGGL((render_bwd_persistent<false, BWD_SMALL_BB, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else if (col) hipLaunchKernelGGL(render_bwd_persistent<false>, dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
+    else hipLaunchKernelGGL((render_bwd_persistent<false, BWD_BATCH, false>), dim3(grid), dim3(GSR_BLOCK), 0, st, tab);
   }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;

@@ -76,7 +76,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping", "gsr_wait_counts",
-           "gsr_gnn_workspace_bytes", "gsr_gnn_propagate", "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail")
+           "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail")
 
 
 def load_library():
@@ -183,10 +183,6 @@ def load_library():
     lib.gsr_gnn_aggregate.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.gsr_gnn_rel_inputs.restype = C.c_int
     lib.gsr_gnn_rel_inputs.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
-    lib.gsr_gnn_workspace_bytes.restype = C.c_int64
-    lib.gsr_gnn_workspace_bytes.argtypes = [i32, i32, i32]
-    lib.gsr_gnn_propagate.restype = C.c_int
-    lib.gsr_gnn_propagate.argtypes = [C.POINTER(GnnModel), i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.gsr_fit_bones.restype = C.c_int
     lib.gsr_fit_bones.argtypes = [i32, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
@@ -932,74 +928,6 @@ def fps_thin(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0,
                                 _stream(dev)), "gsr_fps_thin")
         m = int(cnt.item())
     return out, thin[:m]
-
-
-class GnnModel(C.Structure):       # gsr_gnn_model of include/gsr.h
-    _WEIGHTS = ("pe_w0", "pe_b0", "pe_w1", "pe_b1", "pe_w2", "pe_b2", "re_w0", "re_b0", "re_w1", "re_b1", "re_w2", "re_b2",
-                "rp_w", "rp_b", "pp_w", "pp_b", "h_w0", "h_b0", "h_w1", "h_b1", "h_w2", "h_b2")
-    _fields_ = ([(k, C.c_int32) for k in ("width", "particle_in", "attr_dim", "group_dim", "state_cols", "pstep")]
-                + [("motion_clamp", C.c_float)] + [(k, C.c_void_p) for k in _WEIGHTS])
-
-
-def gnn_rel_inputs(rel_nodes: torch.Tensor, receivers: torch.Tensor, senders: torch.Tensor, attr_dim: int, group_dim: int) -> torch.Tensor:
-    """gsr_gnn_rel_inputs: rel_nodes [N, attr + group + state] -> the relation encoder's input rows [E, 2 attr + 1 + state] in one launch."""
-    lib = load_library()
-    _require_device(rel_nodes)
-    dev = rel_nodes.device
-    E, S = int(receivers.shape[0]), int(rel_nodes.shape[1]) - attr_dim - group_dim
-    with _on(dev):
-        out = torch.empty((E, 2 * attr_dim + 1 + S), dtype=torch.float32, device=dev)
-        if E:
-            _check(lib.gsr_gnn_rel_inputs(E, int(attr_dim), int(group_dim), S, _ptr(rel_nodes), _ptr(receivers), _ptr(senders), _ptr(out), _stream(dev)),
-                   "gsr_gnn_rel_inputs")
-    return out
-
-
-def gnn_aggregate(rel_part: torch.Tensor, node_parts: torch.Tensor, senders: torch.Tensor, row_start: torch.Tensor, n_sum_rows: int = None) -> torch.Tensor:
-    """gsr_gnn_aggregate: rel_part [E, H], node_parts [N, 2 H], senders [E], row_start [N + 1] (int64; receivers ascending) -> agg [N, H];
-    rows >= n_sum_rows (default N) get zeros."""
-    lib = load_library()
-    _require_device(rel_part)
-    dev = rel_part.device
-    N, H = int(node_parts.shape[0]), int(rel_part.shape[1])
-    with _on(dev):
-        agg = torch.empty((N, H), dtype=torch.float32, device=dev)
-        _check(lib.gsr_gnn_aggregate(N, N if n_sum_rows is None else int(n_sum_rows), H, _ptr(rel_part), _ptr(node_parts), _ptr(senders), _ptr(row_start), _ptr(agg), _stream(dev)), "gsr_gnn_aggregate")
-    return agg
-
-
-def gnn_workspace(n_rows: int, n_rel: int, width: int, device) -> torch.Tensor:
-    """Zeroed workspace of gsr_gnn_propagate for graphs of up to these (padded) sizes; its last 16 bytes are the barrier / error words."""
-    lib = load_library()
-    return torch.zeros((int(lib.gsr_gnn_workspace_bytes(int(n_rows), int(n_rel), int(width))),), dtype=torch.uint8, device=device)
-
-
-def gnn_propagate(model: "GnnModel", p_inputs: torch.Tensor, rel_nodes: torch.Tensor, receivers: torch.Tensor, senders: torch.Tensor,
-                  last_pos: torch.Tensor, workspace: torch.Tensor, out_pos: torch.Tensor = None, out_motion: torch.Tensor = None):
-    """gsr_gnn_propagate: the whole propagation network for one graph in one launch.  p_inputs [N, particle_in], rel_nodes [N, attr + group +
-    state], receivers / senders [E] int64 ascending in the receiver, last_pos [N, >= 3 columns' worth of stride]; N, E multiples of 16
-    (padded by the caller).  -> (pred_pos [N,3], pred_motion [N,3])."""
-    lib = load_library()
-    _require_device(p_inputs)
-    dev = p_inputs.device
-    N, E = int(p_inputs.shape[0]), int(receivers.shape[0])
-    for t in (p_inputs, rel_nodes, receivers, senders):
-        if not t.is_contiguous():
-            raise ValueError("gnn_propagate: contiguous inputs, please")
-    if p_inputs.dtype != torch.float32 or rel_nodes.dtype != torch.float32 or receivers.dtype != torch.int64 or senders.dtype != torch.int64:
-        raise ValueError("gnn_propagate: float32 features and int64 relations")
-    if last_pos.dtype != torch.float32 or last_pos.stride(-1) != 1 or last_pos.shape[0] != N:
-        raise ValueError("gnn_propagate: last_pos must be float32 [N, 3] with unit column stride")
-    need = int(lib.gsr_gnn_workspace_bytes(N, E, int(model.width)))
-    if workspace.numel() < need or workspace.dtype != torch.uint8:
-        raise ValueError("gnn_propagate: workspace too small for this graph (gnn_workspace)")
-    with _on(dev):
-        pos = out_pos if out_pos is not None else torch.empty((N, 3), dtype=torch.float32, device=dev)
-        mot = out_motion if out_motion is not None else torch.empty((N, 3), dtype=torch.float32, device=dev)
-        ws = workspace[workspace.numel() - need:] if workspace.numel() != need else workspace     # (the error words are the LAST 16 bytes either way)
-        _check(lib.gsr_gnn_propagate(C.byref(model), N, E, _ptr(p_inputs), _ptr(rel_nodes), _ptr(receivers), _ptr(senders), _ptr(last_pos),
-                                     int(last_pos.stride(0)), _ptr(ws), _ptr(pos), _ptr(mot), _stream(dev)), "gsr_gnn_propagate")
-    return pos, mot
 
 
 def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):

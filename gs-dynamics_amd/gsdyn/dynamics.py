@@ -248,10 +248,7 @@ class DynamicsPredictor(nn.Module):
         g = torch.cat([p_instance[0], torch.zeros(N - n_p, p_instance.shape[2], dtype=a.dtype, device=a.device)], 0)
         act = action[0] if c["action_dim"] > 0 else torch.zeros((N, 0), dtype=a.dtype, device=a.device)
         if a.is_cuda and not torch.is_grad_enabled() and _GRAPH_ROLLOUT and state.shape[3] == 3:
-            if self._fused_ok(a, g):
-                pos, mot = self._propagate_fused_padded(state_t, a, g, act, receivers, senders)
-            else:
-                pos, mot = self._propagate_graphed(state_t, a, g, act, receivers, senders)
+            pos, mot = self._propagate_graphed(state_t, a, g, act, receivers, senders)
         else:
             pos, mot = self._propagate(state_t, a, g, act, receivers, senders)
         return pos[:n_p][None], mot[:n_p][None]
@@ -287,14 +284,6 @@ class DynamicsPredictor(nn.Module):
         pred_motion = self.non_rigid_predictor(effect)
         pred_pos = state_t[:, -3:] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
         return pred_pos, pred_motion
-
-    # ---- the whole network in ONE launch (gsr_gnn_propagate, csrc/gsr_gnn.hip): persistent grid, f32 MFMA, device-wide barriers
-    def _fused_ok(self, a, g) -> bool:
-        c = self.model_config
-        H = c["nf_effect"]
-        return (_GNN_FUSED and a.is_cuda and not torch.is_grad_enabled() and c["nf_particle"] == H and c["nf_relation"] == H and H % 16 == 0 and H <= 512
-                and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["state_dim"] in (0, 1, 3)
-                and a.dtype == torch.float32)
 
     def _particle_inputs(self, state_t, a, act):
         c = self.model_config
@@ -351,57 +340,6 @@ class DynamicsPredictor(nn.Module):
         pred_motion = self.non_rigid_predictor(effect)
         pred_pos = state_t[:, -3:] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
         return pred_pos, pred_motion
-
-    def _gnn_struct(self, a, g, state_t, p_in_dim):
-        """gsr_gnn_model over THIS module's parameter storage (rebuilt when a parameter moves: load_state_dict copies in place, .to() does not)."""
-        from diff_gaussian_rasterization import _hip
-        ws = [self.particle_encoder.model[0], self.particle_encoder.model[2], self.particle_encoder.model[4],
-              self.relation_encoder.model[0], self.relation_encoder.model[2], self.relation_encoder.model[4],
-              self.relation_propagator.linear, self.particle_propagator.linear,
-              self.non_rigid_predictor.linear_0, self.non_rigid_predictor.linear_1, self.non_rigid_predictor.linear_2]
-        tensors = [t for lin in ws for t in (lin.weight, lin.bias)]
-        key = (tuple(t.data_ptr() for t in tensors), int(a.shape[1]), int(g.shape[1]), int(state_t.shape[1]), int(p_in_dim))
-        ent = self.__dict__.get("_gnn_model")
-        if ent is None or ent[0] != key:
-            for t in tensors:
-                if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
-                    raise RuntimeError("DynamicsPredictor: the one-launch propagation needs contiguous float32 parameters on the device")
-            m = _hip.GnnModel()
-            m.width, m.particle_in, m.attr_dim, m.group_dim, m.state_cols = self.model_config["nf_effect"], p_in_dim, a.shape[1], g.shape[1], state_t.shape[1]
-            m.pstep, m.motion_clamp = self.model_config["pstep"], self.motion_clamp
-            for name, t in zip(_hip.GnnModel._WEIGHTS, tensors):
-                setattr(m, name, t.data_ptr())
-            ent = self.__dict__["_gnn_model"] = (key, m)
-        return ent[1]
-
-    def _propagate_fused(self, state_t, a, g, act, receivers, senders, workspace=None):
-        """``_propagate`` as ONE launch.  Rows and relations already padded to multiples of 16 (dummy last row, dummy relations on it),
-        relations ascending in the receiver.  -> (predicted positions, motions) of all rows."""
-        from diff_gaussian_rasterization import _hip
-        p_in = self._particle_inputs(state_t, a, act)
-        nodes = torch.cat([a, g, state_t], 1)
-        m = self._gnn_struct(a, g, state_t, p_in.shape[1])
-        N, E = int(a.shape[0]), int(receivers.shape[0])
-        if workspace is None:
-            cache = self.__dict__.setdefault("_gnn_ws", {})
-            workspace = cache.get((N, E, str(a.device)))
-            if workspace is None:
-                if len(cache) >= 16:
-                    cache.clear()
-                workspace = cache[(N, E, str(a.device))] = _hip.gnn_workspace(N, E, m.width, a.device)
-        return _hip.gnn_propagate(m, p_in, nodes, receivers, senders, state_t[:, -3:], workspace)
-
-    def _propagate_fused_padded(self, state_t, a, g, act, receivers, senders):
-        """Pads one graph like ``_propagate_graphed`` does (N to a multiple of 32 with at least one dummy row, E to a multiple of 128 with
-        dummy relations from the last row to itself) and runs the one-launch propagation."""
-        N, E = int(a.shape[0]), int(receivers.shape[0])
-        n_cap, e_cap = ((N + 1 + 31) // 32) * 32, max(128, ((E + 127) // 128) * 128)
-        pad = lambda t: torch.cat([t, t.new_zeros((n_cap - N, t.shape[1]))], 0)  # noqa: E731
-        fill = receivers.new_full((e_cap - E,), n_cap - 1)
-        receivers, order = torch.sort(receivers, stable=True)                    # ascending receivers (the rollout's lists are already: row-major
-        senders = senders[order]                                                 # order of the adjacency matrix); no host round trip to find out
-        pos, mot = self._propagate_fused(pad(state_t), pad(a), pad(g), pad(act), torch.cat([receivers, fill]), torch.cat([senders, fill]))
-        return pos[:N], mot[:N]
 
     def _propagate_graphed(self, state_t, a, g, act, receivers, senders):
         """``_propagate`` replayed from a hipGraph.  The rollout is bound by how fast the host can issue ~45 small launches per step
@@ -652,11 +590,6 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
 # ------------------------------------------------------------------------------------------ one rollout step
 _STEP_CONSTANTS: Dict = {}
 _GRAPH_ROLLOUT = os.environ.get("GSDYN_GRAPH_ROLLOUT", "1") != "0"     # 0: the GNN propagation of a rollout step runs eagerly (A/B, debugging)
-# 1: the propagation network as ONE launch (gsr_gnn_propagate: persistent grid, f32 MFMA, device-wide barriers).  Built and checked in
-# round 4 (1e-6 of the GEMM-library path), but measured SLOWER than the graph of library GEMMs it was meant to replace (379 us per call
-# against ~290 us: its tiles load 16 rows x 64 bytes per instruction straight into the MFMA operand layout, which the address unit
-# serves at ~6 bytes per clock per CU; profiles/r04_gnn_one_launch.txt) -- opt-in until its products are staged through LDS.
-_GNN_FUSED = os.environ.get("GSDYN_GNN_FUSED", "0") == "1"
 _GNN_SPLIT = os.environ.get("GSDYN_GNN_SPLIT", "1") != "0"              # 0: the propagators' concatenated products as the reference writes them (A/B)
 _GRAPH_ROLLOUT_STEP = os.environ.get("GSDYN_GRAPH_ROLLOUT_STEP", "1") != "0"   # 0: only the propagation is graphed, the rest of a step runs eagerly
 
@@ -724,8 +657,6 @@ class _GraphedStep:
         pad_rows = z(self.n_cap - N, n_his * 3)
         act_obj, act_pad = z(nb, 3), z(self.n_cap - N, 3)
 
-        self.gnn_ws = _hip.gnn_workspace(self.n_cap, self.e_cap, c["nf_effect"], dev) if model._fused_ok(a, g) else None
-
         def body():
             idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
             bones_hist = self.hist[:, idx1[thin]]                                             # [n_his, nb, 3]; rows >= cnt repeat a real particle
@@ -733,9 +664,7 @@ class _GraphedStep:
             recv, send, _, rel = _hip.construct_edges_padded(states[-1], cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1, dense_n=self.n_cap)
             state_t = torch.cat([states.transpose(0, 1).reshape(N, n_his * 3), pad_rows], 0)
             act = torch.cat([act_obj, self.eef_next - self.eef_hist[-1], act_pad], 0)
-            if model._fused_ok(a, g):
-                pos_all, _ = model._propagate_fused(state_t, a, g, act, recv, send, workspace=self.gnn_ws)   # one launch (rows / relations are padded already)
-            elif model._split_ok(a):
+            if model._split_ok(a):
                 pos_all, _ = model._propagate_split(state_t, a, g, act, recv, send, dummy_last_row=True)   # (the padded lists are ascending in the receiver)
             else:
                 pos_all, _ = model._propagate(state_t, a, g, act, recv, send)

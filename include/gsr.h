@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 120 /* 0.1.20: gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 120 /* 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -359,33 +359,11 @@ int gsr_lbs_valid(int32_t P, int32_t n_bones, const int32_t* n_valid, const floa
  * A bone with code 1 has the identity and its quaternion: the caller replaces both (as for gsr_fit_rotations). */
 int gsr_fit_bones(int32_t n_bones, const float* bones, const float* motions, const int64_t* relations, int64_t relations_row_stride,
                   float* rotations, float* quats, int32_t* code, void* stream);
-/* gsr_gnn_propagate (ABI 119): the propagation network of the particle dynamics -- DynamicsPredictor.forward for ONE graph,
- * /root/reference/src/gnn/model.py:70-246: particle encoder, relation encoder, pstep x (relation propagator, aggregation onto the
- * receivers, particle propagator with the residual), the non-rigid head, motion clamp -- in ONE launch: a persistent grid walks the
- * layers with device-wide barriers, the matrix products run on the f32 MFMA (exact f32).  Inputs: p_inputs [n_rows, particle_in] (the
- * rows of torch.cat(attrs, state / motion columns, action) the model feeds its particle encoder); rel_nodes [n_rows, attr_dim + group_dim
- * + state_cols] = per node (attributes, instance columns, state history) from which the relation inputs are formed as the model does
- * (attrs[recv], attrs[send], sum |instance[recv] - instance[send]|, state[recv] - state[send]); receivers / senders [n_rel] int64,
- * ASCENDING in the receiver (the row-major order of the adjacency matrix: the aggregation is a segmented sum in list order).  n_rows,
- * n_rel and width must be multiples of 16: the caller pads with a dummy last row and relations from that row to itself.  Weights as
- * torch.nn.Linear stores them ([out, in], row-major).  last_pos [n_rows, 3] with a row stride: pred_pos = last_pos + clamp(motion).
- * workspace: gsr_gnn_workspace_bytes, ZEROED before its first use (the call leaves it ready for the next one); its last 16 bytes hold
- * {barrier arrivals, exits, error (1: receivers not ascending, 2: barrier timed out), -} for the caller to check. */
-typedef struct gsr_gnn_model {
-  int32_t width, particle_in, attr_dim, group_dim, state_cols, pstep;
-  float motion_clamp;
-  const float *pe_w0, *pe_b0, *pe_w1, *pe_b1, *pe_w2, *pe_b2;      /* particle_encoder.model.{0,2,4} */
-  const float *re_w0, *re_b0, *re_w1, *re_b1, *re_w2, *re_b2;      /* relation_encoder.model.{0,2,4}: re_w0 is [width, 2 attr_dim + 1 + state_cols] */
-  const float *rp_w, *rp_b;                                        /* relation_propagator.linear [width, 3 width] */
-  const float *pp_w, *pp_b;                                        /* particle_propagator.linear [width, 2 width] */
-  const float *h_w0, *h_b0, *h_w1, *h_b1, *h_w2, *h_b2;            /* non_rigid_predictor.linear_{0,1,2}: h_w2 is [3, width] */
-} gsr_gnn_model;
-int64_t gsr_gnn_workspace_bytes(int32_t n_rows, int32_t n_rel, int32_t width);
-int gsr_gnn_propagate(const gsr_gnn_model* model, int32_t n_rows, int32_t n_rel, const float* p_inputs, const float* rel_nodes,
-                      const int64_t* receivers, const int64_t* senders, const float* last_pos, int32_t last_pos_stride, void* workspace,
-                      float* pred_pos, float* pred_motion, void* stream);
-/* The two pieces of the same network that the default path (products through the GEMM library) runs as kernels of this library:
- * gsr_gnn_rel_inputs: out [n_rel, 2 attr_dim + 1 + state_cols] = the relation encoder's input rows, formed from rel_nodes as above;
+/* The propagation network of the particle dynamics (DynamicsPredictor.forward, /root/reference/src/gnn/model.py:70-246) runs its matrix
+ * products through the GEMM library; the two steps between them are kernels of this library.  rel_nodes [n_rows, attr_dim + group_dim +
+ * state_cols] = per node (attributes, instance columns, state history); receivers / senders [n_rel] int64, ASCENDING in the receiver.
+ * (ABI 119 also exported the whole network as one persistent launch, gsr_gnn_propagate: measured 2x slower, removed in ABI 120.) */
+/* gsr_gnn_rel_inputs: out [n_rel, 2 attr_dim + 1 + state_cols] = the relation encoder's input rows, formed from rel_nodes as above;
  * gsr_gnn_aggregate:  agg[i] = sum over the relations e in [row_start[i], row_start[i + 1]) -- receivers ascending -- in list order of
  *   relu(rel_part[e] + node_parts[i][0 : width] + node_parts[senders[e]][width : 2 width]),  rel_part [n_rel, width] = relation_encode
  *   @ W1^T + b, node_parts [n_rows, 2 width] = effect @ [W2 | W3]^T with W = [W1 | W2 | W3] the relation propagator's weight: what

@@ -234,14 +234,10 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
 
 
 def _pin_tile_sort_build(monkeypatch, rcap):
-    """The builds of tile_sort (gsr_launch_binning): "1024" = the default for ordinary scenes (one launch, 20 KiB LDS block), "2048" = the
-    36 KiB block, "4096" = the dense-scene form (wave tickets in a launch without LDS + long tickets with the 2048-entry block),
-    "4096L" = the same with the long tickets on the 4096-entry block (the default of the dense-scene form since round 4)."""
-    monkeypatch.setenv("GSR_TILE_SORT_RCAP", {"1024": "1", "2048": "2048", "4096": "4096", "4096L": "4096"}[rcap])
-    if rcap == "4096":
-        monkeypatch.setenv("GSR_LONG_SORT", "2048")       # the 2048-entry block for the long tickets (the default until round 4)
-    else:
-        monkeypatch.delenv("GSR_LONG_SORT", raising=False)
+    """The builds of tile_sort (gsr_launch_binning): "1024" = the default for ordinary scenes (one launch with the 20 KiB LDS block + the
+    strided launch of the 4096-entry block for lists of more than 2032 entries), "2048" = the 36 KiB block in one launch, "4096" = the
+    dense-scene form (wave tickets in launches without LDS + long tickets on the 4096-entry block)."""
+    monkeypatch.setenv("GSR_TILE_SORT_RCAP", {"1024": "1", "2048": "2048", "4096": "4096"}[rcap])
 
 
 __all__ = [n for n in dir() if not n.startswith("__")]

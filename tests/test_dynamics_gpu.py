@@ -328,59 +328,6 @@ def test_split_propagation_equals_eager(dev, golden_dir, width):
     print(f"split propagation, width {width}: worst error {worst:.2e} of the largest motion")
 
 
-@pytest.mark.parametrize("width", [32, 512])
-def test_one_launch_propagation_equals_the_gemm_library_path(dev, golden_dir, width):
-    """gsr_gnn_propagate (csrc/gsr_gnn.hip: the whole DynamicsPredictor for one graph in ONE launch -- persistent grid, device-wide
-    barriers, f32 MFMA, the propagators' concatenated products split into their step-invariant and per-step parts; opt-in: measured
-    slower than the graph of library GEMMs, see gsdyn.dynamics._GNN_FUSED) against the eager
-    torch path through the GEMM library: width 32 with the golden weights (the ones checked against the imported reference on the CPU)
-    and width 512 (every reference config) with seeded random weights; the graph sizes a rollout meets, relation lists in RANDOM order
-    (the wrapper sorts them by receiver: the aggregation is a segmented sum) and with receivers that have no relation at all; two calls
-    in a row (the barrier words reset themselves); the kernel's error word stays 0.  Both paths are exact f32 with different summation
-    orders: bound 2e-5 of the largest motion."""
-    import gsdyn.dynamics as D
-    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
-    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
-    if width == 32:
-        model = D.DynamicsPredictor(cfg, device=dev).eval()
-        model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
-    else:
-        cfg.update(nf_particle=width, nf_relation=width, nf_effect=width)
-        torch.manual_seed(5)
-        model = D.DynamicsPredictor(cfg, device=dev).eval()
-    g = torch.Generator().manual_seed(11)
-    n_his = cfg["n_his"]
-    worst = 0.0
-    with torch.no_grad():
-        for nobj, E in ((100, 520), (100, 300), (97, 511), (100, 640), (60, 90), (100, 520), (15, 16), (126, 1000)):
-            N = nobj + 1
-            state = (torch.rand(1, n_his, N, 3, generator=g) * 0.4).to(dev)
-            attrs = torch.zeros(1, N, 2, device=dev); attrs[0, :nobj, 0] = 1; attrs[0, nobj:, 1] = 1      # noqa: E702
-            pin = torch.ones(1, nobj, 1, device=dev)
-            action = torch.zeros(1, N, 3, device=dev); action[0, nobj:] = 0.01                             # noqa: E702
-            recv = torch.randint(0, N, (E,), generator=g).to(dev); send = torch.randint(0, N, (E,), generator=g).to(dev)   # noqa: E702
-            D._GRAPH_ROLLOUT = False
-            try:
-                want_pos, want_mot = model(state=state, attrs=attrs, p_instance=pin, action=action, receivers=recv, senders=send)
-            finally:
-                D._GRAPH_ROLLOUT = True
-            for _ in range(2):
-                D._GNN_FUSED = True                                 # (opt-in: GSDYN_GNN_FUSED=1)
-                try:
-                    got_pos, got_mot = model(state=state, attrs=attrs, p_instance=pin, action=action, receivers=recv, senders=send)
-                finally:
-                    D._GNN_FUSED = False
-                assert got_pos.shape == want_pos.shape == (1, nobj, 3) and torch.isfinite(got_pos).all() and torch.isfinite(got_mot).all()
-                scale = max(float(want_mot.abs().max()), 1e-3)
-                err = max(float((got_mot - want_mot).abs().max()), float((got_pos - want_pos).abs().max())) / scale
-                worst = max(worst, err)
-                assert err < 2e-5, (width, nobj, E, err, scale)
-    assert not hasattr(model, "_graphs")                       # the graph-replayed GEMM path was not taken
-    for ws in model._gnn_ws.values():
-        assert ws[-16:].view(torch.int32).tolist() == [0, 0, 0, 0], ws[-16:].view(torch.int32).tolist()
-    print(f"one-launch propagation, width {width}: worst error {worst:.2e} of the largest motion")
-
-
 def test_fixed_shape_relations_kernel(dev):
     """gsr_construct_edges (padded relation lists, counts on the device) against ``construct_edges`` in torch: the same pairs in the
     same order for several bone counts, thresholds and k; the tool sits at the last row of the padded layout."""

@@ -1,4 +1,4 @@
-"""GPU box: error margins of tests/test_hip_gpu.py::test_full_size_direct_step_against_literal_torch_step over several seeds."""
+"""GPU box: error margins of tests/test_losses_step_gpu.py::test_full_size_direct_step_against_literal_torch_step over several seeds."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
