@@ -147,7 +147,7 @@ void skippable_aliases(int V, const int32_t* geometry_of, const float* const* co
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
-  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac16 = 0; t.track = 1;
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac16 = 0; t.track = 1; t.avg_list = 1u << 20;
 }
 
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).
@@ -289,6 +289,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
            uint32_t* counts_dev = nullptr, uint32_t* tile_rows = nullptr, int flags = 0, const float* const* colors_views = nullptr) {   // tile_rows: the batch state's matrix (tile-row binning), or nullptr   // counts_dev != nullptr: capacity mode -- num_rendered[] are capacities, the counts go there
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
+  bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
   GsrRenderViews rt;
   int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH], skip[GSR_MAX_BATCH];
   pair_up(V, geometry_of, num_rendered, partner, fused);
@@ -414,6 +415,7 @@ int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_
   gsr_carve_image(const_cast<void*>(owner_image_state), cam.H, cam.W, &im_owner);
   gsr_carve_binning(const_cast<void*>(owner_binning_state), num_rendered, &bs);
   GsrBinViews bt;
+  bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
   bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512;
   bt.order = im.tile_order; bt.queue = im.queue;
   fill_bin_view(bt.v[0], P, num_rendered, g, bs, im, g.block_sums);
@@ -452,6 +454,7 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
     GsrRenderViews rt;
     render_header(rt, 1, cam, im.tile_order, im.queue);
     rt.no_colour_grad = (!shs && !dL_dcolors) ? 1 : 0;   // precomputed colours and no gradient wanted for them
+    rt.avg_list = num_rendered / (uint32_t)(cam.T > 0 ? cam.T : 1);
     fill_render_view(rt.v[0], cam, g, bs, im, nullptr, nullptr, dL_dcolor, partials);
     if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
   }
@@ -626,6 +629,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
   vw.d_raw_sc = raw ? raw->d_log_scales : nullptr;
   GsrRenderViews rt;
   GsrBinViews bt;          // only for a tile_order rebuild (ranges + flags)
+  bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
   bool any = false;
   // Pairs fused by the forward (pair_up) stay fused in the backward when no colour gradient is wanted (the pair pass carries
   // none); otherwise every view takes its own pass over an LPT order rebuilt WITH the partners' tickets, and the fused order is
@@ -666,6 +670,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     w.W = cam.W; w.H = cam.H; w.tanfovx = cam.tanfovx; w.tanfovy = cam.tanfovy;
   }
   if (any) {
+    { uint64_t tot = 0; for (int v = 0; v < V; ++v) tot += num_rendered[v]; rt.avg_list = (uint32_t)(tot / ((uint64_t)V * (uint64_t)(rt.T > 0 ? rt.T : 1))); }
     const bool rebuild = pairs_fwd && !fuse_bwd;
     if (rebuild)
       if (int rc = gsr_launch_tile_order(bt, st)) return rc;

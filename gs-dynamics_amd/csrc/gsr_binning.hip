@@ -571,7 +571,12 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
 #pragma unroll
     for (int q = 0; q < 4; ++q) { st4[q] = run; run += c4[q]; }
     if (lane == 63) n_busy_s = run;   // buckets 0..254 only: bucket 255 (empty tiles) is never counted in the histograms
-    if (bid == 0 && lane == 0) queue[2] = c4[0];     // lists of more than 2032 entries (bucket 0): the order's first tickets
+    // lists of more than 1016 entries (buckets 0 .. 127): the order's first tickets.  In an ordinary scene (wave_cap 512) they are the 4096-entry
+    // block's; the count also goes to the host's hint word (a launch heuristic for the NEXT call: see gsr_launch_binning)
+    if (bid == 0 && lane == 32) {
+      queue[2] = st4[0];
+      if (tab.vlong_out) __hip_atomic_store(tab.vlong_out, st4[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // tiles longer than 512 entries (tile_sort's workgroup path): (n + 7) >> 3 >= 65, i.e. buckets 0 .. 190
     if (tab.wave_cap == 2048) {      // lists of more than 2032 entries share bucket 0: they are the workgroup tickets; queue[3] = where the lists
       if (lane == 0) n_long_s = st4[0] + c4[0];                                   // of at most 1024 entries start (bucket 127)
@@ -1216,7 +1221,7 @@ __global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES
     // the wave tickets have their own launch; this one STRIDES over the long tickets with a grid that fits the chip once (round 4: it
     // used to be one workgroup per tile of the call -- 32 640 workgroups of 36 KiB of LDS for a configs[4] frame, four resident per
     // CU, nearly all of them returning at once: 110 - 600 us of dispatch for a handful of lists)
-    // (ordinary scenes, wave_cap 512: only the lists of more than 2032 entries -- queue[2] of them -- come here; the one-launch build takes the rest)
+    // (ordinary scenes, wave_cap 512: only the lists of more than 1016 entries -- queue[2] of them -- come here; the one-launch build takes the rest)
     const uint32_t n_mine = tab.wave_cap == 512 ? tab.queue[2] : n_long;
     for (uint32_t ticket = blockIdx.x; ticket < n_mine; ticket += gridDim.x) {
       tile_sort_long_ticket<RCAP, NW>(tab, cur, ticket);
@@ -1224,10 +1229,10 @@ __global__ __launch_bounds__(64 * NW, (RCAP <= 1024 || MODE == 2) ? TS_MIN_WAVES
     }
   } else if constexpr (MODE != 2) {
     if (blockIdx.x >= n_long) return;
-    // An ordinary scene's few VERY long lists (> 2032 entries: close-ups, a cluster behind one tile) would sort in global memory here
-    // (~160 us for one list); they belong to the strided launch of the 4096-entry block that follows (round 5: the build is chosen per
-    // ticket, not per scene)
-    if (RCAP <= 1024 && blockIdx.x < tab.queue[2]) return;
+    // An ordinary scene's few long lists (> 1016 entries: close-ups, a cluster behind one tile) would take this block's compare-exchange
+    // network (LDS up to 2048 entries: ~30 us; global memory above: ~160 us for one list); they belong to the strided launch of the
+    // 4096-entry block that follows (round 5: the build is chosen per ticket, not per scene) -- when the launcher issued it
+    if (RCAP <= 1024 && tab.vlong_launch && blockIdx.x < tab.queue[2]) return;
     tile_sort_long_ticket<RCAP, NW>(tab, cur, blockIdx.x);
   }
 }
@@ -1390,6 +1395,11 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   const char* force = getenv("GSR_TILE_SORT_RCAP");   // tests: "2048" / "4096" pin the build
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
   tab.wave_cap = big ? 2048 : 512;
+  {   // long lists in an ordinary scene: see the tile_sort launches below
+    static uint32_t* hint = [] { uint32_t* p = nullptr; if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) return (uint32_t*)nullptr; *p = 1u; return p; }();
+    tab.vlong_out = hint;
+    tab.vlong_launch = (!hint || __atomic_load_n(hint, __ATOMIC_RELAXED) != 0u) ? 1 : 0;
+  }
   int cur = 0;
   bool order_done = false;
   const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
@@ -1492,9 +1502,11 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
         const bool small_lds = !(force && force[0] == '2');
         if (small_lds) {
           hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
-          // ... and the scene's few lists of more than 2032 entries (queue[2]: normally none -- the workgroups read the count and leave)
-          // on the 4096-entry block: LDS radix sort up to 4096 entries, LDS network up to 8192 (was: the network in GLOBAL memory)
-          hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 8>), dim3(64), dim3(512), 0, st, tab, cur);
+          // ... and the scene's few lists of more than 1016 entries on the 4096-entry block: LDS radix sort up to 4096 entries, LDS network up
+          // to 8192 (was: the LDS network up to 2048, the network in GLOBAL memory above).  16 waves per workgroup: a lone list's latency
+          // counts here, not throughput.  Normally there is no such list and the launch would cost ~2.7 us for nothing, so it is issued only
+          // when the PREVIOUS call reported one (tab.vlong_launch; a call that meets its first long list sorts it the old way, once)
+          if (tab.vlong_launch) hipLaunchKernelGGL((tile_sort_kernel<4096, 1, 16>), dim3(64), dim3(1024), 0, st, tab, cur);
         } else hipLaunchKernelGGL(tile_sort_kernel<2048>, dim3(tab.V * tab.T), dim3(GSR_BLOCK), 0, st, tab, cur);
       } }
     GSR_HIP_CHECK(hipGetLastError());

@@ -221,6 +221,8 @@ struct GsrBinViews {
   uint32_t* counts_out; int P;   // capacity mode: tile_order also copies every view's entry count (offsets_v[P]) to counts_out[v]
   int wave_cap;                  // tile_sort: lists up to this length (512 / 1024 / 2048) are sorted by one wave each (set by gsr_launch_binning)
   int rows;                      // tile-row binning: workgroups per view of the count / emit kernels (0: the radix path)
+  uint32_t* vlong_out;           // pinned host word: the tile order stores the call's number of lists above 1016 entries here (or nullptr)
+  int vlong_launch;              // 1: a launch of the 4096-entry block follows the ordinary tile_sort launch and takes those lists
   int forward_only;              // GSR_FORWARD_ONLY: no backward will read these states (the record-slot offsets are not produced)
   GsrBinView v[GSR_MAX_BATCH];
 };
@@ -240,6 +242,8 @@ struct GsrRenderViews {
   int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
   int prio_frac16;      // backward: the longest prio_frac16 / 16 of the busy tickets run at base wave priority 1 (one-view launches; 0 = off)
   int track;            // forward: 1 = record the contribution bytes (a backward may follow); 0 = forward-only call
+  uint32_t avg_list;    // backward: mean entries per tile over the call's views (from the entry counts / capacities the caller holds): a launch
+                        //   heuristic only (sparse scenes keep the 128-entry build whatever their queue length: profiles/r05_autotune.json)
   GsrRenderView v[GSR_MAX_BATCH];
 };
 

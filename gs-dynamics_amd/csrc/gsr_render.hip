@@ -1468,7 +1468,9 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
     // long queue (>= 2 tiles per resident workgroup slot, counting the empty ones): the small-batch build, more workgroups per CU
     // (round 4, with the exact lists: 80 entries at six per CU; two views -- 5000 tiles -- gain too: render_bwd 132 -> 127 us; one view loses: 81 -> 87)
     static const int small_batch_from = env_int("GSR_BWD_SMALL_BATCH_TILES", 4000);
-    const bool small = !pairs && tiles >= small_batch_from;
+    // ... but not for sparse scenes (mean list below ~100 entries: one batch per tile either way, and fewer workgroups per CU contend less --
+    // the demo's 9 k Gaussians at 640x480: 72.8 -> 64.7 us at four views, 113.6 -> 103.5 at eight; profiles/r05_autotune.json)
+    const bool small = !pairs && tiles >= small_batch_from && tab.avg_list >= 96u;
     const int per_cu = pairs ? 4 : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
     const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     const bool col = !tab.no_colour_grad;

@@ -930,6 +930,33 @@ def fps_thin(pos: torch.Tensor, npoints: int, radius: float, start_idx: int = 0,
     return out, thin[:m]
 
 
+def gnn_rel_inputs(rel_nodes: torch.Tensor, receivers: torch.Tensor, senders: torch.Tensor, attr_dim: int, group_dim: int) -> torch.Tensor:
+    """gsr_gnn_rel_inputs: rel_nodes [N, attr + group + state] -> the relation encoder's input rows [E, 2 attr + 1 + state] in one launch."""
+    lib = load_library()
+    _require_device(rel_nodes)
+    dev = rel_nodes.device
+    E, S = int(receivers.shape[0]), int(rel_nodes.shape[1]) - attr_dim - group_dim
+    with _on(dev):
+        out = torch.empty((E, 2 * attr_dim + 1 + S), dtype=torch.float32, device=dev)
+        if E:
+            _check(lib.gsr_gnn_rel_inputs(E, int(attr_dim), int(group_dim), S, _ptr(rel_nodes), _ptr(receivers), _ptr(senders), _ptr(out), _stream(dev)),
+                   "gsr_gnn_rel_inputs")
+    return out
+
+
+def gnn_aggregate(rel_part: torch.Tensor, node_parts: torch.Tensor, senders: torch.Tensor, row_start: torch.Tensor, n_sum_rows: int = None) -> torch.Tensor:
+    """gsr_gnn_aggregate: rel_part [E, H], node_parts [N, 2 H], senders [E], row_start [N + 1] (int64; receivers ascending) -> agg [N, H];
+    rows >= n_sum_rows (default N) get zeros."""
+    lib = load_library()
+    _require_device(rel_part)
+    dev = rel_part.device
+    N, H = int(node_parts.shape[0]), int(rel_part.shape[1])
+    with _on(dev):
+        agg = torch.empty((N, H), dtype=torch.float32, device=dev)
+        _check(lib.gsr_gnn_aggregate(N, N if n_sum_rows is None else int(n_sum_rows), H, _ptr(rel_part), _ptr(node_parts), _ptr(senders), _ptr(row_start), _ptr(agg), _stream(dev)), "gsr_gnn_aggregate")
+    return agg
+
+
 def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):
     """gsr_fit_bones: bones, motions [nb,3], relations [nb,nb] (int64 0/1; any row stride, unit column stride) on a HIP device ->
     (rotations [nb,3,3], unit quaternions [nb,4], code [nb] int32)."""

@@ -148,10 +148,10 @@ def test_tile_row_binning_lists_vs_oracle(dev, P, W, H):
 
 def test_one_very_long_list_in_an_ordinary_scene(dev):
     """an ordinary (sparse) 800x800 scene whose tile-sort build is chosen from the AVERAGE list length, plus ONE tile
-    with ~3000 entries (a cluster of tiny Gaussians behind one tile: the reference's object close-ups).  Rounds 1 - 4 sorted such a list
-    with the 64-bit network in GLOBAL memory (~+160 us for the one list); the build is now chosen per ticket -- lists of more than
-    2032 entries go to the strided launch of the 4096-entry LDS block.  Lists bit-exact against the oracle, and tile_sort costs at
-    most 2x what it costs without the cluster."""
+    with ~3000 entries (a cluster of tiny Gaussians behind one tile corner: the reference's object close-ups).  Rounds 1 - 4 sorted such
+    lists with the compare-exchange network (LDS up to 2048 entries: ~30 us; GLOBAL memory above: ~+160 us for one list); the build is now
+    chosen per ticket -- lists of more than 1016 entries go to a launch of the 4096-entry LDS block (radix sort), issued when the previous
+    call reported such lists.  Lists bit-exact against the oracle, and the cluster's sorts cost at most ~25 us on top."""
     from diff_gaussian_rasterization import _hip
     W = H = 800
     cam = ring_camera(W, H, bg=(0.1, 0.1, 0.1))
@@ -187,4 +187,4 @@ def test_one_very_long_list_in_an_ordinary_scene(dev):
         return 1e3 * prof["tile_sort"][0] / prof["tile_sort"][1]
     t_base, t_both = sort_us(base), sort_us(both)
     print(f"tile_sort: {t_base:.1f} us without the cluster, {t_both:.1f} us with it (longest list {lens.max()})")
-    assert t_both <= 2.0 * t_base + 5.0, (t_base, t_both)
+    assert t_both <= t_base + 25.0, (t_base, t_both)

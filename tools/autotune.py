@@ -62,7 +62,7 @@ CANDIDATES = {
     "bwd80@6": (None, {"GSR_BWD_SMALL_BATCH_TILES": "0"}),
     "bwd96@5": ("libgsr_at_bb96w5.so", {"GSR_BWD_SMALL_BATCH_TILES": "0"}),
     "bwd64@7": ("libgsr_at_bb64w7.so", {"GSR_BWD_SMALL_BATCH_TILES": "0"}),
-    "bwd_pc@5": (None, {"GSR_BWD_PC": "1", "GSR_BWD_PC_WG_PER_CU": "5"}),
+    "bwd_pc@5": (None, {"GSR_BWD_PC": "1"}),
     "fwd@4": (None, {"GSR_FWD_WG_PER_CU": "4"}),
     "fwd@5": (None, {"GSR_FWD_WG_PER_CU": "5"}),
     "sort1024": (None, {"GSR_TILE_SORT_RCAP": "1024"}),
