@@ -389,18 +389,18 @@ def kernel_roofline(_hip, step, vpl, D, t_step, steps):
         "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
         "per_kernel_timing": "HIP events around every launch of the library (on the launch stream), separate pass after the timed region, same call pattern",
         "frac_source": "in-run HIP events (this run); the rocprofv3 --kernel-trace --stats averages of the same command are committed as "
-                       f"profiles/r04_kernel_stats_v{vpl}.txt (blend kernels read 3-5 % longer there, the small kernels shorter)",
+                       f"profiles/r05_kernel_stats_v{vpl}.txt (blend kernels read 3-5 % longer there, the small kernels shorter)",
     }
     # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_round.sh), corrected with the
     # calibration factors measured on known byte counts (tools/prof_calib.sh): REPLAYED from profiles/, not measured in this run
-    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r04", "r03", "r02")) if j), None) or \
-        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r04", "r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
+    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r05", "r04", "r03", "r02")) if j), None) or \
+        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r05", "r04", "r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
     if tj and dom in tj and tj.get("views_per_launch") == vpl:
         roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
         roofline["traffic_detail"] = {"replayed": True, "source": tj.get("source"), **{k: tj[dom].get(k) for k in
                                       ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "fabric_bytes_per_launch", "note") if k in tj[dom]}}
     # VALU: measured issue model (profiles/r02_valu_table.json) + committed SQ counters (REPLAYED)
-    sj = next((j for j in (_load_json(n) for r in ("r04", "r03", "r02") for n in (f"{r}_sq_counters_v{vpl}.json", f"{r}_sq_counters.json"))
+    sj = next((j for j in (_load_json(n) for r in ("r05", "r04", "r03", "r02") for n in (f"{r}_sq_counters_v{vpl}.json", f"{r}_sq_counters.json"))
                if j and j.get("views_per_launch") == vpl), None)
     valu = {"peak_lane_instr_per_s_spec": VALU_PEAK,
             "measured_issue_model": "one wave-64 VALU op per ~2.2 SIMD-cycles at >= 2 waves per SIMD (1 per ~4.7 cycles from ONE wave); DPP ops ~3.0, "
