@@ -35,6 +35,24 @@ def stats(P, W, H, **kw):
             useless_below += nz[-1] + 1 - nz.size
     print(f"   entries below their tile's deepest blended entry (what the backward walks): {below} = {below / D:.3f} of all; of those NOT blended "
           f"by any quad: {useless_below / max(below, 1):.3f}")
+    # quad imbalance: the backward replays a tile in batches; every batch lasts as long as its LONGEST per-quad list.  Visits wasted by
+    # the lockstep = sum over batches of (4 x max_q - sum_q) visits; "whole tile" = the same with one batch per tile (what a ring that
+    # covers the whole tile -- the producer / consumer form with unbounded LDS -- would still pay: a wave owns a quad)
+    for BB in (80, 128):
+        tot = waste = tot_tile = waste_tile = 0
+        for lo, hi in ranges:
+            nz = np.flatnonzero(c[lo:hi])
+            if not nz.size:
+                continue
+            walked = c[lo:lo + nz[-1] + 1][::-1]                    # deepest first, as the backward walks
+            bits = np.unpackbits(walked[:, None], axis=1)[:, 4:]    # [n, 4] (bit order irrelevant for counts)
+            nb = (len(walked) + BB - 1) // BB
+            pad = np.zeros((nb * BB, 4), np.int64); pad[:len(walked)] = bits
+            per = pad.reshape(nb, BB, 4).sum(1)                     # visits per batch and quad
+            tot += per.sum(); waste += (4 * per.max(1) - per.sum(1)).sum()
+            pt = bits.sum(0)
+            tot_tile += pt.sum(); waste_tile += 4 * pt.max() - pt.sum()
+        print(f"   quad imbalance, batches of {BB}: visits {tot}, lockstep slots {tot + waste} (x{(tot + waste) / tot:.3f}); one batch per tile: x{(tot_tile + waste_tile) / tot_tile:.3f}")
     al256 = lambda x: (x + 255) // 256 * 256
     pl_off = 2 * al256(4 * D) + 2 * al256(8 * D)
     pl = binning[pl_off:pl_off + 4 * D].view(torch.int32).cpu().numpy()
