@@ -1471,10 +1471,18 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
     // ... but not for sparse scenes (mean list below ~100 entries: one batch per tile either way, and fewer workgroups per CU contend less --
     // the demo's 9 k Gaussians at 640x480: 72.8 -> 64.7 us at four views, 113.6 -> 103.5 at eight; profiles/r05_autotune.json)
     const bool small = !pairs && tiles >= small_batch_from && tab.avg_list >= 96u;
-    const int per_cu = pairs ? 4 : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : wg_per_cu);
+    // a sparse scene with a short queue (the demo: 9 k Gaussians, 1200 tiles per 640x480 view, one or two views): three workgroups per CU
+    // (24.7 vs 27.2 us at one view, 42.3 vs 45.9 at two, in both sweeps)
+    const bool few_sparse = !pairs && tab.avg_list < 96u && tiles < 4000;
+    const int per_cu = pairs ? 4 : (small ? wg_per_cu + (BWD_SMALL_WAVES - 4) : (few_sparse && wg_per_cu > 3 ? 3 : wg_per_cu));
     const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     const bool col = !tab.no_colour_grad;
-    static const int use_pc = env_int("GSR_BWD_PC", 0);   // the producer / consumer form (round 5, opt-in: it ties the barrier form) for calls without fused pairs
+    // The producer / consumer form (round 5) for calls without fused pairs: GSR_BWD_PC = 1 / 0 forces it on / off; by default it takes the
+    // DENSE scenes (mean list of 600 entries and more), where the sweep measured it 4 - 6 % ahead of the barrier form at every view count
+    // (500 k Gaussians at 1080p: 241 vs 256 us at one view ... 1413 vs 1470 at eight); at BASELINE's density the two tie, on one sparse view
+    // the barrier form leads (profiles/r05_autotune.json)
+    static const int pc_mode = env_int("GSR_BWD_PC", -1);
+    const bool use_pc = pc_mode >= 0 ? pc_mode != 0 : (tab.avg_list >= 600u && tab.avg_list < (1u << 20));
     if (!pairs && use_pc) {
       const int pgrid = tiles < 256 * PC_WG_PER_CU ? tiles : 256 * PC_WG_PER_CU;
       if (col) hipLaunchKernelGGL(render_bwd_pc<true>, dim3(pgrid), dim3(PC_THREADS), 0, st, tab);

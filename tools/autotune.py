@@ -3,12 +3,12 @@
     python tools/autotune.py                     # the whole grid -> gpurun_out/r05_autotune.json (copied to profiles/ when judged)
     python tools/autotune.py --worker P W H V    # one cell with the current environment: prints one JSON line
 
-Cells: V in {1, 2, 4, 8} views x three densities (the demo's 9 k Gaussians at 640x480, BASELINE's 100 k at 800^2, configs[4]'s 500 k at
-1920x1080); the step timed is gsdyn.step.render_step_views (fused activations, one multi-view forward, one multi-view backward, all
+Cells: V in {1, 2, 4, 8} views x four densities (the demo's 9 k Gaussians at 640x480, the reference's 1280x720 with 50 k, BASELINE's 100 k at 800^2,
+configs[4]'s 500 k at 1920x1080); the step timed is gsdyn.step.render_step_views (fused activations, one multi-view forward, one multi-view backward, all
 gradients), per-kernel times from the library's own HIP events.  Candidates: for render_bwd the batch size x workgroups per CU builds
 (128 @ 3 / 4 / 5, 96 @ 5, 80 @ 6, 64 @ 7) and the producer / consumer form; for render_fwd the workgroups per CU; for tile_sort the
 build the launcher would not pick by itself.  Every candidate is one subprocess (the launchers read their switches once); candidates of a
-cell run interleaved twice, the table keeps the minimum of each kernel's time.  The launch heuristics in gsr_render.hip / gsr_binning.hip
+cell run interleaved three times, the table keeps the minimum of each kernel's time.  The launch heuristics in gsr_render.hip / gsr_binning.hip
 cite this table."""
 import json
 import os
@@ -52,8 +52,9 @@ def worker(P, W, H, V, steps=12):
                       "kernels_us": {k: 1e3 * ms / max(n, 1) for k, (ms, n) in prof.items()}}))
 
 
-CELLS = [(P, W, H, V) for (P, W, H) in ((8_957, 640, 480), (100_000, 800, 800), (500_000, 1920, 1080)) for V in (1, 2, 4, 8)]
+CELLS = [(P, W, H, V) for (P, W, H) in ((8_957, 640, 480), (50_000, 1280, 720), (100_000, 800, 800), (500_000, 1920, 1080)) for V in (1, 2, 4, 8)]
 BIG = 10 ** 9
+ROUNDS = 3          # candidates of a cell run interleaved ROUNDS times; the table keeps each kernel's minimum
 # name -> (library build or None, environment).  "default" = what the launchers pick by themselves.
 CANDIDATES = {
     "default": (None, {}),
@@ -100,7 +101,7 @@ def main():
     for cell in cells:
         key = "P%d_%dx%d_V%d" % cell
         res = {}
-        for rnd in range(2):
+        for rnd in range(ROUNDS):
             for name in CANDIDATES:
                 r = run_cell(cell, name)
                 if "error" in r:
