@@ -220,7 +220,14 @@ def main():
             k["no_host_sync"] = False
             out = orig_b(*a, **k)
             num_rendered.extend(st.num_rendered for st in out[3])
+            torch.cuda.synchronize()
+            for st in out[3]:
+                try:
+                    visit_stats.append(contributing_visits(_hip, st))
+                except Exception as e:  # noqa: BLE001
+                    visit_stats.append({"error": repr(e)})
             return out
+        visit_stats = []
         _hip.rasterize_forward_batch = spy_b
         step()
         _hip.rasterize_forward_batch = orig_b
@@ -250,6 +257,20 @@ def main():
                "grad_bucket_floats": sum(p.numel() for p in bucket.params)}
         if want_roofline:
             res["roofline"] = kernel_roofline(_hip, step, max(len(cams), 1), D, t_step, args.steps)
+            good = [v for v in visit_stats if "error" not in v]
+            if good and "render_bwd" in res["roofline"].get("per_kernel_us_per_launch", {}):
+                visits = sum(v["visits"] for v in good) * len(visit_stats) / len(good)
+                slots = sum(v["lockstep_slots_bb80"] for v in good) * len(visit_stats) / len(good)
+                us = res["roofline"]["per_kernel_us_per_launch"]["render_bwd"]
+                floor_us = visits / 1024.0 * BWD_VISIT_NS_PER_SIMD * 1e-3
+                res["roofline"]["issue_floor"] = {
+                    "kernel": "render_bwd", "contributing_visits_per_launch": visits, "ns_per_visit_per_simd": BWD_VISIT_NS_PER_SIMD,
+                    "floor_us": floor_us, "measured_us": us, "frac_of_floor": floor_us / us, "lockstep_factor": slots / max(visits, 1.0),
+                    "floor_times_lockstep_us": floor_us * slots / max(visits, 1.0),
+                    "what": "render_bwd is VALU-issue bound, not HBM bound: visits (quad, entry pairs some pixel blended, counted in this run from the forward's "
+                            "contribution bytes) x the visit body's own cost (tools/micro/visit_peak.hip, six waves per SIMD: profiles/r05_visit_peak.txt, "
+                            "a committed measurement) / 1024 SIMDs; lockstep_factor = wave slots the four waves of a tile occupy per visit "
+                            "(every 80-entry batch lasts as long as its longest per-quad list)"}
         return res
 
     default_n1 = world == 1 and not force_dist and not args.weak and args.config == 4 and args.views is None and not args.no_optimizer
@@ -341,6 +362,44 @@ def _emit(line):
     _flush_c_stdio()
     sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
+
+
+BWD_VISIT_NS_PER_SIMD = 103.3      # profiles/r05_visit_peak.txt: the backward's visit body alone, six waves per SIMD
+
+
+def contributing_visits(_hip, st):
+    """(quad, entry) visits of one view's backward, from the contribution bytes the tracking forward left behind the tile lists (the last
+    align256(D) bytes of the binning state), restricted to the entries below each tile's deepest used position; and the wave slots the
+    lockstep of a tile's four waves makes of them (batches of 80 entries)."""
+    D, H, W = int(st.num_rendered), int(st.H), int(st.W)
+    v = _hip.debug_views(st)
+    rg = v["ranges"].cpu().numpy().astype(np.int64)
+    nc = v["n_contrib"].cpu().numpy()
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = np.zeros((gy * 16, gx * 16), nc.dtype)
+    pad[:H, :W] = nc
+    max_last = pad.reshape(gy, 16, gx, 16).max((1, 3)).reshape(-1).astype(np.int64)
+    # where gsr_carve_binning (csrc/gsr_common.h) puts the bytes for D entries: behind tkey[2] (4 D each), dg[2] (8 D each), point_list (4 D) and
+    # the radix block histograms (1 KiB x (ceil(D / 2048) + 1)), every sub-array 256-byte aligned.  (The spied call is synchronous: the
+    # library carves its states with the true entry count, whatever size the caller's buffer has.)
+    al = lambda x: (x + 255) // 256 * 256      # noqa: E731
+    nb = max(1, (D + 2047) // 2048)
+    off = 2 * al(4 * D) + 2 * al(8 * D) + al(4 * D) + al(1024 * (nb + 1))
+    c = st.binning[off:off + D].cpu().numpy()
+    pop = np.unpackbits(c[:, None], axis=1)[:, 4:]
+    visits = slots = 0
+    for t in range(rg.shape[0]):
+        lo, ml = rg[t, 0], max_last[t]
+        if ml <= 0:
+            continue
+        bits = pop[lo:lo + ml][::-1]
+        nb = (ml + 79) // 80
+        padb = np.zeros((nb * 80, 4), np.int64)
+        padb[:ml] = bits
+        per = padb.reshape(nb, 80, 4).sum(1)
+        visits += int(per.sum())
+        slots += int(4 * per.max(1).sum())
+    return {"visits": visits, "lockstep_slots_bb80": slots}
 
 
 def kernel_roofline(_hip, step, vpl, D, t_step, steps):
