@@ -309,12 +309,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   uint32_t* __restrict__ block_sums = vw.block_sums;
   __shared__ uint32_t s_wave_sum[GSR_BLOCK / GSR_WAVE];
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
-  const bool in_range = i < P;
   __shared__ float4 s_rec[GSR_BLOCK / GSR_WAVE][256];      // a wave's 64 records on their way to memory (see preprocess_gaussian)
   const PreOut po = preprocess_gaussian(tab, vw, i, P, s_rec[threadIdx.x >> 6], blockIdx.y == 0, W, H, gx, gy, mod, sh_degree, M, means3D, scales, rotations,
                                         opacities, colors_precomp, shs, cov3D_precomp, tight_lists);
-  const uint32_t tiles = po.tiles, tmask = po.tmask;
-  const uint2 rc = po.rc;
+  const uint32_t tiles = po.tiles;
   // Compare mode (single-view entry points, list reuse): is everything the tile lists and the blend decisions depend on bit-equal to an
   // earlier forward's geometry state?  One word per block for the host (it rides in the copy that brings the entry counts): 0 = equal.
   // (Rounds 3 - 4 compared a 64-bit fingerprint instead -- "identical up to a 2^-64 coincidence"; the bar for integer work is bit-exact.)

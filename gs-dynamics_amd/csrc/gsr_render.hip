@@ -879,7 +879,7 @@ __global__ __launch_bounds__(GSR_BLOCK, (!PAIRS && NBB == BWD_SMALL_BB) ? BWD_SM
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     if (PAIRS && vw.partner >= 0)
       bwd_tile<PAIRS>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<PAIRS>&>(L), GSR_BWD_PASS(vw), bwd_partner(tab.v[vw.partner]));
-    else if (ticket * 16u < n_busy * (uint32_t)tab.prio_frac16)
+    else if (ticket * 256u < n_busy * (uint32_t)tab.prio_frac256)
       bwd_tile<false, NBB, COL, 1>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
     else
       bwd_tile<false, NBB, COL>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<BwdLdsT<false, NBB>&>(L), GSR_BWD_PASS(vw), BwdPartner{});
@@ -1460,7 +1460,10 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
   // on the resident workgroups followed by a drain in which they finish one by one: the longest 10/16 of the tickets (the order is
   // longest-first: rank = ticket) run at base priority 1, so that a CU's long lists get a larger share of it and end with the pack:
   // render_bwd 90.5 -> 87 us, the one-view step 213 -> 208.5 us (profiles/r04_small_blend_experiments.txt); nothing at 2+ views (off there).
-  tab.prio_frac16 = tab.V <= 1 ? 10 : 0;
+  // Round 5, 1/256 steps, 3 alternating rounds on one box (profiles/r05_prio_frac.txt): with 3+ views the shortest quarter of the tickets
+  // left at base priority 0 (192/256 raised) takes render_bwd 211.0 -> 207.9 us at four views and 379.1 -> 376.9 at eight; small raised
+  // fractions (8..64/256: only the longest lists) and a second level for the longest did nothing -- the first round of tickets is ALL long.
+  tab.prio_frac256 = tab.V <= 1 ? 160 : (tab.V >= 3 ? 192 : 0);
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
   const bool pairs = has_pairs(tab);
   { GSR_PROF("render_bwd", st);
