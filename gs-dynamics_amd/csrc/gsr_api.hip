@@ -147,7 +147,7 @@ void skippable_aliases(int V, const int32_t* geometry_of, const float* const* co
   }
 }
 void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* order, uint32_t* queue) {
-  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac256 = 0; t.track = 1; t.avg_list = 1u << 20;
+  t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac256 = 0; t.pc_error_out = nullptr; t.track = 1; t.avg_list = 1u << 20;
 }
 
 // Pinned host staging for the per-block entry counts (per host thread; lives for the process).

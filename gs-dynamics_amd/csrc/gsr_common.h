@@ -240,6 +240,7 @@ struct GsrRenderView {         // blend forward / backward
 struct GsrRenderViews {
   int V, W, H, gx, T; const uint4* order; uint32_t* queue;
   int no_colour_grad;   // backward: the caller wants no dL/dcolour (records carry their six geometry sums only)
+  uint32_t* pc_error_out;  // render_bwd_pc: pinned host word, set to 1 when one of its bounded waits ran out (nullptr: not reported)
   int prio_frac256;     // backward: the longest prio_frac256 / 256 of the busy tickets run at base wave priority 1 (0 = off)
   int track;            // forward: 1 = record the contribution bytes (a backward may follow); 0 = forward-only call
   uint32_t avg_list;    // backward: mean entries per tile over the call's views (from the entry counts / capacities the caller holds): a launch

@@ -1370,6 +1370,8 @@ __global__ __launch_bounds__(PC_THREADS, PC_WAVES_PER_EU) __attribute__((amdgpu_
   const int wv = (int)(threadIdx.x >> 6);
   if (wv < 4) pc_consumer<COL>(L, tab, wv);
   else pc_stager<COL>(L, tab);
+  // a wait timed out: this launch's gradients are not to be trusted -- tell the host (pinned word; gsr_launch_render_bwd checks it on entry)
+  if (tab.pc_error_out && gsr_lane() == 0 && pc_peek(&L.abort) != 0u) __hip_atomic_store(tab.pc_error_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace gsr_render
@@ -1421,6 +1423,22 @@ extern "C" int gsr_debug_ticket_trace(uint32_t* out4, int n) {   // debug builds
 }
 #endif
 
+static uint32_t* pc_error_word() {   // pinned, device-visible; nullptr when it could not be allocated (then timeouts only show in g_pc_error)
+  static uint32_t* word = [] {
+    uint32_t* w = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&w), sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return static_cast<uint32_t*>(nullptr);
+    *w = 0u;
+    return w;
+  }();
+  return word;
+}
+extern "C" int gsr_debug_pc_inject_error() {   // tests: pretend a wait of the last render_bwd_pc launch timed out (not part of include/gsr.h)
+  uint32_t* w = pc_error_word();
+  if (!w) return 1;
+  __atomic_store_n(w, 1u, __ATOMIC_RELAXED);
+  return 0;
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -1464,6 +1482,16 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
   // left at base priority 0 (192/256 raised) takes render_bwd 211.0 -> 207.9 us at four views and 379.1 -> 376.9 at eight; small raised
   // fractions (8..64/256: only the longest lists) and a second level for the longest did nothing -- the first round of tickets is ALL long.
   tab.prio_frac256 = tab.V <= 1 ? 160 : (tab.V >= 3 ? 192 : 0);
+  // render_bwd_pc's waits are bounded; one that ran out marks a pinned host word (the launch's gradients are garbage).  Nobody syncs here,
+  // so the report comes with the NEXT backward launch -- late, but loud (the word is cleared: the caller decides whether to go on).
+  uint32_t* const pc_error = pc_error_word();
+  if (pc_error && __atomic_load_n(pc_error, __ATOMIC_RELAXED) != 0u) {
+    __atomic_store_n(pc_error, 0u, __ATOMIC_RELAXED);
+    gsr_set_error("render_bwd_pc: a wait between the staging wave and the replaying waves timed out in an EARLIER backward launch; "
+                  "the gradients of that launch are invalid (set GSR_BWD_PC=0 to use the plain backward and report this)");
+    return -5;
+  }
+  tab.pc_error_out = pc_error;
   static const int wg_per_cu = env_int("GSR_BWD_WG_PER_CU", 4);
   const bool pairs = has_pairs(tab);
   { GSR_PROF("render_bwd", st);

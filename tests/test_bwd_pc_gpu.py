@@ -1,5 +1,5 @@
-"""The producer / consumer form of the backward blend (render_bwd_pc, GSR_BWD_PC=1: round 5, opt-in) must write exactly the records the
-barrier form writes: every gradient of a multi-view fwd + bwd bit for bit, all colour modes.  The launcher reads the switch once per
+"""The producer / consumer form of the backward blend (render_bwd_pc: round 5; the launcher's choice for dense scenes, GSR_BWD_PC=0/1
+forces it off / on) must write exactly the records the barrier form writes: every gradient of a multi-view fwd + bwd bit for bit, all colour modes.  The launcher reads the switch once per
 process, so each arm runs in its own interpreter (tools/r05_pc_check.py is the worker)."""
 import os
 import subprocess
@@ -28,3 +28,27 @@ def test_producer_consumer_backward_is_bit_identical(tmp_path, V, P, S, frozen):
     assert set(a.files) == set(b.files) and len(a.files) >= 5
     for k in a.files:
         assert np.array_equal(a[k], b[k]), f"{k}: producer / consumer backward differs from the barrier form"
+
+
+@pytest.mark.gpu
+def test_timed_out_wait_is_reported_by_the_next_backward(dev):
+    """render_bwd_pc's waits are bounded; one that runs out marks a pinned host word and the launch's gradients are garbage.  The product
+    must say so: the next backward launch fails with the reason (once -- the word is cleared), the one after works again."""
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizer, _hip
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    params = synth_scene_params(2000, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, 128, 96, device=dev)[0]
+
+    def step():
+        for v in params.values():
+            v.grad = None
+        im, _, _ = GaussianRasterizer(raster_settings=cam)(**params2rendervar(params))
+        im.sum().backward()
+        torch.cuda.synchronize()
+        return params["means3D"].grad.clone()
+    g0 = step()
+    assert _hip.load_library().gsr_debug_pc_inject_error() == 0
+    with pytest.raises(RuntimeError, match="render_bwd_pc"):
+        step()
+    assert torch.equal(step(), g0)

@@ -24,6 +24,8 @@ lib.gsr_debug_ticket_trace.argtypes = [C.c_void_p, C.c_int]
 lib.gsr_debug_ticket_trace(buf, n)
 a = np.frombuffer(buf, dtype=np.uint32).reshape(n, 4).astype(np.int64)
 a = a[a[:, 3] > 0]
+if os.environ.get("TRACE_DUMP"):
+    np.save(os.environ["TRACE_DUMP"], a)
 # one launch's tickets: the trace holds the last launch (same ticket ids overwrite)
 base = a[:, 0].min()
 t0, t1, wg, ln = (a[:, 0] - base) / 100.0, (a[:, 1] - base) / 100.0, a[:, 2], a[:, 3]
