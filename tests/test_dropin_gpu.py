@@ -83,7 +83,7 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
     """The reference's own call pattern -- two separate ``GaussianRasterizer`` calls per camera with the same geometry and other colours,
     the second one fed FRESH copies of the geometry tensors (/root/reference/src/tracking/train_utils.py:174-192: ``params2rendervar`` is
     evaluated twice; /root/reference/src/predict.py:115-123: ``copy.deepcopy``) -- through the unchanged drop-in API: the torch C++ layer
-    recognises the second call by the fingerprint of its preprocess outputs and blends from the first call's tile lists.  Images and
+    recognises the second call by comparing its preprocess outputs with the first call's on the device, bit for bit, and blends from the first call's tile lists.  Images and
     every gradient must equal the non-reusing path bit for bit; a changed Gaussian or another camera must NOT reuse."""
     import copy
     import diff_gaussian_rasterization as dgr
@@ -147,7 +147,7 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
         assert float(mask.max()) <= 1.0 + 1e-5 and not torch.equal(im1, im2)
 
         # Same geometry, OTHER OPACITIES, both forwards before either backward: the tile lists would be the same, but the forward leaves
-        # the backward's per-quad contribution bytes next to the lists (round 4) and those depend on the opacities -- the fingerprint
+        # the backward's per-quad contribution bytes next to the lists (round 4) and those depend on the opacities -- the comparison
         # covers them, so the second call bins for itself and the first call's backward still finds its own bytes.
         def two_opacities(reuse):
             C_.set_list_reuse(reuse)
@@ -166,6 +166,24 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
         assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and not torch.equal(ra[0], ra[1])
         for k in ra[2]:
             assert torch.equal(ra[2][k], rb[2][k]) and torch.equal(ra[3][k], rb[3][k]), k
+
+        # An evaluation render under no_grad FIRST (forward-only: it leaves no contribution bytes next to its lists), then the training
+        # render of the same geometry: it reuses those lists, writes the bytes itself, and its backward must equal the non-reusing path.
+        def eval_then_train(reuse):
+            C_.set_list_reuse(reuse)
+            h0 = C_.list_reuse_hits()
+            leaves = {k: params[k].detach().clone().requires_grad_(True) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors")}
+            with torch.no_grad():
+                im_e, _, _ = GaussianRasterizer(raster_settings=cams[1])(**params2rendervar(leaves))
+            im_t, _, _ = GaussianRasterizer(raster_settings=cams[1])(**params2rendervar(leaves))
+            (im_t * g1).sum().backward()
+            torch.cuda.synchronize()
+            return im_e, im_t.detach(), {k: v.grad.clone() for k, v in leaves.items()}, C_.list_reuse_hits() - h0
+        ea, eb = eval_then_train(True), eval_then_train(False)
+        assert ea[3] == 1 and eb[3] == 0, (ea[3], eb[3])
+        assert torch.equal(ea[0], eb[0]) and torch.equal(ea[1], eb[1]) and torch.equal(ea[0], ea[1])
+        for k in ea[2]:
+            assert torch.equal(ea[2][k], eb[2][k]), k
     finally:
         C_.set_list_reuse(True)
 
