@@ -30,13 +30,27 @@ for V in (4, 8, 2):
         for st in streams:
             cur.wait_stream(st)
 
+    def two_nosync():       # the same, and the host does not wait for group A's entry counts before it queues group B (counts checked after both)
+        cur = torch.cuda.current_stream(dev)
+        outs = []
+        for st, (c, d) in zip(streams, groups):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(render_step_views(params, c, d, _defer_counts=True))
+        for st in streams:
+            cur.wait_stream(st)
+        from diff_gaussian_rasterization import _hip
+        for _ims, g in outs:
+            assert _hip.forward_counts_ok(g["_states"])
+        return outs
+
     def two_seq():          # the same two calls on ONE stream (what splitting alone costs)
         for c, d in groups:
             render_step_views(params, c, d)
 
     res = {}
     for rnd in range(3):
-        for name, fn in (("one call", one), ("two streams", two), ("two calls, one stream", two_seq)):
+        for name, fn in (("one call", one), ("two streams", two), ("two streams, counts deferred", two_nosync), ("two calls, one stream", two_seq)):
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
