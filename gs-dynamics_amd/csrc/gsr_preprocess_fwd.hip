@@ -216,7 +216,11 @@ __device__ __forceinline__ PreOut preprocess_gaussian(
           if (tau2 > 0.0f && tx0 < tx1 && ty0 < ty1) {
             tiles = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
             rc = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+#ifdef GSR_ABL_NO_TILE_TEST   /* ablation (tools/build_variant.sh): what the exact per-tile loop costs this kernel */
+            if (false) {
+#else
             if (tiles <= 32u) {
+#endif
               // exact per-tile test: the ellipse {alpha >= 1/255} of an elongated diagonal Gaussian misses the corner
               // tiles of its box (16 % of the benchmark's remaining pairs).  One bit per tile of the rect, row-major.
               const float invA = 1.0f / cA, invC = 1.0f / cC;
