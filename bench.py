@@ -705,7 +705,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         for name, initial in (("getloss_step_t0", True), ("getloss_step", False)):
             res = {}
             for mode in ("separate", "pair", "pair_direct", "all_colour_grads", "all", "all_direct"):
-                ms = _time_ms(make_step(initial, mode), 5, 2)
+                ms = _time_ms(make_step(initial, mode), 12, 4)
                 res[mode] = {"ms_per_step": ms, "ms_per_view": ms / len(views)}
             out[name] = {"views": len(views), **res["all_direct"], "through_autograd": res["all"],
                          "with_seg_colour_gradient": res["all_colour_grads"],
@@ -829,7 +829,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                 ones = dict(data)
                 ones["colors_precomp"] = torch.ones_like(data["colors_precomp"])
                 rdr.render(w2c, k, ones, bg=(0.0, 0.0, 0.0))
-        ms_f, ms_r = _time_ms(frame_fused, 10, 3), _time_ms(frame_reference, 5, 2)
+        ms_f, ms_r = _time_ms(frame_fused, 10, 3), _time_ms(frame_reference, 10, 3)
         out["predict_frame_4cams"] = {"ms_per_frame": ms_f, "ms_per_frame_reference_calls": ms_r, "Mpix_per_s": 8 * H * W / ms_f / 1e3,
                                       "what": "predict.py frame: 4 cameras x (colour + all-ones mask render), 100k Gaussians, 800x800, forward only; "
                                               "fused = one multi-view call, ONE blend per camera, the mask from its final transmittance (gsdyn.render); reference_calls = 8 Renderer.render calls"}
@@ -847,7 +847,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         pick = farthest_point_sampler(rv["means3D"][None], 100, start_idx=0)[0]
         bones = rv["means3D"][pick]
         hist, eef = bones[None].repeat(3, 1, 1), torch.zeros((3, 1, 3), device=dev)
-        t_step = _time_ms(lambda: rollout_step(model, hist, eef, eef[-1] + 0.02, rv["means3D"], rv["rotations"], 0.5, 5), 5, 2)
+        t_step = _time_ms(lambda: rollout_step(model, hist, eef, eef[-1] + 0.02, rv["means3D"], rv["rotations"], 0.5, 5), 10, 3)
         out["rollout_step_cfg1"] = {"ms_per_step": t_step, "fps_1000_of_100k_ms": t_fps,
                                     "what": "row N4: relations + DynamicsPredictor (rope.yaml width 512, random weights, 100 bones) + "
                                             "bone fitting + skinning of 100k Gaussians (gsr_lbs); FPS timed separately (gsr_fps)"}

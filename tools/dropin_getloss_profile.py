@@ -59,3 +59,11 @@ for key, n in (("tottime", 28), ("cumulative", 28)):
     txt = s.getvalue()
     print(f"---- cProfile by {key} ({N * len(views)} camera steps)")
     print("\n".join(l[:170] for l in txt.splitlines()[4:]))
+if os.environ.get("TORCH_PROFILER") == "1":       # host time per torch op / autograd node (self CPU time), same steps
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU]) as tp:
+        for _ in range(N):
+            step()
+        torch.cuda.synchronize()
+    print(f"---- torch.profiler, CPU self time ({N * len(views)} camera steps)")
+    print(tp.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=70))
