@@ -183,7 +183,8 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
            const float* opacities, const float* colors_precomp, const float* const* colors_views, const float* shs,
            const float* cov3D_precomp, void* const* geom_states, int32_t* const* radii, uint32_t* sums,
            uint32_t* num_rendered_host, hipStream_t st, const gsr_raw_params* raw = nullptr, int32_t* same_host = nullptr,
-           const int* skip = nullptr, const int32_t* geometry_of = nullptr, const void* prev_geom = nullptr) {
+           const int* skip = nullptr, const int32_t* geometry_of = nullptr, const void* prev_geom = nullptr,
+           uint32_t* differs_pinned = nullptr) {   // differs_pinned: capacity mode's compare -- the per-block verdict words go straight to pinned host memory
   if (colors_views) {   // every view brings its own colours: they stand in for the shared array in the checks below
     if (shs || colors_precomp) { gsr_set_error("gsr forward: per-view colours exclude colors_precomp / shs"); return -2; }
     for (int v = 0; v < V; ++v) if (!colors_views[v]) { gsr_set_error("gsr forward: NULL per-view colour pointer"); return -2; }
@@ -219,11 +220,14 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     GeomState g;
     gsr_carve_geom(geom_states[v], P, &g);
     fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
-    if (same_host && prev_geom && V == 1 && gsr_host_block_scan(P)) {      // compare mode: this forward against an earlier one's geometry state
-      GeomState pg;
-      gsr_carve_geom(const_cast<void*>(prev_geom), P, &pg);
-      tab.v[v].block_hash = g.block_hash;
-      tab.v[v].cmp_rec = pg.rec; tab.v[v].cmp_rect = pg.rect; tab.v[v].cmp_ekey = pg.ekey; tab.v[v].cmp_tiles = pg.tiles_touched;
+    if (V == 1 && gsr_host_block_scan(P) && (differs_pinned || (same_host && prev_geom))) {
+      // per-block words {differs, entry count}: to the geometry state (they ride in the count readback) or straight to pinned host memory
+      tab.v[v].block_hash = differs_pinned ? reinterpret_cast<uint2*>(differs_pinned) : g.block_hash;
+      if (prev_geom) {      // compare mode: this forward against an earlier one's geometry state
+        GeomState pg;
+        gsr_carve_geom(const_cast<void*>(prev_geom), P, &pg);
+        tab.v[v].cmp_rec = pg.rec; tab.v[v].cmp_rect = pg.rect; tab.v[v].cmp_ekey = pg.ekey; tab.v[v].cmp_tiles = pg.tiles_touched;
+      }
     }
     if (skip && skip[v]) tab.v[v].skip = 1;
   }
@@ -390,6 +394,34 @@ int gsr_forward_render_ex(const gsr_settings* s, int32_t P, uint32_t num_rendere
   return stage2(1, s, P, &num_rendered, &geom, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr,
                 nullptr, nullptr, (hipStream_t)stream, nullptr, (geom && P > 0 && gsr_rows_path_ok(cam.T)) ? g.tile_rows : nullptr,
                 (int)(flags & GSR_FORWARD_ONLY));
+}
+
+int gsr_forward_capacity(const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
+                         const float* opacities, const float* colors_precomp, const float* shs, const float* cov3D_precomp,
+                         void* geom_state, int32_t* radii, void* binning_state, uint32_t capacity_entries, void* image_state,
+                         float* out_color, float* out_depth, const void* prev_geom_state, uint32_t* block_words_pinned,
+                         int32_t* count_pinned, uint32_t flags, void* stream) {
+  GsrRange _range("gsr_forward_capacity");
+  GsrCam cam;
+  if (int rc = make_cam(s, &cam)) return rc;
+  if (P <= 0) { gsr_set_error("gsr_forward_capacity: P must be positive (use gsr_forward_preprocess / gsr_forward_render)"); return -2; }
+  if (!geom_state || !radii || !binning_state || !image_state || !out_color || !out_depth || capacity_entries == 0) {
+    gsr_set_error("gsr_forward_capacity: NULL argument or no capacity");
+    return -2;
+  }
+  const bool words = block_words_pinned && gsr_host_block_scan(P);
+  if (!count_pinned && !words) { gsr_set_error("gsr_forward_capacity: count_pinned is needed (no block_words_pinned, or P > 512 Ki)"); return -2; }
+  if (prev_geom_state == geom_state) { gsr_set_error("gsr_forward_capacity: a forward cannot be compared with the state it writes"); return -2; }
+  GeomState g;
+  gsr_carve_geom(geom_state, P, &g);
+  if (int rc = stage1(1, s, P, means3D, scales, rotations, opacities, colors_precomp, nullptr, shs, cov3D_precomp, &geom_state, &radii,
+                      g.block_sums, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr,
+                      words ? prev_geom_state : nullptr, words ? block_words_pinned : nullptr))
+    return rc;
+  // (the tile-order kernel stores the count too: to the caller's pinned word, or -- nobody waits for it -- to a spare word of the geometry state)
+  uint32_t* late_count = count_pinned ? reinterpret_cast<uint32_t*>(count_pinned) : g.counters + 8;
+  return stage2(1, s, P, &capacity_entries, &geom_state, &binning_state, &image_state, &out_color, &out_depth, nullptr, nullptr, nullptr,
+                nullptr, (hipStream_t)stream, late_count, gsr_rows_path_ok(cam.T) ? g.tile_rows : nullptr, (int)(flags & GSR_FORWARD_ONLY));
 }
 
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
@@ -1032,6 +1064,35 @@ int64_t gsr_wait_counts(const volatile int32_t* counts, int32_t n, int64_t spin_
     int32_t lo = 0x7fffffff, hi = -1;
     for (int32_t i = 0; i < n; ++i) { const int32_t c = counts[i]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
     if (lo >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return (int64_t)hi; }
+    if ((it & 63) == 63) {
+      const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (us > timeout_us) return -1;
+      if (us > spin_us) sched_yield();
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+}
+
+int64_t gsr_wait_block_counts(const volatile uint32_t* words, int32_t nblk, int64_t spin_us, int64_t timeout_us, int32_t* any_differs) {
+  if (!words || nblk <= 0) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  int32_t b = 0;
+  uint64_t total = 0;
+  uint32_t differs = 0;
+  for (uint64_t it = 0;; ++it) {
+    while (b < nblk) {                       // blocks finish roughly in order: resume where the last poll stopped
+      const uint32_t c = words[2 * b + 1];
+      if (c == 0xffffffffu) break;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      differs |= words[2 * b];              // (both words come from one 8-byte store)
+      total += c;
+      ++b;
+    }
+    if (b == nblk) {
+      if (any_differs) *any_differs = differs ? 1 : 0;
+      return (int64_t)total;
+    }
     if ((it & 63) == 63) {
       const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
       if (us > timeout_us) return -1;

@@ -320,17 +320,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_fwd_kernel(
   // Compare mode (single-view entry points, list reuse): is everything the tile lists and the blend decisions depend on bit-equal to an
   // earlier forward's geometry state?  One word per block for the host (it rides in the copy that brings the entry counts): 0 = equal.
   // (Rounds 3 - 4 compared a 64-bit fingerprint instead -- "identical up to a 2^-64 coincidence"; the bar for integer work is bit-exact.)
-  if (vw.block_hash) {
-    const int any = __syncthreads_or(po.differs ? 1 : 0);
-    if (threadIdx.x == 0) vw.block_hash[blockIdx.x] = make_uint2(any ? 1u : 0u, 0u);
-  }
+  const int any = vw.block_hash ? __syncthreads_or(po.differs ? 1 : 0) : 0;
   // per-block total of tiles_touched: feeds the two-level offsets scan (no full-length scan kernel)
   uint32_t wsum = tiles;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m, 64);
   if ((threadIdx.x & 63) == 0) s_wave_sum[threadIdx.x >> 6] = wsum;
   __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+  if (threadIdx.x == 0) {
+    const uint32_t total = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+    block_sums[blockIdx.x] = total;
+    // the verdict word and the block's entry count in one 8-byte store: block_hash may be PINNED HOST memory (gsr_forward_capacity), where
+    // the host adds the counts up as soon as this kernel's blocks are through (gsr_wait_block_counts) -- no readback, no later kernel
+    if (vw.block_hash) vw.block_hash[blockIdx.x] = make_uint2(any ? 1u : 0u, total);
+  }
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float* __restrict__ view,

@@ -12,6 +12,7 @@
 #include <c10/hip/HIPGuard.h>
 
 #include <cstdlib>
+#include <map>
 #include <string>
 #include <tuple>
 
@@ -76,23 +77,47 @@ struct ListCache {
   bool valid = false;
   int dev = -1;
   int64_t P = 0, H = 0, W = 0;
-  uint32_t D = 0;
+  uint32_t D = 0;           // entries of the cached forward
+  uint32_t layout = 0;      // the num_rendered its binning state was laid out for (= D, or the capacity of a capacity-mode forward)
   void* stream = nullptr;   // the stream the lists were produced on: a forward on ANOTHER stream is not ordered behind their writes -- it bins its own
   torch::Tensor geom, binning, image;
 };
 thread_local ListCache g_lists;
+
+// Capacity mode (include/gsr.h: gsr_forward_capacity; round 5).  Upstream's forward -- and this layer until now -- reads
+// the entry count back between its two stages: the GPU idles while the host sizes the binning buffer and queues the remaining launches
+// (~20 us of a 98 us forward at 50 k Gaussians / 800^2).  The node's forward instead sizes the buffer from the previous call of the same
+// (device, P, H, W) plus 25 %, queues BOTH stages, and only then looks at the count (pinned words the preprocess blocks store: by then
+// they have arrived -- the host does not wait and the GPU does not idle).  A count above the capacity -- the scene grew by more than a quarter between two calls -- repeats the forward
+// through the exact path before anything is returned.  The comparison with the previous forward's geometry (tile-list reuse) rides along:
+// its per-block verdict words go to pinned memory too, so this layer KNOWS after every call whether it was a twin of its predecessor, and
+// sends a call through the comparing (synchronising, list-sharing) path when the call two before it was a twin -- the reference's
+// colour / seg and colour / mask alternation, or a static scene; mispredictions cost time (one readback, or one redundant binning), never results.
+struct CapacityState {
+  std::map<std::tuple<int, int64_t, int64_t, int64_t>, uint32_t> cap;   // remembered entry capacity per (device, P, H, W)
+  torch::Tensor pinned;        // int32: [0] the tile-order kernel's count (P > 512 Ki), [1 ...] the preprocess blocks' {differs, entry count} words
+  bool twin[2] = {false, false};   // was the last forward / the one before it a twin of its predecessor
+};
+thread_local CapacityState g_capacity_state;
+bool g_capacity = true;
+int64_t g_capacity_calls = 0, g_capacity_overflows = 0, g_twins_seen_late = 0;
+constexpr int64_t kCompareMaxP = 2048 * 256;     // the library compares up to this many Gaussians (GSR_HOST_SCAN_MAX_BLOCKS blocks)
+void note_twin(bool t) { auto& c = g_capacity_state; c.twin[1] = c.twin[0]; c.twin[0] = t; }
 bool g_reuse = [] { const char* e = getenv("GSR_NO_LIST_REUSE"); return !(e && *e && atoi(e) != 0); }();
 int64_t g_reuse_hits = 0;
 
-// upstream: RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-//           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered)
-//           -> (num_rendered, out_color, out_depth, radii, geomBuffer, binningBuffer, imgBuffer)        [the w-depth fork's tuple]
-std::tuple<int64_t, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
-                    const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
-                    const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
-                    int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
-                    bool will_backward) {     // extension over upstream (default true): false = no input requires a gradient -- the blend records nothing for a backward
+// One forward (both stages) for the upstream-shaped binding and for the autograd node below.
+struct Forward {
+  int64_t D = 0;           // entries
+  int64_t layout = 0;      // the num_rendered the binning state was laid out for: what the backward must be given
+  torch::Tensor color, depth, radii, geom, binning, image;
+};
+Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
+                          const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
+                          const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
+                          int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
+                          bool will_backward,       // false = no input requires a gradient -- the blend records nothing for a backward
+                          bool allow_capacity) {    // false = the caller hands num_rendered on (upstream's tuple): layout must equal the count
   TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build) runs on a HIP device only; there is no CPU fallback");
   const c10::Device dev = means3D.device();
@@ -102,8 +127,10 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
   auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
   if (P == 0) {   // zero-filled outputs without launching anything
-    return std::make_tuple((int64_t)0, torch::zeros({3, H, W}, f32), torch::zeros({1, H, W}, f32),
-                           torch::zeros({0}, f32.dtype(torch::kInt32)), torch::empty({0}, u8), torch::empty({0}, u8), torch::empty({0}, u8));
+    Forward o;
+    o.color = torch::zeros({3, H, W}, f32); o.depth = torch::zeros({1, H, W}, f32); o.radii = torch::zeros({0}, f32.dtype(torch::kInt32));
+    o.geom = torch::empty({0}, u8); o.binning = torch::empty({0}, u8); o.image = torch::empty({0}, u8);
+    return o;
   }
   check_counts("rasterize_gaussians", P, colors, opacity, scales, rotations, cov3D_precomp, sh);
   const torch::Tensor m3 = f32c(means3D, dev), col = f32c(colors, dev), op = f32c(opacity, dev), sc = f32c(scales, dev),
@@ -117,27 +144,95 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
   uint32_t D = 0;
   int32_t same = 0;
   ListCache& lc = g_lists;
-  const bool candidate = g_reuse && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.stream == stream;
+  const bool candidate = g_reuse && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.stream == stream &&
+                         (allow_capacity || lc.layout == lc.D);
+  const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
+  auto finish = [&](uint32_t count, uint32_t layout, const torch::Tensor& binning) {
+    Forward o;
+    o.D = count; o.layout = layout; o.color = color; o.depth = depth; o.radii = radii; o.geom = geom; o.binning = binning; o.image = image;
+    return o;
+  };
+  auto remember = [&](uint32_t count, uint32_t layout, const torch::Tensor& binning) {
+    if (g_reuse && count > 0) {
+      lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = count; lc.layout = layout; lc.stream = stream;
+      lc.geom = geom; lc.binning = binning; lc.image = image;
+    } else {
+      lc = ListCache();
+    }
+  };
+  CapacityState& cs = g_capacity_state;
+  const auto key = std::make_tuple((int)dev.index(), P, H, W);
+  const auto known = cs.cap.find(key);
+  const bool predict_twin = candidate && cs.twin[1];
+  if (allow_capacity && g_capacity && known != cs.cap.end() && !predict_twin) {
+    // ---- both stages queued, then the count (see CapacityState)
+    const uint32_t cap = known->second;
+    const int64_t nblk = (P + 255) / 256;
+    const bool compare = candidate && P <= kCompareMaxP;
+    if (!cs.pinned.defined()) cs.pinned = torch::empty({1 + 2 * (kCompareMaxP / 256)}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    int32_t* pin = cs.pinned.data_ptr<int32_t>();
+    // P <= 512 Ki: every preprocess block stores {differs, its entry count} to pinned words -- the count is known when that kernel is through;
+    // above: the tile-order kernel's count word
+    const bool words = P <= kCompareMaxP;
+    if (words) for (int64_t b = 0; b < nblk; ++b) pin[2 + 2 * b] = -1;
+    else pin[0] = -1;
+    torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(cap, (int32_t)H, (int32_t)W)}, u8);
+    check(gsr_forward_capacity(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
+                               radii.data_ptr<int32_t>(), binning.data_ptr(), cap, image.data_ptr(), color.data_ptr<float>(),
+                               depth.data_ptr<float>(), compare ? lc.geom.data_ptr() : nullptr,
+                               words ? reinterpret_cast<uint32_t*>(pin + 1) : nullptr, words ? nullptr : pin, fwd_flags, stream), "gsr_forward_capacity");
+    ++g_capacity_calls;
+    int32_t any = 1;
+    int64_t count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 1), (int32_t)nblk, 500, 20 * 1000 * 1000, &any)
+                          : gsr_wait_counts(pin, 1, 500, 20 * 1000 * 1000);
+    if (count < 0) {      // twenty seconds without the stores: let the runtime tell what happened to the stream
+      C10_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+      count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 1), (int32_t)nblk, 0, 1000, &any) : (int64_t)pin[0];
+      TORCH_CHECK(count >= 0, "gsr_forward_capacity: the entry count never arrived");
+    }
+    if ((uint64_t)count <= cap) {
+      const bool twin = compare && !any && lc.D == (uint32_t)count;
+      if (twin) ++g_twins_seen_late;       // its lists were built a second time: the predictor sends the next one of the pattern the sharing way
+      note_twin(twin);
+      cs.cap[key] = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)count + (uint64_t)count / 4 + 1024);
+      remember((uint32_t)count, cap, binning);
+      return finish((uint32_t)count, cap, binning);
+    }
+    ++g_capacity_overflows;      // the scene outgrew the estimate: everything again, with the count known (the outputs above are overwritten)
+  }
   check(gsr_forward_preprocess_same(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
                                     radii.data_ptr<int32_t>(), &D, candidate ? lc.geom.data_ptr() : nullptr, candidate ? &same : nullptr, stream),
         "gsr_forward_preprocess");
-  const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
+  cs.cap[key] = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)D + (uint64_t)D / 4 + 1024);
   if (candidate && same && D > 0 && lc.D == D) {
     // same geometry, same camera as the previous forward (compared on the device, bit for bit): its lists are this render's lists
-    check(gsr_forward_render_shared_ex(&st.s, (int32_t)P, D, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
+    check(gsr_forward_render_shared_ex(&st.s, (int32_t)P, lc.layout, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
                                        color.data_ptr<float>(), depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render_shared");
     ++g_reuse_hits;
-    return std::make_tuple((int64_t)D, color, depth, radii, geom, lc.binning, image);
+    note_twin(true);
+    return finish(D, lc.layout, lc.binning);
   }
+  note_twin(false);
   torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
   check(gsr_forward_render_ex(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
                               depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render");
-  if (g_reuse && D > 0) {
-    lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = D; lc.stream = stream; lc.geom = geom; lc.binning = binning; lc.image = image;
-  } else {
-    lc = ListCache();
-  }
-  return std::make_tuple((int64_t)D, color, depth, radii, geom, binning, image);
+  remember(D, D, binning);
+  return finish(D, D, binning);
+}
+
+// upstream: RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+//           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered)
+//           -> (num_rendered, out_color, out_depth, radii, geomBuffer, binningBuffer, imgBuffer)        [the w-depth fork's tuple]
+// (exact mode: the num_rendered it returns is what rasterize_gaussians_backward is handed as R)
+std::tuple<int64_t, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
+                    const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
+                    const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
+                    int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
+                    bool will_backward) {     // extension over upstream (default true)
+  Forward o = rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                                tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, will_backward, false);
+  return std::make_tuple(o.D, o.color, o.depth, o.radii, o.geom, o.binning, o.image);
 }
 
 // upstream: RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
@@ -206,17 +301,16 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                                 int64_t W, double scale_modifier, int64_t degree, bool prefiltered, bool will_backward) {
     (void)means2D;
     ctx->set_materialize_grads(false);        // grad_depth is ignored: do not let autograd fill a zero image for it
-    auto r = rasterize_gaussians(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix, tanfovx,
-                                 tanfovy, H, W, sh, degree, campos, prefiltered, will_backward);
-    torch::Tensor color = std::get<1>(r), depth = std::get<2>(r), radii = std::get<3>(r);
-    ctx->saved_data["R"] = std::get<0>(r);
+    Forward r = rasterize_forward(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix, tanfovx,
+                                  tanfovy, H, W, sh, degree, campos, prefiltered, will_backward, true);
+    torch::Tensor color = r.color, depth = r.depth, radii = r.radii;
+    ctx->saved_data["R"] = r.layout;      // what the states were laid out for (the count, or a capacity-mode forward's capacity)
     ctx->saved_data["tanfovx"] = tanfovx; ctx->saved_data["tanfovy"] = tanfovy; ctx->saved_data["scale_modifier"] = scale_modifier;
     ctx->saved_data["degree"] = degree; ctx->saved_data["H"] = H; ctx->saved_data["W"] = W;
     ctx->saved_data["has_sh"] = sh.numel() > 0; ctx->saved_data["has_col"] = colors.numel() > 0;
     ctx->saved_data["has_sc"] = scales.numel() > 0; ctx->saved_data["has_cov"] = cov3D.numel() > 0;
     ctx->saved_data["empty"] = means3D.size(0) == 0;
-    ctx->save_for_backward({means3D, radii, colors, sh, scales, rotations, cov3D, std::get<4>(r), std::get<5>(r), std::get<6>(r), bg, viewmatrix,
-                            projmatrix, campos});
+    ctx->save_for_backward({means3D, radii, colors, sh, scales, rotations, cov3D, r.geom, r.binning, r.image, bg, viewmatrix, projmatrix, campos});
     ctx->mark_non_differentiable({radii});
     return {color, radii, depth};
   }
@@ -304,5 +398,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_list_reuse", [](bool on) { g_reuse = on; g_lists = ListCache(); });
   m.def("list_reuse_hits", []() { return g_reuse_hits; });
   m.def("drop_list_cache", []() { g_lists = ListCache(); });
+  m.def("set_capacity_mode", [](bool on) { g_capacity = on; g_capacity_state.twin[0] = g_capacity_state.twin[1] = false; });
+  m.def("capacity_stats", []() { return std::make_tuple(g_capacity_calls, g_capacity_overflows, g_twins_seen_late); });   // (calls, repeats after an overflow, twins noticed only afterwards)
+  m.def("forget_capacities", []() { g_capacity_state.cap.clear(); g_capacity_state.twin[0] = g_capacity_state.twin[1] = false; });
   m.def("abi_version", []() { return (int)GSR_VERSION; });   // the header this layer was COMPILED against (compare with the library's gsr_version())
 }

@@ -66,7 +66,7 @@ class GsrRawParams(C.Structure):
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_backward_scratch_bytes", "gsr_forward_preprocess", "gsr_forward_render", "gsr_backward",
-           "gsr_forward_preprocess_same", "gsr_forward_render_shared", "gsr_forward_render_ex", "gsr_forward_render_shared_ex",
+           "gsr_forward_preprocess_same", "gsr_forward_render_shared", "gsr_forward_render_ex", "gsr_forward_render_shared_ex", "gsr_forward_capacity", "gsr_wait_block_counts",
            "gsr_mark_visible", "gsr_debug_get_views", "gsr_selftest", "gsr_profile_begin", "gsr_profile_end",
            "gsr_batch_state_bytes", "gsr_forward_preprocess_batch", "gsr_forward_render_batch", "gsr_forward_batch",
            "gsr_forward_batch_capacity", "gsr_forward_batch_capacity_raw",

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 120 /* 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 121 /* 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -110,6 +110,29 @@ int gsr_forward_preprocess_same(const gsr_settings* s, int32_t P, const float* m
 int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_rendered, void* geom_state,
                               void* owner_binning_state, const void* owner_image_state, void* image_state, float* out_color,
                               float* out_depth, void* stream);
+
+/* ---- the single-view forward WITHOUT a host wait inside (ABI 121; upstream reads num_rendered back in the middle of its forward,
+ * rasterizer_impl.cu -- reached from /root/reference/src/tracking/train_utils.py:178 and src/render/renderer.py:22 -- and the GPU idles
+ * while the host sizes the binning buffers and launches the rest: ~20 us of a 98 us forward at 50 k Gaussians / 800 x 800).
+ * Both stages in one call: binning_state holds gsr_binning_bytes of `capacity_entries` (the caller's estimate: the previous call's
+ * count with some slack), every kernel clamps to it, and the true count arrives in *count_pinned -- PINNED host memory that the caller
+ * pre-set to -1 -- by a system-scope store of the tile-order kernel: wait with gsr_wait_counts (no stream synchronisation) once all the
+ * call's launches are queued.  count <= capacity_entries: the outputs and states are valid, and `capacity_entries` is the num_rendered
+ * that gsr_backward, gsr_forward_render_shared and gsr_backward_scratch_bytes must be given for these states (it fixed their layout).
+ * count > capacity_entries: nothing of the call may be used -- repeat with gsr_forward_preprocess + gsr_forward_render.
+ * Earlier still (P <= 512 Ki): block_words_pinned -- pinned host memory, 2 * ceil(P / 256) words, the ODD words pre-set to 0xffffffff by the
+ * caller.  Every preprocess block stores {differs, its entry count} there with one 8-byte store; gsr_wait_block_counts polls the words and
+ * returns their sum as soon as the preprocess kernel's blocks are through -- typically before the host has finished queueing the rest of
+ * the call -- so the host never waits and the GPU never idles.  count_pinned may then be NULL.  With prev_geom_state as well the blocks
+ * COMPARE as in gsr_forward_preprocess_same: *any_differs = 0 after the wait means every Gaussian equals the compared state.
+ * flags: GSR_FORWARD_ONLY. */
+int gsr_forward_capacity(const gsr_settings* s, int32_t P, const float* means3D, const float* scales, const float* rotations,
+                         const float* opacities, const float* colors_precomp, const float* shs, const float* cov3D_precomp,
+                         void* geom_state, int32_t* radii, void* binning_state, uint32_t capacity_entries, void* image_state,
+                         float* out_color, float* out_depth, const void* prev_geom_state, uint32_t* block_words_pinned,
+                         int32_t* count_pinned, uint32_t flags, void* stream);
+/* -> the sum of the blocks' entry counts (>= 0) once all nblk odd words differ from 0xffffffff; -1 after timeout_us.  Polls as gsr_wait_counts. */
+int64_t gsr_wait_block_counts(const volatile uint32_t* words, int32_t nblk, int64_t spin_us, int64_t timeout_us, int32_t* any_differs);
 
 /* ---- backward  (replaces `rasterize_gaussians_backward`).
  * dL_dcolor[3,H,W] in; gradients out (every output is fully written, no pre-zeroing needed):

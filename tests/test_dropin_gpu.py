@@ -117,6 +117,8 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
         return out, C_.list_reuse_hits() - h0
 
     try:
+        C_.set_capacity_mode(False)      # the count-first path: every second call of a pair compares (capacity mode PREDICTS which calls to compare:
+        #                                  test_capacity_mode_learns_the_two_render_pattern)
         a, hits_a = get_loss_pair(True, cams[0])
         b, hits_b = get_loss_pair(False, cams[0])
         assert hits_a == 1 and hits_b == 0, (hits_a, hits_b)
@@ -186,6 +188,7 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
             assert torch.equal(ea[2][k], eb[2][k]), k
     finally:
         C_.set_list_reuse(True)
+        C_.set_capacity_mode(True)
 
 
 @pytest.mark.parametrize("P,W,H", [(50_000, 1280, 720), (8_957, 640, 480)])
@@ -242,3 +245,100 @@ def test_upstream_made_splat_lands_on_its_images():
     cover = [float(x) for x in re.search(r"coverage of the mask \[([^\]]*)\]", out).group(1).split()]
     assert nominal >= 24.5 and min(cover) >= 0.98, (nominal, cover)
     assert len(shifted) == 2 and max(shifted) <= nominal - 1.0, (nominal, shifted)     # half a pixel in x costs 2.5 - 4 dB
+
+
+def test_capacity_mode_forward_is_the_exact_forward(dev):
+    """ABI 121 / VERDICT r04 item 4: GaussianRasterizer's forward queues both stages with the binning buffer sized from the previous call of the
+    shape and reads the entry count afterwards (gsr_forward_capacity).  Images, radii, depth and every gradient must equal the exact
+    (count first) path bit for bit; a scene that outgrew the estimate is rendered again before anything is returned."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    C_ = dgr._C
+    P, W, H = 30_000, 400, 304
+    cam = synth_ring_cameras(4, W, H, device=dev)[2]
+    small = synth_scene_params(P, device=dev, scale_lo=0.005, scale_hi=0.02)
+    big = synth_scene_params(P, device=dev, scale_lo=0.02, scale_hi=0.06)      # same P, several times the entries
+    dL = torch.tensor(np.random.default_rng(9).uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev)
+
+    def run(params):
+        leaves = {k: params[k].detach().clone().requires_grad_(True) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors")}
+        im, rad, dep = GaussianRasterizer(raster_settings=cam)(**params2rendervar(leaves))
+        (im * dL).sum().backward()
+        torch.cuda.synchronize()
+        return [im.detach(), rad, dep.detach()] + [leaves[k].grad for k in sorted(leaves)]
+    try:
+        C_.set_list_reuse(False)
+        C_.set_capacity_mode(False)
+        ref_small, ref_big = run(small), run(big)
+        C_.set_capacity_mode(True)
+        C_.forget_capacities()
+        c0 = C_.capacity_stats()
+        first = run(small)                         # no estimate yet: the exact path, which leaves one
+        assert C_.capacity_stats()[0] == c0[0]
+        second = run(small)                        # capacity mode
+        c1 = C_.capacity_stats()
+        assert c1[0] == c0[0] + 1 and c1[1] == c0[1]
+        grown = run(big)                           # overflows the estimate: repeated through the exact path
+        c2 = C_.capacity_stats()
+        assert c2[0] == c1[0] + 1 and c2[1] == c1[1] + 1
+        again = run(big)                           # fits now
+        c3 = C_.capacity_stats()
+        assert c3[0] == c2[0] + 1 and c3[1] == c2[1]
+        shrunk = run(small)                        # a smaller scene in the larger buffers
+        for got, ref, what in ((first, ref_small, "first"), (second, ref_small, "capacity"), (grown, ref_big, "overflow"), (again, ref_big, "again"),
+                               (shrunk, ref_small, "shrunk")):
+            for i, (a, b) in enumerate(zip(got, ref)):
+                assert torch.equal(a, b), (what, i)
+        with torch.no_grad():                      # forward-only calls take the same route
+            rv = {k: v.detach() for k, v in params2rendervar(small).items()}
+            im_n, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+        assert torch.equal(im_n, ref_small[0]) and C_.capacity_stats()[0] == c3[0] + 2
+    finally:
+        C_.set_list_reuse(True)
+        C_.set_capacity_mode(True)
+
+
+def test_capacity_mode_learns_the_two_render_pattern(dev):
+    """With tile-list reuse on, a capacity-mode forward compares itself with its predecessor as well (the verdict words travel to pinned
+    memory): the first colour / seg pair is noticed AFTER the seg render built its own lists; from the second pair on the seg render is
+    predicted, goes the comparing way and shares the colour render's lists -- equal results throughout."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    C_ = dgr._C
+    P, W, H = 20_000, 320, 240
+    cam = synth_ring_cameras(4, W, H, device=dev)[1]
+    params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04)
+    g1, g2 = (torch.tensor(np.random.default_rng(s).uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev) for s in (1, 2))
+
+    def pair(shift):
+        leaves = {k: params[k].detach().clone().requires_grad_(True) for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors", "seg_colors")}
+        with torch.no_grad():
+            leaves["means3D"] += shift            # another geometry every iteration, as training has it
+        im, _, _ = GaussianRasterizer(raster_settings=cam)(**params2rendervar(leaves))
+        seg, _, _ = GaussianRasterizer(raster_settings=cam)(**params2rendervar(leaves, colors_key="seg_colors"))
+        ((im * g1).sum() + (seg * g2).sum()).backward()
+        torch.cuda.synchronize()
+        return [im.detach(), seg.detach()] + [leaves[k].grad for k in sorted(leaves)]
+    try:
+        C_.set_list_reuse(True)
+        C_.set_capacity_mode(False)
+        C_.drop_list_cache()
+        ref = [pair(0.001 * i) for i in range(4)]
+        C_.set_capacity_mode(True)
+        C_.forget_capacities()
+        C_.drop_list_cache()
+        h0, s0 = C_.list_reuse_hits(), C_.capacity_stats()
+        got = [pair(0.001 * i) for i in range(4)]
+        h1, s1 = C_.list_reuse_hits(), C_.capacity_stats()
+        for a, b in zip(got, ref):
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), i
+        # pair 0: colour exact (no estimate), seg capacity + noticed late; pairs 1..3: colour capacity, seg predicted -> shared lists
+        assert s1[2] - s0[2] == 1, (s0, s1)
+        assert h1 - h0 == 3, (h0, h1)
+        assert s1[0] - s0[0] == 4 and s1[1] == s0[1], (s0, s1)
+    finally:
+        C_.set_list_reuse(True)
+        C_.set_capacity_mode(True)
