@@ -141,6 +141,13 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
   torch::Tensor geom = torch::empty({(int64_t)gsr_geom_bytes((int32_t)P)}, u8);
   torch::Tensor image = torch::empty({(int64_t)gsr_image_bytes((int32_t)H, (int32_t)W)}, u8);
   void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+  {   // either path needs the entry count on the host before it returns (the count-first path synchronises, the capacity path polls pinned
+      // words): inside a stream capture neither ever arrives -- say so at once (gsdyn.step.GraphedRenderStep is the capturable step)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &capturing) == hipSuccess)
+      TORCH_CHECK(capturing == hipStreamCaptureStatusNone, "GaussianRasterizer cannot be captured into a graph: its forward needs the entry count "
+                  "on the host (as upstream's does); use gsdyn.step.GraphedRenderStep / render_step_views for a capturable step");
+  }
   uint32_t D = 0;
   int32_t same = 0;
   ListCache& lc = g_lists;

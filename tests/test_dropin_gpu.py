@@ -342,3 +342,30 @@ def test_capacity_mode_learns_the_two_render_pattern(dev):
     finally:
         C_.set_list_reuse(True)
         C_.set_capacity_mode(True)
+
+
+def test_capturing_the_drop_in_call_fails_at_once(dev):
+    """The forward needs the entry count on the host (upstream reads it back too): inside a stream capture it never arrives.  The call
+    must say so immediately instead of polling for it, and the stream must be usable afterwards."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    params = synth_scene_params(2000, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, 128, 96, device=dev)[0]
+    with torch.no_grad():
+        rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+        ref, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+        ref2, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        import time
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    GaussianRasterizer(raster_settings=cam)(**rv)
+        assert time.perf_counter() - t0 < 5.0
+        torch.cuda.synchronize()
+        again, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
+    assert torch.equal(ref, again) and torch.equal(ref, ref2)
