@@ -150,10 +150,10 @@ void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* ord
   t.V = V; t.W = cam.W; t.H = cam.H; t.gx = cam.gx; t.T = cam.T; t.order = order; t.queue = queue; t.no_colour_grad = 0; t.prio_frac256 = 0; t.pc_error_out = nullptr; t.track = 1; t.avg_list = 1u << 20;
 }
 
-// Pinned host staging for the per-block entry counts (per host thread; lives for the process).
+// Pinned host words for the per-block {differs, entry count} pairs of up to GSR_MAX_BATCH views (per host thread; lives for the process).
 uint32_t* pinned_sums() {
   static thread_local uint32_t* p = nullptr;
-  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * (GSR_MAX_BATCH + 2) * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
+  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * 2 * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
     p = nullptr;
   return p;
 }
@@ -220,10 +220,18 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
     GeomState g;
     gsr_carve_geom(geom_states[v], P, &g);
     fill_pre_view(tab.v[v], cam, g, radii[v], sums + (size_t)v * nblk, colors_views ? colors_views[v] : nullptr);
-    if (V == 1 && gsr_host_block_scan(P) && (differs_pinned || (same_host && prev_geom))) {
-      // per-block words {differs, entry count}: to the geometry state (they ride in the count readback) or straight to pinned host memory
-      tab.v[v].block_hash = differs_pinned ? reinterpret_cast<uint2*>(differs_pinned) : g.block_hash;
-      if (prev_geom) {      // compare mode: this forward against an earlier one's geometry state
+    // Per-block words {differs, entry count} straight to pinned host memory: the caller's (capacity mode, V = 1) or this thread's own
+    // (count-first mode, P <= 512 Ki: the host adds them up as soon as the preprocess blocks are through -- no copy on the stream, no
+    // stream synchronisation; round 5: ~10 us per forward less than hipMemcpyAsync + hipStreamSynchronize)
+    uint32_t* own_words = (num_rendered_host && gsr_host_block_scan(P) && !(skip && skip[v])) ? pinned_sums() : nullptr;
+    if (differs_pinned && V == 1 && gsr_host_block_scan(P)) tab.v[v].block_hash = reinterpret_cast<uint2*>(differs_pinned);
+    else if (own_words) {
+      uint32_t* w = own_words + (size_t)v * 2 * GSR_HOST_SCAN_MAX_BLOCKS;
+      for (uint32_t b = 0; b < nblk; ++b) w[2 * b + 1] = 0xffffffffu;
+      tab.v[v].block_hash = reinterpret_cast<uint2*>(w);
+    }
+    if (V == 1 && tab.v[v].block_hash && (differs_pinned || same_host) && prev_geom) {
+      {      // compare mode: this forward against an earlier one's geometry state
         GeomState pg;
         gsr_carve_geom(const_cast<void*>(prev_geom), P, &pg);
         tab.v[v].cmp_rec = pg.rec; tab.v[v].cmp_rect = pg.rect; tab.v[v].cmp_ekey = pg.ekey; tab.v[v].cmp_tiles = pg.tiles_touched;
@@ -246,19 +254,22 @@ int stage1(int V, const gsr_settings* s, int32_t P, const float* means3D, const 
   if (!host) { gsr_set_error("gsr forward: pinned host allocation failed"); return -1; }
   if (same_host) *same_host = 0;
   if (gsr_host_block_scan(P)) {
-    GSR_HIP_CHECK(hipMemcpyAsync(host, sums, sizeof(uint32_t) * nblk * V, hipMemcpyDeviceToHost, st));
-    uint32_t* hash_host = host + (size_t)GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS;      // behind the counts (see pinned_sums)
-    if (tab.v[0].block_hash) GSR_HIP_CHECK(hipMemcpyAsync(hash_host, tab.v[0].block_hash, sizeof(uint2) * nblk, hipMemcpyDeviceToHost, st));
-    GSR_HIP_CHECK(hipStreamSynchronize(st));
-    if (tab.v[0].block_hash) {
-      uint32_t any = 0;
-      for (uint32_t b = 0; b < nblk; ++b) any |= hash_host[2 * b];
-      *same_host = any ? 0 : 1;
-    }
     for (int v = 0; v < V; ++v) {
       uint64_t tot = 0;
-      for (uint32_t b = 0; b < nblk; ++b) tot += host[(size_t)v * nblk + b];
-      if (skip && skip[v]) tot = num_rendered_host[geometry_of[v]];     // not preprocessed: its owner's lists are its lists
+      if (skip && skip[v]) {
+        tot = num_rendered_host[geometry_of[v]];     // not preprocessed: its owner's lists are its lists
+      } else {
+        const volatile uint32_t* w = host + (size_t)v * 2 * GSR_HOST_SCAN_MAX_BLOCKS;
+        int32_t any = 1;
+        int64_t got = gsr_wait_block_counts(w, (int32_t)nblk, 2000, 30ll * 1000 * 1000, &any);
+        if (got < 0) {      // thirty seconds without the stores: let the runtime say what happened to the stream
+          GSR_HIP_CHECK(hipStreamSynchronize(st));
+          got = gsr_wait_block_counts(w, (int32_t)nblk, 0, 1000, &any);
+          if (got < 0) { gsr_set_error("gsr forward: the preprocess kernel's per-block counts never reached the host"); return -1; }
+        }
+        tot = (uint64_t)got;
+        if (v == 0 && same_host && tab.v[0].cmp_rec) *same_host = any ? 0 : 1;
+      }
       if (tot > 0xffffffffull) { gsr_set_error("gsr forward: %llu tile entries overflow 32 bits", (unsigned long long)tot); return -3; }
       num_rendered_host[v] = (uint32_t)tot;
     }
