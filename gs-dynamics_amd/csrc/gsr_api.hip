@@ -153,7 +153,7 @@ void render_header(GsrRenderViews& t, int V, const GsrCam& cam, const uint4* ord
 // Pinned host words for the per-block {differs, entry count} pairs of up to GSR_MAX_BATCH views (per host thread; lives for the process).
 uint32_t* pinned_sums() {
   static thread_local uint32_t* p = nullptr;
-  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * 2 * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocDefault) != hipSuccess)
+  if (!p && hipHostMalloc((void**)&p, sizeof(uint32_t) * 2 * GSR_MAX_BATCH * GSR_HOST_SCAN_MAX_BLOCKS, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
     p = nullptr;
   return p;
 }

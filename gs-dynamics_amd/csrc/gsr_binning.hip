@@ -1396,7 +1396,7 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   const bool big = force ? (force[0] == '4') : (maxD / (uint32_t)tab.T > 600u);   // long lists on average
   tab.wave_cap = big ? 2048 : 512;
   {   // long lists in an ordinary scene: see the tile_sort launches below
-    static uint32_t* hint = [] { uint32_t* p = nullptr; if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) return (uint32_t*)nullptr; *p = 1u; return p; }();
+    static uint32_t* hint = [] { uint32_t* p = nullptr; if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return (uint32_t*)nullptr; *p = 1u; return p; }();
     tab.vlong_out = hint;
     tab.vlong_launch = (!hint || __atomic_load_n(hint, __ATOMIC_RELAXED) != 0u) ? 1 : 0;
   }

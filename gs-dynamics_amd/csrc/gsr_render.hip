@@ -1426,7 +1426,7 @@ extern "C" int gsr_debug_ticket_trace(uint32_t* out4, int n) {   // debug builds
 static uint32_t* pc_error_word() {   // pinned, device-visible; nullptr when it could not be allocated (then timeouts only show in g_pc_error)
   static uint32_t* word = [] {
     uint32_t* w = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&w), sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return static_cast<uint32_t*>(nullptr);
+    if (hipHostMalloc(reinterpret_cast<void**>(&w), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return static_cast<uint32_t*>(nullptr);
     *w = 0u;
     return w;
   }();

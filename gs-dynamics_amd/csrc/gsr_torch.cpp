@@ -95,7 +95,7 @@ thread_local ListCache g_lists;
 // colour / seg and colour / mask alternation, or a static scene; mispredictions cost time (one readback, or one redundant binning), never results.
 struct CapacityState {
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, uint32_t> cap;   // remembered entry capacity per (device, P, H, W)
-  torch::Tensor pinned;        // int32: [0] the tile-order kernel's count (P > 512 Ki), [1 ...] the preprocess blocks' {differs, entry count} words
+  int32_t* pinned = nullptr;   // COHERENT pinned host words (lives for the process): [0] the tile-order kernel's count (P > 512 Ki), [1 ...] the preprocess blocks' {differs, entry count} words
   bool twin[2] = {false, false};   // was the last forward / the one before it a twin of its predecessor
 };
 thread_local CapacityState g_capacity_state;
@@ -176,8 +176,9 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
     const uint32_t cap = known->second;
     const int64_t nblk = (P + 255) / 256;
     const bool compare = candidate && P <= kCompareMaxP;
-    if (!cs.pinned.defined()) cs.pinned = torch::empty({1 + 2 * (kCompareMaxP / 256)}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    int32_t* pin = cs.pinned.data_ptr<int32_t>();
+    if (!cs.pinned)      // (explicitly coherent: the stores must be visible to the polling host while kernels of the stream are still running)
+      C10_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cs.pinned), sizeof(int32_t) * (2 + 2 * (kCompareMaxP / 256)), hipHostMallocMapped | hipHostMallocCoherent));
+    int32_t* pin = cs.pinned;
     // P <= 512 Ki: every preprocess block stores {differs, its entry count} to pinned words -- the count is known when that kernel is through;
     // above: the tile-order kernel's count word
     const bool words = P <= kCompareMaxP;
