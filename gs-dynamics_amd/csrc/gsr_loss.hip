@@ -56,6 +56,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     (out)[o_] = s_;                                           \
   }
 
+// base[byte_off / 4] with a wave-uniform base and a 32-bit per-lane byte offset: the global_load saddr + voffset form (no 64-bit VALU
+// address arithmetic per access; a channel plane stays below 4 GiB by far)
+__device__ __forceinline__ float ld_off(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float* __restrict__ base, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 __device__ __forceinline__ void load20(const float* __restrict__ row, float* __restrict__ v) {
   const float4* __restrict__ p = reinterpret_cast<const float4*>(row);
 #pragma unroll
@@ -68,6 +77,38 @@ __device__ __forceinline__ void store8(float* __restrict__ dst, const float* __r
   p[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// One pixel of the SSIM map and its three partials w.r.t. the blurred moments that depend on pred.  Contraction is OFF in here: which
+// product-sum pairs the compiler would fuse depends on where B and D come from -- registers (MODE 0) or loads (MODE 1) -- and MODE 1 must
+// reproduce MODE 0 bit for bit (the first forward of a target runs MODE 0, the later ones MODE 1).
+__device__ __forceinline__ void ssim_point(float A, float B, float Cc, float D, float E, float& ssim, float& vA, float& vC, float& vE) {
+#pragma clang fp contract(off)
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+  const float AB = A * B, AA = A * A, BB = B * B;
+  const float num1 = 2.0f * AB + c1, num2 = 2.0f * (E - AB) + c2;
+  const float den1 = (AA + BB) + c1, den2 = ((Cc - AA) + (D - BB)) + c2;
+  const float i1 = __builtin_amdgcn_rcpf(den1), i2 = __builtin_amdgcn_rcpf(den2), inv = i1 * i2;   // 1 ulp: den >= c1, c2
+  ssim = (num1 * num2) * inv;
+  vA = ((2.0f * B) * (num2 - num1)) * inv - ((ssim * 2.0f) * A) * (i1 - i2);
+  vC = -(ssim * i2);
+  vE = (2.0f * num1) * inv;
+}
+
+// Which tile is this workgroup's?  The launch is ONE-dimensional with 8 * ceil(N / 8) workgroups for the N = tiles x planes of the call,
+// and workgroup w takes slot (w % 8) * ceil(N / 8) + w / 8 of the (plane, tile row, tile column) order: the dispatcher places block b on
+// XCD b % 8 (observed, MI355X_MICROARCH.md: a speed matter only), so every XCD works through a CONTIGUOUS eighth of the tiles and the
+// halos that neighbouring tiles share (a patch is 1.56x its tile) are read from that XCD's L2 instead of crossing the fabric again --
+// with blockIdx.x = tile column, neighbours sat on different XCDs and both kernels ran at the fabric's rate (round 5: FETCH_SIZE x 2 +
+// WRITE_SIZE = 659 / 724 MiB per launch for 236 + 176 / 294 + 59 MiB of compulsory traffic; profiles/r05_loss_kernels.txt).
+struct LossTile { int tx, ty, ch, bidx; };
+__device__ __forceinline__ bool loss_tile(int W, int H, int planes, LossTile& t) {
+  const uint32_t gx = (uint32_t)(W + TW - 1) / TW, gy = (uint32_t)(H + TH - 1) / TH, T = gx * gy, N = T * (uint32_t)planes;
+  const uint32_t per = (N + 7u) / 8u, w = blockIdx.x, slot = (w & 7u) * per + (w >> 3);
+  if (slot >= N) return false;
+  const uint32_t ch = slot / T, r = slot - ch * T, ty = r / gx;
+  t.ch = (int)ch; t.ty = (int)ty; t.tx = (int)(r - ty * gx); t.bidx = (int)slot;     // slot = (ch * gy + ty) * gx + tx: the finishing kernels' order
+  return true;
+}
+
 // MODE 0: all five blurred moments in the kernel.  MODE 1: blur(y) and blur(y*y) of the (fixed) target come from `tmom`
 // (tab.tmom[img]: [2, channels, H, W], written once per target by MODE 2) -- 3 instead of 5 FIRs per pass, 25 instead of 41 KB of
 // LDS.  MODE 2: only those two maps of the target are computed and stored (x is not read).  The arithmetic of a moment is the same
@@ -77,15 +118,19 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
                                                              const float* __restrict__ cam_m, const float* __restrict__ cam_c,
                                                              float* __restrict__ fA, float* __restrict__ fC,
                                                              float* __restrict__ fE, float* __restrict__ block_l1,
-                                                             float* __restrict__ block_ssim) {
+                                                             float* __restrict__ block_ssim, int planes) {
   constexpr int NM = MODE == 0 ? 5 : (MODE == 1 ? 3 : 2);            // blurred moments formed here
-  constexpr int SM = NM * PH * TW > 2 * PH * PS ? NM * PH * TW : 2 * PH * PS;
+  constexpr int MR = PH + 2;     // rows of a blurred-moment plane: the vertical items of the last segment read up to row 65 -- two rows that
+                                 // nobody writes and whose outputs (tile rows >= TH) nobody keeps: no clamp in the read loop
+  constexpr int SM = NM * MR * TW > 2 * PH * PS ? NM * MR * TW : 2 * PH * PS;
   __shared__ __attribute__((aligned(16))) float smem[SM];   // patch x|y (2 * 64 * 44), then the NM blurred moments
   __shared__ float red[2][4];
   float* __restrict__ sx = smem;
   float* __restrict__ sy = smem + PH * PS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, ch = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the patch rows are scalar work)
+  LossTile lt;
+  if (!loss_tile(W, H, planes, lt)) return;
+  const int tx0 = lt.tx * TW, ty0 = lt.ty * TH, ch = lt.ch;
   const int img = ch / tab.channels, c = ch - img * tab.channels;
   const size_t HW = (size_t)H * W;
   const float* __restrict__ yc = tab.target[img] + (size_t)c * HW;
@@ -94,25 +139,46 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
   const int row = MODE == 2 ? -1 : tab.cam_row[img];
   if (row >= 0) { a = expf(cam_m[row * tab.channels + c]); b = cam_c[row * tab.channels + c]; }
 
-  {  // patch load: all 32 global loads of a lane are issued before the first LDS store (addresses clamped, values masked)
-    const int gx = tx0 + lane - HALO, cx = min(max(gx, 0), W - 1);
+  {  // patch load: all 32 global loads of a lane are issued before the first LDS store (addresses clamped, values masked).  A wave loads
+     // whole patch rows: the row pointers are scalar, a lane contributes its (clamped) column as a 32-bit byte offset
+    const int gx = tx0 + lane - HALO;
+    const uint32_t cxb = 4u * (uint32_t)min(max(gx, 0), W - 1);
     const bool okx = gx >= 0 && gx < W && lane < PW;
     float xv[PH / 4], yv[PH / 4];
 #pragma unroll
     for (int i = 0; i < PH / 4; ++i) {
       const int gy = ty0 + wave + 4 * i - HALO, cy = min(max(gy, 0), H - 1);
-      const size_t o = (size_t)cy * W + cx;
-      xv[i] = MODE == 2 ? 0.f : xc[o];
-      yv[i] = yc[o];
+      const size_t ro = (size_t)cy * W;
+      xv[i] = MODE == 2 ? 0.f : ld_off(xc + ro, cxb);
+      yv[i] = ld_off(yc + ro, cxb);
     }
     if (lane < PW) {
+      float* __restrict__ px = sx + wave * PS + lane;
+      float* __restrict__ py = sy + wave * PS + lane;
 #pragma unroll
       for (int i = 0; i < PH / 4; ++i) {
         const int gy = ty0 + wave + 4 * i - HALO;
         const bool ok = okx && gy >= 0 && gy < H;
-        sx[(wave + 4 * i) * PS + lane] = ok ? fmaf(a, xv[i], b) : 0.f;
-        sy[(wave + 4 * i) * PS + lane] = ok ? yv[i] : 0.f;
+        px[4 * i * PS] = ok ? fmaf(a, xv[i], b) : 0.f;
+        py[4 * i * PS] = ok ? yv[i] : 0.f;
       }
+    }
+  }
+  // MODE 1: this thread's 2 x 7 target moments (needed by the SSIM map at the very end) are requested NOW: they travel while the filters run
+  // (they used to be loaded behind the vertical pass: a second memory latency on every workgroup's critical path -- 103 -> ~90 us, round 5)
+  const int vc = tid & 31, vs = tid >> 5, r0 = vs * VSEG;
+  const int gxo = tx0 + vc;
+  const uint32_t pb0 = 4u * ((uint32_t)(ty0 + r0) * (uint32_t)W + (uint32_t)gxo), rowb = 4u * (uint32_t)W;
+  float* __restrict__ tm = const_cast<float*>(tab.tmom[img]);      // MODE 1: read, MODE 2: written
+  float* __restrict__ tmB = tm + (size_t)c * HW;                    // plane bases are scalar; a pixel is a 32-bit byte offset
+  float* __restrict__ tmD = tm + (size_t)(tab.channels + c) * HW;
+  float tB[VSEG], tD[VSEG];
+  if (MODE == 1) {
+#pragma unroll
+    for (int o = 0; o < VSEG; ++o) {
+      const bool in = r0 + o < TH && gxo < W && ty0 + r0 + o < H;
+      const uint32_t pb = in ? pb0 + (uint32_t)o * rowb : 0u;
+      tB[o] = ld_off(tmB, pb); tD[o] = ld_off(tmD, pb);
     }
   }
   __syncthreads();
@@ -131,33 +197,33 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
     float out[8], prod[18];
     float* __restrict__ dst = smem + hr * TW + hs * 8;
     int plane = 0;
-    if (MODE != 2) { GSR_FIR8(out, xr, win.g); store8(dst + plane * PH * TW, out); ++plane; }
-    if (MODE != 1) { GSR_FIR8(out, yr, win.g); store8(dst + plane * PH * TW, out); ++plane; }
+    if (MODE != 2) { GSR_FIR8(out, xr, win.g); store8(dst + plane * MR * TW, out); ++plane; }
+    if (MODE != 1) { GSR_FIR8(out, yr, win.g); store8(dst + plane * MR * TW, out); ++plane; }
     if (MODE != 2) {
 #pragma unroll
       for (int j = 0; j < 18; ++j) prod[j] = xr[j] * xr[j];
-      GSR_FIR8(out, prod, win.g); store8(dst + plane * PH * TW, out); ++plane;
+      GSR_FIR8(out, prod, win.g); store8(dst + plane * MR * TW, out); ++plane;
     }
     if (MODE != 1) {
 #pragma unroll
       for (int j = 0; j < 18; ++j) prod[j] = yr[j] * yr[j];
-      GSR_FIR8(out, prod, win.g); store8(dst + plane * PH * TW, out); ++plane;
+      GSR_FIR8(out, prod, win.g); store8(dst + plane * MR * TW, out); ++plane;
     }
     if (MODE != 2) {
 #pragma unroll
       for (int j = 0; j < 18; ++j) prod[j] = xr[j] * yr[j];
-      GSR_FIR8(out, prod, win.g); store8(dst + plane * PH * TW, out); ++plane;
+      GSR_FIR8(out, prod, win.g); store8(dst + plane * MR * TW, out); ++plane;
     }
   }
   __syncthreads();
   // vertical pass + SSIM map
-  const int vc = tid & 31, vs = tid >> 5, r0 = vs * VSEG;
   float mom[NM][VSEG];
+  const float* __restrict__ vbase = smem + r0 * TW + vc;      // one address; plane and row offsets are immediates
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     float v[VSEG + 10];
 #pragma unroll
-    for (int i = 0; i < VSEG + 10; ++i) v[i] = smem[m * PH * TW + min(r0 + i, PH - 1) * TW + vc];
+    for (int i = 0; i < VSEG + 10; ++i) v[i] = vbase[m * MR * TW + i * TW];
 #pragma unroll
     for (int o = 0; o < VSEG; ++o) {
       float s = 0.f;
@@ -167,30 +233,28 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
     }
   }
   float ssim_sum = 0.f;
-  const int gx = tx0 + vc;
-  float* __restrict__ tm = const_cast<float*>(tab.tmom[img]);      // MODE 1: read, MODE 2: written
+  const int gx = gxo;
+  float* __restrict__ fAc = fA + (size_t)ch * HW;
+  float* __restrict__ fCc = fC + (size_t)ch * HW;
+  float* __restrict__ fEc = fE + (size_t)ch * HW;
 #pragma unroll
   for (int o = 0; o < VSEG; ++o) {
     const int gy = ty0 + r0 + o;
     if (r0 + o < TH && gx < W && gy < H) {
-      const size_t p = (size_t)gy * W + gx;
+      const uint32_t pb = pb0 + (uint32_t)o * rowb;
       if (MODE == 2) {
-        tm[(size_t)c * HW + p] = mom[0][o];
-        tm[(size_t)(tab.channels + c) * HW + p] = mom[1][o];
+        st_off(tmB, pb, mom[0][o]);
+        st_off(tmD, pb, mom[1][o]);
         continue;
       }
       float A, B, Cc, D, E;
       if (MODE == 0) { A = mom[0][o]; B = mom[1][o]; Cc = mom[2][o]; D = mom[3][o]; E = mom[4][o]; }
-      else { A = mom[0][o]; Cc = mom[1][o]; E = mom[2][o]; B = tm[(size_t)c * HW + p]; D = tm[(size_t)(tab.channels + c) * HW + p]; }
-      const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-      const float num1 = 2.0f * A * B + c1, num2 = 2.0f * (E - A * B) + c2;
-      const float den1 = A * A + B * B + c1, den2 = (Cc - A * A) + (D - B * B) + c2;
-      const float i1 = __builtin_amdgcn_rcpf(den1), i2 = __builtin_amdgcn_rcpf(den2), inv = i1 * i2;   // 1 ulp: den >= c1, c2
-      const float ssim = num1 * num2 * inv;
-      const size_t q = (size_t)ch * HW + p;
-      fA[q] = 2.0f * B * (num2 - num1) * inv - ssim * 2.0f * A * (i1 - i2);
-      fC[q] = -ssim * i2;
-      fE[q] = 2.0f * num1 * inv;
+      else { A = mom[0][o]; Cc = mom[1][o]; E = mom[2][o]; B = tB[o]; D = tD[o]; }
+      float ssim, vA, vC, vE;
+      ssim_point(A, B, Cc, D, E, ssim, vA, vC, vE);
+      st_off(fAc, pb, vA);
+      st_off(fCc, pb, vC);
+      st_off(fEc, pb, vE);
       ssim_sum += ssim;
     }
   }
@@ -200,7 +264,7 @@ __global__ __launch_bounds__(256) void image_loss_fwd_kernel(Win win, LossTab ta
   if (lane == 0) { red[0][wave] = ssim_sum; red[1][wave] = l1; }
   __syncthreads();
   if (tid == 0) {
-    const int bidx = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int bidx = lt.bidx;
     block_ssim[bidx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     block_l1[bidx] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
@@ -211,11 +275,14 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
                                                              const float* __restrict__ fA, const float* __restrict__ fC,
                                                              const float* __restrict__ fE, const float* __restrict__ grad,
                                                              float invN, float w_l1, float w_ssim, float* __restrict__ dx,
-                                                             float* __restrict__ block_dm, float* __restrict__ block_dc) {
+                                                             float* __restrict__ block_dm, float* __restrict__ block_dc, int planes) {
   __shared__ __attribute__((aligned(16))) float smem[3 * PH * PS];   // three patches, then the 3 blurred maps (3 * 64 * 32)
   __shared__ float red[2][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, ch = blockIdx.z;
+  constexpr int MR = PH + 2;     // rows of a blurred plane (see image_loss_fwd_kernel)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LossTile lt;
+  if (!loss_tile(W, H, planes, lt)) return;
+  const int tx0 = lt.tx * TW, ty0 = lt.ty * TH, ch = lt.ch;
   const int img = ch / tab.channels, c = ch - img * tab.channels;
   const size_t HW = (size_t)H * W, coff = (size_t)ch * HW;
   float a = 1.0f, b = 0.0f;
@@ -224,25 +291,27 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
   const float g = grad[tab.grad_idx[img]] * tab.weight[img] * invN;
 
   {
-    const int gx = tx0 + lane - HALO, cx = min(max(gx, 0), W - 1);
+    const int gx = tx0 + lane - HALO;
+    const uint32_t cxb = 4u * (uint32_t)min(max(gx, 0), W - 1);       // scalar row pointers + a 32-bit column offset per lane
     const bool okx = gx >= 0 && gx < W && lane < PW;
+    float* __restrict__ pl = smem + wave * PS + lane;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {      // 2 x 24 loads in flight per lane
       float v0[PH / 8], v1[PH / 8], v2[PH / 8];
 #pragma unroll
       for (int i = 0; i < PH / 8; ++i) {
         const int gy = ty0 + wave + 4 * (i + half * (PH / 8)) - HALO, cy = min(max(gy, 0), H - 1);
-        const size_t o = coff + (size_t)cy * W + cx;
-        v0[i] = fA[o]; v1[i] = fC[o]; v2[i] = fE[o];
+        const size_t ro = coff + (size_t)cy * W;
+        v0[i] = ld_off(fA + ro, cxb); v1[i] = ld_off(fC + ro, cxb); v2[i] = ld_off(fE + ro, cxb);
       }
       if (lane < PW) {
 #pragma unroll
         for (int i = 0; i < PH / 8; ++i) {
-          const int r = wave + 4 * (i + half * (PH / 8)), gy = ty0 + r - HALO;
+          const int r4 = 4 * (i + half * (PH / 8)), gy = ty0 + wave + r4 - HALO;
           const bool ok = okx && gy >= 0 && gy < H;
-          smem[r * PS + lane] = ok ? v0[i] : 0.f;
-          smem[PH * PS + r * PS + lane] = ok ? v1[i] : 0.f;
-          smem[2 * PH * PS + r * PS + lane] = ok ? v2[i] : 0.f;
+          pl[r4 * PS] = ok ? v0[i] : 0.f;
+          pl[PH * PS + r4 * PS] = ok ? v1[i] : 0.f;
+          pl[2 * PH * PS + r4 * PS] = ok ? v2[i] : 0.f;
         }
       }
     }
@@ -258,17 +327,18 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
     float out[8];
     float* __restrict__ dst = smem + hr * TW + hs * 8;
     GSR_FIR8(out, r0v, win.g); store8(dst, out);
-    GSR_FIR8(out, r1v, win.g); store8(dst + PH * TW, out);
-    GSR_FIR8(out, r2v, win.g); store8(dst + 2 * PH * TW, out);
+    GSR_FIR8(out, r1v, win.g); store8(dst + MR * TW, out);
+    GSR_FIR8(out, r2v, win.g); store8(dst + 2 * MR * TW, out);
   }
   __syncthreads();
   const int vc = tid & 31, vs = tid >> 5, r0 = vs * VSEG;
   float bl[3][VSEG];
+  const float* __restrict__ vbase = smem + r0 * TW + vc;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     float v[VSEG + 10];
 #pragma unroll
-    for (int i = 0; i < VSEG + 10; ++i) v[i] = smem[m * PH * TW + min(r0 + i, PH - 1) * TW + vc];
+    for (int i = 0; i < VSEG + 10; ++i) v[i] = vbase[m * MR * TW + i * TW];
 #pragma unroll
     for (int o = 0; o < VSEG; ++o) {
       float s = 0.f;
@@ -278,20 +348,23 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
     }
   }
   const float* __restrict__ yc = tab.target[img] + (size_t)c * HW;
+  const float* __restrict__ xcp = x_img + coff;
+  float* __restrict__ dxc = dx + coff;
   const int gx = tx0 + vc;
+  const uint32_t pb0 = 4u * ((uint32_t)(ty0 + r0) * (uint32_t)W + (uint32_t)gx), rowb = 4u * (uint32_t)W;
   float sum_dm = 0.f, sum_dc = 0.f;
 #pragma unroll
   for (int o = 0; o < VSEG; ++o) {
     const int gy = ty0 + r0 + o;
     if (r0 + o < TH && gx < W && gy < H) {
-      const size_t p = (size_t)gy * W + gx;
-      const float xraw = x_img[coff + p], yv = yc[p];
+      const uint32_t pb = pb0 + (uint32_t)o * rowb;
+      const float xraw = ld_off(xcp, pb), yv = ld_off(yc, pb);
       const float xv = fmaf(a, xraw, b);
       const float dssim = bl[0][o] + 2.0f * xv * bl[1][o] + yv * bl[2][o];   // d(sum of SSIM map)/d pred
       const float dl1 = xv > yv ? 1.0f : (xv < yv ? -1.0f : 0.0f);           // torch: sign(x - y), 0 at ties
       const float dpred = g * (w_l1 * dl1 - w_ssim * dssim);
       const float dr = a * dpred;
-      dx[coff + p] = dr;
+      st_off(dxc, pb, dr);
       sum_dm += dr * xraw;       // d/d cam_m: pred = exp(m) render + c
       sum_dc += dpred;
     }
@@ -302,7 +375,7 @@ __global__ __launch_bounds__(256) void image_loss_bwd_kernel(Win win, LossTab ta
     if (lane == 0) { red[0][wave] = sum_dm; red[1][wave] = sum_dc; }
     __syncthreads();
     if (tid == 0) {
-      const int bidx = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const int bidx = lt.bidx;
       block_dm[bidx] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
       block_dc[bidx] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
@@ -388,7 +461,10 @@ LossTab make_tab(const gsr_loss_views* v) {
   return t;
 }
 
-inline dim3 loss_grid(int C, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, C); }
+inline dim3 loss_grid(int C, int H, int W) {      // one-dimensional, a multiple of 8 (see loss_tile)
+  const unsigned N = (unsigned)(((W + TW - 1) / TW) * ((H + TH - 1) / TH)) * (unsigned)C;
+  return dim3(8u * ((N + 7u) / 8u));
+}
 
 }  // namespace gsr_loss
 using namespace gsr_loss;
@@ -413,7 +489,7 @@ int gsr_launch_image_loss_fwd(const float* win11_host, int C, int H, int W, cons
     { GSR_PROF("image_loss_fwd", st);
       hipLaunchKernelGGL(image_loss_fwd_kernel<0>, loss_grid(n, H, W), dim3(256), 0, st, w, t, H, W, x + (size_t)c0 * HW,
                          (const float*)nullptr, (const float*)nullptr, fA + (size_t)c0 * HW, fC + (size_t)c0 * HW,
-                         fE + (size_t)c0 * HW, block_l1 + (size_t)c0 * nb, block_ssim + (size_t)c0 * nb); }
+                         fE + (size_t)c0 * HW, block_l1 + (size_t)c0 * nb, block_ssim + (size_t)c0 * nb, n); }
   }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -437,7 +513,7 @@ int gsr_launch_image_loss_bwd(const float* win11_host, int C, int H, int W, cons
     { GSR_PROF("image_loss_bwd", st);
       hipLaunchKernelGGL(image_loss_bwd_kernel, loss_grid(n, H, W), dim3(256), 0, st, w, t, H, W, x + (size_t)c0 * HW,
                          (const float*)nullptr, (const float*)nullptr, fA + (size_t)c0 * HW, fC + (size_t)c0 * HW,
-                         fE + (size_t)c0 * HW, grad_loss, invN, w_l1, w_ssim, dx + (size_t)c0 * HW, (float*)nullptr, (float*)nullptr); }
+                         fE + (size_t)c0 * HW, grad_loss, invN, w_l1, w_ssim, dx + (size_t)c0 * HW, (float*)nullptr, (float*)nullptr, n); }
   }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
@@ -454,10 +530,8 @@ int gsr_launch_views_loss_fwd(const float* win11_host, const gsr_loss_views* v, 
   bool cached = true;      // every target brought its two blurred maps along: the 3-moment build
   for (int i = 0; i < v->n_images; ++i) cached = cached && v->target_moments[i] != nullptr;
   { GSR_PROF("image_loss_fwd", st);
-    if (cached) hipLaunchKernelGGL(image_loss_fwd_kernel<1>, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC,
-                                   fE, block_l1, block_ssim);
-    else hipLaunchKernelGGL(image_loss_fwd_kernel<0>, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC, fE,
-                            block_l1, block_ssim); }
+    auto k = cached ? image_loss_fwd_kernel<1> : image_loss_fwd_kernel<0>;
+    hipLaunchKernelGGL(k, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC, fE, block_l1, block_ssim, C); }
   const float invN = 1.0f / ((float)v->channels * (float)H * (float)W);
   { GSR_PROF("loss_finish_fwd", st);
     hipLaunchKernelGGL(loss_finish_fwd_kernel, dim3(1), dim3(1024), 0, st, t, v->channels * nb, (const float*)block_l1,
@@ -479,7 +553,7 @@ int gsr_launch_views_loss_bwd(const float* win11_host, const gsr_loss_views* v, 
   const float invN = 1.0f / ((float)v->channels * (float)H * (float)W);
   { GSR_PROF("image_loss_bwd", st);
     hipLaunchKernelGGL(image_loss_bwd_kernel, loss_grid(C, H, W), dim3(256), 0, st, w, t, H, W, renders, cam_m, cam_c, fA, fC, fE,
-                       grad_total, invN, w_l1, w_ssim, d_renders, block_dm, block_dc); }
+                       grad_total, invN, w_l1, w_ssim, d_renders, block_dm, block_dc, C); }
   if (cams) {
     GSR_PROF("loss_finish_bwd", st);
     hipLaunchKernelGGL(loss_finish_bwd_kernel, dim3(1), dim3(1024), 0, st, t, nb, (const float*)block_dm, (const float*)block_dc,
@@ -498,7 +572,7 @@ int gsr_launch_target_moments(const float* win11_host, int channels, int H, int 
   { GSR_PROF("target_moments", st);
     hipLaunchKernelGGL(image_loss_fwd_kernel<2>, loss_grid(channels, H, W), dim3(256), 0, st, w, t, H, W, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr); }
+                       (float*)nullptr, channels); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }
