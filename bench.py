@@ -630,12 +630,49 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
     if world > 1:
         dist.all_reduce(to, op=dist.ReduceOp.MAX)
     dt_overlap = float(to)
+    # the pipelined episode (predict_episode(pipeline=True)): rank 0 rolls out and broadcasts one 8.8 KB skinning packet per moving step, the
+    # other ranks move the Gaussians with it (one skinning launch per frame) and render.  world = 1: its two sides are timed separately
+    # on this GPU -- the producer's streaming rollout with a packet hook, and a render rank's frame production from recorded packets --
+    # which is what the prediction below is made of; world > 1: the episode itself is timed.
+    from gsdyn.predict import collect_scene_data
+    dt_pipe = prod_ms = cons_ms = None
+    if world > 1:
+        predict_episode(model, p, eef[:2], poses, W5, H5, rollout_cfg=roll, rank=rank, world=world, pipeline=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = time.perf_counter()
+        predict_episode(model, p, eef, poses, W5, H5, rollout_cfg=roll, rank=rank, world=world, pipeline=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tp = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dt_pipe = float(tp)
+    else:
+        packets = {}
+        noop = lambda f, d, ev: None  # noqa: E731
+        for rounds in range(2):
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            collect_scene_data(model, p, eef, on_frame=noop, on_skin=lambda i, pk: packets.__setitem__(i, pk.clone()), **roll)
+            torch.cuda.synchronize()
+            prod_ms = (time.perf_counter() - t2) * 1e3
+        for rounds in range(2):
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            collect_scene_data(None, p, eef, on_frame=noop, skin_source=lambda i: packets[i], **roll)
+            torch.cuda.synchronize()
+            cons_ms = (time.perf_counter() - t2) * 1e3
     if rank == 0:
         renders = 2 * CAMS * frames
         _emit(({
             "metric": "fwd Mpix/s, predict.py episode end to end (GNN rollout + colour + mask render per camera), 500k Gaussians, 1920x1080",
             "value": renders * W5 * H5 / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": frames, "warmup": 1, "ms_per_step": dt / frames * 1e3,
             "ms_per_step_overlapped": dt_overlap / frames * 1e3,
+            "ms_per_step_pipelined": None if dt_pipe is None else dt_pipe / frames * 1e3,
+            "pipeline_parts_ms_per_frame": None if prod_ms is None else {
+                "producer_rollout_streaming": prod_ms / frames, "render_rank_frames_from_packets": cons_ms / frames,
+                "note": "one GPU, each side alone: the rank that rolls out (sampling, relations, GNN, rotation fit, skinning, smoothing; packets "
+                        "handed to a hook) and a render rank's frame production from recorded packets (skinning + smoothing; no network)"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[4] END TO END: gsdyn.predict.predict_episode = rollout (every rank) + (frame, camera) pairs "
                                    "sharded round-robin, 4 cameras x (colour + mask)", "gaussians": tm["gaussians"], "image": [H5, W5], "cameras": CAMS,
@@ -648,6 +685,10 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
             "predicted_ms_per_frame_by_gpus": None if world > 1 else {
                 str(n): {"sequential": roll_ms / max(frames - 1, 1) + rend_ms / frames / n,
                          "overlapped": max(roll_ms / max(frames - 1, 1), rend_ms / frames / n),
+                         # pipelined: the producer's rollout against a render rank's skinning + its share of the renders (N - 1 render ranks)
+                         "pipelined": None if n == 1 else max(prod_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
+                         "pipelined_speedup_vs_1": None if n == 1 else (roll_ms / max(frames - 1, 1) + rend_ms / frames)
+                         / max(prod_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
                          "speedup_vs_1": (roll_ms / max(frames - 1, 1) + rend_ms / frames) / (roll_ms / max(frames - 1, 1) + rend_ms / frames / n)}
                 for n in (1, 2, 4, 8)},
             "roofline": None, "cpu_baseline": None}))

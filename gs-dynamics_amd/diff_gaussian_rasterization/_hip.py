@@ -977,9 +977,10 @@ def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tenso
     return R, q, code
 
 
-def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat, n_valid=None, in_place=False):
+def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat, n_valid=None, in_place=False, out=None):
     """gsr_lbs: returns (xyz_new [P,3], quat_new [P,4] or None, None) -- the [P, n_bones] weight matrix of the reference is
-    never materialised.  in_place: xyz / quat (float32, contiguous) are overwritten and returned."""
+    never materialised.  in_place: xyz / quat (float32, contiguous) are overwritten and returned.  out = (xyz_out, quat_out):
+    contiguous float32 tensors of the inputs' shapes that receive the result (a frame's slot of the episode arrays: no copy)."""
     lib = load_library()
     _require_device(xyz)
     dev = xyz.device
@@ -991,6 +992,11 @@ def linear_blend_skinning(bones, rotations, translations, bone_quats, xyz, quat,
             if not (xyz.is_contiguous() and xyz.dtype == torch.float32 and (quat is None or (quat.is_contiguous() and quat.dtype == torch.float32))):
                 raise ValueError("linear_blend_skinning(in_place=True): contiguous float32 tensors, please")
             out_xyz, out_q = xyz, quat
+        elif out is not None:
+            out_xyz, out_q = out[0], (out[1] if quat is not None else None)
+            for o, ref in ((out_xyz, xyz), (out_q, quat)):
+                if o is not None and not (o.is_contiguous() and o.dtype == torch.float32 and o.device == dev and tuple(o.shape) == tuple(ref.shape)):
+                    raise ValueError("linear_blend_skinning(out=...): contiguous float32 tensors of the inputs' shapes on their device, please")
         else:
             out_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
             out_q = torch.empty((P, 4), dtype=torch.float32, device=dev) if quat is not None else None

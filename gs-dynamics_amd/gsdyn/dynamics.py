@@ -553,27 +553,32 @@ def _fit_bone_rotations_loop(bones: torch.Tensor, motions: torch.Tensor, relatio
     return R.to(dev)
 
 
-def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None):
-    """Move every Gaussian with the bones (/root/reference/src/render/utils.py:138-243): per-bone rigid transform
-    (rotation from ``fit_bone_rotations``, translation = the bone's motion), blended with inverse-distance weights
-    (distance clamped at 1e-4); orientations: weighted sum of the bones' unit quaternions, normalised, times the Gaussian's
-    quaternion.  Returns (xyz_new [P,3], quat_new [P,4] or None, weights [P,n_bones])."""
-    if xyz.is_cuda and weights is None and bones.is_cuda:
-        # one launch for the bones (moment matrices, rotation fit, unit quaternions: gsr_fit_bones) and one for the Gaussians (gsr_lbs)
+def bone_transforms(bones, motions, relations):
+    """The per-bone rigid transforms of a step: (R [nb,3,3], unit quaternions [nb,4]) from ``fit_bone_rotations`` -- on a HIP device one
+    launch (gsr_fit_bones: moment matrices, rotation fit, quaternions), rank-1 bones resolved on the host (normally none).  Together
+    with (bones, motions) this is ALL a rank needs to move the Gaussians of a frame (``blend_skinning``): the packet of
+    ``pack_skin`` that the pipelined episode of gsdyn/predict.py sends from the rank that rolls out to the ranks that only render."""
+    if bones.is_cuda:
         from diff_gaussian_rasterization import _hip
         R, base_q, code = _hip.fit_bones(bones, motions, relations)
         flagged = (code == 1).nonzero().squeeze(1)              # the one host round trip: rank-1 bones go to the host's LAPACK (normally none)
         if flagged.numel():
             R = fit_bone_rotations(bones, motions, relations)
             base_q = torch.nn.functional.normalize(mat2quat(R), dim=-1)
-        return _hip.linear_blend_skinning(bones.float().contiguous(), R.contiguous(), motions.float().contiguous(), base_q.contiguous(),
-                                          xyz.float().contiguous(), None if quat is None else quat.float().contiguous())
+        return R, base_q
     R = fit_bone_rotations(bones, motions, relations)
-    base_q = torch.nn.functional.normalize(mat2quat(R), dim=-1)
+    return R, torch.nn.functional.normalize(mat2quat(R), dim=-1)
+
+
+def blend_skinning(bones, R, motions, base_q, xyz, quat=None, weights=None, out=None):
+    """Linear blend skinning of the Gaussians with given bone transforms (/root/reference/src/render/utils.py:207-243): inverse-distance
+    weights (distance clamped at 1e-4), positions = weighted sum of the bones' rigid images, orientations = normalised weighted sum
+    of the bones' unit quaternions times the Gaussian's quaternion.  ``out`` = (xyz_out, quat_out): HIP devices write there (no copy
+    into the per-frame arrays).  Returns (xyz_new, quat_new or None, weights or None)."""
     if xyz.is_cuda and weights is None:
         from diff_gaussian_rasterization import _hip
         return _hip.linear_blend_skinning(bones.float().contiguous(), R.contiguous(), motions.float().contiguous(), base_q.contiguous(),
-                                          xyz.float().contiguous(), None if quat is None else quat.float().contiguous())
+                                          xyz.float().contiguous(), None if quat is None else quat.float().contiguous(), out=out)
     if weights is None:
         d = torch.clamp(torch.cdist(xyz[None].float(), bones[None].float())[0], min=1e-4)
         weights = 1.0 / d
@@ -584,7 +589,57 @@ def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None)
     if quat is not None:
         q = torch.nn.functional.normalize((base_q[None] * weights[:, :, None]).sum(1), dim=-1)
         rot = quat_multiply(q, quat)
+    if out is not None:
+        out[0].copy_(xyz_new)
+        if rot is not None:
+            out[1].copy_(rot)
+        return out[0], (out[1] if rot is not None else None), weights
     return xyz_new, rot, weights
+
+
+def interpolate_motions(bones, motions, relations, xyz, quat=None, weights=None):
+    """Move every Gaussian with the bones (/root/reference/src/render/utils.py:138-243): per-bone rigid transform
+    (rotation from ``fit_bone_rotations``, translation = the bone's motion), blended with inverse-distance weights
+    (distance clamped at 1e-4); orientations: weighted sum of the bones' unit quaternions, normalised, times the Gaussian's
+    quaternion.  Returns (xyz_new [P,3], quat_new [P,4] or None, weights [P,n_bones]).  = ``bone_transforms`` + ``blend_skinning``."""
+    R, base_q = bone_transforms(bones, motions, relations)
+    return blend_skinning(bones, R, motions, base_q, xyz, quat, weights)
+
+
+# ------------------------------------------------------------------------------------------ the skinning packet of a step
+# What a rollout step leaves behind for the Gaussians: n_valid bones with their rest positions, rotations, translations, unit
+# quaternions, and the predicted bone positions (the keypoints of the visualisation).  One flat float32 vector of fixed length
+# (``max_nobj`` bone rows, the unused ones zero) so that it can be broadcast as is: 22 floats per bone + 2.
+SKIN_HEAD = 2            # [0] = number of real bones, [1] = 1.0 (a packet is never all zeros: the receiver can tell it arrived)
+
+
+def skin_packet_len(max_nobj: int) -> int:
+    return SKIN_HEAD + 22 * int(max_nobj)
+
+
+def pack_skin(max_nobj: int, bones, R, motions, base_q, pred) -> torch.Tensor:
+    nb, dev = int(bones.shape[0]), bones.device
+    pk = torch.zeros(skin_packet_len(max_nobj), dtype=torch.float32, device=dev)
+    pk[0], pk[1] = float(nb), 1.0
+    o = SKIN_HEAD
+    for t, w in ((bones, 3), (R.reshape(nb, 9), 9), (motions, 3), (base_q, 4), (pred, 3)):
+        pk[o:o + w * nb] = t.reshape(-1).float()
+        o += w * int(max_nobj)
+    return pk
+
+
+def unpack_skin(pk: torch.Tensor, max_nobj: int, n_valid: Optional[int] = None):
+    """(bones, R, motions, base_q, pred) of a packet; ``n_valid`` = the number of real bones when the caller knows it (the host path
+    reads it from the packet: one scalar read-back), None = all ``max_nobj`` rows (fixed-shape device callers pass the count to
+    gsr_lbs_valid as a device word instead)."""
+    m = int(max_nobj)
+    n = m if n_valid is None else int(n_valid)
+    o, parts = SKIN_HEAD, []
+    for w in (3, 9, 3, 4, 3):
+        parts.append(pk[o:o + w * m].reshape(m, w)[:n])
+        o += w * m
+    bones, R, motions, base_q, pred = parts
+    return bones, R.reshape(n, 3, 3), motions, base_q, pred
 
 
 # ------------------------------------------------------------------------------------------ one rollout step
@@ -614,10 +669,12 @@ def _step_constants(nobj: int, dev):
 
 @torch.no_grad()
 def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_history: torch.Tensor, eef_next: torch.Tensor,
-                 all_xyz: torch.Tensor, all_quat: torch.Tensor, adj_thresh: float, topk: int, connect_all: bool = False):
+                 all_xyz: torch.Tensor, all_quat: torch.Tensor, adj_thresh: float, topk: int, connect_all: bool = False,
+                 skin_out: Optional[list] = None):
     """One step of /root/reference/src/render/dynamics_module.py:99-170: graph on the last positions, GNN prediction of the
     object particles, interpolation of all Gaussians.  particle_history [n_his,nobj,3], eef_history [n_his,1,3],
-    eef_next [1,3].  Returns (pred_particles [nobj,3], xyz_new, quat_new, (receivers, senders))."""
+    eef_next [1,3].  Returns (pred_particles [nobj,3], xyz_new, quat_new, (receivers, senders)); ``skin_out``: a list that receives
+    the step's (bones, R, motions, unit quaternions)."""
     dev = particle_history.device
     n_his, nobj = particle_history.shape[0], particle_history.shape[1]
     attrs, mask, tool, p_inst, zero_act = _step_constants(nobj, dev)
@@ -627,7 +684,11 @@ def rollout_step(model: DynamicsPredictor, particle_history: torch.Tensor, eef_h
     pred, _ = model(state=states, attrs=attrs, p_instance=p_inst, action=action, receivers=recv, senders=send)
     bones = particle_history[-1]
     rel = relations_to_matrix(recv, send, nobj + 1)[:nobj, :nobj]
-    xyz_new, quat_new, _ = interpolate_motions(bones, pred[0] - bones, rel, all_xyz, quat=all_quat)
+    motions = pred[0] - bones
+    R, base_q = bone_transforms(bones, motions, rel)
+    xyz_new, quat_new, _ = blend_skinning(bones, R, motions, base_q, all_xyz, all_quat)
+    if skin_out is not None:
+        skin_out.append((bones, R, motions, base_q))
     return pred[0], xyz_new, quat_new, (recv, send)
 
 
@@ -651,6 +712,8 @@ class _GraphedStep:
         self.pos_track, self.hist, self.eef_hist, self.eef_next = z(n_track, 3), z(n_his, n_track, 3), z(n_his, 1, 3), z(1, 3)
         self.all_pos, self.all_rot = z(P, 3), z(P, 4)
         self.pred, self.n_valid, self.bad = z(nb, 3), z(1, dtype=torch.int32), z(1, dtype=torch.long)
+        self.skin = z(skin_packet_len(nb))              # the step's skinning packet (pack_skin's layout), rewritten by every replay
+        one = torch.ones(1, device=dev)
         c = model.model_config
         a = z(self.n_cap, c["attr_dim"]); a[:nb, 0] = 1.0; a[nb, 1] = 1.0                      # noqa: E702
         g = z(self.n_cap, 1); g[:nb] = 1.0                                                      # noqa: E702
@@ -671,6 +734,8 @@ class _GraphedStep:
             bones, pred = bones_hist[-1], pos_all[:nb]
             motion = pred - bones
             R, q, code = _hip.fit_bones(bones, motion, rel[:nb, :nb])
+            # what a rank that only renders needs of this step (gsdyn/predict.py: the pipelined episode): one small launch
+            torch.cat([cnt.to(torch.float32), one, bones.reshape(-1), R.reshape(-1), motion.reshape(-1), q.reshape(-1), pred.reshape(-1)], out=self.skin)
             _hip.linear_blend_skinning(bones, R, motion, q, self.all_pos, self.all_rot, n_valid=cnt, in_place=True)
             # the tracked particles' new positions, both history windows shifted, the bones masked to the valid ones, the count of bones
             # the device could not resolve (rank 1: none, normally): one launch
@@ -735,17 +800,41 @@ def downsample_vertices(xyz: torch.Tensor, max_nobj: int, radius: float, start_i
 @torch.no_grad()
 def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_steps: int, inlier_idx_all, *, max_nobj: int,
             fps_radius_value: float, adj_thresh: float, topk: int, connect_all: bool, dist_thresh: float, n_fps_all: int = 1000,
-            thin_start_idx: int = 0, storage_device=None, after_step=None):
+            thin_start_idx: int = 0, storage_device=None, after_step=None, on_skin=None, skin_source=None):
     """The autoregressive loop of /root/reference/src/render/dynamics_module.py:53-172.  1000 (``n_fps_all``) farthest points of the
     inlier Gaussians carry the particle history; per step the bones are re-sampled from them, the GNN predicts the bones' next
     positions from the last ``n_his`` states and the end-effector motion, and all Gaussians follow the bones
     (``interpolate_motions``).  A step whose end-effector target moved less than ``dist_thresh`` repeats the previous frame.
     Everything stays on the device of ``xyz_0`` (the reference shuttles every frame to the CPU); ``storage_device`` moves the
     per-frame arrays elsewhere if wanted.  ``after_step(i, arrays, repeated)`` is called once frame i is written (arrays = the six
-    result arrays, ``repeated`` = the frame copied its predecessor): the hook of a consumer that does not wait for the whole episode.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
+    result arrays, ``repeated`` = the frame copied its predecessor): the hook of a consumer that does not wait for the whole episode.
+    ``on_skin(i, packet)``: called for every step that moved the Gaussians with the step's skinning packet (``pack_skin``: bones,
+    rotations, translations, quaternions, predicted bones) BEFORE ``after_step`` -- on a HIP device the packet is a static buffer the
+    next step overwrites, to be consumed in stream order.  ``skin_source(i)`` -> packet: the RECEIVING side of that hand-over -- no
+    network, no sampling, no graph: every moving step applies the packet it is given to the previous frame's Gaussians (the ranks of a
+    pipelined episode that only render; gsdyn/predict.py).  Same frames as the rank that rolled out: the skinning is per Gaussian.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
     eef [S,1,3])."""
     dev = xyz_0.device
     store = dev if storage_device is None else torch.device(storage_device)
+    rep = lambda t: t.to(store)[None].repeat(n_steps, *([1] * t.dim()))  # noqa: E731
+    quat, xyz, rgb, opa = rep(quat_0), rep(xyz_0), rep(rgb_0), rep(opa_0)
+    xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
+    eef = rep(eef_xyz[0])
+    arrays = (xyz, rgb, quat, opa, xyz_bones, eef)
+    # which steps repeat the previous frame: decided from the end-effector targets alone -- on the host, once, with the arithmetic of the
+    # reference's per-step test (fp32 norm of the difference to the last target that was acted on)
+    eef_host = eef_xyz.detach().to("cpu", torch.float32)
+    skip, last = [False] * n_steps, eef_host[0]
+    for i in range(1, n_steps):
+        skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
+        if not skip[i]:
+            last = eef_host[i]
+    if skin_source is not None:       # (no sampling here: frame 0's keypoints arrive as packet 0)
+        pk0 = skin_source(0).to(dev)
+        xyz_bones[0] = unpack_skin(pk0, max_nobj)[4].to(store)
+        if after_step is not None:
+            after_step(0, arrays, False)
+        return _rollout_from_packets(skin_source, arrays, skip, eef_xyz, max_nobj, dev, store, after_step)
     n_his = int(model.model_config["n_his"])
     inl = torch.as_tensor(inlier_idx_all, device=dev, dtype=torch.long)
     all_pos = xyz_0
@@ -756,22 +845,14 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     eef_hist = eef_xyz[0][None].repeat(n_his, 1, 1)
     eef_pos = eef_xyz[0]
     p0, _ = downsample_vertices(fps_all_pos, max_nobj, fps_radius_value, thin_start_idx)
-    rep = lambda t: t.to(store)[None].repeat(n_steps, *([1] * t.dim()))  # noqa: E731
-    quat, xyz, rgb, opa = rep(quat_0), rep(xyz_0), rep(rgb_0), rep(opa_0)
-    xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
-    eef = rep(eef_xyz[0])
     xyz_bones[0, :p0.shape[0]] = p0.to(store)
-    arrays = (xyz, rgb, quat, opa, xyz_bones, eef)
+    if on_skin is not None:           # packet 0 carries frame 0's keypoints only (no bones: nothing moves)
+        z = p0.new_zeros((0, 3))
+        pk0 = pack_skin(max_nobj, z, p0.new_zeros((0, 3, 3)), z, p0.new_zeros((0, 4)), z)
+        pk0[SKIN_HEAD + 19 * int(max_nobj):SKIN_HEAD + 19 * int(max_nobj) + 3 * p0.shape[0]] = p0.reshape(-1).float()
+        on_skin(0, pk0)
     if after_step is not None:
         after_step(0, arrays, False)
-    # which steps repeat the previous frame: decided from the end-effector targets alone -- on the host, once, with the arithmetic of the
-    # reference's per-step test (fp32 norm of the difference to the last target that was acted on)
-    eef_host = eef_xyz.detach().to("cpu", torch.float32)
-    skip, last = [False] * n_steps, eef_host[0]
-    for i in range(1, n_steps):
-        skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
-        if not skip[i]:
-            last = eef_host[i]
     c = model.model_config
     gs = None
     if (dev.type == "cuda" and _GRAPH_ROLLOUT and _GRAPH_ROLLOUT_STEP and store == dev and not connect_all and n_fps_all <= 1024 and max_nobj <= 126
@@ -788,7 +869,9 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
                     a[i] = a[i - 1]
             else:
                 gs.step(eef_xyz[i])
-                quat[i], xyz[i], rgb[i], opa[i] = gs.all_rot, gs.all_pos, rgb[i - 1], opa[i - 1]
+                if on_skin is not None:
+                    on_skin(i, gs.skin)
+                quat[i], xyz[i] = gs.all_rot, gs.all_pos        # (rgb / opa: every frame already holds frame 0's -- ``rep`` above)
                 xyz_bones[i], eef[i] = gs.pred, eef_xyz[i]
             if after_step is not None:
                 after_step(i, arrays, skip[i])
@@ -806,18 +889,49 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
             continue
         eef_next = eef_xyz[i]
         bones, fps_idx = downsample_vertices(fps_all_pos, max_nobj, fps_radius_value, thin_start_idx)
+        sk = [] if on_skin is not None else None
         pred, all_pos, all_rot, _ = rollout_step(model, hist[:, fps_idx], eef_hist, eef_next, all_pos, quat[i - 1].to(dev),
-                                                 adj_thresh, topk, connect_all)
+                                                 adj_thresh, topk, connect_all, skin_out=sk)
+        if on_skin is not None:
+            on_skin(i, pack_skin(max_nobj, *sk[0], pred))
         eef_hist = torch.cat([eef_hist[1:], eef_next[None]], 0)
         eef_pos = eef_next
         fps_all_pos = all_pos[track]
         hist = torch.cat([hist[1:], fps_all_pos[None]], 0)
-        quat[i], xyz[i], rgb[i], opa[i] = all_rot.to(store), all_pos.to(store), rgb[i - 1], opa[i - 1]
+        quat[i], xyz[i] = all_rot.to(store), all_pos.to(store)
         xyz_bones[i, :bones.shape[0]] = pred.to(store)
         eef[i] = eef_pos.to(store)
         if after_step is not None:
             after_step(i, arrays, False)
     return xyz, rgb, quat, opa, xyz_bones, eef
+
+
+def _rollout_from_packets(skin_source, arrays, skip, eef_xyz, max_nobj: int, dev, store, after_step):
+    """``rollout`` on a rank that is handed every moving step's skinning packet instead of computing it: frame i = the packet of step i
+    applied to frame i - 1 (``blend_skinning``, written straight into the frame's slot on a HIP device), repeated frames copied."""
+    xyz, rgb, quat, opa, xyz_bones, eef = arrays
+    n_steps = xyz.shape[0]
+    for i in range(1, n_steps):
+        if skip[i]:
+            for a in arrays:
+                a[i] = a[i - 1]
+        else:
+            pk = skin_source(i).to(dev)
+            if dev.type == "cuda" and store == dev:
+                from diff_gaussian_rasterization import _hip
+                bones, R, motions, base_q, pred = unpack_skin(pk, max_nobj)
+                _hip.linear_blend_skinning(bones, R, motions, base_q, xyz[i - 1], quat[i - 1], n_valid=pk[:1].to(torch.int32), out=(xyz[i], quat[i]))
+                # (fixed shapes, no read-back: the rows behind the real bones are zero in the keypoints, as on the rank that rolled out)
+                pred = torch.where((torch.arange(int(max_nobj), device=dev, dtype=torch.float32) < pk[0])[:, None], pred, torch.zeros_like(pred))
+            else:
+                bones, R, motions, base_q, pred = unpack_skin(pk, max_nobj, n_valid=int(pk[0].item()))
+                x, q, _ = blend_skinning(bones, R, motions, base_q, xyz[i - 1].to(dev), quat[i - 1].to(dev))
+                xyz[i], quat[i] = x.to(store), q.to(store)
+            xyz_bones[i, :pred.shape[0]] = pred.to(store)
+            eef[i] = eef_xyz[i].to(store)
+        if after_step is not None:
+            after_step(i, arrays, skip[i])
+    return arrays
 
 
 def smooth_frames(xyz, rgb, quat, opa, xyz_bones, eef):
@@ -867,10 +981,11 @@ def spatial_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
 def pack_scene_data(xyz, rgb, quat, opa, scales, xyz_bones, eef):
     """Per-frame render inputs and keypoints, as ``collect_scene_data`` hands them to the renderer (dynamics_module.py:239-257)."""
     scene, vis = [], []
+    kp, tool = xyz_bones.cpu().numpy(), eef.cpu().numpy()       # two transfers per episode (not two per frame)
     for t in range(xyz.shape[0]):
         scene.append({"means3D": xyz[t], "colors_precomp": rgb[t], "rotations": quat[t], "opacities": opa[t], "scales": scales,
                       "means2D": torch.zeros_like(xyz[t])})
-        vis.append({"kp": xyz_bones[t].cpu().numpy(), "tool_kp": eef[t].cpu().numpy()})
+        vis.append({"kp": kp[t], "tool_kp": tool[t]})
     return scene, vis
 
 

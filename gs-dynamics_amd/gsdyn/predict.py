@@ -102,7 +102,8 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
 @torch.no_grad()
 def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
                        dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
-                       remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True, on_frame=None):
+                       remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True, on_frame=None,
+                       on_skin=None, skin_source=None):
     """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
     the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
@@ -113,7 +114,10 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     ``on_frame(t, frame_dict, event)``: STREAMING mode -- every frame is handed over as soon as it is final (a frame in which the
     Gaussians moved: at once; the repeated frames before it: interpolated right then), with a device event recorded behind its
     last producer on the current stream; the returned scene data are those same per-frame dicts.  Same values as the batch mode
-    (the interpolation is ``smooth_segment`` either way)."""
+    (the interpolation is ``smooth_segment`` either way).
+    ``on_skin`` / ``skin_source``: ``dynamics.rollout``'s two ends of the pipelined episode -- the rank that rolls out hands every moving
+    step's skinning packet to ``on_skin``; a rank given a ``skin_source`` runs no outlier filter, no sampling and no network, it only
+    moves the Gaussians with the packets it receives (``model`` is not used and may be None)."""
     import time
     from . import dynamics as D
     first = lambda t: t[0] if t.dim() == 3 else t   # noqa: E731
@@ -125,7 +129,10 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     keep = opa_0[:, 0] >= low_opacity
     xyz_0, rgb_0, quat_0, opa_0, scales_0 = xyz_0[keep], rgb_0[keep], quat_0[keep], opa_0[keep], scales_0[keep]
     t0 = time.perf_counter()
-    inlier = D.remove_statistical_outliers(xyz_0) if remove_outliers else torch.arange(xyz_0.shape[0], device=dev)
+    if skin_source is not None:
+        inlier = torch.zeros(0, dtype=torch.long, device=dev)          # (the receiving side samples nothing)
+    else:
+        inlier = D.remove_statistical_outliers(xyz_0) if remove_outliers else torch.arange(xyz_0.shape[0], device=dev)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
@@ -163,16 +170,18 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
 
         out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
                         adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
-                        n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, after_step=after_step)
+                        n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, after_step=after_step,
+                        on_skin=on_skin, skin_source=skin_source)
         emit(out, n_steps - 1)                      # trailing repeats of the last moving frame
-        vis = [{"kp": out[4][t].cpu().numpy(), "tool_kp": out[5][t].cpu().numpy()} for t in range(n_steps)]
+        kp, tool = out[4].cpu().numpy(), out[5].cpu().numpy()
+        vis = [{"kp": kp[t], "tool_kp": tool[t]} for t in range(n_steps)]
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         return scene, vis, {"outlier_filter_ms": (t1 - t0) * 1e3, "rollout_ms": (t2 - t1) * 1e3, "frames": n_steps, "gaussians": int(xyz_0.shape[0])}
     out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
                     adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
-                    n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx)
+                    n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, on_skin=on_skin, skin_source=skin_source)
     out = D.smooth_frames(*out)
     if spatial_sort and int(xyz_0.shape[0]) > 1:
         perm = D.spatial_order(out[0][0].to(dev)).to(out[0].device)
@@ -194,7 +203,8 @@ def compose_rgba(im: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: int, *, rollout_cfg: dict, rank: Optional[int] = None,
                     world: Optional[int] = None, gather_to: Optional[int] = None, bg=(0.0, 0.0, 0.0), rgba: bool = False,
-                    scene_out: Optional[list] = None, overlap: bool = False):
+                    scene_out: Optional[list] = None, overlap: bool = False, pipeline: bool = False, producer: int = 0,
+                    producer_renders: bool = False, group=None):
     """One episode of /root/reference/src/predict.py:74-164 on this rank: GNN rollout (every rank, identical), then this rank's
     (frame, camera) pairs -- colour + all-ones mask render per pair, all cameras of a frame in one rasterizer call.
     ``poses``: the cameras as (w2c, K); ``rollout_cfg``: the keyword arguments of ``collect_scene_data`` (max_nobj, fps_radius,
@@ -206,9 +216,17 @@ def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: in
     -- the rollout is bound by the host issuing small launches and leaves the GPU idle most of the time, the renders are GPU-bound;
     each frame is rendered as soon as it is final (``collect_scene_data(on_frame=...)``).  Same values as the sequential form.
     Measured at configs[4] size on two MI355X boxes: 2.29 - 2.44 ms per frame on one, 3.8 - 4.0 on the other, against 2.7 - 2.8
-    sequential on both -- two host threads that both spin on device synchronisations need the cores for it; hence not the default."""
+    sequential on both -- two host threads that both spin on device synchronisations need the cores for it; hence not the default.
+    ``pipeline`` (world > 1): ONE rank (``producer``) rolls out and broadcasts every moving step's skinning packet (``dynamics.pack_skin``:
+    22 floats per bone, 8.8 KB at 100 bones); the other ranks only move the Gaussians with the packets (one skinning launch per frame)
+    and render -- see ``_predict_episode_pipelined``.  Same frames as the replicated form; the rollout leaves the render ranks' time."""
     import time
     dev = params["means3D"].device
+    if pipeline:
+        w_ = world if world is not None else (dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1)
+        if w_ > 1:
+            return _predict_episode_pipelined(model, params, eef_xyz, poses, w, h, rollout_cfg, rank, w_, gather_to, bg, rgba, scene_out,
+                                              int(producer), bool(producer_renders), group)
     if overlap and dev.type == "cuda":
         return _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg, rank, world, gather_to, bg, rgba, scene_out)
     scene, vis, tm = collect_scene_data(model, params, eef_xyz, **rollout_cfg)
@@ -281,4 +299,69 @@ def _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg
     frames = dict(sorted(frames.items()))
     if gather_to is not None:
         frames = gather_frames(frames, dst=gather_to)
+    return frames, vis, tm
+
+
+def render_ranks_of(world: int, producer: int = 0, producer_renders: bool = False) -> List[int]:
+    """The ranks of a pipelined episode that render: all of them, or all but the one that rolls out."""
+    return [r for r in range(int(world)) if producer_renders or r != int(producer)]
+
+
+def _predict_episode_pipelined(model, params, eef_xyz, poses, w, h, rollout_cfg, rank, world, gather_to, bg, rgba, scene_out, producer,
+                               producer_renders, group):
+    """predict_episode with the rollout on ONE rank (the reference has no distributed code: new design).
+
+    The rollout is autoregressive (/root/reference/src/render/dynamics_module.py:99-170: frame t + 1 needs frame t), so it cannot be
+    sharded by frames, and replicated on every rank it is an Amdahl term as large as the renders (0.5 - 0.9 ms per frame against 1.0 ms
+    at 500 k Gaussians / 1080p x 4 cameras).  But what a step DOES to the Gaussians is tiny: <= ``max_nobj`` bones, each with a rest
+    position, a rotation, a translation and a unit quaternion (``dynamics.bone_transforms``) -- the sampling, the relations, the GNN and
+    the rotation fit only ever look at the ~1000 tracked particles.  So rank ``producer`` runs ``collect_scene_data`` as before and
+    broadcasts each moving step's packet (one ``dist.broadcast`` of 22 x max_nobj + 2 floats; RCCL: the device buffer in stream order,
+    no host round trip; gloo: a host copy); every other rank applies the packet to its copy of the previous frame with ONE skinning
+    launch (gsr_lbs, written into the frame's slot) -- per Gaussian the same arithmetic on the same inputs, hence the same frames --
+    smooths repeated frames exactly as the producer does, and renders its (frame, camera) pairs as soon as a frame is final.  The
+    pairs are dealt round-robin over the RENDER ranks (``render_ranks_of``: by default the producer renders nothing -- its rollout is
+    the pipeline's critical path).  Per frame a render rank then costs skinning + render / (N - 1) instead of rollout + render / N.
+    There is still no collective on the render path; the broadcast is the path's one exchange step."""
+    import time
+    from . import dynamics as D
+    dev = params["means3D"].device
+    if rank is None:
+        rank = dist.get_rank(group)
+    rr = render_ranks_of(world, producer, producer_renders)
+    shard = FrameShard(dev, w, h, poses, rr.index(rank), len(rr), bg=bg) if rank in rr else None
+    max_nobj = int(rollout_cfg["max_nobj"])
+    plen = D.skin_packet_len(max_nobj)
+    on_host = dist.get_backend(group) != "nccl"          # gloo (CPU tests, multi-process on one GPU): packets travel as host tensors
+    src = producer if group is None else dist.get_global_rank(group, producer)
+    frames: Dict[Tuple[int, int], tuple] = {}
+
+    def on_frame(f, d, ev):
+        if shard is not None:
+            for c, v in shard.render_frame(f, d).items():
+                frames[(f, c)] = (compose_rgba(v[0], v[2]), v[1], v[2]) if rgba else v
+
+    t0 = time.perf_counter()
+    if rank == producer:
+        def on_skin(i, pk):
+            buf = pk.detach().to("cpu").contiguous() if on_host else pk      # (RCCL: the current stream waits for the broadcast: the next
+            dist.broadcast(buf, src=src, group=group)                          #  step's graph replay does not overwrite the packet under it)
+        scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=on_frame, on_skin=on_skin, **rollout_cfg)
+    else:
+        def skin_source(i):
+            buf = torch.empty(plen, dtype=torch.float32, device="cpu" if on_host else dev)
+            dist.broadcast(buf, src=src, group=group)
+            return buf
+        scene, vis, tm = collect_scene_data(None, params, eef_xyz, on_frame=on_frame, skin_source=skin_source, **rollout_cfg)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    if scene_out is not None:
+        scene_out.extend(scene)
+    tm["episode_ms"] = (time.perf_counter() - t0) * 1e3
+    tm["render_ms"] = float("nan")                      # not separable: frames are rendered as they become final
+    tm["pairs_on_this_rank"] = len(frames)
+    tm["pipelined"], tm["producer"], tm["render_ranks"] = True, producer, rr
+    frames = dict(sorted(frames.items()))
+    if gather_to is not None:
+        frames = gather_frames(frames, dst=gather_to, group=group)
     return frames, vis, tm

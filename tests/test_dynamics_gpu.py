@@ -461,3 +461,37 @@ def test_small_scene_with_fewer_tracked_points_than_bones_takes_the_eager_loop(d
         D._GRAPH_ROLLOUT_STEP = True
     for a, b in zip(got, want):
         assert a.shape == b.shape and torch.isfinite(a).all() and float((a - b).abs().max()) < 2e-5
+
+
+def test_frames_from_skin_packets_are_the_rollouts_frames(dev, golden_dir):
+    """The two ends of the pipelined episode (gsdyn/predict.py) on one device: ``collect_scene_data(on_skin=...)`` hands out one skinning
+    packet per moving step (the graphed step's static buffer, cloned here as a broadcast would consume it); a second call that is GIVEN
+    the packets -- no model, no sampling -- produces the same per-frame render inputs and keypoints bit for bit (one gsr_lbs launch per
+    frame, written into the frame's slot), in both the streaming and the batch mode."""
+    from gsdyn import synth_scene_params
+    from gsdyn import dynamics as D
+    from gsdyn.predict import collect_scene_data
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = D.DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    params = {k: v.detach() for k, v in synth_scene_params(30000, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    eef = torch.tensor([[0.04, 0.0, 0.02]], device=dev) * torch.tensor([0.0, 1.0, 1.01, 2.0, 3.0, 4.0], device=dev)[:, None]
+    roll = dict(max_nobj=100, fps_radius=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=1000, remove_outliers=False)
+    packets = {}
+    scene, vis, _ = collect_scene_data(model, params, eef, on_frame=lambda t, d, ev: None, on_skin=lambda i, pk: packets.__setitem__(i, pk.clone()), **roll)
+    assert sorted(packets) == [0, 1, 3, 4, 5]                       # step 2 repeats frame 1: no packet
+    assert all(p.shape == (D.skin_packet_len(100),) and float(p[1]) == 1.0 for p in packets.values())
+    n_valid = int(packets[1][0])
+    assert 10 < n_valid <= 100 and float(packets[0][0]) == 0.0
+    asked = []
+    for mode in ("stream", "batch"):
+        kw = dict(on_frame=lambda t, d, ev: None) if mode == "stream" else {}
+        scene2, vis2, _ = collect_scene_data(None, params, eef, skin_source=lambda i: (asked.append(i), packets[i])[1], **kw, **roll)
+        for t, (a, b) in enumerate(zip(scene, scene2)):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (mode, t, k)
+        for a, b in zip(vis, vis2):
+            assert np.array_equal(a["kp"], b["kp"]) and np.array_equal(a["tool_kp"], b["tool_kp"])
+    assert asked == [0, 1, 3, 4, 5] * 2
+    assert float((scene[-1]["means3D"] - scene[0]["means3D"]).norm(dim=-1).max()) > 1e-3

@@ -274,6 +274,79 @@ def test_frame_shards_on_the_real_kernels(tmp_path, world):
     assert seen == set(want)
 
 
+# ------------------------------------------------------------------------------------------ the pipelined episode (one rank rolls out, the others skin + render)
+EP_P, EP_W, EP_H, EP_S = 30_000, 480, 272, 6
+EP_ROLL = dict(max_nobj=100, fps_radius=0.3, adj_thresh=0.6, topk=5, connect_all=False, dist_thresh=0.005, n_fps_all=1000, remove_outliers=False)
+
+
+def _episode_problem(dev):
+    from gsdyn import synth_scene_params
+    from gsdyn.dynamics import DynamicsPredictor
+    gold = np.load(os.path.join(HERE, "golden", "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    params = {k: v.detach() for k, v in synth_scene_params(EP_P, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    eef = torch.tensor([[0.04, 0.0, 0.02]], device=dev) * torch.tensor([0.0, 1.0, 1.01, 2.0, 3.0, 4.0], device=dev)[:, None]   # step 2: a repeated frame
+    return model, params, eef
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    dev = _init(rank, world, port)
+    from gsdyn.predict import predict_episode, render_ranks_of, ring_poses, shard_pairs
+    model, params, eef = _episode_problem(dev)
+    scene = []
+    frames, vis, tm = predict_episode(model if rank == 0 else None, params, eef, ring_poses(CAMS, EP_W, EP_H), EP_W, EP_H, rollout_cfg=EP_ROLL,
+                                      pipeline=True, scene_out=scene)
+    torch.cuda.synchronize()
+    rr = render_ranks_of(world)
+    assert tm["pipelined"] and rr == list(range(1, world)) and len(scene) == EP_S and len(vis) == EP_S
+    assert sorted(frames) == (sorted(shard_pairs(EP_S, CAMS, rr.index(rank), len(rr))) if rank in rr else [])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=np.array(sorted(frames)).reshape(-1, 2),
+             **{f"sc_{t}_{k}": v.cpu().numpy() for t, d in enumerate(scene) for k, v in d.items() if k != "means2D"},
+             **{f"kp_{t}": v["kp"] for t, v in enumerate(vis)},
+             **{f"fr_{f}_{c}_{i}": t.cpu().numpy() for (f, c), v in frames.items() for i, t in enumerate(v)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_episode_on_the_real_kernels(tmp_path, world):
+    """predict_episode(pipeline=True) with 2 / 3 processes on this GPU (gloo: the packets travel as host tensors): rank 0 runs the graphed
+    rollout and broadcasts the skinning packets, the others produce every frame from the packets with gsr_lbs alone -- the SAME render
+    inputs and keypoints bit for bit (the rollout itself differs by ulps from run to run: every rank is compared with rank 0 of ITS run)
+    -- and their renders are the single-process renders of those inputs, every (frame, camera) pair exactly once."""
+    _setup_paths()
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda", 0)
+    from gsdyn.predict import FrameShard, ring_poses
+    z0 = np.load(tmp_path / "rank0.npz")
+    assert z0["keys"].size == 0                                  # the producer renders nothing by default
+    scene = []
+    for t in range(EP_S):
+        d = {k: torch.tensor(z0[f"sc_{t}_{k}"], device=dev) for k in ("means3D", "colors_precomp", "rotations", "opacities", "scales")}
+        d["means2D"] = torch.zeros_like(d["means3D"])
+        scene.append(d)
+    assert float((scene[-1]["means3D"] - scene[0]["means3D"]).norm(dim=-1).max()) > 1e-3
+    mid = torch.lerp(scene[1]["means3D"], scene[3]["means3D"], 0.5)   # (the Morton permutation is per episode: rows correspond)
+    assert float((scene[2]["means3D"] - mid).abs().max()) < 1e-6
+    want = FrameShard(dev, EP_W, EP_H, ring_poses(CAMS, EP_W, EP_H), rank=0, world=1).render_episode(scene)
+    torch.cuda.synchronize()
+    seen = set()
+    for r in range(1, world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for name in z0.files:
+            if name.startswith(("sc_", "kp_")):
+                assert np.array_equal(z[name], z0[name]), (r, name)
+        for f, c in z["keys"].tolist():
+            assert (f, c) not in seen
+            seen.add((f, c))
+            for i in range(3):
+                assert np.array_equal(z[f"fr_{f}_{c}_{i}"], want[(f, c)][i].cpu().numpy()), (r, f, c, i)
+    assert seen == set(want)
+
+
 @pytest.mark.timeout(600)
 def test_bench_reduce_leg_over_rccl_with_one_rank(tmp_path):
     """``bench.py`` with GSR_BENCH_FORCE_DIST=1: the ``nccl`` (= RCCL) process group on this box's one GPU, the step's reduce leg on the

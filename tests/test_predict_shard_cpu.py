@@ -188,3 +188,82 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
     for (f, c), (im, depth, mask) in ref.items():
         assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
         assert np.array_equal(z[f"{f}_{c}_1"], depth.numpy()) and np.array_equal(z[f"{f}_{c}_2"], mask.numpy())
+
+
+# ------------------------------------------------------------------------------------------ the pipelined episode: one rank rolls out, the others skin + render
+def _pipelined_worker(rank, world, port, out_dir, producer_renders):
+    _setup()
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_double()
+    from gsdyn import dynamics as D
+    from gsdyn.predict import predict_episode, render_ranks_of, ring_poses, shard_pairs
+    model, params, eef = _episode_inputs()
+    ran = {"fps": 0, "gnn": 0}
+    fps0, fwd0 = D.farthest_point_sampler, D.DynamicsPredictor.forward
+    D.farthest_point_sampler = lambda *a, **k: (ran.__setitem__("fps", ran["fps"] + 1), fps0(*a, **k))[1]
+    D.DynamicsPredictor.forward = lambda self, *a, **k: (ran.__setitem__("gnn", ran["gnn"] + 1), fwd0(self, *a, **k))[1]
+    scene = []
+    frames, vis, tm = predict_episode(model if rank == 0 else None, params, eef, ring_poses(CAMS, W, H), W, H, rollout_cfg=ROLL, gather_to=0,
+                                      rgba=True, pipeline=True, producer_renders=producer_renders, scene_out=scene)
+    rr = render_ranks_of(world, 0, producer_renders)
+    assert tm["pipelined"] and tm["render_ranks"] == rr and tm["frames"] == EP_STEPS and len(vis) == EP_STEPS and len(scene) == EP_STEPS
+    # only the producer samples and runs the network; a render rank renders exactly its share of the pairs
+    assert (ran["fps"] > 0 and ran["gnn"] > 0) if rank == 0 else (ran["fps"] == 0 and ran["gnn"] == 0)
+    assert tm["pairs_on_this_rank"] == (len(shard_pairs(EP_STEPS, CAMS, rr.index(rank), len(rr))) if rank in rr else 0)
+    np.savez(os.path.join(out_dir, f"scene_{rank}.npz"), **{f"{t}_{k}": v.numpy() for t, d in enumerate(scene) for k, v in d.items()},
+             **{f"kp_{t}": v["kp"] for t, v in enumerate(vis)}, **{f"tool_{t}": v["tool_kp"] for t, v in enumerate(vis)})
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "episode.npz"), **{f"{f}_{c}_{i}": t.numpy() for (f, c), v in frames.items() for i, t in enumerate(v)})
+    else:
+        assert frames is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,producer_renders", [(2, False), (3, False), (3, True)])
+def test_pipelined_episode_equals_the_replicated_one(tmp_path, world, producer_renders):
+    """predict_episode(pipeline=True): rank 0 rolls out and broadcasts one skinning packet per moving step; the other ranks never sample,
+    never run the network -- they move the Gaussians with the packets and render.  Every rank ends up with the SAME per-frame render
+    inputs and keypoints as the single-process episode, bit for bit, and the union of the render ranks' images is its images."""
+    _setup()
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path), producer_renders), nprocs=world, join=True)
+    _install_double()
+    from gsdyn.predict import collect_scene_data, compose_rgba, FrameShard, ring_poses
+    model, params, eef = _episode_inputs()
+    scene, vis, _ = collect_scene_data(model, params, eef, **ROLL)
+    assert sum(int(not np.array_equal(vis[t]["tool_kp"], vis[t - 1]["tool_kp"])) for t in range(1, EP_STEPS)) >= 3   # frames that moved
+    for r in range(world):
+        z = np.load(tmp_path / f"scene_{r}.npz")
+        for t, d in enumerate(scene):
+            for k, v in d.items():
+                assert np.array_equal(z[f"{t}_{k}"], v.numpy()), (r, t, k)
+            assert np.array_equal(z[f"kp_{t}"], vis[t]["kp"]) and np.array_equal(z[f"tool_{t}"], vis[t]["tool_kp"]), (r, t)
+    ref = FrameShard("cpu", W, H, ring_poses(CAMS, W, H), rank=0, world=1).render_episode(scene)
+    z = np.load(tmp_path / "episode.npz")
+    assert len(z.files) == 3 * EP_STEPS * CAMS
+    for (f, c), (im, depth, mask) in ref.items():
+        assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
+        assert np.array_equal(z[f"{f}_{c}_1"], depth.numpy()) and np.array_equal(z[f"{f}_{c}_2"], mask.numpy())
+
+
+def test_skin_packet_round_trip():
+    _setup()
+    from gsdyn import dynamics as D
+    g = torch.Generator().manual_seed(3)
+    nb, cap = 5, 8
+    bones, mot, pred = torch.randn(nb, 3, generator=g), torch.randn(nb, 3, generator=g), torch.randn(nb, 3, generator=g)
+    rel = (torch.rand(nb, nb, generator=g) < 0.6).long()
+    rel = ((rel + rel.T) > 0).long().fill_diagonal_(0)
+    R, q = D.bone_transforms(bones, mot, rel)
+    pk = D.pack_skin(cap, bones, R, mot, q, pred)
+    assert pk.shape == (D.skin_packet_len(cap),) and float(pk[0]) == nb and float(pk[1]) == 1.0
+    for a, b in zip(D.unpack_skin(pk, cap, n_valid=nb), (bones, R, mot, q, pred)):
+        assert torch.equal(a, b)
+    assert all(t.shape[0] == cap for t in D.unpack_skin(pk, cap)) and float(D.unpack_skin(pk, cap)[0][nb:].abs().max()) == 0.0
+    xyz, quat = torch.randn(40, 3, generator=g), torch.nn.functional.normalize(torch.randn(40, 4, generator=g), dim=-1)
+    a = D.interpolate_motions(bones, mot, rel, xyz, quat=quat)
+    b = D.blend_skinning(*D.unpack_skin(pk, cap, n_valid=nb)[:4], xyz, quat)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
