@@ -6,11 +6,19 @@ Every (frame, camera) pair is independent, so here the pairs are dealt round-rob
 cam`` goes to rank ``(frame * n_cams + cam) mod world`` -- and a rank renders all of its cameras of a frame (colour + mask
 each) in ONE multi-view rasterizer call (``Renderer.render_cameras_with_mask``: the two renders of a camera share their tile
 lists and are blended in one tile pass).  There is NO collective on the render path; ``gather_frames`` optionally brings
-the images to one rank afterwards.  The scene data of a frame (the GNN rollout's output) is the same on every rank: the rollout
-is deterministic and autoregressive (/root/reference/src/render/dynamics_module.py:53-172: step t + 1 needs step t), so every rank runs
-it.  It is NOT cheap next to the renders any more (round 4: 0.75 ms per frame against 0.9 - 1.0 ms of renders on one GPU at 500 k /
-1080p): with the renders sharded over N ranks the episode costs about rollout + render / N per frame -- an Amdahl term that caps 8 GPUs at
-~2x (``bench.py --config 5 --with-rollout`` prints the prediction from its measured parts).
+the images to one rank afterwards.  The scene data of a frame (the GNN rollout's output) is needed on every rank, and the rollout is
+autoregressive (/root/reference/src/render/dynamics_module.py:53-172: step t + 1 needs step t), so it cannot be sharded by frames.  Two
+forms:
+
+* replicated (default; the reference's structure): every rank runs the rollout.  It is NOT cheap next to the renders (round 5: 0.5 - 0.8 ms
+  per frame against 1.0 - 1.5 ms of renders on one GPU at 500 k / 1080p), so the episode costs about rollout + render / N per frame -- an
+  Amdahl term that caps 8 GPUs at ~2 - 2.7x;
+* pipelined (``predict_episode(pipeline=True)``, round 5): ONE rank rolls out and broadcasts what each moving step does to the Gaussians --
+  <= ``max_nobj`` bones with a rotation, a translation and a quaternion each: 8.8 KB -- and the other ranks apply it with one skinning
+  launch per frame and render (``_predict_episode_pipelined``).  A render rank then costs skinning + render / (N - 1) per frame, the
+  producer's rollout is the pipeline's critical path: predicted 3.0 - 3.7x at 8 GPUs from the parts measured on one
+  (``bench.py --config 5 --with-rollout``).  Same frames, bit for bit (tests/test_predict_shard_cpu.py with gloo,
+  tests/test_multirank_gpu.py with 2 / 3 processes on the real kernels).
 
 ``predict_episode`` composes the whole of /root/reference/src/predict.py:74-164 for one episode -- ``collect_scene_data``
 (/root/reference/src/render/dynamics_module.py:174-257: activations, low-opacity and outlier filtering, the autoregressive GNN
@@ -109,8 +117,8 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
     sampling (:194-212), then rollout -> smoothing -> per-frame render inputs.  Returns (scene_data, vis_data, timings).
     ``spatial_sort`` (not in the reference): the per-frame arrays are handed to the renderer in Morton order of the frame-0
-    positions (``dynamics.spatial_order``: one permutation per episode, applied AFTER the rollout, whose farthest-point picks
-    depend on the index order) -- the same images up to exact depth ties, a twice faster entry scatter in the rasterizer.
+    positions (``dynamics.spatial_order``: one permutation per episode; the farthest-point picks, which depend on the index order,
+    are kept by mapping the inlier list) -- the same images up to exact depth ties, a twice faster entry scatter in the rasterizer.
     ``on_frame(t, frame_dict, event)``: STREAMING mode -- every frame is handed over as soon as it is final (a frame in which the
     Gaussians moved: at once; the repeated frames before it: interpolated right then), with a device event recorded behind its
     last producer on the current stream; the returned scene data are those same per-frame dicts.  Same values as the batch mode
@@ -140,19 +148,25 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     if eef.dim() == 2:
         eef = eef[:, None, :]
     n_steps = min(int(eef.shape[0]), max_steps)
+    # Morton order BEFORE the rollout (round 5; after it until then: five 500 k-row gathers per frame, ~0.2 ms of every frame on every
+    # rank): the skinning is per Gaussian, and the only index-order-dependent piece -- the farthest-point picks over xyz_0[inlier] --
+    # sees the same sequence of points when the inlier list is mapped through the inverse permutation.  Same values, bit for bit, as
+    # permuting the finished frames (tests/test_predict_shard_cpu.py).
+    if spatial_sort and int(xyz_0.shape[0]) > 1:
+        perm = D.spatial_order(xyz_0)                 # frame 0 IS xyz_0
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        xyz_0, rgb_0, quat_0, opa_0, scales_0 = xyz_0[perm], rgb_0[perm], quat_0[perm], opa_0[perm], scales_0[perm]
+        inlier = inv[inlier]
     if on_frame is not None:
         # ---- streaming: frames leave in order as they become final
-        perm = D.spatial_order(xyz_0) if (spatial_sort and int(xyz_0.shape[0]) > 1) else None     # frame 0 IS xyz_0
-        pick = (lambda t: t) if perm is None else (lambda t: t[perm])
-        scales_p = pick(scales_0)
         scene, state = [], {"cp": 0, "next": 0}
 
         def emit(arrays, upto):                   # frames state["next"] .. upto are final
             xyz, rgb, quat, opa = arrays[0], arrays[1], arrays[2], arrays[3]
             for t in range(state["next"], upto + 1):
-                m = pick(xyz[t])
-                d = {"means3D": m, "colors_precomp": pick(rgb[t]), "rotations": pick(torch.nn.functional.normalize(quat[t], dim=-1)),
-                     "opacities": pick(opa[t]), "scales": scales_p, "means2D": torch.zeros_like(m)}
+                d = {"means3D": xyz[t], "colors_precomp": rgb[t], "rotations": torch.nn.functional.normalize(quat[t], dim=-1),
+                     "opacities": opa[t], "scales": scales_0, "means2D": torch.zeros_like(xyz[t])}
                 scene.append(d)
                 ev = None
                 if dev.type == "cuda":
@@ -183,10 +197,6 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
                     adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
                     n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, on_skin=on_skin, skin_source=skin_source)
     out = D.smooth_frames(*out)
-    if spatial_sort and int(xyz_0.shape[0]) > 1:
-        perm = D.spatial_order(out[0][0].to(dev)).to(out[0].device)
-        out = (out[0][:, perm], out[1][:, perm], out[2][:, perm], out[3][:, perm], out[4], out[5])
-        scales_0 = scales_0[perm.to(dev)]
     scene, vis = D.pack_scene_data(out[0], out[1], out[2], out[3], scales_0, out[4], out[5])
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)

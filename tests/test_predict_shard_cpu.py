@@ -155,9 +155,12 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
     from gsdyn.dynamics import spatial_order
     perm = spatial_order(scene[0]["means3D"])
     assert sorted(perm.tolist()) == list(range(scene[0]["means3D"].shape[0])) and not torch.equal(perm, torch.arange(perm.numel()))
-    for a, b in zip(scene_sorted, scene):          # one permutation for the whole episode, every per-Gaussian array
-        for k in a:
-            assert torch.equal(a[k], b[k][perm]), k
+    for t, (a, b) in enumerate(zip(scene_sorted, scene)):    # one permutation for the whole episode, every per-Gaussian array.  The order is
+        for k in a:                                          # applied BEFORE the rollout (the inlier list mapped through its inverse: the same
+            if t == 0 or k not in ("means3D", "rotations"):  # farthest-point picks); the skinning is per Gaussian, but torch's CPU cdist / einsum
+                assert torch.equal(a[k], b[k][perm]), (t, k)  # block over rows, so moved frames agree to rounding here (the HIP kernel: one thread
+            else:                                            # per Gaussian)
+                assert float((a[k] - b[k][perm]).abs().max()) < 2e-6, (t, k, float((a[k] - b[k][perm]).abs().max()))
     # streaming mode (frames handed over while the rollout goes on: predict_episode(overlap=True)) == batch mode, bit for bit, in order
     got = []
     scene_stream, vis_stream, _ = collect_scene_data(model, params, eef, on_frame=lambda t, d, ev: got.append((t, d, ev)), **ROLL)
