@@ -906,6 +906,41 @@ int gsr_construct_edges_dense(const float* positions, int32_t n_obj_cap, const i
   return gsr_launch_construct_edges(positions, n_obj_cap, (const int*)n_valid, thresh_sq, topk, (long long)dummy_index, e_cap, (long long*)receivers,
                                     (long long*)senders, (int*)count, (long long*)relations, relations_n, (hipStream_t)stream);
 }
+int gsr_construct_edges_rows(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                             int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, int64_t* relations, int32_t relations_n,
+                             int64_t* row_start, void* stream) {
+  GsrRange _range("gsr_construct_edges");
+  if (!positions || !n_valid || !receivers || !senders || !count || !relations || !row_start || n_obj_cap < 1 || n_obj_cap > 127 || topk < 1 || topk > 16 ||
+      e_cap < 1 || relations_n < n_obj_cap + 1 || dummy_index < n_obj_cap + 1 || dummy_index >= relations_n) {
+    gsr_set_error("gsr_construct_edges_rows: bad argument (1 <= n_obj_cap <= 127, 1 <= topk <= 16, n_obj_cap < dummy_index < relations_n)");
+    return -2;
+  }
+  return gsr_launch_construct_edges(positions, n_obj_cap, (const int*)n_valid, thresh_sq, topk, (long long)dummy_index, e_cap, (long long*)receivers,
+                                    (long long*)senders, (int*)count, (long long*)relations, relations_n, (hipStream_t)stream, (long long*)row_start);
+}
+int gsr_rollout_step_head(int32_t n_track, int32_t n_his, int32_t n_bones, int32_t n_rows, int32_t attr_dim, int32_t with_state, const float* hist,
+                          const int64_t* sample_idx, const int64_t* thin_idx, const float* eef_hist, const float* eef_next, const float* attrs,
+                          const float* instance, float* bones_last, float* states_last, float* state_rows, float* action_rows, float* particle_inputs,
+                          float* rel_nodes, void* stream) {
+  GsrRange _range("gsr_rollout_step_head");
+  if (n_track < 1 || n_his < 1 || n_bones < 1 || n_rows < n_bones + 1 || attr_dim < 0 || !hist || !sample_idx || !thin_idx || !eef_hist || !eef_next ||
+      (attr_dim > 0 && !attrs) || !instance || !bones_last || !states_last || !state_rows || !action_rows || !particle_inputs || !rel_nodes) {
+    gsr_set_error("gsr_rollout_step_head: bad argument (n_rows > n_bones)");
+    return -2;
+  }
+  return gsr_launch_rollout_head(n_track, n_his, n_bones, n_rows, attr_dim, with_state ? 1 : 0, hist, (const long long*)sample_idx, (const long long*)thin_idx,
+                                 eef_hist, eef_next, attrs, instance, bones_last, states_last, state_rows, action_rows, particle_inputs, rel_nodes,
+                                 (hipStream_t)stream);
+}
+int gsr_rollout_step_motion(int32_t n_bones, int32_t n_his, float motion_clamp, const float* state_rows, const float* pred_motion, const int32_t* n_valid,
+                            float* skin_packet, void* stream) {
+  GsrRange _range("gsr_rollout_step_motion");
+  if (n_bones < 1 || n_his < 1 || !(motion_clamp >= 0.0f) || !state_rows || !pred_motion || !n_valid || !skin_packet) {
+    gsr_set_error("gsr_rollout_step_motion: bad argument");
+    return -2;
+  }
+  return gsr_launch_rollout_motion(n_bones, n_his, motion_clamp, state_rows, pred_motion, (const int*)n_valid, skin_packet, (hipStream_t)stream);
+}
 int gsr_rollout_step_tail(int32_t n_track, int32_t n_his, int32_t n_bones, const float* all_pos, const int64_t* track, float* pos_track, float* hist,
                           float* eef_hist, const float* eef_next, const float* pred_in, const int32_t* n_valid, const int32_t* code, float* pred_out,
                           int32_t* n_valid_out, int64_t* bad, void* stream) {
@@ -938,6 +973,17 @@ int gsr_gnn_aggregate(int32_t n_rows, int32_t n_sum_rows, int32_t width, const f
     return -2;
   }
   return gsr_launch_gnn_aggregate(n_rows, n_sum_rows, width, rel_part, node_parts, (const long long*)senders, (const long long*)row_start, agg, (hipStream_t)stream);
+}
+int gsr_gnn_aggregate_res(int32_t n_rows, int32_t n_sum_rows, int32_t width, const float* rel_part, const float* node_parts, const int64_t* senders,
+                          const int64_t* row_start, float* agg, const float* res_a, const float* res_b, float* res_out, void* stream) {
+  GsrRange _range("gsr_gnn_aggregate");
+  if (n_rows <= 0 || n_sum_rows < 0 || n_sum_rows > n_rows || width <= 0 || (width & 3) || !rel_part || !node_parts || !senders || !row_start || !agg ||
+      !res_a || !res_b || !res_out) {
+    gsr_set_error("gsr_gnn_aggregate_res: bad argument (width a multiple of 4)");
+    return -2;
+  }
+  return gsr_launch_gnn_aggregate(n_rows, n_sum_rows, width, rel_part, node_parts, (const long long*)senders, (const long long*)row_start, agg, (hipStream_t)stream,
+                                  res_a, res_b, res_out);
 }
 int gsr_gnn_rel_inputs(int32_t n_rel, int32_t attr_dim, int32_t group_dim, int32_t state_cols, const float* rel_nodes, const int64_t* receivers,
                        const int64_t* senders, float* out, void* stream) {

@@ -135,7 +135,8 @@ static inline size_t gsr_carve_binning(void* base, uint32_t D, BinningState* bs)
 static inline bool gsr_host_block_scan(int P) { return (P + GSR_BLOCK - 1) / GSR_BLOCK <= GSR_HOST_SCAN_MAX_BLOCKS; }
 
 // ---------------------------------------------------------------- propagation network pieces (gsr_gnn.hip)
-int gsr_launch_gnn_aggregate(int N, int n_sum, int H, const float* rew1, const float* a23, const long long* send, const long long* row_start, float* agg, hipStream_t st);
+int gsr_launch_gnn_aggregate(int N, int n_sum, int H, const float* rew1, const float* a23, const long long* send, const long long* row_start, float* agg, hipStream_t st,
+                             const float* res_a = nullptr, const float* res_b = nullptr, float* res_out = nullptr);
 int gsr_launch_gnn_rel_inputs(int E, int A, int G, int S, const float* nodes, const long long* recv, const long long* send, float* out, hipStream_t st);
 
 // ---------------------------------------------------------------- error plumbing (gsr_api.hip)
@@ -368,7 +369,12 @@ int gsr_launch_fps_thin(int N, const float* pos, int npoints, int start, float r
 int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const float* t, const float* bq, const float* xyz,
                    const float* quat, float* out_xyz, float* out_quat, hipStream_t st, const int* nb_valid = nullptr);
 int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
-                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st);
+                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st, long long* row_start = nullptr);
+int gsr_launch_rollout_head(int n_track, int n_his, int nb, int n_cap, int A, int with_state, const float* hist, const long long* idx1,
+                            const long long* thin, const float* eef_hist, const float* eef_next, const float* attrs, const float* inst,
+                            float* bones_last, float* states_last, float* state_t, float* act, float* p_in, float* nodes, hipStream_t st);
+int gsr_launch_rollout_motion(int nb, int n_his, float clampv, const float* state_t, const float* pred_motion, const int* cnt, float* packet,
+                              hipStream_t st);
 int gsr_launch_rollout_tail(int n_track, int n_his, int nb, const float* all_pos, const long long* track, float* pos_track, float* hist,
                             float* eef_hist, const float* eef_next, const float* pred_in, const int* cnt, const int* code, float* pred_out,
                             int* n_valid_out, long long* bad, hipStream_t st);

@@ -69,9 +69,14 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos
 // first lane holding it (ballot + ffs) -- no LDS crossbar trip; workgroup level: one LDS word pair per wave and ONE barrier (two
 // buffers, alternated by the caller), every thread reduces the FT_THREADS / 64 candidates itself.
 #define FT_THREADS 256
+typedef float gsr_f2 __attribute__((ext_vector_type(2)));
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float ft_dpp_max(float v) {
   return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false)));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int ft_dpp_imax(int v) {      // for non-negative integers (the zeros a masked DPP step reads are neutral)
+  return max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ void block_argmax_first(float& best, int& besti, float* s_val, int* s_idx, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
@@ -174,36 +179,60 @@ __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restri
   __shared__ float sp[3 * 128];           // the picked points, in pick order
   __shared__ float sa[3 * 1024];          // the whole cloud (a pick's coordinates)
   const int lane = threadIdx.x;
-  float px[16], py[16], pz[16], mind[16];
+  // Round 5: the points sit in registers as PAIRS (<2 x float>: v_pk_add_f32 / v_pk_mul_f32 do two points per issue -- 8 packed issues
+  // per pair for the 16 scalar ones of dx, dy, dz, their squares and the two adds, in the same order and rounding), and a lane no longer
+  // tracks the index of its maximum while it updates (a compare and two selects per point): the wave maximum is found on the values alone
+  // (v_max3), and only then the first slot that holds it -- 16 compares whose lane masks are read at the winning lane by scalar code.
+  // 176 -> ~110 VALU issues per pick of one wave that issues one every ~4.5 cycles: 77 -> ?? us per call at 1000 points / 100 picks.
+  // The running minima are kept as their BIT PATTERNS and compared as signed integers: squared distances are >= +0 (or +inf at the start),
+  // for which the integer order is the float order; the -1.0f of a slot beyond N is a negative integer, below all of them; a NaN distance
+  // (a NaN coordinate) is above +inf and never replaces a minimum -- fminf's choice too.  Integer min / max need no canonicalising
+  // v_max_f32 x, x in front (the float forms cost one per operand that is carried around the loop).
+  gsr_f2 px[8], py[8], pz[8];
+  int mind[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = 16 * lane + q;
     const bool have = i < N;
-    px[q] = have ? pos[3 * i] : 0.f; py[q] = have ? pos[3 * i + 1] : 0.f; pz[q] = have ? pos[3 * i + 2] : 0.f;
-    sa[3 * i] = px[q]; sa[3 * i + 1] = py[q]; sa[3 * i + 2] = pz[q];
-    mind[q] = have ? __builtin_inff() : -1.0f;      // a slot beyond N never beats `best` (>= -1): the pick loop needs no bounds test
+    const float x = have ? pos[3 * i] : 0.f, y = have ? pos[3 * i + 1] : 0.f, z = have ? pos[3 * i + 2] : 0.f;
+    sa[3 * i] = x; sa[3 * i + 1] = y; sa[3 * i + 2] = z;
+    mind[q] = have ? 0x7f800000 : (int)0xbf800000;         // +inf; -1.0f: a slot beyond N never reaches the wave maximum (>= 0): no bounds test in the loop
+    if (q & 1) { px[q >> 1].y = x; py[q >> 1].y = y; pz[q >> 1].y = z; }
+    else { px[q >> 1].x = x; py[q >> 1].x = y; pz[q >> 1].x = z; }
   }
   __syncthreads();
   int cur = start;
   for (int k = 0; k < npoints; ++k) {
     const float cx = sa[3 * cur], cy = sa[3 * cur + 1], cz = sa[3 * cur + 2];
     if (lane == 0) { out_idx[k] = cur; sp[3 * k] = cx; sp[3 * k + 1] = cy; sp[3 * k + 2] = cz; }
-    float best = -1.0f;
-    int besti = 0x7fffffff;
+    const gsr_f2 c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
+    int mx = -1;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      mind[q] = fminf(mind[q], d);
-      if (mind[q] > best) { best = mind[q]; besti = 16 * lane + q; }      // ascending index: the lane's first maximum
+    for (int p = 0; p < 8; ++p) {
+      gsr_f2 d;
+      {
+#pragma clang fp contract(off)
+        const gsr_f2 dx = px[p] - c_x, dy = py[p] - c_y, dz = pz[p] - c_z;
+        d = (dx * dx + dy * dy) + dz * dz;                 // = __fadd_rn(__fadd_rn(dx dx, dy dy), dz dz) per point
+      }
+      mind[2 * p] = min(mind[2 * p], __float_as_int(d.x));
+      mind[2 * p + 1] = min(mind[2 * p + 1], __float_as_int(d.y));
+      mx = max(mx, max(mind[2 * p], mind[2 * p + 1]));
     }
-    float m = fmaxf(best, 0.0f);
-    m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
-    m = ft_dpp_max<0x142, 0xA>(m); m = ft_dpp_max<0x143, 0xC>(m);
-    const float wmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
-    const uint64_t who = __ballot(best == wmax && best >= 0.0f);
-    cur = who ? __builtin_amdgcn_readlane(besti, __ffsll((long long)who) - 1) : 0x7fffffff;
+    int m = max(mx, 0);
+    m = ft_dpp_imax<0xB1>(m); m = ft_dpp_imax<0x4E>(m); m = ft_dpp_imax<0x141>(m); m = ft_dpp_imax<0x140>(m);
+    m = ft_dpp_imax<0x142, 0xA>(m); m = ft_dpp_imax<0x143, 0xC>(m);
+    const int wmax = __builtin_amdgcn_readlane(m, 63);
+    const uint64_t who = __ballot(mx == wmax);             // (mx = -1 -- a lane without points -- never equals wmax >= 0)
     if (!who) break;                        // (N == 0: nothing to pick; the launcher does not get here)
+    const int L = __ffsll((long long)who) - 1;             // the first lane that holds the maximum: the lowest indices
+    int qf = 15;                                           // ... and its first slot that does (descending: the last assignment wins)
+#pragma unroll
+    for (int q = 15; q >= 0; --q) {
+      const uint64_t eq = __ballot(mind[q] == wmax);
+      if ((eq >> L) & 1ull) qf = q;
+    }
+    cur = 16 * L + qf;
   }
   __syncthreads();                          // sp[] complete (one wave: orders the LDS writes of lane 0 before the reads below)
   float qx[2], qy[2], qz[2], dist[2];
@@ -272,7 +301,8 @@ __device__ __forceinline__ unsigned long long ce_wave_min(unsigned long long v) 
 __global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float* __restrict__ pos, int n_obj_cap, const int* __restrict__ n_valid_p,
                                                                    float thr2, int topk, long long dummy, int e_cap,
                                                                    long long* __restrict__ recv, long long* __restrict__ send,
-                                                                   int* __restrict__ count, long long* __restrict__ rel, int rel_n) {
+                                                                   int* __restrict__ count, long long* __restrict__ rel, int rel_n,
+                                                                   long long* __restrict__ row_start) {
   __shared__ float sp[3 * 128];
   __shared__ unsigned long long s_mask[128][2];      // row i: which senders it is related to
   __shared__ int s_base[128];
@@ -350,6 +380,11 @@ __global__ __launch_bounds__(CE_THREADS) void construct_edges_kernel(const float
       const int i = o / rel_n, j = o - i * rel_n;
       rel[o] = (i < N && j < N) ? (long long)((s_mask[i][j >> 6] >> (j & 63)) & 1ull) : 0ll;
     }
+  // row_start[i] = the number of list entries whose receiver is below i, i = 0 .. rel_n (what torch.searchsorted(receivers, arange(rel_n + 1))
+  // gives on the padded list: the padding's receiver is `dummy`) -- the segment bounds of gsr_gnn_aggregate, two launches less per step
+  if (row_start)
+    for (int i = tid; i <= rel_n; i += CE_THREADS)
+      row_start[i] = i < N ? (long long)min(s_base[i], e_cap) : ((long long)i <= dummy ? (long long)min(total, e_cap) : (long long)e_cap);
 }
 
 // ---------------------------------------------------------------- farthest point sampling, several workgroups
@@ -749,6 +784,84 @@ int gsr_launch_lbs(int P, int nb, const float* bones, const float* R, const floa
   return 0;
 }
 
+// ---------------------------------------------------------------- the torch glue of a graphed rollout step, as two launches
+// A step replayed from a hipGraph is a CHAIN of ~55 nodes and lasts about 4.5 us per node whatever the node does (round 5: 433 us per step
+// of which the kernels with real work -- sampling, skinning, relations, rotation fit -- are 160): what counts is the node count.
+// rollout_head_kernel: everything between the bone sampling and the network that torch spelled as gathers, transposes and concatenations
+// (/root/reference/src/render/dynamics_module.py:104-131 builds the same tensors with torch.cat per step) -- one thread per padded row r:
+//   state row  = the n_his positions of bone r (hist[:, idx1[thin[r]]]), of the tool (row nb: eef_hist), zeros behind;
+//   action row = eef_next - eef_hist[-1] for the tool, zeros elsewhere;
+//   p_in  [n_cap, A + (S ? 3 n_his : 0) + 3] = (attributes, [state], action)      -- the particle encoder's input
+//   nodes [n_cap, A + 1 + 3 n_his]           = (attributes, instance, state)      -- what gsr_gnn_rel_inputs gathers from
+//   bones_last [nb, 3], states_last [nb + 1, 3] = the last frame's positions (for gsr_fit_bones / gsr_construct_edges).
+// Nine launches (2 gathers, 5 concatenations, a transpose copy, a subtraction) become one.
+__global__ __launch_bounds__(GSR_BLOCK) void rollout_head_kernel(int n_track, int n_his, int nb, int n_cap, int A, int with_state,
+                                                                const float* __restrict__ hist, const long long* __restrict__ idx1,
+                                                                const long long* __restrict__ thin, const float* __restrict__ eef_hist,
+                                                                const float* __restrict__ eef_next, const float* __restrict__ attrs,
+                                                                const float* __restrict__ inst, float* __restrict__ bones_last,
+                                                                float* __restrict__ states_last, float* __restrict__ state_t,
+                                                                float* __restrict__ act, float* __restrict__ p_in, float* __restrict__ nodes) {
+  const int r = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (r >= n_cap) return;
+  const int S3 = 3 * n_his, Dp = A + (with_state ? S3 : 0) + 3, Dn = A + 1 + S3;
+  const long long p = r < nb ? idx1[thin[r]] : 0;
+  float a3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a3[c] = r == nb ? eef_next[c] - eef_hist[3 * (n_his - 1) + c] : 0.f;
+  for (int k = 0; k < A; ++k) { const float v = attrs[(size_t)r * A + k]; p_in[(size_t)r * Dp + k] = v; nodes[(size_t)r * Dn + k] = v; }
+  nodes[(size_t)r * Dn + A] = inst[r];
+  for (int h = 0; h < n_his; ++h)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = r < nb ? hist[((size_t)h * n_track + p) * 3 + c] : (r == nb ? eef_hist[3 * h + c] : 0.f);
+      state_t[(size_t)r * S3 + 3 * h + c] = v;
+      nodes[(size_t)r * Dn + A + 1 + 3 * h + c] = v;
+      if (with_state) p_in[(size_t)r * Dp + A + 3 * h + c] = v;
+      if (h == n_his - 1) {
+        if (r < nb) bones_last[3 * r + c] = v;
+        if (r <= nb) states_last[3 * r + c] = v;
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { act[3 * r + c] = a3[c]; p_in[(size_t)r * Dp + Dp - 3 + c] = a3[c]; }
+}
+// rollout_motion_kernel: behind the network's last product -- predicted position = last position + clamp(predicted motion) (model.py:240-244),
+// the bones' motion = predicted - last (dynamics_module.py:133), written straight into the step's skinning packet (gsdyn.dynamics.pack_skin:
+// head, bones, [rotations], motions, [quaternions], predicted; gsr_fit_bones writes the two bracketed blocks in place): a clamp, an add, a
+// subtraction, a conversion and a concatenation become one launch.  The arithmetic and its order are torch's (NaN stays NaN).
+__global__ __launch_bounds__(GSR_BLOCK) void rollout_motion_kernel(int nb, int n_his, float clampv, const float* __restrict__ state_t,
+                                                                  const float* __restrict__ pred_motion, const int* __restrict__ cnt,
+                                                                  float* __restrict__ packet) {
+  const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+  if (i == 0) { packet[0] = (float)*cnt; packet[1] = 1.0f; }
+  if (i >= 3 * nb) return;
+  const int r = i / 3, c = i - 3 * r;
+  const float s = state_t[(size_t)r * 3 * n_his + 3 * (n_his - 1) + c], m = pred_motion[3 * r + c];
+  const float cl = m < -clampv ? -clampv : (m > clampv ? clampv : m);
+  const float pr = s + cl;
+  packet[2 + i] = s;
+  packet[2 + 12 * nb + i] = pr - s;
+  packet[2 + 19 * nb + i] = pr;
+}
+int gsr_launch_rollout_head(int n_track, int n_his, int nb, int n_cap, int A, int with_state, const float* hist, const long long* idx1,
+                            const long long* thin, const float* eef_hist, const float* eef_next, const float* attrs, const float* inst,
+                            float* bones_last, float* states_last, float* state_t, float* act, float* p_in, float* nodes, hipStream_t st) {
+  { GSR_PROF("rollout_head", st);
+    hipLaunchKernelGGL(rollout_head_kernel, dim3((n_cap + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, n_track, n_his, nb, n_cap, A, with_state, hist, idx1,
+                       thin, eef_hist, eef_next, attrs, inst, bones_last, states_last, state_t, act, p_in, nodes); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int gsr_launch_rollout_motion(int nb, int n_his, float clampv, const float* state_t, const float* pred_motion, const int* cnt, float* packet,
+                              hipStream_t st) {
+  { GSR_PROF("rollout_motion", st);
+    hipLaunchKernelGGL(rollout_motion_kernel, dim3((3 * nb + GSR_BLOCK - 1) / GSR_BLOCK > 0 ? (3 * nb + GSR_BLOCK - 1) / GSR_BLOCK : 1), dim3(GSR_BLOCK), 0, st, nb,
+                       n_his, clampv, state_t, pred_motion, cnt, packet); }
+  GSR_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- bookkeeping at the end of a graphed rollout step
 // After the skinning: the tracked particles' new positions gathered out of the cloud, the history windows shifted by one frame
 // (dynamics_module.py:150-165 of the reference does this with torch.cat per step), the predicted bones masked to the valid ones, the
@@ -801,9 +914,10 @@ int gsr_launch_rollout_tail(int n_track, int n_his, int nb, const float* all_pos
 }
 
 int gsr_launch_construct_edges(const float* pos, int n_obj_cap, const int* n_valid, float thr2, int topk, long long dummy, int e_cap,
-                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st) {
+                               long long* recv, long long* send, int* count, long long* rel, int rel_n, hipStream_t st, long long* row_start) {
   { GSR_PROF("construct_edges", st);
-    hipLaunchKernelGGL(construct_edges_kernel, dim3(1), dim3(CE_THREADS), 0, st, pos, n_obj_cap, n_valid, thr2, topk, dummy, e_cap, recv, send, count, rel, rel_n); }
+    hipLaunchKernelGGL(construct_edges_kernel, dim3(1), dim3(CE_THREADS), 0, st, pos, n_obj_cap, n_valid, thr2, topk, dummy, e_cap, recv, send, count, rel, rel_n,
+                       row_start); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

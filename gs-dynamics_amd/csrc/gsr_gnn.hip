@@ -15,10 +15,15 @@
 namespace gsr_gnn {
 __global__ __launch_bounds__(256) void aggregate_kernel(int N, int n_sum, int H, const float* __restrict__ rew1, const float* __restrict__ a23,
                                                         const long long* __restrict__ send, const long long* __restrict__ row_start,
-                                                        float* __restrict__ agg) {
+                                                        float* __restrict__ agg, const float* __restrict__ res_a, const float* __restrict__ res_b,
+                                                        float* __restrict__ res_out) {
   const int o = blockIdx.x * 256 + threadIdx.x, q = H >> 2;
   if (o >= N * q) return;
   const int i = o / q, k4 = (o - i * q) << 2;
+  if (res_out) {   // the particle propagator's addend of this step, res_a + res_b (= particle_encode @ Wp1^T + b, and the effect as the residual):
+    const float4 x = *reinterpret_cast<const float4*>(res_a + (size_t)i * H + k4), y = *reinterpret_cast<const float4*>(res_b + (size_t)i * H + k4);
+    *reinterpret_cast<float4*>(res_out + (size_t)i * H + k4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);   // one launch less per step
+  }
   const float4 a2 = *reinterpret_cast<const float4*>(a23 + (size_t)i * 2 * H + k4);
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int e1 = i < n_sum ? (int)row_start[i + 1] : 0;      // rows >= n_sum (the padding's dummy row, which collects every dummy relation) get zeros
@@ -49,9 +54,10 @@ __global__ __launch_bounds__(256) void rel_inputs_kernel(int E, int A, int G, in
 }  // namespace gsr_gnn
 
 int gsr_launch_gnn_aggregate(int N, int n_sum, int H, const float* rew1, const float* a23, const long long* send, const long long* row_start, float* agg,
-                             hipStream_t st) {
+                             hipStream_t st, const float* res_a, const float* res_b, float* res_out) {
   { GSR_PROF("gnn_aggregate", st);
-    hipLaunchKernelGGL(gsr_gnn::aggregate_kernel, dim3((N * (H >> 2) + 255) / 256), dim3(256), 0, st, N, n_sum, H, rew1, a23, send, row_start, agg); }
+    hipLaunchKernelGGL(gsr_gnn::aggregate_kernel, dim3((N * (H >> 2) + 255) / 256), dim3(256), 0, st, N, n_sum, H, rew1, a23, send, row_start, agg, res_a, res_b,
+                       res_out); }
   GSR_HIP_CHECK(hipGetLastError());
   return 0;
 }

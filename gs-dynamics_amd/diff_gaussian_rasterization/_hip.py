@@ -76,7 +76,8 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_views_loss_blocks", "gsr_views_loss_forward", "gsr_views_loss_backward", "gsr_target_moments",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping", "gsr_wait_counts",
-           "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail")
+           "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail",
+           "gsr_construct_edges_rows", "gsr_rollout_step_head", "gsr_rollout_step_motion", "gsr_gnn_aggregate_res")
 
 
 def load_library():
@@ -183,6 +184,14 @@ def load_library():
     lib.gsr_gnn_aggregate.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.gsr_gnn_rel_inputs.restype = C.c_int
     lib.gsr_gnn_rel_inputs.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gsr_gnn_aggregate_res.restype = C.c_int
+    lib.gsr_gnn_aggregate_res.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_construct_edges_rows.restype = C.c_int
+    lib.gsr_construct_edges_rows.argtypes = [vp, i32, vp, C.c_float, i32, C.c_int64, i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.gsr_rollout_step_head.restype = C.c_int
+    lib.gsr_rollout_step_head.argtypes = [i32] * 6 + [vp] * 14
+    lib.gsr_rollout_step_motion.restype = C.c_int
+    lib.gsr_rollout_step_motion.argtypes = [i32, i32, C.c_float, vp, vp, vp, vp, vp]
     lib.gsr_fit_bones.restype = C.c_int
     lib.gsr_fit_bones.argtypes = [i32, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_lbs.restype = C.c_int
@@ -877,10 +886,12 @@ def fps_thin_padded(pos: torch.Tensor, npoints: int, radius: float, start_idx: i
     return out, thin, cnt
 
 
-def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: float, topk: int, e_cap: int, dummy: int, dense_n: int = 0):
+def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: float, topk: int, e_cap: int, dummy: int, dense_n: int = 0,
+                           row_start: bool = False):
     """gsr_construct_edges: pos [n_obj_cap + 1, 3] (the tool last), n_valid [1] int32 on the device -> (receivers [e_cap], senders [e_cap]
     int64 padded with ``dummy``, count [1] int32); dense_n > 0: also the relations as a dense [dense_n, dense_n] int64 0 / 1 matrix
-    (gsr_construct_edges_dense) as a fourth result."""
+    (gsr_construct_edges_dense) as a fourth result; row_start (with dense_n): also the segment bounds [dense_n + 1] of the receiver-sorted
+    list (gsr_construct_edges_rows: what searchsorted(receivers, arange(dense_n + 1)) gives) as a fifth."""
     import numpy as np
     lib = load_library()
     _require_device(pos)
@@ -891,6 +902,12 @@ def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: flo
         send = torch.empty((e_cap,), dtype=torch.int64, device=dev)
         cnt = torch.empty((1,), dtype=torch.int32, device=dev)
         thr2 = float(np.float32(float(thresh) * float(thresh)))          # the scalar a float32 tensor is compared with
+        if dense_n and row_start:
+            rel = torch.empty((int(dense_n), int(dense_n)), dtype=torch.int64, device=dev)
+            rows = torch.empty((int(dense_n) + 1,), dtype=torch.int64, device=dev)
+            _check(lib.gsr_construct_edges_rows(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
+                                                _ptr(cnt), _ptr(rel), int(dense_n), _ptr(rows), _stream(dev)), "gsr_construct_edges_rows")
+            return recv, send, cnt, rel, rows
         if dense_n:
             rel = torch.empty((int(dense_n), int(dense_n)), dtype=torch.int64, device=dev)
             _check(lib.gsr_construct_edges_dense(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
@@ -899,6 +916,40 @@ def construct_edges_padded(pos: torch.Tensor, n_valid: torch.Tensor, thresh: flo
         _check(lib.gsr_construct_edges(_ptr(p), int(p.shape[0]) - 1, _ptr(n_valid), thr2, int(topk), int(dummy), int(e_cap), _ptr(recv), _ptr(send),
                                        _ptr(cnt), _stream(dev)), "gsr_construct_edges")
     return recv, send, cnt
+
+
+def rollout_step_head(hist, sample_idx, thin_idx, eef_hist, eef_next, attrs, instance, with_state: bool):
+    """gsr_rollout_step_head (include/gsr.h): the inputs of a graphed rollout step's network from the tracked particles' history and the
+    step's bone picks, one launch.  hist [n_his, n_track, 3], sample_idx / thin_idx [n_bones] int64, eef_hist [n_his, 1, 3], eef_next [1, 3],
+    attrs [n_rows, A], instance [n_rows, 1]; returns (bones_last [nb,3], states_last [nb+1,3], state_rows [n_rows, 3 n_his], action_rows
+    [n_rows,3], particle_inputs, rel_nodes)."""
+    lib = load_library()
+    _require_device(hist)
+    dev = hist.device
+    n_his, n_track, nb, n_rows, A = int(hist.shape[0]), int(hist.shape[1]), int(sample_idx.shape[0]), int(attrs.shape[0]), int(attrs.shape[1])
+    for t in (hist, eef_hist, eef_next, attrs, instance):
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.device == dev):
+            raise ValueError("rollout_step_head: contiguous float32 tensors on one device, please")
+    with _on(dev):
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        bones, states, st, act = e(nb, 3), e(nb + 1, 3), e(n_rows, 3 * n_his), e(n_rows, 3)
+        p_in, nodes = e(n_rows, A + (3 * n_his if with_state else 0) + 3), e(n_rows, A + 1 + 3 * n_his)
+        _check(lib.gsr_rollout_step_head(n_track, n_his, nb, n_rows, A, 1 if with_state else 0, _ptr(hist), _ptr(sample_idx), _ptr(thin_idx), _ptr(eef_hist),
+                                         _ptr(eef_next), _ptr(attrs), _ptr(instance), _ptr(bones), _ptr(states), _ptr(st), _ptr(act), _ptr(p_in), _ptr(nodes),
+                                         _stream(dev)), "gsr_rollout_step_head")
+    return bones, states, st, act, p_in, nodes
+
+
+def rollout_step_motion(state_rows, pred_motion, n_valid, packet, n_bones: int, n_his: int, motion_clamp: float):
+    """gsr_rollout_step_motion (include/gsr.h): predicted bone positions and motions of a step into its skinning packet (head, bones,
+    motions, predicted blocks); state_rows [n_rows, 3 n_his], pred_motion [n_rows, 3] contiguous float32, n_valid [1] int32."""
+    lib = load_library()
+    dev = packet.device
+    if not (pred_motion.is_contiguous() and state_rows.is_contiguous() and packet.is_contiguous() and int(packet.numel()) >= 2 + 22 * int(n_bones)):
+        raise ValueError("rollout_step_motion: contiguous tensors and a packet of 2 + 22 n_bones floats, please")
+    with _on(dev):
+        _check(lib.gsr_rollout_step_motion(int(n_bones), int(n_his), float(motion_clamp), _ptr(state_rows), _ptr(pred_motion), _ptr(n_valid), _ptr(packet),
+                                           _stream(dev)), "gsr_rollout_step_motion")
 
 
 def rollout_step_tail(all_pos, track, pos_track, hist, eef_hist, eef_next, pred_in, n_valid, code, pred_out, n_valid_out, bad):
@@ -944,22 +995,32 @@ def gnn_rel_inputs(rel_nodes: torch.Tensor, receivers: torch.Tensor, senders: to
     return out
 
 
-def gnn_aggregate(rel_part: torch.Tensor, node_parts: torch.Tensor, senders: torch.Tensor, row_start: torch.Tensor, n_sum_rows: int = None) -> torch.Tensor:
+def gnn_aggregate(rel_part: torch.Tensor, node_parts: torch.Tensor, senders: torch.Tensor, row_start: torch.Tensor, n_sum_rows: int = None, res=None):
     """gsr_gnn_aggregate: rel_part [E, H], node_parts [N, 2 H], senders [E], row_start [N + 1] (int64; receivers ascending) -> agg [N, H];
-    rows >= n_sum_rows (default N) get zeros."""
+    rows >= n_sum_rows (default N) get zeros.  res = (a, b), two contiguous float32 [N, H]: also returns a + b, written by the same launch
+    (gsr_gnn_aggregate_res) -> (agg, a + b)."""
     lib = load_library()
     _require_device(rel_part)
     dev = rel_part.device
     N, H = int(node_parts.shape[0]), int(rel_part.shape[1])
     with _on(dev):
         agg = torch.empty((N, H), dtype=torch.float32, device=dev)
+        if res is not None:
+            ra, rb = res
+            if not all(t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == (N, H) for t in (ra, rb)):
+                raise ValueError("gnn_aggregate(res=...): two contiguous float32 [N, H] tensors, please")
+            out = torch.empty((N, H), dtype=torch.float32, device=dev)
+            _check(lib.gsr_gnn_aggregate_res(N, N if n_sum_rows is None else int(n_sum_rows), H, _ptr(rel_part), _ptr(node_parts), _ptr(senders), _ptr(row_start),
+                                             _ptr(agg), _ptr(ra), _ptr(rb), _ptr(out), _stream(dev)), "gsr_gnn_aggregate_res")
+            return agg, out
         _check(lib.gsr_gnn_aggregate(N, N if n_sum_rows is None else int(n_sum_rows), H, _ptr(rel_part), _ptr(node_parts), _ptr(senders), _ptr(row_start), _ptr(agg), _stream(dev)), "gsr_gnn_aggregate")
     return agg
 
 
-def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor):
+def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tensor, out=None):
     """gsr_fit_bones: bones, motions [nb,3], relations [nb,nb] (int64 0/1; any row stride, unit column stride) on a HIP device ->
-    (rotations [nb,3,3], unit quaternions [nb,4], code [nb] int32)."""
+    (rotations [nb,3,3], unit quaternions [nb,4], code [nb] int32).  out = (rotations, quaternions): contiguous float32 tensors of 9 nb and
+    4 nb elements that receive them (two blocks of a step's skinning packet: no concatenation afterwards)."""
     lib = load_library()
     _require_device(bones)
     dev = bones.device
@@ -970,8 +1031,13 @@ def fit_bones(bones: torch.Tensor, motions: torch.Tensor, relations: torch.Tenso
         rel = relations if (relations.dtype == torch.int64 and relations.dim() == 2 and (nb == 0 or relations.stride(1) == 1)) else relations.to(torch.int64).contiguous()
         if tuple(rel.shape) != (nb, nb):
             raise ValueError("fit_bones: relations must be [n_bones, n_bones]")
-        R = torch.empty((nb, 3, 3), dtype=torch.float32, device=dev)
-        q = torch.empty((nb, 4), dtype=torch.float32, device=dev)
+        if out is not None:
+            R, q = out[0].view(nb, 3, 3), out[1].view(nb, 4)
+            if not (R.is_contiguous() and q.is_contiguous() and R.dtype == torch.float32 and q.dtype == torch.float32 and R.device == dev and q.device == dev):
+                raise ValueError("fit_bones(out=...): contiguous float32 tensors on the bones' device, please")
+        else:
+            R = torch.empty((nb, 3, 3), dtype=torch.float32, device=dev)
+            q = torch.empty((nb, 4), dtype=torch.float32, device=dev)
         code = torch.empty((nb,), dtype=torch.int32, device=dev)
         _check(lib.gsr_fit_bones(nb, _ptr(b), _ptr(m), _ptr(rel), int(rel.stride(0)) if nb else 0, _ptr(R), _ptr(q), _ptr(code), _stream(dev)), "gsr_fit_bones")
     return R, q, code

@@ -306,20 +306,26 @@ class DynamicsPredictor(nn.Module):
         return (_GNN_SPLIT and a.is_cuda and not torch.is_grad_enabled() and a.dtype == torch.float32 and c["nf_effect"] % 4 == 0
                 and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["state_dim"] in (0, 1, 3))
 
-    def _propagate_split(self, state_t, a, g, act, receivers, senders, dummy_last_row: bool = False):
+    def _propagate_split(self, state_t, a, g, act, receivers, senders, dummy_last_row: bool = False, p_in=None, nodes=None, row_start=None,
+                         motion_only: bool = False):
         """``_propagate`` for relations ASCENDING in the receiver, inference on a device.  The relation propagator's product
         cat(relation_encode, effect[recv], effect[send]) @ [W1 | W2 | W3]^T is evaluated as relation_encode @ W1^T + b (once: it does not
         change over the propagation steps) + (effect @ W2^T)[recv] + (effect @ W3^T)[send] -- products on the N nodes instead of the E
         relations -- and the particle propagator's cat(particle_encode, agg) @ [Wp1 | Wp2]^T likewise; the ReLU of the relation effects
         and their sum onto the receivers are one kernel (gsr_gnn_aggregate: a segmented sum in list order, deterministic, where
-        index_add's atomics are not), the relation encoder's input rows another (gsr_gnn_rel_inputs).  Per step 5 launches instead of
+        index_add's atomics are not), the relation encoder's input rows another (gsr_gnn_rel_inputs).  Per step 4 launches instead of
         10, and an N x H x 2H product instead of an E x 3H x H one.  Exact in real arithmetic; in f32 a different summation order
-        (test_split_propagation_equals_eager: 2e-6 of the largest motion)."""
+        (test_split_propagation_equals_eager: 2e-6 of the largest motion).
+        ``p_in`` / ``nodes`` / ``row_start``: the particle encoder's input, the relation kernel's node rows and the list's segment bounds
+        when the caller has them already (the graphed rollout step: gsr_rollout_step_head, gsr_construct_edges_rows); ``motion_only``:
+        return (None, predicted motion) -- the caller clamps and adds (gsr_rollout_step_motion)."""
         from diff_gaussian_rasterization import _hip
         c = self.model_config
         H, N = c["nf_effect"], int(a.shape[0])
-        p_in = self._particle_inputs(state_t, a, act)
-        nodes = torch.cat([a, g, state_t], 1)
+        if p_in is None:
+            p_in = self._particle_inputs(state_t, a, act)
+        if nodes is None:
+            nodes = torch.cat([a, g, state_t], 1)
         rel_in = _hip.gnn_rel_inputs(nodes, receivers, senders, a.shape[1], g.shape[1])
         pe = self.particle_encoder(p_in)
         re = self.relation_encoder(rel_in)
@@ -331,13 +337,17 @@ class DynamicsPredictor(nn.Module):
         rew1 = torch.addmm(self.relation_propagator.linear.bias, re, Wr[:, :H].t())
         pewp = torch.addmm(self.particle_propagator.linear.bias, pe, Wp[:, :H].t())
         wp2t = Wp[:, H:].t()
-        row_start = torch.searchsorted(receivers, torch.arange(N + 1, device=a.device, dtype=receivers.dtype))
+        if row_start is None:
+            row_start = torch.searchsorted(receivers, torch.arange(N + 1, device=a.device, dtype=receivers.dtype))
         effect = pe
         for _ in range(c["pstep"]):
             a23 = torch.mm(effect, w23)
-            agg = _hip.gnn_aggregate(rew1, a23, senders, row_start, N - 1 if dummy_last_row else N)   # (the dummy row of a padded graph: nobody reads its effect)
-            effect = torch.relu_(torch.addmm(pewp + effect, agg, wp2t))
+            # (the dummy row of a padded graph: nobody reads its effect); pewp + effect -- the product's addend -- leaves the same launch
+            agg, base = _hip.gnn_aggregate(rew1, a23, senders, row_start, N - 1 if dummy_last_row else N, res=(pewp, effect))
+            effect = torch.relu_(torch.addmm(base, agg, wp2t))
         pred_motion = self.non_rigid_predictor(effect)
+        if motion_only:
+            return None, pred_motion
         pred_pos = state_t[:, -3:] + torch.clamp(pred_motion, -self.motion_clamp, self.motion_clamp)
         return pred_pos, pred_motion
 
@@ -647,6 +657,7 @@ _STEP_CONSTANTS: Dict = {}
 _GRAPH_ROLLOUT = os.environ.get("GSDYN_GRAPH_ROLLOUT", "1") != "0"     # 0: the GNN propagation of a rollout step runs eagerly (A/B, debugging)
 _GNN_SPLIT = os.environ.get("GSDYN_GNN_SPLIT", "1") != "0"              # 0: the propagators' concatenated products as the reference writes them (A/B)
 _GRAPH_ROLLOUT_STEP = os.environ.get("GSDYN_GRAPH_ROLLOUT_STEP", "1") != "0"   # 0: only the propagation is graphed, the rest of a step runs eagerly
+_STEP_FUSED_GLUE = os.environ.get("GSDYN_STEP_FUSED_GLUE", "1") != "0"         # 0: the graphed step's glue as torch ops (A/B, tests: the two forms are bit-identical)
 
 
 def _step_constants(nobj: int, dev):
@@ -720,6 +731,25 @@ class _GraphedStep:
         pad_rows = z(self.n_cap - N, n_his * 3)
         act_obj, act_pad = z(nb, 3), z(self.n_cap - N, 3)
 
+        fused = model._split_ok(a) and model.motion_dim == 0 and c["state_dim"] in (0, 3) and c["action_dim"] == 3 and _STEP_FUSED_GLUE
+        o_R, o_mot, o_q, o_pred = SKIN_HEAD + 3 * nb, SKIN_HEAD + 12 * nb, SKIN_HEAD + 15 * nb, SKIN_HEAD + 19 * nb
+
+        def body_fused():
+            # 33 graph nodes instead of ~51 (round 5): the gathers / concatenations between the sampling and the network are ONE launch
+            # (gsr_rollout_step_head), the list's segment bounds leave the relations kernel, clamp + add + subtract + the packet's assembly are
+            # ONE launch (gsr_rollout_step_motion), the rotation fit writes into the packet.  Same values as ``body`` below, bit for bit.
+            idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
+            bones, states_last, state_t, act, p_in, nodes = _hip.rollout_step_head(self.hist, idx1, thin, self.eef_hist, self.eef_next, a, g, c["state_dim"] == 3)
+            recv, send, _, rel, rows = _hip.construct_edges_padded(states_last, cnt, adj_thresh, topk, self.e_cap, self.n_cap - 1, dense_n=self.n_cap,
+                                                                   row_start=True)
+            _, mot = model._propagate_split(state_t, a, g, act, recv, send, dummy_last_row=True, p_in=p_in, nodes=nodes, row_start=rows, motion_only=True)
+            _hip.rollout_step_motion(state_t, mot.contiguous(), cnt, self.skin, nb, n_his, model.motion_clamp)
+            motion, pred = self.skin[o_mot:o_mot + 3 * nb].view(nb, 3), self.skin[o_pred:o_pred + 3 * nb].view(nb, 3)
+            R, q, code = _hip.fit_bones(bones, motion, rel[:nb, :nb], out=(self.skin[o_R:o_R + 9 * nb], self.skin[o_q:o_q + 4 * nb]))
+            _hip.linear_blend_skinning(bones, R, motion, q, self.all_pos, self.all_rot, n_valid=cnt, in_place=True)
+            _hip.rollout_step_tail(self.all_pos, self.track, self.pos_track, self.hist, self.eef_hist, self.eef_next, pred, cnt, code,
+                                   self.pred, self.n_valid, self.bad)
+
         def body():
             idx1, thin, cnt = _hip.fps_thin_padded(self.pos_track, nb, radius, 0, thin_start)
             bones_hist = self.hist[:, idx1[thin]]                                             # [n_his, nb, 3]; rows >= cnt repeat a real particle
@@ -741,6 +771,8 @@ class _GraphedStep:
             # the device could not resolve (rank 1: none, normally): one launch
             _hip.rollout_step_tail(self.all_pos, self.track, self.pos_track, self.hist, self.eef_hist, self.eef_next, pred.contiguous(), cnt, code,
                                    self.pred, self.n_valid, self.bad)
+        if fused:
+            body = body_fused
         self._body, self.graph = body, None
 
     def load(self, track, pos_track, hist, eef_hist, all_pos, all_rot):
@@ -830,10 +862,10 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
         if not skip[i]:
             last = eef_host[i]
     if skin_source is not None:       # (no sampling here: frame 0's keypoints arrive as packet 0)
+        if after_step is not None:    # frame 0's Gaussians need nothing from the rank that rolls out: a streaming consumer renders them
+            after_step(0, arrays, False)   # while that rank is still sampling its tracked particles (4 ms at 500 k Gaussians)
         pk0 = skin_source(0).to(dev)
         xyz_bones[0] = unpack_skin(pk0, max_nobj)[4].to(store)
-        if after_step is not None:
-            after_step(0, arrays, False)
         return _rollout_from_packets(skin_source, arrays, skip, eef_xyz, max_nobj, dev, store, after_step)
     n_his = int(model.model_config["n_his"])
     inl = torch.as_tensor(inlier_idx_all, device=dev, dtype=torch.long)

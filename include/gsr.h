@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 121 /* 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 122 /* 0.1.22: + gsr_rollout_step_head, gsr_rollout_step_motion, gsr_construct_edges_rows, gsr_gnn_aggregate_res -- the torch glue of a graphed rollout step as kernels of this library (a replayed step is a chain of nodes: fewer nodes, shorter step); 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -372,6 +372,30 @@ int gsr_construct_edges_dense(const float* positions, int32_t n_obj_cap, const i
 int gsr_rollout_step_tail(int32_t n_track, int32_t n_his, int32_t n_bones, const float* all_pos, const int64_t* track, float* pos_track, float* hist,
                           float* eef_hist, const float* eef_next, const float* pred_in, const int32_t* n_valid, const int32_t* code, float* pred_out,
                           int32_t* n_valid_out, int64_t* bad, void* stream);
+/* ABI 122 -- the glue of a rollout step (/root/reference/src/render/dynamics_module.py:104-133 spells it with torch.cat / index / clamp per
+ * step) as launches of this library; a step replayed from a hipGraph lasts ~4.5 us per node whatever the node does.
+ * gsr_construct_edges_rows = gsr_construct_edges_dense + row_start [relations_n + 1]: row_start[i] = the number of list entries whose
+ *   receiver is below i (torch.searchsorted(receivers, arange(relations_n + 1)) on the padded list; n_obj_cap < dummy_index < relations_n).
+ * gsr_rollout_step_head: from the tracked particles' history hist [n_his, n_track, 3], the step's bone picks sample_idx[thin_idx[r]]
+ *   (gsr_fps_thin's two outputs, n_bones of each), the tool's history eef_hist [n_his, 3] and target eef_next [3], and the constant
+ *   per-row attributes attrs [n_rows, attr_dim] / instance [n_rows] -- one thread per padded row r < n_rows (bones 0 .. n_bones - 1, the
+ *   tool at n_bones, zero rows behind):  state_rows [n_rows, 3 n_his] (a row = its n_his positions), action_rows [n_rows, 3] (the tool's
+ *   eef_next - eef_hist[-1], zeros elsewhere), particle_inputs [n_rows, attr_dim + (with_state ? 3 n_his : 0) + 3] = (attributes, [state],
+ *   action), rel_nodes [n_rows, attr_dim + 1 + 3 n_his] = (attributes, instance, state), bones_last [n_bones, 3] and states_last
+ *   [n_bones + 1, 3] = the last frame's positions.
+ * gsr_rollout_step_motion: predicted = last position + clamp(pred_motion, +-motion_clamp), motion = predicted - last, for the n_bones bone
+ *   rows, written into the step's skinning packet (gsdyn.dynamics.pack_skin: [0] = *n_valid as a float, [1] = 1, then blocks of n_bones
+ *   rows: bones 3, rotations 9, motions 3, quaternions 4, predicted 3 floats per row) -- the rotations and quaternions blocks are
+ *   gsr_fit_bones' outputs, which may point into the packet. */
+int gsr_construct_edges_rows(const float* positions, int32_t n_obj_cap, const int32_t* n_valid, float thresh_sq, int32_t topk, int64_t dummy_index,
+                             int32_t e_cap, int64_t* receivers, int64_t* senders, int32_t* count, int64_t* relations, int32_t relations_n,
+                             int64_t* row_start, void* stream);
+int gsr_rollout_step_head(int32_t n_track, int32_t n_his, int32_t n_bones, int32_t n_rows, int32_t attr_dim, int32_t with_state, const float* hist,
+                          const int64_t* sample_idx, const int64_t* thin_idx, const float* eef_hist, const float* eef_next, const float* attrs,
+                          const float* instance, float* bones_last, float* states_last, float* state_rows, float* action_rows, float* particle_inputs,
+                          float* rel_nodes, void* stream);
+int gsr_rollout_step_motion(int32_t n_bones, int32_t n_his, float motion_clamp, const float* state_rows, const float* pred_motion, const int32_t* n_valid,
+                            float* skin_packet, void* stream);
 int gsr_lbs_valid(int32_t P, int32_t n_bones, const int32_t* n_valid, const float* bones, const float* rotations, const float* translations,
                   const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);
 /* gsr_fit_bones: the moment matrices, gsr_fit_rotations and the bones' unit quaternions in one launch -- what interpolate_motions
@@ -396,6 +420,10 @@ int gsr_gnn_rel_inputs(int32_t n_rel, int32_t attr_dim, int32_t group_dim, int32
                        const int64_t* senders, float* out, void* stream);
 int gsr_gnn_aggregate(int32_t n_rows, int32_t n_sum_rows, int32_t width, const float* rel_part, const float* node_parts, const int64_t* senders,
                       const int64_t* row_start, float* agg, void* stream);
+/* gsr_gnn_aggregate_res (ABI 122) = gsr_gnn_aggregate that also writes res_out = res_a + res_b ([n_rows, width] each): the particle
+ * propagator's addend of the step (particle_encode @ Wp1^T + b, plus the effect as the residual) -- one launch less per propagation step. */
+int gsr_gnn_aggregate_res(int32_t n_rows, int32_t n_sum_rows, int32_t width, const float* rel_part, const float* node_parts, const int64_t* senders,
+                          const int64_t* row_start, float* agg, const float* res_a, const float* res_b, float* res_out, void* stream);
 int gsr_fps(int32_t N, const float* pos, int32_t npoints, int32_t start_idx, float* scratch, int64_t* out_idx, void* stream);
 int gsr_lbs(int32_t P, int32_t n_bones, const float* bones, const float* rotations, const float* translations,
             const float* bone_quats, const float* xyz, const float* quat, float* out_xyz, float* out_quat, void* stream);

@@ -152,6 +152,10 @@ def _check_lists(views, H, W, o_point_list, o_ranges, o_n_contrib, ok, o_means2D
     # kept entries, in the oracle's order, laid out tile by tile in tile-id order of first appearance
     exp_pl = o_point_list[keep]
     kept_per_tile = np.bincount(tile_of[keep], minlength=gx * gy)
+    if pl.size == 0:      # the HIP path kept no pair at all (soak case 278: the only visible Gaussian's 3-sigma rect touches a tile row below
+        #                   the image's last pixel row): no binning ran, offsets[] was never written -- every oracle pair must be a dropped one
+        assert int(keep.sum()) == 0 and np.array_equal(rg[:, 0], rg[:, 1]) and not nc[ok].any(), "the HIP path has no list entries, the oracle's filtered lists do"
+        return
     assert int(views["offsets"][-1]) == int(keep.sum())
     assert np.array_equal(rg[:, 1] - rg[:, 0], kept_per_tile.astype(np.uint32)), "tile list lengths differ"
     # HIP ranges are contiguous in increasing tile id (global sort key = tile id), like the oracle's

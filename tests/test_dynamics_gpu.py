@@ -495,3 +495,92 @@ def test_frames_from_skin_packets_are_the_rollouts_frames(dev, golden_dir):
             assert np.array_equal(a["kp"], b["kp"]) and np.array_equal(a["tool_kp"], b["tool_kp"])
     assert asked == [0, 1, 3, 4, 5] * 2
     assert float((scene[-1]["means3D"] - scene[0]["means3D"]).norm(dim=-1).max()) > 1e-3
+
+
+def test_step_glue_kernels_equal_the_torch_statements(dev):
+    """ABI 122: gsr_rollout_step_head / gsr_rollout_step_motion / gsr_construct_edges_rows / gsr_gnn_aggregate_res against the torch statements
+    of the graphed rollout step they replace (gathers, transposes, concatenations, searchsorted, clamp + add + subtract, the residual add) --
+    bit for bit, with and without the state columns in the particle encoder's input."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import dynamics as D
+    g = torch.Generator().manual_seed(5)
+    n_his, n_track, nb, A = 3, 1000, 100, 2
+    N, n_cap = nb + 1, 128
+    hist = torch.rand(n_his, n_track, 3, generator=g).to(dev)
+    eef_hist, eef_next = torch.rand(n_his, 1, 3, generator=g).to(dev), torch.rand(1, 3, generator=g).to(dev)
+    idx1 = torch.randperm(n_track, generator=g)[:nb].to(dev)
+    thin = torch.cat([torch.randperm(nb, generator=g)[:85], torch.zeros(15, dtype=torch.long)]).to(dev)
+    a = torch.zeros(n_cap, A, device=dev); a[:nb, 0] = 1.0; a[nb, 1] = 1.0                      # noqa: E702
+    inst = torch.zeros(n_cap, 1, device=dev); inst[:nb] = 1.0                                    # noqa: E702
+    bones_hist = hist[:, idx1[thin]]
+    states = torch.cat([bones_hist, eef_hist], 1)
+    state_t = torch.cat([states.transpose(0, 1).reshape(N, n_his * 3), torch.zeros(n_cap - N, n_his * 3, device=dev)], 0)
+    act = torch.cat([torch.zeros(nb, 3, device=dev), eef_next - eef_hist[-1], torch.zeros(n_cap - N, 3, device=dev)], 0)
+    for with_state in (False, True):
+        bones, states_last, st, ac, p_in, nodes = _hip.rollout_step_head(hist, idx1, thin, eef_hist, eef_next, a, inst, with_state)
+        assert torch.equal(bones, bones_hist[-1]) and torch.equal(states_last, states[-1]) and torch.equal(st, state_t) and torch.equal(ac, act)
+        assert torch.equal(p_in, torch.cat([a] + ([state_t] if with_state else []) + [act], 1)) and torch.equal(nodes, torch.cat([a, inst, state_t], 1))
+    # relations with their segment bounds
+    cnt = torch.tensor([85], dtype=torch.int32, device=dev)
+    pos = torch.rand(N, 3, generator=g).to(dev)
+    e_cap = 768
+    recv, send, count, rel = _hip.construct_edges_padded(pos, cnt, 0.35, 5, e_cap, n_cap - 1, dense_n=n_cap)
+    recv2, send2, count2, rel2, rows = _hip.construct_edges_padded(pos, cnt, 0.35, 5, e_cap, n_cap - 1, dense_n=n_cap, row_start=True)
+    assert torch.equal(recv, recv2) and torch.equal(send, send2) and torch.equal(rel, rel2) and int(count) == int(count2) > 100
+    assert torch.equal(rows, torch.searchsorted(recv, torch.arange(n_cap + 1, device=dev, dtype=recv.dtype)))
+    few = _hip.construct_edges_padded(pos, cnt, 0.35, 5, 128, n_cap - 1, dense_n=n_cap, row_start=True)       # a list that does not fit: truncated alike
+    assert torch.equal(few[4], torch.searchsorted(few[0], torch.arange(n_cap + 1, device=dev, dtype=recv.dtype))) and int(few[2]) == 128
+    # the step's motion into the packet
+    mot_in = (torch.randn(n_cap, 3, generator=g) * 60.0).to(dev)                                 # some beyond the clamp
+    mot_in[3, 1] = float("nan")
+    packet = torch.full((D.skin_packet_len(nb),), -7.0, device=dev)
+    _hip.rollout_step_motion(state_t, mot_in, cnt, packet, nb, n_his, 100.0)
+    pos_all = state_t[:, -3:] + torch.clamp(mot_in, -100.0, 100.0)
+    pred, bones = pos_all[:nb], bones_hist[-1]
+    b2, R2, m2, q2, p2 = D.unpack_skin(packet, nb)
+    assert float(packet[0]) == 85.0 and float(packet[1]) == 1.0 and torch.equal(b2, bones)
+    assert torch.equal(torch.nan_to_num(m2, nan=-3.0), torch.nan_to_num(pred - bones, nan=-3.0)) and torch.equal(torch.nan_to_num(p2, nan=-3.0), torch.nan_to_num(pred, nan=-3.0))
+    assert bool(torch.isnan(p2[3, 1])) and float(R2.min()) == -7.0 and float(q2.max()) == -7.0 and float(torch.nan_to_num(mot_in).abs().max()) > 100.0   # the other blocks untouched
+    # the aggregate with the propagator's addend
+    H = 64
+    rew1, a23 = torch.randn(e_cap, H, generator=g).to(dev), torch.randn(n_cap, 2 * H, generator=g).to(dev)
+    ra, rb = torch.randn(n_cap, H, generator=g).to(dev), torch.randn(n_cap, H, generator=g).to(dev)
+    agg = _hip.gnn_aggregate(rew1, a23, send, rows, n_cap - 1)
+    agg2, base = _hip.gnn_aggregate(rew1, a23, send, rows, n_cap - 1, res=(ra, rb))
+    assert torch.equal(agg, agg2) and torch.equal(base, ra + rb)
+
+
+def test_graphed_step_with_fused_glue_equals_the_torch_glue(dev, golden_dir):
+    """The graphed rollout step with its glue as kernels of the library (33 graph nodes; default) against the same step with the glue as
+    torch ops (GSDYN_STEP_FUSED_GLUE=0): from the same loaded state, step after step, the same skinning packets, Gaussians and histories."""
+    import gsdyn.dynamics as D
+    from gsdyn import synth_scene_params
+    gold = np.load(os.path.join(golden_dir, "dynamics_host.npz"))
+    cfg = {str(k): int(v) for k, v in zip(gold["gnn_cfg_keys"], gold["gnn_cfg_vals"])}
+    model = D.DynamicsPredictor(cfg, device=dev).eval()
+    model.load_state_dict({k[len("gnn_w_"):]: torch.tensor(gold[k]) for k in gold.files if k.startswith("gnn_w_")})
+    P = 20000
+    params = {k: v.detach() for k, v in synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04).items()}
+    xyz, quat = params["means3D"], torch.nn.functional.normalize(params["unnorm_rotations"])
+    with torch.no_grad():
+        track = D.farthest_point_sampler(xyz[None], 1000)[0]
+        runs = {}
+        for fused in (True, False):
+            D._STEP_FUSED_GLUE = fused
+            model.__dict__.pop("_step_graphs", None)
+            try:
+                gs = D._graphed_step_for(model, P, 1000, 3, 100, 0.3, 0, 0.6, 5, dev)
+                gs.load(track, xyz[track], xyz[track][None].repeat(3, 1, 1), torch.zeros((3, 1, 3), device=dev), xyz, quat)
+                out = []
+                for i in range(4):
+                    gs.step(torch.tensor([[0.03 * (i + 1), 0.0, 0.01 * (i + 1)]], device=dev))
+                    out.append([t.clone() for t in (gs.skin, gs.all_pos, gs.all_rot, gs.hist, gs.eef_hist, gs.pred, gs.n_valid)])
+                torch.cuda.synchronize()
+                runs[fused] = out
+            finally:
+                D._STEP_FUSED_GLUE = True
+                model.__dict__.pop("_step_graphs", None)
+    assert 10 < int(runs[True][0][6]) <= 100 and float((runs[True][-1][1] - xyz).norm(dim=-1).max()) > 1e-3
+    for i, (a, b) in enumerate(zip(runs[True], runs[False])):
+        for j, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (i, j, float((x.float() - y.float()).abs().max()))
