@@ -69,14 +69,9 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pos
 // first lane holding it (ballot + ffs) -- no LDS crossbar trip; workgroup level: one LDS word pair per wave and ONE barrier (two
 // buffers, alternated by the caller), every thread reduces the FT_THREADS / 64 candidates itself.
 #define FT_THREADS 256
-typedef float gsr_f2 __attribute__((ext_vector_type(2)));
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float ft_dpp_max(float v) {
   return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false)));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ int ft_dpp_imax(int v) {      // for non-negative integers (the zeros a masked DPP step reads are neutral)
-  return max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ void block_argmax_first(float& best, int& besti, float* s_val, int* s_idx, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
@@ -173,66 +168,46 @@ __global__ __launch_bounds__(FT_THREADS) void fps_thin_small_kernel(const float*
 // barrier, no LDS exchange, one LDS read for the pick's coordinates.  Four waves with a barrier per pick cost 0.65 us per pick, the
 // per-lane arithmetic was a quarter of it: 131 -> ~70 us per rollout step for the 100 picks + ~85 thinning rounds.  Same arithmetic,
 // same tie rule (first maximum), bit-identical picks (test_bones_sampling_and_thinning_in_one_launch).
+// (Round 5, measured and not kept: the pick loop on packed f32 -- v_pk_add / v_pk_mul, two points per issue -- with the minima compared as
+// integers and the winner's slot found after the wave maximum: 208 -> 121 VALU + 22 -> 79 SALU instructions per pick, and 79.0 -> 82.4 us per
+// call, same box, three alternating rounds: a lone wave's pick is bound by its dependent chain -- LDS read of the pick, the DPP maximum, the
+// readlanes -- not by how many independent VALU operations sit between them.)
 __global__ __launch_bounds__(64) void fps_thin_wave_kernel(const float* __restrict__ pos, int N, int npoints, int start, float radius,
                                                            int thin_start, long long* __restrict__ out_idx,
                                                            long long* __restrict__ thin_idx, int* __restrict__ thin_count) {
   __shared__ float sp[3 * 128];           // the picked points, in pick order
   __shared__ float sa[3 * 1024];          // the whole cloud (a pick's coordinates)
   const int lane = threadIdx.x;
-  // Round 5: the points sit in registers as PAIRS (<2 x float>: v_pk_add_f32 / v_pk_mul_f32 do two points per issue -- 8 packed issues
-  // per pair for the 16 scalar ones of dx, dy, dz, their squares and the two adds, in the same order and rounding), and a lane no longer
-  // tracks the index of its maximum while it updates (a compare and two selects per point): the wave maximum is found on the values alone
-  // (v_max3), and only then the first slot that holds it -- 16 compares whose lane masks are read at the winning lane by scalar code.
-  // 176 -> ~110 VALU issues per pick of one wave that issues one every ~4.5 cycles: 77 -> ?? us per call at 1000 points / 100 picks.
-  // The running minima are kept as their BIT PATTERNS and compared as signed integers: squared distances are >= +0 (or +inf at the start),
-  // for which the integer order is the float order; the -1.0f of a slot beyond N is a negative integer, below all of them; a NaN distance
-  // (a NaN coordinate) is above +inf and never replaces a minimum -- fminf's choice too.  Integer min / max need no canonicalising
-  // v_max_f32 x, x in front (the float forms cost one per operand that is carried around the loop).
-  gsr_f2 px[8], py[8], pz[8];
-  int mind[16];
+  float px[16], py[16], pz[16], mind[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int i = 16 * lane + q;
     const bool have = i < N;
-    const float x = have ? pos[3 * i] : 0.f, y = have ? pos[3 * i + 1] : 0.f, z = have ? pos[3 * i + 2] : 0.f;
-    sa[3 * i] = x; sa[3 * i + 1] = y; sa[3 * i + 2] = z;
-    mind[q] = have ? 0x7f800000 : (int)0xbf800000;         // +inf; -1.0f: a slot beyond N never reaches the wave maximum (>= 0): no bounds test in the loop
-    if (q & 1) { px[q >> 1].y = x; py[q >> 1].y = y; pz[q >> 1].y = z; }
-    else { px[q >> 1].x = x; py[q >> 1].x = y; pz[q >> 1].x = z; }
+    px[q] = have ? pos[3 * i] : 0.f; py[q] = have ? pos[3 * i + 1] : 0.f; pz[q] = have ? pos[3 * i + 2] : 0.f;
+    sa[3 * i] = px[q]; sa[3 * i + 1] = py[q]; sa[3 * i + 2] = pz[q];
+    mind[q] = have ? __builtin_inff() : -1.0f;      // a slot beyond N never beats `best` (>= -1): the pick loop needs no bounds test
   }
   __syncthreads();
   int cur = start;
   for (int k = 0; k < npoints; ++k) {
     const float cx = sa[3 * cur], cy = sa[3 * cur + 1], cz = sa[3 * cur + 2];
     if (lane == 0) { out_idx[k] = cur; sp[3 * k] = cx; sp[3 * k + 1] = cy; sp[3 * k + 2] = cz; }
-    const gsr_f2 c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
-    int mx = -1;
+    float best = -1.0f;
+    int besti = 0x7fffffff;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      gsr_f2 d;
-      {
-#pragma clang fp contract(off)
-        const gsr_f2 dx = px[p] - c_x, dy = py[p] - c_y, dz = pz[p] - c_z;
-        d = (dx * dx + dy * dy) + dz * dz;                 // = __fadd_rn(__fadd_rn(dx dx, dy dy), dz dz) per point
-      }
-      mind[2 * p] = min(mind[2 * p], __float_as_int(d.x));
-      mind[2 * p + 1] = min(mind[2 * p + 1], __float_as_int(d.y));
-      mx = max(mx, max(mind[2 * p], mind[2 * p + 1]));
+    for (int q = 0; q < 16; ++q) {
+      const float dx = px[q] - cx, dy = py[q] - cy, dz = pz[q] - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      mind[q] = fminf(mind[q], d);
+      if (mind[q] > best) { best = mind[q]; besti = 16 * lane + q; }      // ascending index: the lane's first maximum
     }
-    int m = max(mx, 0);
-    m = ft_dpp_imax<0xB1>(m); m = ft_dpp_imax<0x4E>(m); m = ft_dpp_imax<0x141>(m); m = ft_dpp_imax<0x140>(m);
-    m = ft_dpp_imax<0x142, 0xA>(m); m = ft_dpp_imax<0x143, 0xC>(m);
-    const int wmax = __builtin_amdgcn_readlane(m, 63);
-    const uint64_t who = __ballot(mx == wmax);             // (mx = -1 -- a lane without points -- never equals wmax >= 0)
+    float m = fmaxf(best, 0.0f);
+    m = ft_dpp_max<0xB1>(m); m = ft_dpp_max<0x4E>(m); m = ft_dpp_max<0x141>(m); m = ft_dpp_max<0x140>(m);
+    m = ft_dpp_max<0x142, 0xA>(m); m = ft_dpp_max<0x143, 0xC>(m);
+    const float wmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    const uint64_t who = __ballot(best == wmax && best >= 0.0f);
+    cur = who ? __builtin_amdgcn_readlane(besti, __ffsll((long long)who) - 1) : 0x7fffffff;
     if (!who) break;                        // (N == 0: nothing to pick; the launcher does not get here)
-    const int L = __ffsll((long long)who) - 1;             // the first lane that holds the maximum: the lowest indices
-    int qf = 15;                                           // ... and its first slot that does (descending: the last assignment wins)
-#pragma unroll
-    for (int q = 15; q >= 0; --q) {
-      const uint64_t eq = __ballot(mind[q] == wmax);
-      if ((eq >> L) & 1ull) qf = q;
-    }
-    cur = 16 * L + qf;
   }
   __syncthreads();                          // sp[] complete (one wave: orders the LDS writes of lane 0 before the reads below)
   float qx[2], qy[2], qz[2], dist[2];
