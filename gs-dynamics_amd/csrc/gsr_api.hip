@@ -104,10 +104,14 @@ void fill_pre_view(GsrPreView& o, const GsrCam& cam, const GeomState& g, int32_t
   o.block_sums = block_sums; o.ekey = g.ekey; o.block_hash = nullptr; o.cmp_rec = nullptr; o.cmp_rect = nullptr; o.cmp_ekey = nullptr; o.cmp_tiles = nullptr; o.skip = 0;
   o.used = g.used; o.tracked = g.counters + 1;
 }
+
+// Speculative depth cuts armed by gsr_arm_depth_cuts for the NEXT forward-only binning + blend of this host thread (one-shot).
+struct ArmedCuts { int V = 0; const uint32_t* in[GSR_MAX_BATCH]; uint32_t* out[GSR_MAX_BATCH]; uint32_t* redo = nullptr; float margin = 1.0f; };
+thread_local ArmedCuts t_cuts;
 void fill_bin_view(GsrBinView& o, int P, uint32_t D, const GeomState& g, const BinningState& bs, const ImageState& im,
                    const uint32_t* block_sums) {
   o.shares_lists = 0; o.fused_alias = 0; o.D_dev = nullptr; o.owner = 0;
-  o.ekey = g.ekey; o.rec_w = g.rec; o.tile_rows = nullptr;
+  o.ekey = g.ekey; o.rec_w = g.rec; o.tile_rows = nullptr; o.depth_cut = nullptr;
   o.rec = g.rec; o.rect = g.rect; o.tiles_touched = g.tiles_touched; o.block_sums = block_sums;
   o.block_offsets = gsr_host_block_scan(P) ? nullptr : g.block_offsets;
   o.offsets = g.offsets;
@@ -121,6 +125,7 @@ void fill_render_view(GsrRenderView& o, const GsrCam& cam, const GeomState& g, c
   o.out_color = out_color; o.out_depth = out_depth; o.dL_dcolor = dL_dcolor; o.rect = g.rect; o.offsets = g.offsets;
   o.partials = partials; o.ranges = im.ranges; o.partner = -1; o.fused_alias = 0; o.colors = nullptr; o.contrib = bs.contrib;
   o.used = g.used; o.tracked = g.counters + 1;
+  o.cut_in = nullptr; o.cut_out = nullptr; o.redo = nullptr; o.cut_margin = 1.0f;
 }
 
 // Fused pairs: the FIRST alias of a view (same camera, other colours) is blended inside its owner's tile pass instead of
@@ -349,6 +354,19 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
     }
     if (counts_dev && owner == v) bt.v[v].D_dev = g.offsets + P;
   }
+  if (t_cuts.V) {       // one-shot, whatever happens below
+    const ArmedCuts ac = t_cuts;
+    t_cuts.V = 0;
+    if (ac.V != V || !(flags & GSR_FORWARD_ONLY) || !tile_rows) {
+      gsr_set_error("gsr_arm_depth_cuts: the armed cuts need a forward-only call of %d views on the tile-row binning path", ac.V);
+      return -2;
+    }
+    for (int v = 0; v < V; ++v) {
+      if (bt.v[v].shares_lists || rt.v[v].partner >= 0 || rt.v[v].fused_alias) { gsr_set_error("gsr_arm_depth_cuts: views that share tile lists cannot be cut"); return -2; }
+      bt.v[v].depth_cut = ac.in[v];
+      rt.v[v].cut_in = ac.in[v]; rt.v[v].cut_out = ac.out[v]; rt.v[v].redo = ac.redo ? ac.redo + v : nullptr; rt.v[v].cut_margin = ac.margin;
+    }
+  }
   if (int rc = gsr_launch_binning(bt, P, st)) return rc;
   rt.track = (flags & GSR_FORWARD_ONLY) ? 0 : 1;
   return gsr_launch_render_fwd(rt, st);
@@ -520,6 +538,17 @@ static int check_batch(const char* who, int32_t V, const gsr_settings* s, const 
   return 0;
 }
 
+int gsr_arm_depth_cuts(int32_t V, const uint32_t* const* cut_in, uint32_t* const* cut_out, uint32_t* redo_flags, float margin) {
+  if (V == 0) { t_cuts.V = 0; return 0; }      // disarm (a caller whose forward failed before it got to the binning)
+  if (V < 1 || V > GSR_MAX_BATCH || !cut_out || !redo_flags || !(margin >= 1.0f) || !(margin < 1e6f)) { gsr_set_error("gsr_arm_depth_cuts: bad argument (margin >= 1)"); return -2; }
+  t_cuts.V = V; t_cuts.redo = redo_flags; t_cuts.margin = margin;
+  for (int v = 0; v < V; ++v) {
+    if (!cut_out[v]) { t_cuts.V = 0; gsr_set_error("gsr_arm_depth_cuts: cut_out[%d] is NULL", v); return -2; }
+    t_cuts.in[v] = cut_in ? cut_in[v] : nullptr;
+    t_cuts.out[v] = cut_out[v];
+  }
+  return 0;
+}
 int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, const float* means3D, const float* scales,
                                  const float* rotations, const float* opacities, const float* colors_precomp,
                                  const float* const* colors_views, const float* shs, const float* cov3D_precomp,

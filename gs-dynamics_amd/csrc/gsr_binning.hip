@@ -654,11 +654,20 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
   __shared__ uint32_t s_red[BIN_THREADS / 64];
   __shared__ uint32_t s_wave[BIN_THREADS / 64];
   __shared__ uint2 s_big[BIN_BIG_MAX];                // rects of the Gaussians that are walked by a whole wave (area > BIN_BIG_AREA)
+  __shared__ uint32_t s_bigdepth[BIN_BIG_MAX];        // ... and their depth bits (depth cuts)
   __shared__ uint32_t s_nbig;
   const GsrBinView& vw = tab.v[blockIdx.y];
   const int T = tab.T, Ts = gsr_bin_stride(T), gx = tab.gx, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = (int)blockIdx.x * GSR_BIN_G;
   const bool lists = !vw.shares_lists;
+  // Speculative depth cuts (forward-only calls, gsr_arm_depth_cuts): a pair deeper than its tile's cut is not counted here and not emitted by
+  // bin_emit -- the same test in both, so the lists stay consistent; render_fwd reports every cut tile whose list then ran out.
+  const uint32_t* __restrict__ cut = vw.depth_cut;
+  const bool cut_l = cut && tab.cut_lds;     // the cuts next to the counters: the test is one LDS read per pair (from global memory it cost the walk 50 %)
+  const uint32_t* s_cut = s_cnt + T;
+  if (cut_l)
+    for (int t = tid; t < T; t += BIN_THREADS) s_cnt[T + t] = cut[t];      // (published by the barrier in front of the tile counts)
+  auto cut_at = [&](uint32_t t) { return cut_l ? s_cut[t] : cut[t]; };
   // forward-only calls: offsets[] and the offset word of the records have no reader (only the backward addresses record slots); a
   // view that shares its lists has nothing else to do here.  (The word is ONE scattered 4-byte store per Gaussian and view into the
   // 64-byte records: 57 of this kernel's 134 us at 500 k Gaussians x 8 views.)
@@ -718,15 +727,21 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, GsrBinVie
     const BinGauss b = bin_gauss(rc[q], ek[q].y);
     if (b.area > BIN_BIG_AREA) {                      // a large rect (taken whole): parked for a whole wave (a lane walking hundreds
       const uint32_t slot = atomicAdd(&s_nbig, 1u);   // of tiles alone would hold its wave up); a full list: the lane does walk it
-      if (slot < BIN_BIG_MAX) { s_big[slot] = rc[q]; continue; }
+      if (slot < BIN_BIG_MAX) { s_big[slot] = rc[q]; s_bigdepth[slot] = ek[q].x; continue; }
     }
-    bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
+    const uint32_t dbits = ek[q].x;
+    if (cut) bin_for_tiles(b, gx, [&](uint32_t t) { if (dbits <= cut_at(t)) atomicAdd(&s_cnt[t], 1u); });
+    else bin_for_tiles(b, gx, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); });
   }
   __syncthreads();
   const uint32_t nbig = min(s_nbig, (uint32_t)BIN_BIG_MAX);
   for (uint32_t i = wv; i < nbig; i += BIN_THREADS / 64) {   // one wave per parked Gaussian, a lane per tile
     const BinGauss b = bin_gauss(s_big[i], 0u);
-    for (uint32_t k = lane; k < b.area; k += 64) atomicAdd(&s_cnt[bin_tile_of(b, k, gx)], 1u);
+    const uint32_t dbits = s_bigdepth[i];
+    for (uint32_t k = lane; k < b.area; k += 64) {
+      const uint32_t t = bin_tile_of(b, k, gx);
+      if (!cut || dbits <= cut_at(t)) atomicAdd(&s_cnt[t], 1u);
+    }
   }
   if (nbig) __syncthreads();
   uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
@@ -896,6 +911,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
   if (vw.shares_lists) return;
   const uint32_t cap = vw.D;
   const uint32_t* __restrict__ row = vw.tile_rows + (size_t)blockIdx.x * Ts;
+  const uint32_t* __restrict__ cut = vw.depth_cut;    // (see bin_count_kernel: the same test, pair by pair)
+  const bool cut_l = cut && tab.cut_lds;
+  const uint32_t* s_cut = s_cur + T;
+  if (cut_l)
+    for (int t = tid; t < T; t += BIN_THREADS) s_cur[T + t] = cut[t];      // (published by the barrier behind the cursors' set-up)
+  auto cut_at = [&](uint32_t t) { return cut_l ? s_cut[t] : cut[t]; };
   uint64_t* __restrict__ dg = vw.dg[0];
   uint2 rc[BIN_PER_THREAD], ek[BIN_PER_THREAD];
 #pragma unroll
@@ -916,7 +937,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
       const uint32_t slot = atomicAdd(&s_nbig, 1u);
       if (slot < BIN_BIG_MAX) { s_big[slot] = rc[q]; s_bigkey[slot] = key; continue; }
     }
+    const uint32_t dbits = ek[q].x;
     bin_for_tiles(b, gx, [&](uint32_t t) {
+      if (cut && dbits > cut_at(t)) return;
       const uint32_t slot = atomicAdd(&s_cur[t], 1u);
       if (slot < cap) dg[slot] = key;
     });
@@ -927,7 +950,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_emit_kernel(int P, GsrBinView
     const BinGauss b = bin_gauss(s_big[i], 0u);
     const uint64_t key = s_bigkey[i];
     for (uint32_t k = lane; k < b.area; k += 64) {
-      const uint32_t slot = atomicAdd(&s_cur[bin_tile_of(b, k, gx)], 1u);
+      const uint32_t t = bin_tile_of(b, k, gx);
+      if (cut && (uint32_t)(key >> 32) > cut_at(t)) continue;
+      const uint32_t slot = atomicAdd(&s_cur[t], 1u);
       if (slot < cap) dg[slot] = key;
     }
   }
@@ -1402,7 +1427,10 @@ int gsr_launch_binning(const GsrBinViews& tab_in, int P, hipStream_t st) {
   }
   int cur = 0;
   bool order_done = false;
-  const size_t lds = sizeof(uint32_t) * (size_t)tab.T;
+  bool any_cut = false;
+  for (int v = 0; v < tab.V; ++v) any_cut = any_cut || tab.v[v].depth_cut != nullptr;
+  tab.cut_lds = (any_cut && bin_lds_static() + 2 * sizeof(uint32_t) * (size_t)tab.T <= bin_lds_limit()) ? 1 : 0;
+  const size_t lds = sizeof(uint32_t) * (size_t)tab.T * (tab.cut_lds ? 2 : 1);
   const bool rows_path = tab.rows > 0 && gsr_rows_path_ok(tab.T) && maxD > 0 && P > 0;
   if (rows_path) {             // tile-row binning: count -> (column prefix) -> scan -> emit, each ONE launch for all views
     { GSR_PROF("bin_count", st);

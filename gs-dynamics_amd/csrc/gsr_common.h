@@ -216,6 +216,8 @@ struct GsrBinView {            // emit .. tile_sort
   const uint2* ekey;       // tile-row binning: {depth bits, tile mask} per Gaussian
   float4* rec_w;           // the record array again, writable (the offset word of a record is filled in by the binning stage)
   uint32_t* tile_rows;     // tile-row binning: [rows + 1][T] per-workgroup tile counts (-> exclusive prefixes over the workgroups), row `rows` = totals
+  const uint32_t* depth_cut;   // speculative depth cuts (gsr_arm_depth_cuts; forward-only calls): [T] depth bits per tile, a (Gaussian, tile) pair with a
+                               //   larger depth is neither counted nor emitted; nullptr = none
 };
 struct GsrBinViews {
   int V, T, gx; uint4* order; uint32_t* queue;
@@ -225,6 +227,7 @@ struct GsrBinViews {
   uint32_t* vlong_out;           // pinned host word: the tile order stores the call's number of lists above 1016 entries here (or nullptr)
   int vlong_launch;              // 1: a launch of the 4096-entry block follows the ordinary tile_sort launch and takes those lists
   int forward_only;              // GSR_FORWARD_ONLY: no backward will read these states (the record-slot offsets are not produced)
+  int cut_lds;                   // 1: the count / emit walks were given LDS for a copy of their view's depth cuts (behind the tile counters / cursors)
   GsrBinView v[GSR_MAX_BATCH];
 };
 struct GsrRenderView {         // blend forward / backward
@@ -237,6 +240,9 @@ struct GsrRenderView {         // blend forward / backward
   uint8_t* used; uint32_t* tracked;   // this view's GeomState::used / &counters[1] (forward: written; see GeomState)
   int partner;       // >= 0: index of a view with the same camera whose colours are blended in this view's tile pass (6 channels)
   int fused_alias;   // 1: this view is some view's partner (it owns no tickets)
+  float cut_margin;                                            // ... the factor on the proposed depths (gsr_arm_depth_cuts' margin)
+  const uint32_t* cut_in; uint32_t* cut_out; uint32_t* redo;   // speculative depth cuts (see gsr_arm_depth_cuts): the cuts this call binned with, the
+                                                               //   cuts it proposes for the next frame, the word it sets when a cut tile ran out of list
 };
 struct GsrRenderViews {
   int V, W, H, gx, T; const uint4* order; uint32_t* queue;

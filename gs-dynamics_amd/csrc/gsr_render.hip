@@ -206,7 +206,9 @@ __device__ __forceinline__ int fwd_tile(
     const int tile, const uint2 rg, FwdLdsT<PAIR>& L, int W, int H, int gx,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth, const FwdPartner pt, uint8_t* __restrict__ contrib, uint8_t* __restrict__ used, uint32_t& pend_g) {
+    float* __restrict__ out_depth, const FwdPartner pt, uint8_t* __restrict__ contrib, uint8_t* __restrict__ used, uint32_t& pend_g,
+    const uint32_t* __restrict__ cut_in = nullptr, uint32_t* __restrict__ cut_out = nullptr, uint32_t* __restrict__ redo = nullptr,
+    const float cut_margin = 1.0f) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
   const int px = tx0 + GSR_QW * (wv & 1) + (lane & 7), py = ty0 + GSR_QH * (wv >> 1) + (lane >> 3);
@@ -239,6 +241,7 @@ __device__ __forceinline__ int fwd_tile(
     if (PAIR) np = fwd_partner_colour(pt, g);
   }
   GSR_TP(0);
+  int stop_base = -1;             // >= 0: every pixel had finished when batch `stop_base` came up (the walk ended before the list did)
   int pend_base = -1;             // TRACK (wave-uniform): first list position of the batch whose contribution bytes are due -- they are written
   //                                 by the staging threads once the waves' masks are in LDS (the positions of their entries in the four
   //                                 compacted lists wait in L.cpos: no per-thread register lives across the blend loop for this)
@@ -249,7 +252,7 @@ __device__ __forceinline__ int fwd_tile(
       pend_base = -1;
       if (!all_done && used && tid >= FWD_BATCH && base + tid - FWD_BATCH < n) pend_g = point_list[rg.x + base + tid - FWD_BATCH];
     }
-    if (all_done) break;
+    if (all_done) { stop_base = base; break; }
     GSR_TP(1);
     // ---- stage: threads 0..127 each classify the entry they prefetched against the four strips
     const float4 a = na, b = nb;
@@ -415,6 +418,22 @@ __device__ __forceinline__ int fwd_tile(
     GSR_TP(5);
   }
   GSR_TP(1);
+  // Speculative depth cuts (gsr_arm_depth_cuts; forward-only calls of a frame sequence): this tile's proposal for the NEXT frame, and the
+  // verdict on the cut THIS frame was binned with.  The walk ended before the list did: every pixel is finished whatever lies deeper -- the
+  // result is exact under any cut, and the deepest entry already prefetched (up to 128 positions past the last one walked) bounds what the
+  // next frame needs, times the caller's margin.  The list ran out: with pixels still alive, entries a cut removed might have reached them -- if this
+  // tile was cut, the frame must be redone without cuts (the caller's flag); either way the tile proposes no cut.
+  if (cut_out) {
+    if (stop_base >= 0) {
+      if (tid == min(FWD_BATCH - 1, n - 1 - stop_base)) cut_out[tile] = __float_as_uint(nc.y * cut_margin);
+    } else {
+      const bool alive = __syncthreads_count(!done) != 0;
+      if (tid == 0) {
+        cut_out[tile] = 0x7f800000u;
+        if (alive && cut_in && cut_in[tile] != 0x7f800000u && redo) atomicAdd(redo, 1u);   // (rare; the count of such tiles is a diagnostic, any non-zero value means redo)
+      }
+    }
+  }
 #undef done
   T = __builtin_fabsf(T);
   if (inside) {
@@ -802,6 +821,10 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
       const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
       const int tile = (int)ord.x;
       const int px = (tile % gx) * GSR_TILE + (threadIdx.x & 15), py = (tile / gx) * GSR_TILE + (threadIdx.x >> 4);
+      if (!TRACK && vw.cut_out && threadIdx.x == 0) {   // an empty tile proposes no cut; one that was CUT empty cannot vouch for its background
+        vw.cut_out[tile] = 0x7f800000u;
+        if (vw.cut_in && vw.cut_in[tile] != 0x7f800000u && vw.redo) atomicAdd(vw.redo, 1u);
+      }
       if (px < W && py < H) {
         const int pix = py * W + px;
         vw.final_T[pix] = 1.0f; vw.n_contrib[pix] = 0u;
@@ -826,7 +849,8 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
     if (PAIRS && vw.partner >= 0)
       pend = fwd_tile<PAIRS, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib, vw.used, pend_g);
     else
-      pend = fwd_tile<false, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib, vw.used, pend_g);
+      pend = fwd_tile<false, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), reinterpret_cast<FwdLdsT<false>&>(L), GSR_FWD_PASS(vw), FwdPartner{}, vw.contrib, vw.used, pend_g,
+                                    TRACK ? nullptr : vw.cut_in, TRACK ? nullptr : vw.cut_out, TRACK ? nullptr : vw.redo, vw.cut_margin);
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif

@@ -77,7 +77,7 @@ EXPORTS = ("gsr_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes",
            "gsr_shared_terms_partials", "gsr_shared_terms_scratch", "gsr_shared_terms_forward", "gsr_shared_terms_backward",
            "gsr_activate_forward", "gsr_activate_backward", "gsr_adam_step", "gsr_radius_bookkeeping", "gsr_wait_counts",
            "gsr_gnn_aggregate", "gsr_gnn_rel_inputs", "gsr_construct_edges_dense", "gsr_rollout_step_tail",
-           "gsr_construct_edges_rows", "gsr_rollout_step_head", "gsr_rollout_step_motion", "gsr_gnn_aggregate_res")
+           "gsr_construct_edges_rows", "gsr_rollout_step_head", "gsr_rollout_step_motion", "gsr_gnn_aggregate_res", "gsr_arm_depth_cuts")
 
 
 def load_library():
@@ -190,6 +190,8 @@ def load_library():
     lib.gsr_construct_edges_rows.argtypes = [vp, i32, vp, C.c_float, i32, C.c_int64, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gsr_rollout_step_head.restype = C.c_int
     lib.gsr_rollout_step_head.argtypes = [i32] * 6 + [vp] * 14
+    lib.gsr_arm_depth_cuts.restype = C.c_int
+    lib.gsr_arm_depth_cuts.argtypes = [i32, vp, vp, vp, C.c_float]
     lib.gsr_rollout_step_motion.restype = C.c_int
     lib.gsr_rollout_step_motion.argtypes = [i32, i32, C.c_float, vp, vp, vp, vp, vp]
     lib.gsr_fit_bones.restype = C.c_int
@@ -426,8 +428,10 @@ FORWARD_ONLY = 1        # GSR_FORWARD_ONLY of include/gsr.h
 
 def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, shs, scales, rotations, cov3D_precomp,
                             prepare_backward: bool = False, no_host_sync: bool = False, raw=None, forward_only: bool = False,
-                            grad_out=None):
+                            grad_out=None, depth_cuts=None):
     """All views of a step in one call: one launch per stage for all views, one host sync for all duplicate counts.  Returns (color[V,3,H,W], radii[V,P] int32, depth[V,1,H,W], states[V]).
+    ``depth_cuts = (cut_in, cut_out, redo[, margin = 1.01])`` (forward_only calls; include/gsr.h: gsr_arm_depth_cuts): per view a [T] int32 tensor of depth
+    bits to bin with (or None), a [T] int32 tensor that receives the next frame's proposal, and one zeroed [V] int32 tensor of redo flags.
     ``raw = (unnorm_rotations, logit_opacities, log_scales)`` (then ``opacities`` / ``scales`` / ``rotations`` are None): the
     activations are applied inside the preprocess kernel when the call runs in capacity mode (``states[0].raw_fused``), by
     ``activate_forward`` otherwise; either way ``states[0].act = (rotations, opacities, scales)`` holds the activated tensors."""
@@ -562,20 +566,36 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
             raise ValueError("rasterize_forward_batch: per-view colours must be [V,P,3]")
         col_shared = None if per_view_col else colors_precomp
         col_views = _ptr_array([colors_precomp[v] for v in range(V)]) if per_view_col else None
-        rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                   _ptr(col_shared), col_views, _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
-                                   _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
-                                   _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), Ds,
-                                   FORWARD_ONLY if forward_only else 0, st)
-        if rc not in (0, 1):
-            _check(rc, "gsr_forward_batch")
-        need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
-        if rc == 1:
-            binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) if owner[v] else None for v in range(V)]
-            _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
-                                                _ptr(batch), geometry_of, col_views, _ptr_array(color_v), _ptr_array(depth_v),
-                                                FORWARD_ONLY if forward_only else 0, st),
-                   "gsr_forward_render_batch")
+        if depth_cuts is not None:
+            if not forward_only or geometry_of is not None:
+                raise ValueError("rasterize_forward_batch(depth_cuts=...): forward_only calls of views with their own tile lists only")
+            cin, cout, redo = depth_cuts[:3]
+            margin = float(depth_cuts[3]) if len(depth_cuts) > 3 else 1.01
+            T_ = ((H + 15) // 16) * ((W + 15) // 16)
+            for t_ in list(cout) + [c for c in (cin or []) if c is not None]:
+                if not (t_.is_contiguous() and t_.dtype == torch.int32 and t_.numel() == T_ and t_.device == dev):
+                    raise ValueError("rasterize_forward_batch(depth_cuts=...): contiguous int32 tensors of one word per tile, please")
+            if not (redo.dtype == torch.int32 and redo.numel() == V and redo.is_contiguous() and redo.device == dev):
+                raise ValueError("rasterize_forward_batch(depth_cuts=...): redo = a contiguous int32 tensor of V words")
+            _check(lib.gsr_arm_depth_cuts(V, _ptr_array(list(cin)) if cin is not None else None, _ptr_array(list(cout)), _ptr(redo), margin), "gsr_arm_depth_cuts")
+        try:
+            rc = lib.gsr_forward_batch(V, sarr, P, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                       _ptr(col_shared), col_views, _ptr(shs), _ptr(cov3D_precomp), _ptr_array(geoms),
+                                       _ptr_array([radii[v] for v in range(V)]), _ptr_array(binnings), caps,
+                                       _ptr_array(images), _ptr(batch), geometry_of, _ptr_array(color_v), _ptr_array(depth_v), Ds,
+                                       FORWARD_ONLY if forward_only else 0, st)
+            if rc not in (0, 1):
+                _check(rc, "gsr_forward_batch")
+            need = max(lib.gsr_binning_bytes(Ds[v], H, W) for v in range(V))
+            if rc == 1:
+                binnings = [torch.empty((lib.gsr_binning_bytes(Ds[v], H, W),), **u8) if owner[v] else None for v in range(V)]
+                _check(lib.gsr_forward_render_batch(V, sarr, P, Ds, _ptr_array(geoms), _ptr_array(binnings), _ptr_array(images),
+                                                    _ptr(batch), geometry_of, col_views, _ptr_array(color_v), _ptr_array(depth_v),
+                                                    FORWARD_ONLY if forward_only else 0, st),
+                       "gsr_forward_render_batch")
+        finally:
+            if depth_cuts is not None:
+                lib.gsr_arm_depth_cuts(0, None, None, None, 1.0)      # (consumed by the binning above; disarmed here if the call failed before it)
         if forward_only and geometry_of is not None:      # a fused alias is not preprocessed in this mode: its radii are its owner's
             if V % 2 == 0 and all(geo[v] == v - (v & 1) for v in range(V)):      # (colour, mask) pairs: one strided copy
                 radii[1::2].copy_(radii[0::2])

@@ -37,7 +37,7 @@ import torch
 import torch.distributed as dist
 
 from .camera import look_at_w2c
-from .render import Renderer
+from .render import DepthCuts, Renderer
 
 
 def shard_pairs(n_frames: int, n_cams: int, rank: int, world: int) -> List[Tuple[int, int]]:
@@ -56,7 +56,7 @@ class FrameShard:
     """This rank's share of an episode's renders.  ``poses``: list of (w2c, K) -- predict.py's four cameras."""
 
     def __init__(self, device, w: int, h: int, poses: Sequence, rank: Optional[int] = None, world: Optional[int] = None,
-                 bg=(0.0, 0.0, 0.0), near: float = 0.01, far: float = 100.0, mask_from_alpha: bool = True):
+                 bg=(0.0, 0.0, 0.0), near: float = 0.01, far: float = 100.0, mask_from_alpha: bool = True, speculative: Optional[bool] = None):
         if rank is None:
             rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         if world is None:
@@ -64,6 +64,11 @@ class FrameShard:
         self.rank, self.world, self.poses, self.bg = int(rank), int(world), list(poses), tuple(bg)
         self.renderer = Renderer(device, w=w, h=h, near=near, far=far)
         self.mask_from_alpha = bool(mask_from_alpha)   # the mask render = 1 - final transmittance of the colour render (gsdyn/render.py)
+        # Speculative depth cuts (gsdyn.render.DepthCuts; HIP devices): each frame bins only what the previous frame of the same cameras
+        # needed, the blend validates it, ``validate`` renders the frames that failed again.  Every frame handed out is exact.
+        if speculative is None:
+            speculative = torch.device(device).type == "cuda" and os.environ.get("GSDYN_DEPTH_CUTS", "1") != "0"
+        self.cuts = DepthCuts() if (speculative and self.mask_from_alpha) else None
 
     def my_pairs(self, n_frames: int) -> List[Tuple[int, int]]:
         return shard_pairs(n_frames, len(self.poses), self.rank, self.world)
@@ -73,14 +78,32 @@ class FrameShard:
         return [c for c in range(n) if (frame * n + c) % self.world == self.rank]
 
     @torch.no_grad()
-    def render_frame(self, frame: int, timestep_data: dict) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        """{camera: (image [3,H,W], depth [1,H,W], mask [3,H,W])} for this rank's cameras of ``frame`` -- one rasterizer call."""
+    def render_frame(self, frame: int, timestep_data: dict, exact: bool = False, only=None) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """{camera: (image [3,H,W], depth [1,H,W], mask [3,H,W])} for this rank's cameras of ``frame`` -- one rasterizer call.  With
+        speculative depth cuts (``self.cuts``) the result is provisional until ``validate`` has run; ``exact``: no cuts for this call;
+        ``only``: positions in this rank's camera list of the frame to render (the views ``validate`` repeats)."""
         cams = self.cams_of_frame(frame)
+        if only is not None:
+            cams = [cams[i] for i in only]
         if not cams:
             return {}
         ims, depths, masks = self.renderer.render_cameras_with_mask([self.poses[c] for c in cams], timestep_data, bg=self.bg,
-                                                                        mask_from_alpha=self.mask_from_alpha)
+                                                                        mask_from_alpha=self.mask_from_alpha,
+                                                                        cuts=None if exact else self.cuts, cuts_key=tuple(cams), frame_id=frame)
         return {c: (ims[i], depths[i], masks[i]) for i, c in enumerate(cams)}
+
+    @torch.no_grad()
+    def validate(self, frames_out: dict, scene_of_frame, post=None) -> List[int]:
+        """After a run of ``render_frame`` calls: the views whose speculative cuts did not hold (``DepthCuts.failed``) are rendered again
+        without cuts and replace their entries of ``frames_out`` ({(frame, camera): tensors}); ``scene_of_frame(f)`` -> the frame's render
+        inputs, ``post(v)`` -> what the caller stores per pair.  Returns the frames that had such views.  No-op without speculation."""
+        if self.cuts is None:
+            return []
+        bad = self.cuts.failed()
+        for f, views in bad.items():
+            for c, v in self.render_frame(f, scene_of_frame(f), exact=True, only=views).items():
+                frames_out[(f, c)] = v if post is None else post(v)
+        return sorted(bad)
 
     @torch.no_grad()
     def render_episode(self, scene_data: Sequence[dict]) -> Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
@@ -88,6 +111,7 @@ class FrameShard:
         for f, d in enumerate(scene_data):
             for c, v in self.render_frame(f, d).items():
                 out[(f, c)] = v
+        self.validate(out, lambda f: scene_data[f])
         return out
 
 
@@ -251,6 +275,8 @@ def predict_episode(model, params: dict, eef_xyz, poses: Sequence, w: int, h: in
         torch.cuda.synchronize(dev)
     tm["render_ms"] = (time.perf_counter() - t0) * 1e3
     tm["pairs_on_this_rank"] = len(frames)
+    if shard.cuts is not None:
+        tm["depth_cut_calls"], tm["frames_redone"] = shard.cuts.cut_calls, shard.cuts.redone
     if gather_to is not None:
         frames = gather_frames(frames, dst=gather_to)
     return frames, vis, tm
@@ -300,6 +326,12 @@ def _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg
     if failure:
         raise failure[0]
     torch.cuda.synchronize(dev)
+    post = (lambda v: (compose_rgba(v[0], v[2]), v[1], v[2])) if rgba else None
+    with torch.no_grad():
+        shard.validate(frames, lambda f: scene[f], post)            # speculative depth cuts that did not hold: those frames again, exactly
+    torch.cuda.synchronize(dev)
+    if shard.cuts is not None:
+        tm["depth_cut_calls"], tm["frames_redone"] = shard.cuts.cut_calls, shard.cuts.redone
     if scene_out is not None:
         scene_out.extend(scene)
     tm["episode_ms"] = (time.perf_counter() - t0) * 1e3
@@ -363,6 +395,12 @@ def _predict_episode_pipelined(model, params, eef_xyz, poses, w, h, rollout_cfg,
             dist.broadcast(buf, src=src, group=group)
             return buf
         scene, vis, tm = collect_scene_data(None, params, eef_xyz, on_frame=on_frame, skin_source=skin_source, **rollout_cfg)
+    if shard is not None:
+        post = (lambda v: (compose_rgba(v[0], v[2]), v[1], v[2])) if rgba else None
+        with torch.no_grad():
+            shard.validate(frames, lambda f: scene[f], post)        # speculative depth cuts that did not hold: those frames again, exactly
+        if shard.cuts is not None:
+            tm["depth_cut_calls"], tm["frames_redone"] = shard.cuts.cut_calls, shard.cuts.redone
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     if scene_out is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 122 /* 0.1.22: + gsr_rollout_step_head, gsr_rollout_step_motion, gsr_construct_edges_rows, gsr_gnn_aggregate_res -- the torch glue of a graphed rollout step as kernels of this library (a replayed step is a chain of nodes: fewer nodes, shorter step); 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 123 /* 0.1.23: + gsr_arm_depth_cuts -- speculative per-tile depth cuts for forward-only frame sequences, validated by the blend; 0.1.22: + gsr_rollout_step_head, gsr_rollout_step_motion, gsr_construct_edges_rows, gsr_gnn_aggregate_res -- the torch glue of a graphed rollout step as kernels of this library (a replayed step is a chain of nodes: fewer nodes, shorter step); 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).
@@ -173,6 +173,21 @@ int gsr_forward_preprocess_batch(int32_t V, const gsr_settings* s, int32_t P, co
                                  const float* const* colors_views, const float* shs, const float* cov3D_precomp,
                                  void* const* geom_states,
                                  int32_t* const* radii, void* batch_state, uint32_t* num_rendered_host, void* stream);
+/* ABI 123 -- speculative depth cuts for FORWARD-ONLY frame sequences (predict.py renders the same cameras frame after frame, and in a dense
+ * scene ~90 % of the (Gaussian, tile) pairs lie behind the depth at which every pixel of their tile has saturated: they are binned, sorted
+ * and never blended).  gsr_arm_depth_cuts arms the NEXT gsr_forward_batch / gsr_forward_render_batch of this host thread (flags must carry
+ * GSR_FORWARD_ONLY; V views without shared lists; tile grids the tile-row binning serves):
+ *   cut_in[v]   [T] uint32 per tile, device: depth bits (a positive float's bits order like the float); a pair whose depth is LARGER than its
+ *               tile's cut is neither counted nor emitted.  0x7f800000 (+inf) = no cut for the tile.  cut_in == NULL or cut_in[v] == NULL: no cuts.
+ *   cut_out[v]  [T] written by the blend: the tile's proposal for the next frame -- the depth of the deepest entry it had prefetched when the
+ *               last pixel finished (up to 128 list positions past the last one walked) x margin (>= 1), or +inf when its list ran out first.
+ *   redo_flags  [V] uint32, device, zeroed by the caller: redo_flags[v] counts the tiles of view v that WERE cut and ran out of list with a
+ *               pixel still alive (or were cut empty); non-zero: entries the cut removed might have reached that pixel, the images of view v are not
+ *               to be trusted and the caller renders the frame again without cuts.  A flag that stays 0 PROVES the frame exact: every cut
+ *               tile finished all of its pixels inside the kept prefix of its list, which is a prefix of the full list.
+ * The arming is one-shot (V = 0 disarms) and costs nothing when unused.  Lists, n_contrib and final_T of a validated frame equal the uncut frame's on the
+ * kept prefix; the states of a cut call must not be handed to a backward (forward-only calls never are). */
+int gsr_arm_depth_cuts(int32_t V, const uint32_t* const* cut_in, uint32_t* const* cut_out, uint32_t* redo_flags, float margin);
 /* flags of the batch forward: GSR_FORWARD_ONLY = the caller will NOT run gsr_backward_batch on the states of this call (the
  * no-grad renders of /root/reference/src/render/renderer.py:18-23, /root/reference/src/predict.py:115-123): the forward then skips
  * what only the backward reads (the per-Gaussian record-slot offsets: one scattered store per Gaussian and view), and a view that is

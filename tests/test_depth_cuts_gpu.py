@@ -1,0 +1,130 @@
+"""Speculative depth cuts of forward-only frame sequences (ABI 123: gsr_arm_depth_cuts; gsdyn.render.DepthCuts; gsdyn.predict.FrameShard):
+a frame bins only the (Gaussian, tile) pairs in front of the per-tile depth the previous frame of the same cameras needed; the blend
+validates the guess.  What must hold: a frame whose redo flag stays zero is BIT-IDENTICAL to the uncut render; a frame the cuts do not
+serve is flagged, every time; FrameShard hands out exact frames either way."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "gs-dynamics_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+P, W, H, CAMS = 120_000, 640, 368, 4
+
+
+def _scene(dev, seed=0):
+    """A DENSE scene (large, fairly opaque Gaussians: most pixels saturate well before their tile's list ends)."""
+    from gsdyn import params2rendervar, synth_scene_params
+    params = synth_scene_params(P, seed=seed, device=dev, scale_lo=0.03, scale_hi=0.09)
+    with torch.no_grad():
+        d = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+        d["opacities"] = d["opacities"].clamp_min(0.6)
+    return d
+
+
+def _entries(states):
+    from diff_gaussian_rasterization import _hip
+    tot = 0
+    for st in states:
+        rg = _hip.debug_views(st)["ranges"]
+        tot += int((rg[:, 1] - rg[:, 0]).sum())
+    return tot
+
+
+def test_cut_frames_are_bit_identical_or_flagged(dev):
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.predict import ring_poses
+    from gsdyn.render import Renderer
+    rdr = Renderer(dev, w=W, h=H)
+    d = _scene(dev)
+    cams = [rdr._camera(w2c, k, (0.0, 0.0, 0.0)) for w2c, k in ring_poses(CAMS, W, H)]
+    args = (cams, d["means3D"].contiguous(), d["opacities"].contiguous(), d["colors_precomp"].contiguous(), None, d["scales"].contiguous(),
+            d["rotations"].contiguous(), None)
+    want = _hip.rasterize_forward_batch(*args, forward_only=True)
+    full = _entries(want[3])
+    T = ((H + 15) // 16) * ((W + 15) // 16)
+    new = lambda: [torch.full((T,), -1, dtype=torch.int32, device=dev) for _ in range(CAMS)]  # noqa: E731
+    z = lambda: torch.zeros(CAMS, dtype=torch.int32, device=dev)                                 # noqa: E731
+    INF = 0x7f800000
+    # frame 0: no cuts in, proposals out -- the uncut render, and a proposal for every tile
+    c0, r0 = new(), z()
+    got = _hip.rasterize_forward_batch(*args, forward_only=True, depth_cuts=(None, c0, r0))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[1], want[1]) and int(r0.max()) == 0
+    assert _entries(got[3]) == full and all(int(c.min()) > 0 for c in c0)
+    finite = sum(int((c != INF).sum()) for c in c0)
+    assert finite > 0.5 * CAMS * T, (finite, CAMS * T)          # the scene is dense: most tiles finish before their lists do
+    # frame 1, same scene, binned with frame 0's proposals: far fewer entries, the same images bit for bit, no flag; its proposals = frame 0's
+    c1, r1 = new(), z()
+    got = _hip.rasterize_forward_batch(*args, forward_only=True, depth_cuts=(c0, c1, r1))
+    kept = _entries(got[3])
+    assert int(r1.max()) == 0 and kept < 0.6 * full, (kept, full)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[1], want[1])
+    for v in range(CAMS):       # final transmittance / contributor counts (the mask image comes from them) as well
+        a, b = _hip.debug_views(got[3][v]), _hip.debug_views(want[3][v])
+        assert torch.equal(a["final_T"], b["final_T"]) and torch.equal(a["n_contrib"], b["n_contrib"])
+    assert all(torch.equal(a, b) for a, b in zip(c0, c1))
+    # a scene the cuts do NOT serve: the nearest Gaussians of every camera fade away, so pixels now reach deeper than the cuts allow
+    d2 = {k: v.clone() for k, v in d.items()}
+    d2["opacities"] = torch.where(torch.rand(P, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) < 0.7,
+                                  torch.full_like(d["opacities"], 0.02), d["opacities"])
+    args2 = (cams, d2["means3D"].contiguous(), d2["opacities"].contiguous(), d2["colors_precomp"].contiguous(), None, d2["scales"].contiguous(),
+             d2["rotations"].contiguous(), None)
+    want2 = _hip.rasterize_forward_batch(*args2, forward_only=True)
+    c2, r2 = new(), z()
+    got2 = _hip.rasterize_forward_batch(*args2, forward_only=True, depth_cuts=(c1, c2, r2))
+    assert int(r2.min()) >= 1, r2.tolist()                       # every camera: flagged (the words count the failing tiles)
+    assert not torch.equal(got2[0], want2[0])                    # (and rightly so: the cut images ARE wrong here)
+    # the proposals of the flagged frame are still sound for the NEXT frame of that scene: exact again, or flagged -- never silently wrong
+    c3, r3 = new(), z()
+    got3 = _hip.rasterize_forward_batch(*args2, forward_only=True, depth_cuts=(c2, c3, r3))
+    for v in range(CAMS):
+        assert int(r3[v]) >= 1 or (torch.equal(got3[0][v], want2[0][v]) and torch.equal(got3[2][v], want2[2][v])), v
+    assert int(r3.sum()) == 0                                    # (here: the flagged tiles proposed no cut, the others' proposals held)
+    # cuts of +inf everywhere = no cuts
+    cinf = [torch.full((T,), INF, dtype=torch.int32, device=dev) for _ in range(CAMS)]
+    c4, r4 = new(), z()
+    got4 = _hip.rasterize_forward_batch(*args, forward_only=True, depth_cuts=(cinf, c4, r4))
+    assert _entries(got4[3]) == full and torch.equal(got4[0], want[0]) and int(r4.max()) == 0
+    # the arming is one-shot: the next plain call is uncut
+    again = _hip.rasterize_forward_batch(*args, forward_only=True)
+    assert _entries(again[3]) == full and torch.equal(again[0], want[0])
+    # a call that is not forward-only refuses cuts
+    with pytest.raises(ValueError):
+        _hip.rasterize_forward_batch(*args, forward_only=False, depth_cuts=(None, new(), z()))
+
+
+def test_frame_shard_hands_out_exact_frames(dev):
+    """FrameShard with speculative cuts over a drifting scene with one abrupt change: every (frame, camera) result equals the exact
+    render of that frame, the abrupt frame is among the repeated ones, and most frames were served by cuts."""
+    from gsdyn.predict import FrameShard, ring_poses
+    d = _scene(dev, seed=3)
+    frames = []
+    g = torch.Generator(device=dev).manual_seed(5)
+    fade = torch.rand(P, 1, device=dev, generator=g) < 0.6
+    for f in range(8):
+        e = {k: v.clone() for k, v in d.items()}
+        e["means3D"] = d["means3D"] + 0.002 * f                               # a slow drift ...
+        if f >= 5:
+            e["opacities"] = torch.where(fade, torch.full_like(d["opacities"], 0.02), d["opacities"])   # ... and an abrupt change at frame 5
+        frames.append(e)
+    poses = ring_poses(CAMS, W, H)
+    exact = FrameShard(dev, W, H, poses, rank=0, world=1, speculative=False).render_episode(frames)
+    shard = FrameShard(dev, W, H, poses, rank=0, world=1, speculative=True)
+    assert shard.cuts is not None
+    got = shard.render_episode(frames)
+    assert sorted(got) == sorted(exact)
+    for k in exact:
+        for i in range(3):
+            assert torch.equal(got[k][i], exact[k][i]), (k, i)
+    assert shard.cuts.calls == 8 and shard.cuts.cut_calls == 7 and 1 <= shard.cuts.redone <= 4 and shard.cuts.dilate >= 2, (shard.cuts.calls, shard.cuts.cut_calls, shard.cuts.redone, shard.cuts.dilate)
+    # two ranks' shares (camera subsets differ per frame parity): still exact
+    for r in range(2):
+        part = FrameShard(dev, W, H, poses, rank=r, world=2, speculative=True).render_episode(frames)
+        for k, v in part.items():
+            assert all(torch.equal(v[i], exact[k][i]) for i in range(3)), (r, k)
