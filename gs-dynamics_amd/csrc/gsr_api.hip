@@ -310,6 +310,7 @@ int stage2(int V, const gsr_settings* s, int32_t P, const uint32_t* num_rendered
   if (int rc = check_geometry_of(V, geometry_of)) return rc;
   GsrBinViews bt;
   bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
+  bt.cut_lds = 0;
   GsrRenderViews rt;
   int partner[GSR_MAX_BATCH], fused[GSR_MAX_BATCH], skip[GSR_MAX_BATCH];
   pair_up(V, geometry_of, num_rendered, partner, fused);
@@ -477,7 +478,7 @@ int gsr_forward_render_shared_ex(const gsr_settings* s, int32_t P, uint32_t num_
   gsr_carve_binning(const_cast<void*>(owner_binning_state), num_rendered, &bs);
   GsrBinViews bt;
   bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
-  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512;
+  bt.V = 1; bt.T = cam.T; bt.gx = cam.gx; bt.counts_out = nullptr; bt.P = P; bt.rows = 0; bt.forward_only = 0; bt.wave_cap = 512; bt.cut_lds = 0;
   bt.order = im.tile_order; bt.queue = im.queue;
   fill_bin_view(bt.v[0], P, num_rendered, g, bs, im, g.block_sums);
   if (int rc = gsr_launch_shared_lists(bt, P, num_rendered, im_owner.ranges, im_owner.tile_order, im_owner.queue, im.ranges, im.tile_order,
@@ -702,6 +703,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
   GsrRenderViews rt;
   GsrBinViews bt;          // only for a tile_order rebuild (ranges + flags)
   bt.vlong_out = nullptr; bt.vlong_launch = 0;      // (set by gsr_launch_binning: the long-list hint of tile_sort)
+  bt.cut_lds = 0;
   bool any = false;
   // Pairs fused by the forward (pair_up) stay fused in the backward when no colour gradient is wanted (the pair pass carries
   // none); otherwise every view takes its own pass over an LPT order rebuilt WITH the partners' tickets, and the fused order is

@@ -33,6 +33,7 @@ class DepthCuts:
         self.dilate, self.margin, self.adapt = int(dilate), float(margin), bool(adapt)
         self._buf = {}           # camera-set key -> [ping, pong] lists of per-view [T] int32 tensors, index of the last one written (or None)
         self._pending = []       # [frame id, redo words on the device [V], their pinned host copy, the copy's event, seen by the adaptation]
+        self._pinned = {}        # free pinned slots by word count
         self._clean = 0
         self.calls = self.cut_calls = self.redone = 0
 
@@ -80,7 +81,9 @@ class DepthCuts:
         for ent in reversed(self._pending):
             if ent[1] is redo:
                 if redo.is_cuda:
-                    ent[2] = torch.empty(redo.shape, dtype=redo.dtype, pin_memory=True)
+                    n = int(redo.numel())
+                    free = self._pinned.setdefault(n, [])      # pinned slots are recycled (a pinned allocation per call costs ~0.1 ms)
+                    ent[2] = free.pop() if free else torch.empty(n, dtype=redo.dtype, pin_memory=True)
                     ent[2].copy_(redo, non_blocking=True)
                     ent[3] = torch.cuda.Event()
                     ent[3].record(torch.cuda.current_stream(redo.device))
@@ -107,6 +110,8 @@ class DepthCuts:
             if views:
                 bad[fid] = views
                 self.redone += 1
+            if host is not None and host is not redo:
+                self._pinned.setdefault(int(host.numel()), []).append(host)
         self._pending = []
         return bad
 
