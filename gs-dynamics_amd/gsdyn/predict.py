@@ -16,7 +16,7 @@ forms:
 * pipelined (``predict_episode(pipeline=True)``, round 5): ONE rank rolls out and broadcasts what each moving step does to the Gaussians --
   <= ``max_nobj`` bones with a rotation, a translation and a quaternion each: 8.8 KB -- and the other ranks apply it with one skinning
   launch per frame and render (``_predict_episode_pipelined``).  A render rank then costs skinning + render / (N - 1) per frame, the
-  producer's rollout is the pipeline's critical path: predicted 3.0 - 3.7x at 8 GPUs from the parts measured on one
+  producer's rollout is the pipeline's critical path: predicted ~3.2x at 8 GPUs (60 frames) from the parts measured on one
   (``bench.py --config 5 --with-rollout``).  Same frames, bit for bit (tests/test_predict_shard_cpu.py with gloo,
   tests/test_multirank_gpu.py with 2 / 3 processes on the real kernels).
 
