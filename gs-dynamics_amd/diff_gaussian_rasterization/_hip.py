@@ -438,6 +438,8 @@ def rasterize_forward_batch(settings_list, means3D, opacities, colors_precomp, s
     lib = load_library()
     _require_device(means3D)
     act = None
+    if depth_cuts is not None and (no_host_sync or raw is not None or shs is not None):
+        raise ValueError("rasterize_forward_batch(depth_cuts=...): the count-first forward-only call with precomputed colours only")
     if raw is not None:
         if cov3D_precomp is not None or shs is not None:
             raise ValueError("rasterize_forward_batch(raw=...): precomputed colours and scales / rotations only")
