@@ -1,5 +1,5 @@
-# round 5, session 2: the final check of the tree as committed -- the whole GPU suite, the driver's bench line, the round's profile set
-O=gpurun_out/s2final; mkdir -p $O
+# Round check on the GPU box (tools/r05_round_check.sh): the whole GPU suite, smoke, the driver bench line, cfg5 frame + 60-frame episode, the 2-rank smoke, the profile set of tools/prof_round.sh at four views -> gpurun_out/r05_round_check/
+O=gpurun_out/r05_round_check; mkdir -p $O
 export GSR_ROW_MARGINS_LOG=$PWD/$O/row_margins.log
 ( time python -m pytest tests -m gpu -x -q --durations=10 ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -16 $O/pytest.log
