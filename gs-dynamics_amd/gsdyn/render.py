@@ -56,8 +56,11 @@ class DepthCuts:
             return None
         if self.adapt:
             self._feedback()
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:       # ("cuda" names the current device: compare like with like below)
+            device = torch.device("cuda", torch.cuda.current_device())
         ent = self._buf.get(key)
-        if ent is None or ent[0][0][0].numel() != T or ent[0][0][0].device != torch.device(device):
+        if ent is None or ent[0][0][0].numel() != T or ent[0][0][0].device != device or len(ent[0][0]) != n_views:
             if len(self._buf) >= 16:
                 self._buf.clear()
             ent = self._buf[key] = [[[torch.empty(T, dtype=torch.int32, device=device) for _ in range(n_views)] for _ in (0, 1)], None]

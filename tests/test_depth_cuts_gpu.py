@@ -128,3 +128,44 @@ def test_frame_shard_hands_out_exact_frames(dev):
         part = FrameShard(dev, W, H, poses, rank=r, world=2, speculative=True).render_episode(frames)
         for k, v in part.items():
             assert all(torch.equal(v[i], exact[k][i]) for i in range(3)), (r, k)
+
+
+def test_depth_cuts_policy_edge_cases(dev):
+    """DepthCuts / FrameShard off the beaten path: a device named "cuda" (no index), another Gaussian count from one frame to the next, a
+    changed camera set under the same key, an image with more tiles than the tile-row binning serves -- always the exact frames."""
+    from gsdyn.predict import FrameShard, ring_poses
+    from gsdyn.render import DepthCuts, Renderer
+    d = _scene(dev, seed=7)
+    poses = ring_poses(CAMS, W, H)
+    exact = FrameShard(dev, W, H, poses, rank=0, world=1, speculative=False)
+    want = exact.render_episode([d, d])
+    # "cuda" instead of cuda:0: the proposal buffers must survive from frame to frame (cut_calls counts the calls that binned with cuts)
+    shard = FrameShard("cuda", W, H, poses, rank=0, world=1, speculative=True)
+    got = shard.render_episode([d, d, d])
+    assert shard.cuts.cut_calls == 2
+    for k in want:
+        assert all(torch.equal(got[k][i], want[k][i]) for i in range(3)), k
+    # fewer Gaussians in the next frame (the per-tile proposals do not care), then a different scene altogether
+    half = {k: (v[: P // 2].contiguous() if v.shape[0] == P else v) for k, v in d.items()}
+    other = _scene(dev, seed=11)
+    seq = [d, half, other, other]
+    got = FrameShard(dev, W, H, poses, rank=0, world=1, speculative=True).render_episode(seq)
+    ref = exact.render_episode(seq)
+    for k in ref:
+        assert all(torch.equal(got[k][i], ref[k][i]) for i in range(3)), k
+    # the same key with other cameras behind it (a caller that keys by position): validated like any bad guess
+    rdr = Renderer(dev, w=W, h=H)
+    dc = DepthCuts()
+    a = rdr.render_cameras_with_mask(poses[:2], d, cuts=dc, cuts_key="k", frame_id=0)
+    b = rdr.render_cameras_with_mask(poses[2:], d, cuts=dc, cuts_key="k", frame_id=1)      # binned with the OTHER cameras' proposals
+    bad = dc.failed()
+    b_exact = rdr.render_cameras_with_mask(poses[2:], d)
+    for v in range(2):
+        assert v in bad.get(1, []) or all(torch.equal(b[j][v], b_exact[j][v]) for j in range(3)), v
+    assert 0 not in bad and len(a[0]) == 2
+    # 4K: 240 x 135 tiles > 10 240 -- no cuts are armed, the call is the plain one
+    big = Renderer(dev, w=3840, h=2160)
+    dc2 = DepthCuts()
+    few = {k: (v[:20000].contiguous() if v.shape[0] == P else v) for k, v in d.items()}
+    big.render_cameras_with_mask(ring_poses(1, 3840, 2160), few, cuts=dc2, cuts_key="k", frame_id=0)
+    assert dc2.calls == 0 and dc2.failed() == {}
