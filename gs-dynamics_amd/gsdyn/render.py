@@ -39,7 +39,7 @@ class DepthCuts:
 
     def _feedback(self):
         for ent in self._pending:
-            if not ent[4] and ent[3] is not None and ent[3].query():
+            if not ent[4] and ent[2] is not None and (ent[3] is None or ent[3].query()):      # (no event: host tensors, the words are there)
                 ent[4] = True
                 if int(ent[2].max()) > 0:
                     self.dilate, self._clean = min(self.dilate + 1, 6), 0

@@ -270,3 +270,40 @@ def test_skin_packet_round_trip():
     a = D.interpolate_motions(bones, mot, rel, xyz, quat=quat)
     b = D.blend_skinning(*D.unpack_skin(pk, cap, n_valid=nb)[:4], xyz, quat)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_depth_cuts_policy_on_host_tensors():
+    """gsdyn.render.DepthCuts without a device: the ping-pong of the proposal buffers, the dilation (a tile bins with the deepest proposal of
+    its neighbourhood; +inf -- "my list ran out" -- spreads to the neighbours), the redo bookkeeping and the adaptation of the dilation."""
+    _setup()
+    from gsdyn.render import DepthCuts
+    INF = 0x7f800000
+    h, w = 48, 80                     # 3 x 5 tiles
+    T = 15
+    dc = DepthCuts(dilate=1, adapt=True)
+    cin, cout, redo, margin = dc.arm("cams", 2, h, w, "cpu", 0)
+    assert cin is None and len(cout) == 2 and cout[0].numel() == T and redo.tolist() == [0, 0] and margin == 1.01
+    prop = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0])
+    cout[0].copy_(prop.view(torch.int32)); cout[1].copy_((prop * 2).view(torch.int32))          # noqa: E702  (what the blend would write)
+    cout[1][7] = INF
+    dc.sent(redo)
+    cin2, cout2, redo2, _ = dc.arm("cams", 2, h, w, "cpu", 1)
+    assert cout2[0].data_ptr() != cout[0].data_ptr()                  # the other buffer of the pair
+    want0 = torch.nn.functional.max_pool2d(prop.view(1, 1, 3, 5), 3, stride=1, padding=1).reshape(-1)
+    assert torch.equal(cin2[0].view(torch.float32), want0)
+    got1 = cin2[1].view(3, 5)
+    assert (got1[0:3, 1:4] == INF).all() and int(got1[0, 0]) != INF and float(got1[0, 0].view(torch.float32)) == 14.0   # max of (1,2,6,7) x 2
+    redo2[1] = 3                                                      # the blend found three failing tiles in view 1
+    dc.sent(redo2)
+    cin3, cout3, redo3, _ = dc.arm("cams", 2, h, w, "cpu", 2)
+    assert cout3[0].data_ptr() == cout[0].data_ptr() and dc.dilate == 2          # adapted: the earlier frame's words were there to read
+    dc.sent(redo3)
+    assert dc.failed() == {1: [1]} and dc.failed() == {} and dc.calls == 3 and dc.cut_calls == 2 and dc.redone == 1
+    for f in range(16):                                               # sixteen clean frames: one tile narrower again
+        a = dc.arm("cams", 2, h, w, "cpu", 3 + f)
+        dc.sent(a[2])
+    dc.arm("cams", 2, h, w, "cpu", 99)
+    assert dc.dilate == 1
+    other = dc.arm("other cameras", 1, h, w, "cpu", 100)
+    assert other[0] is None                                           # a new camera set starts without cuts
+    assert DepthCuts().arm("k", 1, 2160, 3840, "cpu", 0) is None      # 135 x 240 tiles: not served
