@@ -32,7 +32,7 @@ class DepthCuts:
     def __init__(self, dilate: int = 2, margin: float = 1.01, adapt: bool = True):
         self.dilate, self.margin, self.adapt = int(dilate), float(margin), bool(adapt)
         self._buf = {}           # camera-set key -> [ping, pong] lists of per-view [T] int32 tensors, index of the last one written (or None)
-        self._pending = []       # [frame id, redo words on the device [V], their pinned host copy, the copy's event, seen by the adaptation]
+        self._pending = []       # [frame id, redo words on the device [V], their pinned host copy, the copy's event, seen by the adaptation, dilation used]
         self._pinned = {}        # free pinned slots by word count
         self._clean = 0
         self.calls = self.cut_calls = self.redone = 0
@@ -42,7 +42,9 @@ class DepthCuts:
             if not ent[4] and ent[2] is not None and (ent[3] is None or ent[3].query()):      # (no event: host tensors, the words are there)
                 ent[4] = True
                 if int(ent[2].max()) > 0:
-                    self.dilate, self._clean = min(self.dilate + 1, 6), 0
+                    if ent[5] >= self.dilate:       # (a failure of a frame armed with a narrower neighbourhood than today's says nothing new:
+                        self.dilate = min(self.dilate + 1, 6)    # the words come back a few frames late, and every one of those frames fails)
+                    self._clean = 0
                 else:
                     self._clean += 1
                     if self._clean >= 16:
@@ -74,7 +76,7 @@ class DepthCuts:
         nxt = 0 if last is None else 1 - last
         ent[1] = nxt
         redo = torch.zeros(n_views, dtype=torch.int32, device=device)
-        self._pending.append([frame_id, redo, None, None, cin is None])       # (a call without cuts cannot fail: nothing to learn from it)
+        self._pending.append([frame_id, redo, None, None, cin is None, self.dilate])   # (a call without cuts cannot fail: nothing to learn from it)
         self.calls += 1
         self.cut_calls += cin is not None
         return cin, bufs[nxt], redo, self.margin
@@ -105,7 +107,7 @@ class DepthCuts:
         """{frame id: [positions of the call's views whose speculative render must be repeated without cuts]} for the frames since the last
         call (waits for their redo words: they are long there unless the caller asks right behind a render)."""
         bad = {}
-        for fid, redo, host, ev, _ in self._pending:
+        for fid, redo, host, ev, _, _ in self._pending:
             if ev is not None:
                 ev.synchronize()
             words = (host if host is not None else redo.cpu()).tolist()
