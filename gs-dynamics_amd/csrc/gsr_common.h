@@ -591,7 +591,7 @@ __device__ __forceinline__ float4 gsr_act_rotation_bwd(float4 q, float4 dr) {
     const float inv = 1.0f / n;
     const float rx = q.x * inv, ry = q.y * inv, rz = q.z * inv, rw = q.w * inv;
     const float dot = fmaf(rw, dr.w, fmaf(rz, dr.z, fmaf(ry, dr.y, rx * dr.x)));
-    return make_float4((dr.x - rx * dot) * inv, (dr.y - ry * dot) * inv, (dr.z - rz * dot) * inv, (dr.w - rw * dot) * inv);
+    return make_float4(fmaf(-rx, dot, dr.x) * inv, fmaf(-ry, dot, dr.y) * inv, fmaf(-rz, dot, dr.z) * inv, fmaf(-rw, dot, dr.w) * inv);   // (spelled out: see above)
   }
   return make_float4(dr.x * 1e12f, dr.y * 1e12f, dr.z * 1e12f, dr.w * 1e12f);   // clamped denominator: a constant
 }

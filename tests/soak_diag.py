@@ -1,0 +1,54 @@
+"""Debug helper (GPU box): one case of tests/test_soak_gpu.py against the fp32 AND the fp64 oracle, every gradient tensor: norm-wise and
+worst-row distance of the HIP path and of the fp32 oracle from fp64.  python tests/soak_diag.py CASE [SEED]"""
+import os, sys
+import numpy as np, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "gs-dynamics_amd")):
+    sys.path.insert(0, p)
+from hipcheck import _run_hip
+from util import oracle_camera, random_gaussians, look_at, rel_err, row_err
+from oracle import TiledOracle
+want, seed0 = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 77
+rng = np.random.default_rng(seed0)
+for case in range(want + 1):
+    P = int(rng.choice([1, 5, 40, 150, 600, 1500, 4000]))
+    W, H = int(rng.integers(8, 260)), int(rng.integers(8, 200))
+    lo = float(rng.choice([0.003, 0.02, 0.08]))
+    hi = lo * float(rng.choice([1.5, 8.0, 30.0]))
+    kind = str(rng.choice(["rgb", "rgb", "sh", "cov3d"]))
+    deg = int(rng.integers(0, 4))
+    g = random_gaussians(P, seed=seed0 * 1000 + case, scale_lo=lo, scale_hi=hi, spread=float(rng.choice([0.4, 1.0, 2.0])), sh_M=16 if kind == "sh" else 0)
+    shift = float(rng.choice([-2.5, 0.0, 2.0]))
+    g["opacities"] = (1.0 / (1.0 + np.exp(-(np.log(g["opacities"] / (1.0 - g["opacities"])) + shift)))).astype(np.float32)
+    ang, rad, hgt = float(rng.uniform(0, 6.28)), float(rng.choice([0.7, 2.0, 4.0, 8.0])), float(rng.choice([-0.6, 0.5, 2.5]))
+    f = float(rng.choice([0.6, 1.0, 1.8])) * W
+    cam = oracle_camera(W, H, look_at((rad * np.cos(ang), hgt, rad * np.sin(ang))), fx=f, fy=f * float(rng.choice([1.0, 1.2])),
+                        cx=W / 2 + float(rng.choice([0.0, 0.0, 0.13 * W])), cy=H / 2 - float(rng.choice([0.0, 0.09 * H])),
+                        bg=tuple(float(x) for x in rng.uniform(0, 1, 3)), sh_degree=deg if kind == "sh" else 0)
+if kind == "sh":
+    del g["colors_precomp"]
+elif kind == "cov3d":
+    probe = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"], rotations=g["rotations"])
+    g = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=g["colors_precomp"], cov3D_precomp=probe.cov3D)
+print("case", want, kind, "P", P, W, H, "scales", lo, hi)
+dev = torch.device("cuda:0")
+kw = dict(colors_precomp=g.get("colors_precomp"), shs=g.get("shs"), scales=g.get("scales"), rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"), nthreads=4)
+o32 = TiledOracle(cam, g["means3D"], g["opacities"], **kw)
+o64 = TiledOracle(cam, g["means3D"], g["opacities"], f64=True, decisions_of=o32, **kw)
+ok = ~o32.ambiguous
+dL = np.random.default_rng(want).uniform(-1, 1, (3, H, W)).astype(np.float32)
+dL[:, ~ok] = 0.0
+g32, g64 = o32.backward(dL), o64.backward(dL)
+_, _, _, grads, _ = _run_hip(cam, g, dev, dL=dL)
+np.set_printoptions(precision=4, linewidth=220)
+print("radii", o32.radii.tolist(), "means2D range", o32.means2D.min(0), o32.means2D.max(0))
+for k, v in grads.items():
+    e_h, e_o = rel_err(v, g64[k]), rel_err(g32[k], g64[k])
+    (r_h, i_h), (r_o, i_o) = row_err(v, g64[k]), row_err(g32[k], g64[k])
+    print(f"{k:16s} norm-wise HIP {e_h:.2e} oracle32 {e_o:.2e} | worst row HIP {r_h:.2e} (row {i_h}) oracle32 {r_o:.2e} (row {i_o}) | max|g| {np.abs(g64[k]).max():.3e}")
+k = "means3D"
+i = int(np.abs(grads[k] - g64[k]).max(1).argmax())
+print("worst means3D row", i, "hip", grads[k][i], "o32", g32[k][i], "o64", g64[k][i], "| radius", int(o32.radii[i]), "mean2D", o32.means2D[i], "conic_op", o32.conic_opacity[i])
+print("   means2D grad of that row: hip", grads["means2D"][i], "o32", g32["means2D"][i], "o64", g64["means2D"][i])
+if "cov3D_precomp" in grads:
+    print("   cov3D grad of that row: hip", grads["cov3D_precomp"][i], "\n      o32", g32["cov3D_precomp"][i], "\n      o64", g64["cov3D_precomp"][i])

@@ -4,7 +4,7 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/gs-dynamics_amd/csrc; D=/tmp/gsr_full_$1; mkdir -p $D
 OBJS=""
 for o in gsr_preprocess_fwd gsr_binning gsr_render gsr_preprocess_bwd gsr_loss gsr_dynamics gsr_gnn gsr_rigidity gsr_step gsr_api; do
-  EXTRA=""; [ $o = gsr_preprocess_fwd ] && EXTRA="-ffp-contract=off"
+  EXTRA=""; { [ $o = gsr_preprocess_fwd ] || [ $o = gsr_preprocess_bwd ]; } && EXTRA="-ffp-contract=off"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA $2 -c $C/$o.hip -o $D/$o.o &
   OBJS="$OBJS $D/$o.o"
 done
