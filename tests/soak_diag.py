@@ -52,3 +52,9 @@ print("worst means3D row", i, "hip", grads[k][i], "o32", g32[k][i], "o64", g64[k
 print("   means2D grad of that row: hip", grads["means2D"][i], "o32", g32["means2D"][i], "o64", g64["means2D"][i])
 if "cov3D_precomp" in grads:
     print("   cov3D grad of that row: hip", grads["cov3D_precomp"][i], "\n      o32", g32["cov3D_precomp"][i], "\n      o64", g64["cov3D_precomp"][i])
+
+for k2 in grads:
+    if k2 not in ("means3D", "means2D", "cov3D_precomp") and grads[k2].ndim >= 2:
+        print(f"   {k2} of that row: hip", grads[k2][i].reshape(-1)[:9], "o32", g32[k2][i].reshape(-1)[:9], "o64", g64[k2][i].reshape(-1)[:9])
+print("   means2D grad of that row: hip", grads["means2D"][i], "o32", g32["means2D"][i], "o64", g64["means2D"][i])
+print("   tiles_touched", o32.tiles_touched[i], "rect", o32.rect[i], "depth", o32.depths[i] if hasattr(o32, "depths") else None)
