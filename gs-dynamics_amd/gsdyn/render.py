@@ -22,15 +22,17 @@ class DepthCuts:
     approximately right.  One object per stream of frames (FrameShard owns one); buffers are kept per camera set.
 
     ``dilate``: a tile bins with the DEEPEST proposal of its (2 dilate + 1)^2 neighbourhood -- where a silhouette moves by up to 16 dilate
-    pixels per frame, the tiles it uncovers inherit "no cut" from a neighbour that already saw the background.  It ADAPTS: the redo words
+    pixels per frame, the tiles it uncovers inherit "no cut" from a neighbour that already saw the background (default: what the process' last adapting object ended with, 2 at first).  It ADAPTS: the redo words
     of earlier frames come back through pinned memory without a wait (they are read once their copy's event has fired); a frame with a
     failing tile widens the neighbourhood by one tile (up to 6), sixteen clean frames in a row narrow it (down to 1).  Measured on the
     bench episode (Gaussians move 27 pixels per frame: tools/r05_depth_cut_probe.py): dilate 1 fails in every frame (100 tiles of 32 640),
     dilate 4 in 2 of 19 (a handful of tiles), keeping 38 % of the entries instead of 28 %."""
     MAX_TILES = 10240            # GSR_BIN_MAX_T: larger tile grids take the radix binning, which does not cut
+    _learned = {"dilate": 2}     # what the last adapting object of this process ended with: predict.py renders episode after episode of one scene
+    #                              (/root/reference/src/predict.py:74-164), and the next episode need not find the scene's speed again
 
-    def __init__(self, dilate: int = 2, margin: float = 1.01, adapt: bool = True):
-        self.dilate, self.margin, self.adapt = int(dilate), float(margin), bool(adapt)
+    def __init__(self, dilate: int = None, margin: float = 1.01, adapt: bool = True):
+        self.dilate, self.margin, self.adapt = int(DepthCuts._learned["dilate"] if dilate is None else dilate), float(margin), bool(adapt)
         self._buf = {}           # camera-set key -> [ping, pong] lists of per-view [T] int32 tensors, index of the last one written (or None)
         self._pending = []       # [frame id, redo words on the device [V], their pinned host copy, the copy's event, seen by the adaptation, dilation used]
         self._pinned = {}        # free pinned slots by word count
@@ -118,6 +120,8 @@ class DepthCuts:
             if host is not None and host is not redo:
                 self._pinned.setdefault(int(host.numel()), []).append(host)
         self._pending = []
+        if self.adapt:
+            DepthCuts._learned["dilate"] = self.dilate
         return bad
 
 

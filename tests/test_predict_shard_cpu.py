@@ -307,3 +307,7 @@ def test_depth_cuts_policy_on_host_tensors():
     other = dc.arm("other cameras", 1, h, w, "cpu", 100)
     assert other[0] is None                                           # a new camera set starts without cuts
     assert DepthCuts().arm("k", 1, 2160, 3840, "cpu", 0) is None      # 135 x 240 tiles: not served
+    dc.dilate = 5
+    dc.failed()
+    assert DepthCuts().dilate == 5 and DepthCuts(dilate=3).dilate == 3                      # the next episode of the process starts where this one ended
+    DepthCuts._learned["dilate"] = 2
