@@ -414,7 +414,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void fps_multi_kernel(const float* __res
         __hip_atomic_store(&row[blockIdx.x], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // sweep the whole row at once -- up to 256 slots, four per lane, all four loads in flight together -- until every slot is filled:
-      // one memory round trip per poll instead of one per 64 slots (round 5: 4.9 -> ?? ms for 1000 picks of 500 k points)
+      // one memory round trip per poll instead of one per 64 slots (round 5, with the two-barrier loop: 4.9 -> 4.2 ms for 1000 picks of 500 k points)
       unsigned long long v[4];
       bool missing;
       do {
