@@ -925,6 +925,39 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                             "bone fitting + skinning of 100k Gaussians (gsr_lbs); FPS timed separately (gsr_fps)"}
     except Exception as e:  # noqa: BLE001
         out["rollout_step_cfg1"] = {"error": repr(e)}
+    try:   # BASELINE.json configs[4]'s frames as a SEQUENCE (row A11): 500k Gaussians, 1920x1080, 4 cameras x (colour + mask), a scene that drifts ~3 px per frame
+        from gsdyn.dynamics import spatial_order
+        from gsdyn.predict import FrameShard, ring_poses
+        P5, W5, H5, NF = 500_000, 1920, 1080, 12
+        p5 = synth_scene_params(P5, seed=0, device=dev)
+        with torch.no_grad():
+            d5 = {k: v.detach() for k, v in params2rendervar(p5).items()}
+            perm = spatial_order(d5["means3D"])
+            d5 = {k: v[perm].contiguous() for k, v in d5.items()}
+            seq = []
+            for f in range(NF):
+                e = dict(d5)
+                e["means3D"] = d5["means3D"] + torch.tensor([0.006, 0.0, 0.003], device=dev) * f       # 0.006 units at distance 4, fx = 1920: ~3 px
+                seq.append(e)
+        res = {}
+        for name, spec in (("from_scratch", False), ("depth_cuts", True)):
+            shard = FrameShard(dev, W5, H5, ring_poses(4, W5, H5), 0, 1, speculative=spec)
+            shard.render_episode(seq[:3])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            shard.render_episode(seq)
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / NF * 1e3
+            if spec:
+                redone = shard.cuts.redone
+        out["predict_sequence_cfg5"] = {"ms_per_frame_from_scratch": res["from_scratch"], "ms_per_frame_depth_cuts": res["depth_cuts"],
+                                        "frames_with_a_repeated_view": redone, "frames": NF,
+                                        "what": "BASELINE.json configs[4] frames as a sequence: 500k Gaussians, 1920x1080, 4 cameras x (colour + mask), the scene drifting ~3 px "
+                                                "per frame; depth_cuts = every frame bins only what the previous frame of the same cameras needed, the blend validates the "
+                                                "guess, failed views are rendered again (gsdyn.render.DepthCuts: every frame handed out is exact); `--config 5 [--with-rollout]` "
+                                                "has the full lines"}
+    except Exception as e:  # noqa: BLE001
+        out["predict_sequence_cfg5"] = {"error": repr(e)}
     return out
 
 
