@@ -958,6 +958,25 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                                                 "has the full lines"}
     except Exception as e:  # noqa: BLE001
         out["predict_sequence_cfg5"] = {"error": repr(e)}
+    try:   # the graphed rollout step of configs[4] (row N4): 500k Gaussians, 1000 tracked particles, 100 bones, GNN width 512 -- one hipGraph replay per step
+        from gsdyn import dynamics as Dm
+        with torch.no_grad():
+            xyz5 = p5["means3D"].detach()
+            quat5 = torch.nn.functional.normalize(p5["unnorm_rotations"].detach())
+            torch.manual_seed(0)
+            model5 = Dm.DynamicsPredictor(dict(nf_particle=512, nf_relation=512, nf_effect=512, attr_dim=2, state_dim=0, action_dim=3, pstep=3,
+                                               rel_attr_dim=2, rel_group_dim=1, rel_distance_dim=3, n_his=3), device=dev).eval()
+            t_fps5 = _time_ms(lambda: Dm.farthest_point_sampler(xyz5[None], 1000), 2, 1)
+            track = Dm.farthest_point_sampler(xyz5[None], 1000)[0]
+            gs = Dm._graphed_step_for(model5, P5, 1000, 3, 100, 0.3, 0, 0.6, 5, dev)
+            gs.load(track, xyz5[track], xyz5[track][None].repeat(3, 1, 1), torch.zeros((3, 1, 3), device=dev), xyz5, quat5)
+            eef5 = torch.tensor([[0.02, 0.0, 0.01]], device=dev)
+            t_gs = _time_ms(lambda: gs.step(eef5), 50, 5)
+        out["rollout_graphed_step_cfg5"] = {"ms_per_step": t_gs, "fps_1000_of_500k_ms": t_fps5, "bones_kept": int(gs.n_valid),
+                                            "what": "configs[4]'s rollout step as ONE hipGraph replay (bone sampling + thinning, relations, propagation network, rotation "
+                                                    "fit, skinning of 500k Gaussians, history shift: 33 graph nodes) and the episode's one-off farthest-point sampling"}
+    except Exception as e:  # noqa: BLE001
+        out["rollout_graphed_step_cfg5"] = {"error": repr(e)}
     return out
 
 
