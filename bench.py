@@ -663,7 +663,7 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
     # on this GPU -- the producer's streaming rollout with a packet hook, and a render rank's frame production from recorded packets --
     # which is what the prediction below is made of; world > 1: the episode itself is timed.
     from gsdyn.predict import collect_scene_data
-    dt_pipe = prod_ms = cons_ms = None
+    dt_pipe = prod_ms = prod_light_ms = cons_ms = None
     if world > 1:
         predict_episode(model, p, eef[:2], poses, W5, H5, rollout_cfg=roll, rank=rank, world=world, pipeline=True)
         torch.cuda.synchronize()
@@ -684,6 +684,12 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
             collect_scene_data(model, p, eef, on_frame=noop, on_skin=lambda i, pk: packets.__setitem__(i, pk.clone()), **roll)
             torch.cuda.synchronize()
             prod_ms = (time.perf_counter() - t2) * 1e3
+        for rounds in range(2):       # what the producer of predict_episode(pipeline=True) runs when it renders nothing: its tracked particles only
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            collect_scene_data(model, p, eef, on_skin=lambda i, pk: packets.__setitem__(-1, pk), tracked_only=True, **roll)
+            torch.cuda.synchronize()
+            prod_light_ms = (time.perf_counter() - t2) * 1e3
         for rounds in range(2):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -698,9 +704,12 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
             "ms_per_step_overlapped": dt_overlap / frames * 1e3,
             "ms_per_step_pipelined": None if dt_pipe is None else dt_pipe / frames * 1e3,
             "pipeline_parts_ms_per_frame": None if prod_ms is None else {
-                "producer_rollout_streaming": prod_ms / frames, "render_rank_frames_from_packets": cons_ms / frames,
+                "producer_rollout_streaming": prod_ms / frames, "producer_tracked_only": prod_light_ms / frames,
+                "render_rank_frames_from_packets": cons_ms / frames,
                 "note": "one GPU, each side alone: the rank that rolls out (sampling, relations, GNN, rotation fit, skinning, smoothing; packets "
-                        "handed to a hook) and a render rank's frame production from recorded packets (skinning + smoothing; no network)"},
+                        "handed to a hook) -- with all Gaussians (a producer that also renders) and with its tracked particles only (the default "
+                        "producer, which renders nothing: same packets) -- and a render rank's frame production from recorded packets (skinning + "
+                        "smoothing; no network); `pipelined` below uses the tracked-only producer"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[4] END TO END: gsdyn.predict.predict_episode = rollout (every rank) + (frame, camera) pairs "
                                    "sharded round-robin, 4 cameras x (colour + mask)", "gaussians": tm["gaussians"], "image": [H5, W5], "cameras": CAMS,
@@ -717,9 +726,9 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
                 str(n): {"sequential": roll_ms / max(frames - 1, 1) + rend_ms / frames / n,
                          "overlapped": max(roll_ms / max(frames - 1, 1), rend_ms / frames / n),
                          # pipelined: the producer's rollout against a render rank's skinning + its share of the renders (N - 1 render ranks)
-                         "pipelined": None if n == 1 else max(prod_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
+                         "pipelined": None if n == 1 else max(prod_light_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
                          "pipelined_speedup_vs_1": None if n == 1 else (roll_ms / max(frames - 1, 1) + rend_ms / frames)
-                         / max(prod_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
+                         / max(prod_light_ms / frames, cons_ms / frames + rend_ms / frames / (n - 1)),
                          "speedup_vs_1": (roll_ms / max(frames - 1, 1) + rend_ms / frames) / (roll_ms / max(frames - 1, 1) + rend_ms / frames / n)}
                 for n in (1, 2, 4, 8)},
             "roofline": None, "cpu_baseline": None}))

@@ -589,11 +589,15 @@ def blend_skinning(bones, R, motions, base_q, xyz, quat=None, weights=None, out=
         from diff_gaussian_rasterization import _hip
         return _hip.linear_blend_skinning(bones.float().contiguous(), R.contiguous(), motions.float().contiguous(), base_q.contiguous(),
                                           xyz.float().contiguous(), None if quat is None else quat.float().contiguous(), out=out)
+    # Host tensors: every Gaussian's row is computed from its own differences only (no cdist / einsum: their matrix-product forms
+    # block over rows, so a Gaussian's result would depend on which others are in the call) -- as on the device, where a thread owns
+    # a Gaussian.  The pipelined episode's tracked-only producer relies on it (predict.collect_scene_data(tracked_only=True)).
+    diff = xyz[:, None, :].float() - bones[None].float()
     if weights is None:
-        d = torch.clamp(torch.cdist(xyz[None].float(), bones[None].float())[0], min=1e-4)
+        d = torch.clamp((diff * diff).sum(-1).sqrt(), min=1e-4)
         weights = 1.0 / d
         weights = weights / weights.sum(1, keepdim=True)
-    moved = torch.einsum("pbk,bjk->pbj", xyz[:, None, :] - bones[None], R) + motions[None] + bones[None]
+    moved = (diff[:, :, None, :] * R[None]).sum(-1) + motions[None] + bones[None]
     xyz_new = (moved * weights[:, :, None]).sum(1)
     rot = None
     if quat is not None:

@@ -135,7 +135,7 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
 def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
                        dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
                        remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True, on_frame=None,
-                       on_skin=None, skin_source=None):
+                       on_skin=None, skin_source=None, tracked_only: bool = False):
     """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
     the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
@@ -149,7 +149,11 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     (the interpolation is ``smooth_segment`` either way).
     ``on_skin`` / ``skin_source``: ``dynamics.rollout``'s two ends of the pipelined episode -- the rank that rolls out hands every moving
     step's skinning packet to ``on_skin``; a rank given a ``skin_source`` runs no outlier filter, no sampling and no network, it only
-    moves the Gaussians with the packets it receives (``model`` is not used and may be None)."""
+    moves the Gaussians with the packets it receives (``model`` is not used and may be None).
+    ``tracked_only``: the rank that rolls out for OTHERS and neither renders nor returns the scene moves only its tracked particles
+    (the ``n_fps_all`` farthest points of the inliers, picked here exactly as the rollout would pick them): sampling, relations, network,
+    rotation fit and the packets never look at anything else, and the skinning is per particle -- same packets, same keypoints, bit
+    for bit; the returned scene data then hold the tracked particles only."""
     import time
     from . import dynamics as D
     first = lambda t: t[0] if t.dim() == 3 else t   # noqa: E731
@@ -176,6 +180,13 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
     # rank): the skinning is per Gaussian, and the only index-order-dependent piece -- the farthest-point picks over xyz_0[inlier] --
     # sees the same sequence of points when the inlier list is mapped through the inverse permutation.  Same values, bit for bit, as
     # permuting the finished frames (tests/test_predict_shard_cpu.py).
+    if tracked_only and skin_source is None:
+        # farthest-point sampling over the picked points, in pick order and from the same start, picks them again in that order
+        # (pick k was the farthest of ALL inliers from picks 0 .. k-1, first index on ties: it still is among the picks)
+        n_t = min(n_fps_all, int(inlier.shape[0]))
+        track = inlier[D.farthest_point_sampler(xyz_0[inlier][None], n_t, start_idx=0)[0]]
+        xyz_0, rgb_0, quat_0, opa_0, scales_0 = xyz_0[track], rgb_0[track], quat_0[track], opa_0[track], scales_0[track]
+        inlier, spatial_sort = torch.arange(n_t, device=dev), False
     if spatial_sort and int(xyz_0.shape[0]) > 1:
         perm = D.spatial_order(xyz_0)                 # frame 0 IS xyz_0
         inv = torch.empty_like(perm)
@@ -388,7 +399,11 @@ def _predict_episode_pipelined(model, params, eef_xyz, poses, w, h, rollout_cfg,
         def on_skin(i, pk):
             buf = pk.detach().to("cpu").contiguous() if on_host else pk      # (RCCL: the current stream waits for the broadcast: the next
             dist.broadcast(buf, src=src, group=group)                          #  step's graph replay does not overwrite the packet under it)
-        scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=on_frame, on_skin=on_skin, **rollout_cfg)
+        # a producer that renders nothing and hands no scene back only needs its tracked particles (collect_scene_data)
+        light = shard is None and scene_out is None
+        scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=None if light else on_frame, on_skin=on_skin,
+                                            tracked_only=light, **rollout_cfg)
+        tm["producer_tracked_only"] = light
     else:
         def skin_source(i):
             buf = torch.empty(plen, dtype=torch.float32, device="cpu" if on_host else dev)

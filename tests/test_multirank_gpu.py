@@ -291,16 +291,18 @@ def _episode_problem(dev):
     return model, params, eef
 
 
-def _pipelined_worker(rank, world, port, out_dir):
+def _pipelined_worker(rank, world, port, out_dir, light):
     dev = _init(rank, world, port)
     from gsdyn.predict import predict_episode, render_ranks_of, ring_poses, shard_pairs
     model, params, eef = _episode_problem(dev)
     scene = []
+    light = light and rank == 0        # a producer that wants no scene back rolls out its tracked particles only
     frames, vis, tm = predict_episode(model if rank == 0 else None, params, eef, ring_poses(CAMS, EP_W, EP_H), EP_W, EP_H, rollout_cfg=EP_ROLL,
-                                      pipeline=True, scene_out=scene)
+                                      pipeline=True, scene_out=None if light else scene)
     torch.cuda.synchronize()
     rr = render_ranks_of(world)
-    assert tm["pipelined"] and rr == list(range(1, world)) and len(scene) == EP_S and len(vis) == EP_S
+    assert tm["pipelined"] and rr == list(range(1, world)) and len(scene) == (0 if light else EP_S) and len(vis) == EP_S
+    assert rank != 0 or (tm["producer_tracked_only"] == light and (tm["gaussians"] == EP_ROLL["n_fps_all"]) == light)
     assert sorted(frames) == (sorted(shard_pairs(EP_S, CAMS, rr.index(rank), len(rr))) if rank in rr else [])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=np.array(sorted(frames)).reshape(-1, 2),
              **{f"sc_{t}_{k}": v.cpu().numpy() for t, d in enumerate(scene) for k, v in d.items() if k != "means2D"},
@@ -311,18 +313,24 @@ def _pipelined_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipelined_episode_on_the_real_kernels(tmp_path, world):
+@pytest.mark.parametrize("world,light", [(2, False), (3, True)])
+def test_pipelined_episode_on_the_real_kernels(tmp_path, world, light):
     """predict_episode(pipeline=True) with 2 / 3 processes on this GPU (gloo: the packets travel as host tensors): rank 0 runs the graphed
     rollout and broadcasts the skinning packets, the others produce every frame from the packets with gsr_lbs alone -- the SAME render
     inputs and keypoints bit for bit (the rollout itself differs by ulps from run to run: every rank is compared with rank 0 of ITS run)
-    -- and their renders are the single-process renders of those inputs, every (frame, camera) pair exactly once."""
+    -- and their renders are the single-process renders of those inputs, every (frame, camera) pair exactly once.  ``light``: rank 0
+    asks for no scene back, so it rolls out its ~1000 tracked particles ONLY (collect_scene_data(tracked_only=True)): its keypoints are
+    still the render ranks', bit for bit, and the render ranks' frames still move (the packets are the same kind)."""
     _setup_paths()
-    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path), light), nprocs=world, join=True)
     dev = torch.device("cuda", 0)
     from gsdyn.predict import FrameShard, ring_poses
-    z0 = np.load(tmp_path / "rank0.npz")
-    assert z0["keys"].size == 0                                  # the producer renders nothing by default
+    zp = np.load(tmp_path / "rank0.npz")
+    assert zp["keys"].size == 0                                  # the producer renders nothing by default
+    assert light == (not any(n.startswith("sc_") for n in zp.files))
+    z0 = np.load(tmp_path / "rank1.npz") if light else zp       # whose scene the others are compared with
+    for t in range(EP_S):
+        assert np.array_equal(zp[f"kp_{t}"], z0[f"kp_{t}"]), t
     scene = []
     for t in range(EP_S):
         d = {k: torch.tensor(z0[f"sc_{t}_{k}"], device=dev) for k in ("means3D", "colors_precomp", "rotations", "opacities", "scales")}
