@@ -106,7 +106,7 @@ typedef struct {
   /* image state */
   float *final_T;        /* [H*W] */
   uint32_t *n_contrib;   /* [H*W] */
-  uint8_t *ambiguous;    /* [H*W] 1 if any threshold decision was within rel. 1e-5 of flipping */
+  uint8_t *ambiguous;    /* [H*W] 1 if any threshold decision was within rel. 1e-5 (+ the rounding slack of a cancelling exponent) of flipping */
   float *out_color;      /* [3,H,W] */
   float *out_depth;      /* [H*W] */
 } gsro_ctx;
@@ -321,10 +321,16 @@ static void render_tile_fwd(gsro_ctx *c, int tile) {
         float dx = c->means2D[2 * g] - pxf, dy = c->means2D[2 * g + 1] - pyf;
         const float *co = c->conic_opacity + 4 * g;
         float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        /* What ANY fp32 evaluation order can move the exponent by: its three terms cancel (a nearly singular conic far from its
+           centre: terms of +-400 that sum to -5), so the decisions taken on it -- power > 0, alpha >= 1/255 -- are ambiguous within
+           a few roundings of the terms' magnitudes, not within a fixed 1e-5 (soak seed 4242 case 126: alpha 1.3e-5 above 1/255 in
+           fp64, 5.5e-6 below it with the conic pre-scaled by log2 e; terms' magnitudes 801). */
+        float slack = 4.0f * 5.9604645e-8f * (0.5f * fabsf(co[0]) * dx * dx + 0.5f * fabsf(co[2]) * dy * dy + fabsf(co[1] * dx * dy));
+        if (fabsf(power) <= slack && co[3] >= ALPHA_MIN) amb = 1;
         if (power > 0.0f) continue;
         float alpha = co[3] * expf(power);
         if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
-        if (near_rel(alpha, ALPHA_MIN)) amb = 1;
+        if (fabsf(alpha - ALPHA_MIN) <= (1e-5f + slack) * ALPHA_MIN) amb = 1;
         if (alpha < ALPHA_MIN) continue;
         float test_T = T * (1.0f - alpha);
         if (near_rel(test_T, T_EPS)) amb = 1;

@@ -31,7 +31,7 @@ def _adjudicate(cam, g, dev, seed, tol_worst):
     dL = np.random.default_rng(seed).uniform(-1, 1, (3, cam.image_height, cam.image_width)).astype(np.float32)
     dL[:, ~ok] = 0.0
     g32, g64 = o32.backward(dL), o64.backward(dL)
-    color, _, _, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
+    color, _, depth, grads, views = _run_hip(cam, g, dev, dL=dL, want_state=True)
     notes, rows = [], []
     # final transmittance: a product of up to hundreds of (1 - alpha) factors, each carrying alpha's absolute rounding error -- 1e-5 RELATIVE where
     # alpha sits at the 0.99 clamp -- so where T is small two fp32 evaluations differ by more than 1e-4 of it (the images do not: T only ever
@@ -41,7 +41,10 @@ def _adjudicate(cam, g, dev, seed, tol_worst):
         tT_h, tT_o = mixed_err(views["final_T"].cpu().numpy()[okT], o64.final_T[okT].astype(np.float32)), mixed_err(o32.final_T[okT], o64.final_T[okT].astype(np.float32))
         notes.append(f"final_T: vs fp64 HIP {tT_h:.2e} / fp32 oracle {tT_o:.2e}")
         assert tT_h <= max(TOL, 2.0 * tT_o + 2e-5), ("final_T", tT_h, tT_o)
-    assert mixed_err(color[:, okT], o64.color[:, okT].astype(np.float32)) < TOL, "colour vs fp64"
+    for name, img_h, img_o, img_64 in (("colour", color, o32.color, o64.color), ("depth", depth, o32.depth, o64.depth)):
+        i_h, i_o = mixed_err(img_h[:, okT], img_64[:, okT].astype(np.float32)), mixed_err(img_o[:, okT], img_64[:, okT].astype(np.float32))
+        notes.append(f"{name}: vs fp64 HIP {i_h:.2e} / fp32 oracle {i_o:.2e}")
+        assert i_h <= max(TOL, 2.0 * i_o + 2e-5), (name + " vs fp64", i_h, i_o)
     for k, v in grads.items():
         e_hip, e_o = rel_err(v, g64[k]), rel_err(g32[k], g64[k])
         r_hip, r_o = row_err(v, g64[k])[0], row_err(g32[k], g64[k])[0]
@@ -88,7 +91,10 @@ def test_parity_soak(dev):
                 try:
                     _check_against_oracle(cam, g, dev, seed=case, min_ok=0.98, tol_worst=tol_worst)
                 except AssertionError as e:
-                    if not str(e).startswith(("grad ", "oracle P=", "final_T")):   # gradient bars and the transmittance go to the referee; integers and images never
+                    # gradient bars and the transmittance go to the referee, and so does a colour / depth pixel off by more than 1e-4 OF ITSELF (a nearly
+                    # empty pixel: the sum of dozens of alpha ~ 1/255 contributions of huge Gaussians, each alpha carrying the rounding of a cancelling
+                    # exponent -- seed 4242 case 933: depth 0.0177 at final_T 0.992, 1.2e-4 apart); integers and ambiguous-pixel bounds never
+                    if not (str(e).startswith(("grad ", "oracle P=", "final_T")) or str(e) in ("depth", "colour")):
                         raise
                     note, rows = _adjudicate(cam, g, dev, case, tol_worst)
                     conditioned += 1
