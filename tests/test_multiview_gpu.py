@@ -485,3 +485,47 @@ def test_batch_with_a_view_that_sees_nothing(dev):
     assert torch.equal(im3[0], im2[0]) and torch.equal(im3[2], im2[1]) and torch.all(m3[1] == 0)
     for kk in g2:
         assert (g3[kk] - g2[kk]).abs().max().item() <= 1e-6 * g2[kk].abs().max().item(), kk
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "12"))))      # GSR_MV_SOAK=N: a longer hunt
+def test_random_batches_equal_per_view_calls(dev, seed):
+    """Seeded random scenes through the multi-view call against V separate drop-in calls: Gaussian count, ragged image sizes, view count,
+    camera distance (inside the cloud included) and Gaussian size vary.  Images, radii and depth bit for bit; gradients = the sum over the
+    views up to the summation order of the two per-Gaussian backward kernels."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    rng = np.random.default_rng(500 + seed)
+    P = int(rng.choice([1, 60, 900, 6000, 30000]))
+    W, H, V = int(rng.integers(17, 420)), int(rng.integers(17, 300)), int(rng.integers(1, 6))
+    lo = float(rng.choice([0.004, 0.02, 0.08]))
+    params = synth_scene_params(P, seed=seed, device=dev, scale_lo=lo, scale_hi=lo * float(rng.choice([1.5, 6.0])))
+    cams = synth_ring_cameras(V, W, H, device=dev, radius=float(rng.choice([0.6, 2.5, 5.0])), height=float(rng.choice([-0.5, 0.8])))
+    dL = torch.tensor(rng.uniform(-1, 1, (V, 3, H, W)).astype(np.float32), device=dev)
+
+    def leaves():
+        with torch.no_grad():
+            rv = params2rendervar(params)
+        return {k: v.detach().clone().requires_grad_(True) for k, v in rv.items()}
+
+    a = leaves()
+    ims, rads, deps, m2g = [], [], [], []
+    for v in range(V):
+        m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+        im, radii, depth = GaussianRasterizer(raster_settings=cams[v])(
+            means3D=a["means3D"], means2D=m2, opacities=a["opacities"], colors_precomp=a["colors_precomp"], scales=a["scales"], rotations=a["rotations"])
+        im.backward(gradient=dL[v])
+        ims.append(im.detach()); rads.append(radii); deps.append(depth.detach()); m2g.append(m2.grad if m2.grad is not None else torch.zeros_like(m2))  # noqa: E702
+    b = leaves()
+    m2v = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+    imb, radb, depb = rasterize_gaussians_views(cams, b["means3D"], m2v, b["opacities"], colors_precomp=b["colors_precomp"], scales=b["scales"],
+                                                rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    torch.cuda.synchronize()
+    tag = (seed, P, W, H, V)
+    assert torch.equal(imb.detach(), torch.stack(ims)) and torch.equal(radb, torch.stack(rads)) and torch.equal(depb.detach(), torch.stack(deps)), tag
+    ref = torch.stack(m2g)
+    assert (m2v.grad - ref).abs().max().item() <= 4e-6 * max(ref.abs().max().item(), 1e-30), tag
+    for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
+        ga = a[k].grad if a[k].grad is not None else torch.zeros_like(a[k])
+        gb = b[k].grad if b[k].grad is not None else torch.zeros_like(b[k])
+        assert (ga - gb).abs().max().item() <= 1e-5 * max(ga.abs().max().item(), 1e-30), (k,) + tag
