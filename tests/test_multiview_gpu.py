@@ -529,3 +529,47 @@ def test_random_batches_equal_per_view_calls(dev, seed):
         ga = a[k].grad if a[k].grad is not None else torch.zeros_like(a[k])
         gb = b[k].grad if b[k].grad is not None else torch.zeros_like(b[k])
         assert (ga - gb).abs().max().item() <= 1e-5 * max(ga.abs().max().item(), 1e-30), (k,) + tag
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "12"))))
+def test_random_fused_pairs_equal_separate_renders(dev, seed):
+    """Row N1 on seeded random scenes: C cameras x (colour, segmentation) as ONE call with per-view colours (the second view of a camera is
+    blended inside the first one's tile pass) against 2 C separate drop-in calls -- images bit for bit, colour gradients per colour set,
+    geometry gradients summed (up to the summation order)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_gaussians_views
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    rng = np.random.default_rng(900 + seed)
+    P = int(rng.choice([1, 60, 900, 6000, 30000]))
+    W, H, C = int(rng.integers(17, 420)), int(rng.integers(17, 300)), int(rng.integers(1, 4))
+    lo = float(rng.choice([0.004, 0.02, 0.08]))
+    params = synth_scene_params(P, seed=seed, device=dev, scale_lo=lo, scale_hi=lo * float(rng.choice([1.5, 6.0])))
+    cams = synth_ring_cameras(C, W, H, device=dev, radius=float(rng.choice([0.6, 2.5, 5.0])), height=float(rng.choice([-0.5, 0.8])))
+    dL = torch.tensor(rng.uniform(-1, 1, (2 * C, 3, H, W)).astype(np.float32), device=dev)
+    with torch.no_grad():
+        rv = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+    cols = torch.stack([rv["colors_precomp"], params["seg_colors"].detach()])             # [2,P,3]
+    zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)                # noqa: E731
+    a = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    ca = cols.clone().requires_grad_(True)
+    ims = []
+    for v in range(2 * C):
+        im, _, _ = GaussianRasterizer(raster_settings=cams[v // 2])(
+            means3D=a["means3D"], means2D=torch.zeros((P, 3), device=dev, requires_grad=True), opacities=a["opacities"],
+            colors_precomp=ca[v % 2], scales=a["scales"], rotations=a["rotations"])
+        im.backward(gradient=dL[v])
+        ims.append(im.detach())
+    b = {k: v.clone().requires_grad_(True) for k, v in rv.items() if k not in ("colors_precomp", "means2D")}
+    cb = cols.repeat(C, 1, 1).clone().requires_grad_(True)                                # [2C,P,3]
+    m2 = torch.zeros((2 * C, P, 3), device=dev, requires_grad=True)
+    imb, _, _ = rasterize_gaussians_views([cams[v // 2] for v in range(2 * C)], b["means3D"], m2, b["opacities"], colors_precomp=cb,
+                                          scales=b["scales"], rotations=b["rotations"])
+    imb.backward(gradient=dL)
+    torch.cuda.synchronize()
+    tag = (seed, P, W, H, C)
+    assert torch.equal(imb.detach(), torch.stack(ims)), tag
+    gcb, gca = zero(cb), zero(ca)
+    for s in range(2):
+        assert (gcb[s::2].sum(0) - gca[s]).abs().max().item() <= 1e-5 * max(gca[s].abs().max().item(), 1e-30), (s,) + tag
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        ga, gb = zero(a[k]), zero(b[k])
+        assert (ga - gb).abs().max().item() <= 1e-5 * max(ga.abs().max().item(), 1e-30), (k,) + tag
