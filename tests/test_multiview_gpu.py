@@ -573,3 +573,34 @@ def test_random_fused_pairs_equal_separate_renders(dev, seed):
     for k in ("means3D", "opacities", "scales", "rotations"):
         ga, gb = zero(a[k]), zero(b[k])
         assert (ga - gb).abs().max().item() <= 1e-5 * max(ga.abs().max().item(), 1e-30), (k,) + tag
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "12"))))
+def test_random_forward_only_frames_equal_the_reference_shaped_calls(dev, seed):
+    """Row A11 on seeded random scenes (dense ones included: the forward-only call picks its sort / binning builds from the list lengths): the
+    predict.py frame -- C cameras x (colour + mask) as one forward-only call -- against two reference-shaped renders per camera."""
+    from gsdyn import params2rendervar, synth_scene_params
+    from gsdyn.predict import ring_poses
+    from gsdyn.render import Renderer
+    rng = np.random.default_rng(1300 + seed)
+    P = int(rng.choice([1, 300, 5000, 40000, 150000]))
+    W, H, C = int(rng.integers(17, 700)), int(rng.integers(17, 420)), int(rng.integers(1, 5))
+    lo = float(rng.choice([0.004, 0.02, 0.06]))
+    params = synth_scene_params(P, seed=seed, device=dev, scale_lo=lo, scale_hi=lo * float(rng.choice([1.5, 4.0])))
+    with torch.no_grad():
+        data = {k: v.detach() for k, v in params2rendervar(params).items()}
+        data["opacities"] = data["opacities"].clamp_min(float(rng.choice([0.0, 0.5])))
+    r = Renderer(dev, w=W, h=H)
+    cams = ring_poses(C, W, H)
+    bg = tuple(float(x) for x in rng.choice([0.0, 0.3], 3))
+    ims, depths, masks = r.render_cameras_with_mask(cams, data, bg=bg)
+    ims2, depths2, masks2 = r.render_cameras_with_mask(cams, data, bg=bg, mask_from_alpha=False)
+    ones = dict(data)
+    ones["colors_precomp"] = torch.ones_like(data["colors_precomp"])
+    tag = (seed, P, W, H, C)
+    for i, (w2c, kk) in enumerate(cams):
+        im, depth = r.render(w2c, kk, data, bg=bg)
+        mask, _ = r.render(w2c, kk, ones, bg=bg)
+        assert torch.equal(ims[i], im) and torch.equal(depths[i], depth), tag + (i,)
+        assert torch.equal(ims2[i], im) and torch.equal(depths2[i], depth) and torch.equal(masks2[i], mask), tag + (i,)
+        assert float((masks[i] - mask).abs().max()) <= 3e-5, tag + (i, float((masks[i] - mask).abs().max()))
