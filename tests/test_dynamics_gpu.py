@@ -584,3 +584,57 @@ def test_graphed_step_with_fused_glue_equals_the_torch_glue(dev, golden_dir):
     for i, (a, b) in enumerate(zip(runs[True], runs[False])):
         for j, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), (i, j, float((x.float() - y.float()).abs().max()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "12"))))
+def test_random_sampling_thinning_and_relations(dev, seed):
+    """Seeded random clouds through the decision-heavy kernels of a rollout step -- gsr_fps (both forms), gsr_fps_thin, gsr_construct_edges
+    -- against the host statements: the same indices, the same relation lists in the same order.  Clouds with duplicates, points on a
+    lattice (exact distance ties), clusters; radii / thresholds / k at random."""
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import construct_edges, farthest_point_sampler, fps_radius
+    rng = np.random.default_rng(1700 + seed)
+    g = torch.Generator().manual_seed(1700 + seed)
+    # ---- sampling + thinning of up to 1024 tracked points
+    N = int(rng.choice([1, 2, 63, 64, 65, 200, 777, 1000, 1024]))
+    kind = int(rng.integers(0, 4))
+    xyz = torch.rand(N, 3, generator=g) * 2 - 1
+    if kind == 1:
+        xyz = torch.round(xyz * 4) / 4                          # a lattice: exact ties everywhere
+    elif kind == 2 and N > 4:
+        xyz[N // 2:] = xyz[: N - N // 2].clone()                # every point twice
+    elif kind == 3:
+        xyz = xyz * 0.05 + torch.round(xyz)                     # eight tight clusters
+    npts = int(min(N, rng.choice([1, 7, 64, 100, 128])))
+    radius, start = float(rng.choice([0.02, 0.12, 0.3, 0.9])), int(rng.integers(0, npts))
+    idx1 = farthest_point_sampler(xyz[None], npts, start_idx=0)[0]
+    _, idx2 = fps_radius(xyz[idx1], radius, start_idx=start)
+    got1, got2 = _hip.fps_thin(xyz.to(dev), npts, radius, 0, start)
+    assert torch.equal(got1.cpu(), idx1) and torch.equal(got2.cpu(), idx2), ("fps_thin", seed, N, kind, npts, radius, start)
+    # ---- the big sampler (single- and multi-workgroup forms) on a cloud of a few thousand points
+    M = int(rng.choice([1500, 2049, 5000, 20000]))
+    big = torch.rand(M, 3, generator=g)
+    if kind == 1:
+        big = torch.round(big * 16) / 16
+    k_big, s_big = int(rng.choice([1, 50, 300])), int(rng.integers(0, M))
+    want = farthest_point_sampler(big[None], k_big, start_idx=s_big)[0]
+    got = farthest_point_sampler(big.to(dev)[None], k_big, start_idx=s_big)[0]
+    assert torch.equal(got.cpu(), want), ("fps", seed, M, kind, k_big, s_big)
+    # ---- relations on the padded layout
+    cap = int(rng.choice([8, 50, 100, 126]))
+    n_valid = int(rng.integers(1, cap + 1))
+    thr, k = float(rng.choice([0.1, 0.35, 0.6, 5.0])), int(rng.choice([1, 3, 5, 8, 16]))
+    pos = torch.rand(cap + 1, 3, generator=g)      # (no lattice here: among EXACTLY equal distances at the k-th neighbour torch.topk -- the host statement, and
+    pos[cap] = pos[:n_valid].mean(0)               #  the reference -- picks an unspecified one, the kernel the lower index: 300 lattice cases differed only there)
+    comp = torch.cat([pos[:n_valid], pos[cap:]], 0)
+    mask = torch.ones(n_valid + 1, dtype=torch.bool)
+    tool = torch.zeros(n_valid + 1, dtype=torch.bool)
+    tool[n_valid] = True
+    r, s_ = construct_edges(comp, thr, mask, tool, topk=k)
+    remap = torch.cat([torch.arange(n_valid), torch.tensor([cap])])
+    want = torch.stack([remap[r], remap[s_]], 1)
+    e_cap = ((cap * (k + 2) + 127) // 128) * 128
+    recv, send, cnt = _hip.construct_edges_padded(pos.to(dev), torch.tensor([n_valid], dtype=torch.int32, device=dev), thr, k, e_cap, 127)
+    m = int(cnt.item())
+    got_e = torch.stack([recv[:m], send[:m]], 1).cpu()
+    assert m == want.shape[0] and torch.equal(got_e, want), ("edges", seed, cap, n_valid, thr, k, kind, m, want.shape[0])
