@@ -675,3 +675,27 @@ def test_fused_activations_in_the_direct_step(dev):
         assert torch.equal(g0[k], g1[k]), k
     for k in ("means3D", "unnorm_rotations", "logit_opacities", "log_scales"):     # frozen colours: another reduction tree
         assert (g0[k] - g2[k]).abs().max().item() <= 4e-6 * g0[k].abs().max().item(), k
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "12"))))
+def test_random_shapes_of_the_fused_image_loss(dev, seed):
+    """Seeded random image shapes (down to one pixel row, ragged against the kernels' 16 x 16 tiles and the 11-tap window, smooth and noisy
+    content) through the fused 0.8 L1 + 0.2 (1 - SSIM) kernels against the fp64 torch statement of the reference formula: value, gradient."""
+    from gsdyn import losses as L
+    rng = np.random.default_rng(2100 + seed)
+    H, W = int(rng.choice([1, 5, 10, 11, 12, 16, 17, int(rng.integers(18, 500))])), int(rng.choice([1, 7, 11, 16, 31, 33, int(rng.integers(18, 700))]))
+    smooth = bool(rng.integers(0, 2))
+    base = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    if smooth:
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = (0.5 + 0.5 * np.sin(0.07 * xx + 0.05 * yy)[None] * rng.uniform(0.2, 1.0, (3, 1, 1))).astype(np.float32)
+    x = torch.tensor(np.clip(base + 0.05 * rng.normal(size=base.shape), 0, 1).astype(np.float32), device=dev, requires_grad=True)
+    y = torch.tensor(base, device=dev)
+    xd = x.double()
+    ref = 0.8 * L.l1_loss_v1(xd, y.double()) + 0.2 * (1.0 - L.calc_ssim(xd, y.double()))
+    (gref,) = torch.autograd.grad(ref * 3.0, x)
+    x2 = x.detach().clone().requires_grad_(True)
+    got = L.image_loss(x2, y)
+    (ggot,) = torch.autograd.grad(got * 3.0, x2)
+    assert abs(got.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7, (seed, H, W, smooth, got.item(), ref.item())
+    assert (ggot - gref).abs().max().item() <= 2e-4 * gref.abs().max().item(), (seed, H, W, smooth, (ggot - gref).abs().max().item(), gref.abs().max().item())
