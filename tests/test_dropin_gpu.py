@@ -369,3 +369,54 @@ def test_capturing_the_drop_in_call_fails_at_once(dev):
         torch.cuda.synchronize()
         again, _, _ = GaussianRasterizer(raster_settings=cam)(**rv)
     assert torch.equal(ref, again) and torch.equal(ref, ref2)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "6"))))
+def test_random_call_sequences_through_the_stateful_layer(dev, seed):
+    """The drop-in layer carries state from call to call (capacity estimates per shape, the previous forward's geometry for tile-list reuse, the
+    two-render predictor).  Seeded random SEQUENCES of calls -- scenes of the same shape with very different entry counts, repeats (twins),
+    two cameras, with and without gradients -- must return, call by call, exactly what a stateless layer returns."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    C_ = dgr._C
+    rng = np.random.default_rng(2500 + seed)
+    P, W, H = int(rng.choice([2000, 15000])), int(rng.integers(60, 330)), int(rng.integers(60, 260))
+    cams = synth_ring_cameras(3, W, H, device=dev)[:2]
+    scenes = [synth_scene_params(P, seed=10 * seed + i, device=dev, scale_lo=lo, scale_hi=3 * lo) for i, lo in enumerate((0.004, 0.012, 0.03, 0.07))]
+    dL = torch.tensor(rng.uniform(-1, 1, (3, H, W)).astype(np.float32), device=dev)
+    keys = ("means3D", "unnorm_rotations", "logit_opacities", "log_scales", "rgb_colors")
+
+    def run(si, ci, grad):
+        if not grad:
+            with torch.no_grad():
+                rv = {k: v.detach() for k, v in params2rendervar(scenes[si]).items()}
+                im, rad, dep = GaussianRasterizer(raster_settings=cams[ci])(**rv)
+            torch.cuda.synchronize()
+            return [im, rad, dep]
+        leaves = {k: scenes[si][k].detach().clone().requires_grad_(True) for k in keys}
+        im, rad, dep = GaussianRasterizer(raster_settings=cams[ci])(**params2rendervar(leaves))
+        (im * dL).sum().backward()
+        torch.cuda.synchronize()
+        return [im.detach(), rad, dep.detach()] + [leaves[k].grad for k in sorted(leaves)]
+    try:
+        C_.set_list_reuse(False)
+        C_.set_capacity_mode(False)
+        ref = {(si, ci, gr): run(si, ci, gr) for si in range(len(scenes)) for ci in range(2) for gr in (False, True)}
+        C_.set_list_reuse(True)
+        C_.set_capacity_mode(True)
+        C_.forget_capacities()
+        prev = None
+        for step in range(40):
+            if prev is not None and rng.uniform() < 0.35:
+                si, ci = prev                                # a twin of the previous call (the colour / mask pattern)
+            else:
+                si, ci = int(rng.integers(0, len(scenes))), int(rng.integers(0, 2))
+            gr = bool(rng.integers(0, 2))
+            got = run(si, ci, gr)
+            for i, (a, b) in enumerate(zip(got, ref[(si, ci, gr)])):
+                assert torch.equal(a, b), (seed, step, si, ci, gr, i)
+            prev = (si, ci)
+    finally:
+        C_.set_list_reuse(True)
+        C_.set_capacity_mode(True)
