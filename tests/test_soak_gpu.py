@@ -58,6 +58,7 @@ def _adjudicate(cam, g, dev, seed, tol_worst):
 def test_parity_soak(dev):
     n_cases, seed0 = int(os.environ.get("GSR_SOAK_CASES", "200")), int(os.environ.get("GSR_SOAK_SEED", "77"))
     rng = np.random.default_rng(seed0)
+    big = os.environ.get("GSR_SOAK_BIG") == "1"
     done, skipped, conditioned, kinds = 0, 0, 0, {"rgb": 0, "sh": 0, "cov3d": 0}
     missed, row_missed, seen_ref = [], [], 0
     log = os.path.join(os.path.dirname(HERE), "gpurun_out", "parity_soak.txt")
@@ -67,6 +68,8 @@ def test_parity_soak(dev):
         for case in range(n_cases):
             P = int(rng.choice([1, 5, 40, 150, 600, 1500, 4000]))
             W, H = int(rng.integers(8, 260)), int(rng.integers(8, 200))
+            if big:        # GSR_SOAK_BIG=1: the same stream of choices at 10 - 40 x the Gaussians and ~3 x the image side (long lists, every sort build)
+                P, W, H = int(rng.choice([8000, 20000, 50000])), 3 * W + 5, 3 * H + 3
             lo = float(rng.choice([0.003, 0.02, 0.08]))
             hi = lo * float(rng.choice([1.5, 8.0, 30.0]))
             kind = str(rng.choice(["rgb", "rgb", "sh", "cov3d"]))
@@ -124,4 +127,4 @@ def test_parity_soak(dev):
             seen_ref = conditioned
         fh.write(f"# passed {done} (of which {conditioned} through the fp64 referee), skipped {skipped}, bars missed in {len(missed)} scenes of Gaussians larger "
                  f"than the scene, a single row beyond the referee's rule in {len(row_missed)}, of {n_cases}; by colour model {kinds}\n")
-    assert done >= 0.8 * n_cases and conditioned <= 0.1 * n_cases + 2 and len(missed) <= 0.02 * n_cases + 1 and len(row_missed) <= 0.01 * n_cases + 1, (done, skipped, conditioned, missed, row_missed)
+    assert done >= 0.8 * n_cases and conditioned <= (0.3 if big else 0.1) * n_cases + 2 and len(missed) <= 0.02 * n_cases + 1 and len(row_missed) <= 0.01 * n_cases + 1, (done, skipped, conditioned, missed, row_missed)
