@@ -595,6 +595,17 @@ def test_random_sampling_thinning_and_relations(dev, seed):
     from gsdyn.dynamics import construct_edges, farthest_point_sampler, fps_radius
     rng = np.random.default_rng(1700 + seed)
     g = torch.Generator().manual_seed(1700 + seed)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)       # the host statements are Python loops over small tensor ops: with the oracle's OpenMP runtime loaded in the same
+    try:                           # process (any earlier test) torch's intra-op pool made three of twelve cases take 110 s each
+        _random_sampling_case(dev, seed, rng, g)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _random_sampling_case(dev, seed, rng, g):
+    from diff_gaussian_rasterization import _hip
+    from gsdyn.dynamics import construct_edges, farthest_point_sampler, fps_radius
     # ---- sampling + thinning of up to 1024 tracked points
     N = int(rng.choice([1, 2, 63, 64, 65, 200, 777, 1000, 1024]))
     kind = int(rng.integers(0, 4))
@@ -612,7 +623,7 @@ def test_random_sampling_thinning_and_relations(dev, seed):
     got1, got2 = _hip.fps_thin(xyz.to(dev), npts, radius, 0, start)
     assert torch.equal(got1.cpu(), idx1) and torch.equal(got2.cpu(), idx2), ("fps_thin", seed, N, kind, npts, radius, start)
     # ---- the big sampler (single- and multi-workgroup forms) on a cloud of a few thousand points
-    M = int(rng.choice([1500, 2049, 5000, 20000]))
+    M = int(rng.choice([1500, 2049, 5000, 12000]))
     big = torch.rand(M, 3, generator=g)
     if kind == 1:
         big = torch.round(big * 16) / 16
