@@ -699,3 +699,40 @@ def test_random_shapes_of_the_fused_image_loss(dev, seed):
     (ggot,) = torch.autograd.grad(got * 3.0, x2)
     assert abs(got.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-7, (seed, H, W, smooth, got.item(), ref.item())
     assert (ggot - gref).abs().max().item() <= 2e-4 * gref.abs().max().item(), (seed, H, W, smooth, (ggot - gref).abs().max().item(), gref.abs().max().item())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "6"))))
+def test_random_sequences_of_the_direct_step(dev, seed):
+    """The direct get_loss step keeps capacities from call to call and renders without a host wait.  Seeded random sequences -- the Gaussians
+    grow, shrink and move between calls, by little or by a lot (overflowing the previous call's buffers), one or two cameras -- against the
+    synchronous autograd step, call by call: radii bit for bit, loss and gradients within rounding."""
+    from gsdyn import LossWeights, get_loss_views, loss_and_grads_views, synth_ring_cameras, synth_scene_params, synth_targets
+    from gsdyn.dp import init_variables
+    rng = np.random.default_rng(2900 + seed)
+    P, W, H = int(rng.choice([700, 4000, 12000])), int(rng.integers(40, 280)), int(rng.integers(40, 220))
+    params = synth_scene_params(P, seed=seed, device=dev, scale_lo=0.01, scale_hi=0.04)
+    cams = synth_ring_cameras(2, W, H, device=dev)
+    im_gt, seg_gt = synth_targets(W, H, device=dev)
+    w = LossWeights()
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for step in range(10):
+        views = [dict(cam=cams[i], im=im_gt, seg=seg_gt, id=i) for i in range(int(rng.integers(1, 3)))]
+        with torch.no_grad():
+            params["log_scales"].add_(float(rng.choice([-0.8, -0.1, 0.0, 0.1, 0.9])))
+            params["log_scales"].clamp_(-7.0, -1.0)
+            params["means3D"].add_(float(rng.choice([0.0, 0.01, 0.2])) * torch.randn(P, 3, device=dev, generator=g))
+        for p_ in params.values():
+            p_.grad = None
+        la, _, aux_a = get_loss_views(params, views, init_variables(P, dev), True, w, frozen_colours=True)
+        la.backward()
+        ga = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+        for p_ in params.values():
+            p_.grad = None
+        lb, _, aux_b = loss_and_grads_views(params, views, init_variables(P, dev), True, w)
+        gb = {k: v.grad.clone() for k, v in params.items() if v.grad is not None}
+        tag = (seed, step, P, W, H, len(views))
+        assert abs(float(la.detach()) - float(lb)) <= 2e-6 * abs(float(lb)), tag
+        assert torch.equal(aux_a["radii"], aux_b["radii"]), tag
+        assert sorted(ga) == sorted(gb), tag
+        for k in ga:
+            assert (ga[k] - gb[k]).abs().max().item() <= 2e-6 * ga[k].abs().max().item() + 1e-20, tag + (k,)
