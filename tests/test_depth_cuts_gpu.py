@@ -229,3 +229,47 @@ def test_random_sequences_exact_or_flagged(dev, seed):
         prev = cout
     print(f"depth-cut sequence {seed}: n={n} {w}x{h} cams={cams_n}: {clean} views exact under cuts, {flagged} flagged")
     assert clean >= cams_n         # (frame 0 at least: it had no cuts)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GSR_MV_SOAK", "6"))))
+def test_random_episodes_through_frame_shard(dev, seed):
+    """The whole policy layer on seeded random episodes (drift, jitter, rotation, opacity flicker, repeats; one to three ranks' shares):
+    FrameShard with speculative cuts hands out exactly the frames of FrameShard without them."""
+    from gsdyn import params2rendervar, synth_scene_params
+    from gsdyn.predict import FrameShard, ring_poses
+    rng = np.random.default_rng(3300 + seed)
+    n = int(rng.choice([20000, 80000]))
+    w, h, cams_n = int(rng.integers(100, 520)), int(rng.integers(80, 400)), int(rng.integers(1, 5))
+    lo = float(rng.choice([0.02, 0.05]))
+    params = synth_scene_params(n, seed=seed, device=dev, scale_lo=lo, scale_hi=3 * lo)
+    with torch.no_grad():
+        d = {k: v.detach().clone() for k, v in params2rendervar(params).items()}
+        d["opacities"] = d["opacities"].clamp_min(float(rng.choice([0.3, 0.7])))
+    g = torch.Generator(device=dev).manual_seed(seed)
+    frames = []
+    for f in range(10):
+        kind = int(rng.integers(0, 5))
+        e = {k: v.clone() for k, v in (frames[-1] if frames else d).items()}
+        if kind == 0:
+            e["means3D"] = e["means3D"] + float(rng.uniform(0.0, 0.01))
+        elif kind == 1:
+            e["means3D"] = e["means3D"] + float(rng.uniform(0.0, 0.01)) * torch.randn(n, 3, device=dev, generator=g)
+        elif kind == 2:
+            a = float(rng.uniform(0.0, 0.04))
+            rot = torch.tensor([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], device=dev, dtype=torch.float32)
+            e["means3D"] = e["means3D"] @ rot.T
+        elif kind == 3:
+            keep = torch.rand(n, 1, device=dev, generator=g) > float(rng.uniform(0.0, 0.4))
+            e["opacities"] = torch.where(keep, e["opacities"], torch.full_like(e["opacities"], 0.02))
+        frames.append(e)
+    poses = ring_poses(cams_n, w, h)
+    exact = FrameShard(dev, w, h, poses, rank=0, world=1, speculative=False).render_episode(frames)
+    world = int(rng.integers(1, 4))
+    seen = set()
+    for r in range(world):
+        shard = FrameShard(dev, w, h, poses, rank=r, world=world, speculative=True)
+        got = shard.render_episode(frames)
+        for k, v in got.items():
+            assert k not in seen and all(torch.equal(v[i], exact[k][i]) for i in range(3)), (seed, r, world, k)
+            seen.add(k)
+    assert seen == set(exact)
