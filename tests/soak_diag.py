@@ -13,6 +13,8 @@ rng = np.random.default_rng(seed0)
 for case in range(want + 1):
     P = int(rng.choice([1, 5, 40, 150, 600, 1500, 4000]))
     W, H = int(rng.integers(8, 260)), int(rng.integers(8, 200))
+    if os.environ.get("GSR_SOAK_BIG") == "1":
+        P, W, H = int(rng.choice([8000, 20000, 50000])), 3 * W + 5, 3 * H + 3
     lo = float(rng.choice([0.003, 0.02, 0.08]))
     hi = lo * float(rng.choice([1.5, 8.0, 30.0]))
     kind = str(rng.choice(["rgb", "rgb", "sh", "cov3d"]))

@@ -116,11 +116,13 @@ def test_parity_soak(dev):
                 # the 0.99 clamp over most of the image, quadratic forms that are differences of terms in the hundreds) are recorded and counted --
                 # they are outside what the bars are stated for and the long runs exist to show how often they occur;
                 # anywhere else a miss fails the test on the spot.
-                if hi < 1.0:
+                # (GSR_SOAK_BIG=1, the exploratory size class: every miss is recorded and counted -- at three times the image side and 50 k Gaussians a
+                # scale of 0.6 is a radius of 100+ pixels on a 60-pixel-wide image -- and the run fails on their NUMBER, below)
+                if hi < 1.0 and not big:
                     fh.write(tag + f": FAILED {e}\n")
                     raise AssertionError(f"{tag}: {e}") from e
                 missed.append(tag)
-                fh.write(tag + f": BAR MISSED in a scene of Gaussians larger than the scene -- {str(e)[:300]}\n")
+                fh.write(tag + (": BAR MISSED in a scene of Gaussians larger than the scene -- " if hi >= 1.0 else ": BAR MISSED (big size class) -- ") + f"{str(e)[:300]}\n")
                 continue
             if conditioned == seen_ref:
                 fh.write(tag + ": ok\n")
