@@ -67,6 +67,9 @@ KERNEL_GROUP = {"preprocess_fwd": "preprocess_fwd", "scan_exclusive": "scan", "e
                 "preprocess_bwd": "preprocess_bwd"}
 
 
+PROFILE_ROUND = "r06"      # the round whose committed rocprofv3 --pmc runs (tools/prof_round.sh) the roofline object replays: this one, never an older one
+
+
 def _load_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -451,19 +454,38 @@ def kernel_roofline(_hip, step, vpl, D, t_step, steps):
         "gsr_kernels_busy_us_per_step": round(busy_us, 1), "step_us": round(t_step * 1e6, 1),
         "per_kernel_timing": "HIP events around every launch of the library (on the launch stream), separate pass after the timed region, same call pattern",
         "frac_source": "in-run HIP events (this run); the rocprofv3 --kernel-trace --stats averages of the same command are committed as "
-                       f"profiles/r05_kernel_stats_v{vpl}.txt (blend kernels read 3-5 % longer there, the small kernels shorter)",
+                       f"profiles/{PROFILE_ROUND}_kernel_stats_v{vpl}.txt (blend kernels read 3-5 % longer there, the small kernels shorter): "
+                       "`frac_rocprof` below is the same fraction from that file's average, when it is in the tree",
     }
+    # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this command (what a reader recomputing from profiles/ gets)
+    try:
+        for ln in open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_kernel_stats_v{vpl}.txt")):
+            f = ln.split()
+            if len(f) == 5 and f[0] == dom:
+                roofline["frac_rocprof"] = {"avg_launch_us": float(f[3]), "frac": dom_bytes / (float(f[3]) * 1e-6) / HBM_PEAK,
+                                            "profile": f"profiles/{PROFILE_ROUND}_kernel_stats_v{vpl}.txt"}
+    except OSError:
+        pass
     # HBM traffic of the blend kernels from a committed rocprofv3 --pmc run of this round (tools/prof_round.sh), corrected with the
     # calibration factors measured on known byte counts (tools/prof_calib.sh): REPLAYED from profiles/, not measured in this run
-    tj = next((j for j in (_load_json(f"{r}_pmc_traffic_v{vpl}.json") for r in ("r05", "r04", "r03", "r02")) if j), None) or \
-        next((j for j in (_load_json(f"{r}_pmc_traffic.json") for r in ("r05", "r04", "r03", "r02")) if j and j.get("views_per_launch") == vpl), None)
-    if tj and dom in tj and tj.get("views_per_launch") == vpl:
+    # (ONE named profile, no fall-back to older rounds, and refused when it was taken at another entry count)
+    tj, tname = None, next((n for n in (f"{PROFILE_ROUND}_pmc_traffic_v{vpl}.json",) if _load_json(n)), None)
+    if tname:
+        tj = _load_json(tname)
+        d_prof = float(tj.get("entries_per_view") or 0.0)
+        if tj.get("views_per_launch") != vpl or dom not in tj or not D or abs(d_prof - D) > 1e-3 * D:
+            roofline["traffic_detail"] = {"replayed": False, "refused": f"profiles/{tname}: views_per_launch {tj.get('views_per_launch')} / entries_per_view {d_prof} "
+                                                                          f"do not match this run ({vpl} / {D})"}
+            tj = None
+    if tj:
         roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
-        roofline["traffic_detail"] = {"replayed": True, "source": tj.get("source"), **{k: tj[dom].get(k) for k in
+        roofline["traffic_detail"] = {"replayed": True, "profile": f"profiles/{tname}", "entries_per_view_of_profile": tj.get("entries_per_view"),
+                                      "source": tj.get("source"), **{k: tj[dom].get(k) for k in
                                       ("FETCH_SIZE_KiB_raw", "WRITE_SIZE_KiB_raw", "fabric_bytes_per_launch", "note") if k in tj[dom]}}
     # VALU: measured issue model (profiles/r02_valu_table.json) + committed SQ counters (REPLAYED)
-    sj = next((j for j in (_load_json(n) for r in ("r05", "r04", "r03", "r02") for n in (f"{r}_sq_counters_v{vpl}.json", f"{r}_sq_counters.json"))
-               if j and j.get("views_per_launch") == vpl), None)
+    sj = _load_json(f"{PROFILE_ROUND}_sq_counters_v{vpl}.json")
+    if sj and sj.get("views_per_launch") != vpl:
+        sj = None
     valu = {"peak_lane_instr_per_s_spec": VALU_PEAK,
             "measured_issue_model": "one wave-64 VALU op per ~2.2 SIMD-cycles at >= 2 waves per SIMD (1 per ~4.7 cycles from ONE wave); DPP ops ~3.0, "
                                     "v_exp/v_rcp/permlane-swap ~6.0 (tools/micro/valu_table.hip -> profiles/r02_valu_table.json)",
@@ -739,15 +761,33 @@ def bench_config5_episode(args, dev, rank, world, params, P5, W5, H5, CAMS):
         dist.destroy_process_group()
 
 
-def _time_ms(fn, iters, warmup):
-    for _ in range(warmup):
+class _Timed(float):
+    """A secondary timing: the MEDIAN of ``reps`` wall-clock passes (json sees a float); ``.min`` / ``.max`` / ``.reps`` ride along."""
+    min = max = None
+    reps = 0
+
+
+def _median_of(passes_ms):
+    v = sorted(passes_ms)
+    t = _Timed(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]))
+    t.min, t.max, t.reps = v[0], v[-1], len(v)
+    return t
+
+
+def _time_ms(fn, iters, warmup, reps=5):
+    """ms per call: ``warmup`` untimed calls, then the median of ``reps`` passes of ``iters`` calls each (a single pass put a
+    first-touch allocation or a capacity repeat into the number the driver recorded)."""
+    for _ in range(max(warmup, 1)):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3 / iters
+    passes = []
+    for _ in range(max(reps, 1)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        passes.append((time.perf_counter() - t0) * 1e3 / iters)
+    return _median_of(passes)
 
 
 def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
@@ -927,7 +967,7 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
         model = DynamicsPredictor(cfg, device=dev).eval()
         with torch.no_grad():
             rv = {k: v.detach() for k, v in params2rendervar(params).items()}
-        t_fps = _time_ms(lambda: farthest_point_sampler(rv["means3D"][None], 1000, start_idx=0), 5, 2)
+        t_fps = _time_ms(lambda: farthest_point_sampler(rv["means3D"][None], 1000, start_idx=0), 3, 2)
         pick = farthest_point_sampler(rv["means3D"][None], 100, start_idx=0)[0]
         bones = rv["means3D"][pick]
         hist, eef = bones[None].repeat(3, 1, 1), torch.zeros((3, 1, 3), device=dev)
@@ -953,16 +993,23 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                 seq.append(e)
         res = {}
         for name, spec in (("from_scratch", False), ("depth_cuts", True)):
-            shard = FrameShard(dev, W5, H5, ring_poses(4, W5, H5), 0, 1, speculative=spec)
-            shard.render_episode(seq[:3])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            shard.render_episode(seq)
-            torch.cuda.synchronize()
-            res[name] = (time.perf_counter() - t0) / NF * 1e3
+            # the WHOLE sequence once untimed (every output of every frame has been allocated once, every capacity estimate has settled), then the
+            # median of five timed passes, each on a fresh shard (a pass starts without proposals, as an episode does)
+            FrameShard(dev, W5, H5, ring_poses(4, W5, H5), 0, 1, speculative=spec).render_episode(seq)
+            passes = []
+            for _ in range(5):
+                shard = FrameShard(dev, W5, H5, ring_poses(4, W5, H5), 0, 1, speculative=spec)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                shard.render_episode(seq)
+                torch.cuda.synchronize()
+                passes.append((time.perf_counter() - t0) / NF * 1e3)
+            res[name] = _median_of(passes)
             if spec:
                 redone = shard.cuts.redone
         out["predict_sequence_cfg5"] = {"ms_per_frame_from_scratch": res["from_scratch"], "ms_per_frame_depth_cuts": res["depth_cuts"],
+                                        "min_ms_per_frame_from_scratch": res["from_scratch"].min, "min_ms_per_frame_depth_cuts": res["depth_cuts"].min,
+                                        "timing": "one untimed pass over the whole sequence, then median (min beside it) of 5 timed passes, a fresh FrameShard each",
                                         "frames_with_a_repeated_view": redone, "frames": NF,
                                         "what": "BASELINE.json configs[4] frames as a sequence: 500k Gaussians, 1920x1080, 4 cameras x (colour + mask), the scene drifting ~3 px "
                                                 "per frame; depth_cuts = every frame bins only what the previous frame of the same cameras needed, the blend validates the "
@@ -1006,17 +1053,20 @@ def run_cpu_baseline(params, cam, dL, params2rendervar):
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     g = dL.cpu().numpy()
-    reps, t0 = 0, time.perf_counter()
-    while True:  # bounded sample: whole views until ~20 s of CPU-core time (threads x wall), at most 16 views
+    passes, t0 = [], time.perf_counter()
+    while True:  # bounded sample: whole views, each timed by itself, until ~20 s of CPU-core time (threads x wall); at least 3, at most 16 views
+        t1 = time.perf_counter()
         o2 = TiledOracle(ocam, rv["means3D"], rv["opacities"], colors_precomp=rv["colors_precomp"], scales=rv["scales"],
                          rotations=rv["rotations"], nthreads=threads)
         o2.backward(g)
-        reps += 1
+        passes.append(time.perf_counter() - t1)
         dt = time.perf_counter() - t0
-        if dt * threads >= 20.0 or reps >= 16:
+        if (dt * threads >= 20.0 and len(passes) >= 3) or len(passes) >= 16:
             break
-    return {"value": reps * H * W / dt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x (1 view 800x800, 100k Gaussians, fwd+bwd) with oracle/gsr_oracle.c, OpenMP over tiles",
+    med = float(_median_of(passes))
+    return {"value": H * W / med / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": f"median of {len(passes)} x (1 view 800x800, 100k Gaussians, fwd+bwd) with oracle/gsr_oracle.c, OpenMP over tiles",
+            "value_best_pass": H * W / min(passes) / 1e6, "value_worst_pass": H * W / max(passes) / 1e6,
             "seconds": dt, "host_cpu_count": cores}
 
 

@@ -439,6 +439,10 @@ int gsr_forward_capacity(const gsr_settings* s, int32_t P, const float* means3D,
     gsr_set_error("gsr_forward_capacity: NULL argument or no capacity");
     return -2;
   }
+  if (block_words_pinned && (reinterpret_cast<uintptr_t>(block_words_pinned) & 7u)) {
+    gsr_set_error("gsr_forward_capacity: block_words_pinned must be 8-byte aligned (every block stores its word pair with one 8-byte store)");
+    return -2;
+  }
   const bool words = block_words_pinned && gsr_host_block_scan(P);
   if (!count_pinned && !words) { gsr_set_error("gsr_forward_capacity: count_pinned is needed (no block_words_pinned, or P > 512 Ki)"); return -2; }
   if (prev_geom_state == geom_state) { gsr_set_error("gsr_forward_capacity: a forward cannot be compared with the state it writes"); return -2; }
@@ -522,7 +526,7 @@ int gsr_backward(const gsr_settings* s, int32_t P, uint32_t num_rendered, const 
   }
   return gsr_launch_preprocess_bwd(cam, P, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g,
                                    partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales,
-                                   dL_drotations, dL_dcov3D, dL_dsh, st);
+                                   dL_drotations, dL_dcov3D, dL_dsh, num_rendered > 0 ? im.queue + GSR_QUEUE_BWD_ERROR : nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------ multi-view batch
@@ -697,6 +701,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
   gsr_carve_batch(batch_state, V, P, s[0].image_height, s[0].image_width, &b);
   GsrBwdViews vw;
   vw.V = V;
+  vw.bwd_error = nullptr;
   vw.raw_rot = raw ? raw->unnorm_rotations : nullptr; vw.act_op = raw ? raw->opacities_out : nullptr; vw.act_sc = raw ? scales : nullptr;
   vw.d_raw_rot = raw ? raw->d_unnorm_rotations : nullptr; vw.d_raw_op = raw ? raw->d_logit_opacities : nullptr;
   vw.d_raw_sc = raw ? raw->d_log_scales : nullptr;
@@ -749,6 +754,7 @@ int gsr_backward_batch_raw(int32_t V, const gsr_settings* s, int32_t P, const ui
     if (rebuild)
       if (int rc = gsr_launch_tile_order(bt, st)) return rc;
     if (int rc = gsr_launch_render_bwd(rt, st)) return rc;
+    vw.bwd_error = rt.queue + GSR_QUEUE_BWD_ERROR;
     if (rebuild) {
       pair_up(V, geometry_of, num_rendered, partner, fused);
       for (int v = 0; v < V; ++v) bt.v[v].fused_alias = (uint32_t)fused[v];
@@ -1140,6 +1146,18 @@ int gsr_debug_get_views(int32_t P, uint32_t num_rendered, int32_t H, int32_t W, 
     gsr_carve_image(const_cast<void*>(image_state), H, W, &im);
     out->ranges = (const uint32_t*)im.ranges; out->final_T = im.final_T; out->n_contrib = im.n_contrib;
   }
+  return 0;
+}
+
+// Tests: mark the backward error word of a single-view image state as render_bwd_pc does when one of its waits times out (the per-Gaussian
+// backward of that state then writes NaN for dL/dmeans3D).  Not part of include/gsr.h, like the other gsr_debug_pc_* exports.
+extern "C" int gsr_debug_pc_mark_call_error(int32_t H, int32_t W, void* image_state, void* stream) {
+  if (!image_state) return -2;
+  ImageState im;
+  gsr_carve_image(image_state, H, W, &im);
+  const uint32_t one = 1u;
+  GSR_HIP_CHECK(hipMemcpyAsync(im.queue + GSR_QUEUE_BWD_ERROR, &one, sizeof one, hipMemcpyHostToDevice, (hipStream_t)stream));
+  GSR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 

@@ -509,7 +509,7 @@ __device__ __forceinline__ void tile_order_body(const GsrBinViews& tab, int item
   for (int i = tid; i < ORD_WAVES * 256; i += 1024) { (&h_before[0][0])[i] = 0; (&h_rest[0][0])[i] = 0; }
   if (tid == 0) { empty_before_s = 0; n_empty_s = 0; }
   if (bid == 0) {
-    if (tid < 8) queue[tid] = 0;
+    if (tid < 9) queue[tid] = 0;     // (word 8: the error word of the call's backward, see GsrRenderViews::queue)
     // capacity mode: the counts for the host.  counts_out may be PINNED HOST memory (the caller then needs no copy on the stream --
     // a 4 us blit plus a 6 us bubble between the forward and the backward): a system-scope store, visible once this kernel has ended
     if (tab.counts_out && tid < tab.V)
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void copy_tile_state_kernel(int T, int n
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   if (i < T) ranges[i] = src_ranges[i];
   if (i < n_order) order[i] = src_order[i];
-  if (i < 8) queue[i] = (i == 4 || i == 6 || i == 7) ? src_queue[i] : 0u;
+  if (i < 9) queue[i] = (i == 4 || i == 6 || i == 7) ? src_queue[i] : 0u;
 }
 
 }  // namespace gsr_binning

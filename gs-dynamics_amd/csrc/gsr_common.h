@@ -59,7 +59,9 @@ struct ImageState {
   uint32_t* n_contrib;    // [H*W]
   uint2* ranges;          // [T]
   uint4* tile_order;      // [T] {tile id, list start, list end, 0} sorted by list length, longest first (LPT queue)
-  uint32_t* queue;        // [8] work-queue heads: [0] render_fwd, [1] render_bwd; [4] = number of non-empty tiles
+  uint32_t* queue;        // [16] work-queue heads: [0] render_fwd, [1] render_bwd; [4] = number of non-empty tiles; [8] = error word of the call's
+                          //   backward (zeroed with the heads by every forward; render_bwd_pc sets it when one of its bounded waits ran out, and the
+                          //   per-Gaussian backward behind it then hands out NaN instead of garbage: GSR_QUEUE_BWD_ERROR)
 };
 // Binning state: tile-key / (depth,gid) entries, double-buffered for the radix passes.
 struct BinningState {
@@ -297,7 +299,7 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
                               const float* cov3D_precomp, const int32_t* radii, const GeomState& g,
                               const float4* partials, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                               float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                              float* dL_dsh, hipStream_t st);
+                              float* dL_dsh, const uint32_t* bwd_error, hipStream_t st);
 // Per-view pointers of the multi-view preprocess backward (passed by value as a kernel argument).
 struct GsrBwdView {
   const float *view, *proj;
@@ -315,8 +317,10 @@ struct GsrBwdView {
   int W, H;
   float tanfovx, tanfovy;
 };
+#define GSR_QUEUE_BWD_ERROR 8
 struct GsrBwdViews {
   int V;
+  const uint32_t* bwd_error;   // the call's queue word GSR_QUEUE_BWD_ERROR (or nullptr): != 0 -> dL_dmeans3D is written as NaN
   // raw-parameter mode: chain through the activations applied at the end of the per-Gaussian kernel (all nullptr otherwise)
   const float *raw_rot, *act_op, *act_sc;
   float *d_raw_rot, *d_raw_op, *d_raw_sc;

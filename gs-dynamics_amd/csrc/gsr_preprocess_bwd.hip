@@ -274,7 +274,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     const float4* __restrict__ partials, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drot, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    const uint8_t* __restrict__ used, const uint32_t* __restrict__ tracked) {
+    const uint8_t* __restrict__ used, const uint32_t* __restrict__ tracked, const uint32_t* __restrict__ bwd_error) {
   const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
   if (i >= P) return;
   float gm3[3] = {0.f, 0.f, 0.f}, gm2[2] = {0.f, 0.f}, gcol[3] = {0.f, 0.f, 0.f}, gop = 0.f;
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_kernel(
     view_chain(view, proj, W, H, tanfovx, tanfovy, p, cv.c, ps, gcov, gm3, gm2);
     if (!cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
   }
+  if (bwd_error && *bwd_error != 0u) gm3[0] = gm3[1] = gm3[2] = __builtin_nanf("");   // the blend backward of this call aborted: loud, not garbage (GSR_QUEUE_BWD_ERROR)
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   dL_dmeans2D[3 * i] = gm2[0]; dL_dmeans2D[3 * i + 1] = gm2[1]; dL_dmeans2D[3 * i + 2] = 0.f;
   if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
     }
   }
   if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
+  if (vw.bwd_error && *vw.bwd_error != 0u) gm3[0] = gm3[1] = gm3[2] = __builtin_nanf("");   // the blend backward of this call aborted: loud, not garbage (GSR_QUEUE_BWD_ERROR)
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
   if (vw.d_raw_rot) {   // raw-parameter mode: the chain through normalize / sigmoid / exp, here instead of in a launch of its own
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(64 * GSR_MAX_BATCH, PBW_MIN_WAVES) void preprocess_
   }
   float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   if (any && !cov3D_precomp) cov3_to_scale_rot(cv, mod, gcov, gs, gq);
+  if (vw.bwd_error && *vw.bwd_error != 0u) gm3[0] = gm3[1] = gm3[2] = __builtin_nanf("");   // the blend backward of this call aborted: loud, not garbage (GSR_QUEUE_BWD_ERROR)
   dL_dmeans3D[3 * i] = gm3[0]; dL_dmeans3D[3 * i + 1] = gm3[1]; dL_dmeans3D[3 * i + 2] = gm3[2];
   if (dL_dcolors) { dL_dcolors[3 * i] = gcol[0]; dL_dcolors[3 * i + 1] = gcol[1]; dL_dcolors[3 * i + 2] = gcol[2]; }
   if (vw.d_raw_rot) {
@@ -486,13 +489,13 @@ int gsr_launch_preprocess_bwd(const GsrCam& cam, int P, const float* means3D, co
                               const float* cov3D_precomp, const int32_t* radii, const GeomState& g,
                               const float4* partials, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                               float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                              float* dL_dsh, hipStream_t st) {
+                              float* dL_dsh, const uint32_t* bwd_error, hipStream_t st) {
   if (P <= 0) return 0;
   const dim3 grid((P + GSR_BLOCK - 1) / GSR_BLOCK), block(GSR_BLOCK);
 #define GSR_PBWD_ARGS                                                                                              \
   P, cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.scale_modifier, cam.sh_degree, cam.M, cam.view, cam.proj,       \
       cam.campos, means3D, scales, rotations, colors_precomp, shs, cov3D_precomp, radii, g.offsets, g.clamped,  \
-      partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dsh, g.used, g.counters + 1
+      partials, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dsh, g.used, g.counters + 1, bwd_error
   if (shs) {
     if (!dL_dsh) { gsr_set_error("gsr_backward: shs given but dL_dsh is NULL"); return -2; }
     { GSR_PROF("preprocess_bwd", st);

@@ -57,32 +57,15 @@ namespace gsr_render {
 // rounding -- and the exponent is converted to v_exp_f32's base-2 units per visit (one multiply).  Round 5 staged (-A/2, -B, -C/2) * log2(e):
 // one rounding of each coefficient per Gaussian, the same for every pixel -- a 6e-8 perturbation that a nearly singular conic (elongated
 // Gaussians larger than their image) amplified to 1e-4 .. 1e-3 of that Gaussian's gradient row (profiles/r05_conic_prescale_precision.txt;
-// the parity soak's seed 77 case 671 and GSR_SOAK_BIG seed 6 case 23 missed the norm-wise bar by it).
-#ifndef GSR_CONIC_FORM
-#define GSR_CONIC_FORM 1
-#endif
-#if GSR_CONIC_FORM == 0      // (experiment) round 5's pre-scaled conic
-#define GSR_STAGE_A(A) (-0.5f * GSR_LOG2E * (A))
-#define GSR_STAGE_B(B) (-GSR_LOG2E * (B))
-__device__ __forceinline__ float gsr_power(float hA, float hB, float hC, float dx, float dy) {
-  return __builtin_fmaf(__builtin_fmaf(hB, dy, hA * dx), dx, (hC * dy) * dy);
-}
-#define GSR_EXP_OF_POWER(p) __builtin_amdgcn_exp2f(p)
-#elif GSR_CONIC_FORM == 1
+// the parity soak's seed 77 case 671 and GSR_SOAK_BIG seed 6 case 23 missed the norm-wise bar by it; round 6, profiles/r06_conic_forms.txt:
+// this form puts case 671's `scales` 1.9e-5 from fp64 where the pre-scaled one sat at 1.17e-4, for +1.0 % of the step; the oracle's
+// operation order -- every product rounded -- is no closer to fp64 than this one and costs three issues more).
 #define GSR_STAGE_A(A) (-0.5f * (A))
 #define GSR_STAGE_B(B) (-(B))
 __device__ __forceinline__ float gsr_power(float hA, float hB, float hC, float dx, float dy) {
   return __builtin_fmaf(__builtin_fmaf(hB, dy, hA * dx), dx, (hC * dy) * dy);
 }
 #define GSR_EXP_OF_POWER(p) __builtin_amdgcn_exp2f(GSR_LOG2E * (p))
-#else                        // (experiment) the oracle's order, every product rounded
-#define GSR_STAGE_A(A) (-0.5f * (A))
-#define GSR_STAGE_B(B) (-(B))
-__device__ __forceinline__ float gsr_power(float hA, float hB, float hC, float dx, float dy) {
-  return __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(hA, dx), dx), __fmul_rn(__fmul_rn(hC, dy), dy)), __fmul_rn(__fmul_rn(hB, dx), dy));
-}
-#define GSR_EXP_OF_POWER(p) __builtin_amdgcn_exp2f(GSR_LOG2E * (p))
-#endif
 #ifndef FWD_BATCH
 #define FWD_BATCH 128
 #define FWD_UNROLL 8     // entries per unrolled block of the forward blend loop
@@ -1423,8 +1406,13 @@ __global__ __launch_bounds__(PC_THREADS, PC_WAVES_PER_EU) __attribute__((amdgpu_
   const int wv = (int)(threadIdx.x >> 6);
   if (wv < 4) pc_consumer<COL>(L, tab, wv);
   else pc_stager<COL>(L, tab);
-  // a wait timed out: this launch's gradients are not to be trusted -- tell the host (pinned word; gsr_launch_render_bwd checks it on entry)
-  if (tab.pc_error_out && gsr_lane() == 0 && pc_peek(&L.abort) != 0u) __hip_atomic_store(tab.pc_error_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // a wait timed out: this launch's gradients are not to be trusted.  The CALL's error word (device memory, zeroed by its forward) makes the
+  // per-Gaussian backward queued behind this kernel write NaN for dL/dmeans3D -- loud in the stream, whoever consumes the gradients -- and
+  // the device's pinned word tells the host at its next backward launch on this device (gsr_launch_render_bwd)
+  if (gsr_lane() == 0 && pc_peek(&L.abort) != 0u) {
+    atomicExch(&tab.queue[GSR_QUEUE_BWD_ERROR], 1u);
+    if (tab.pc_error_out) __hip_atomic_store(tab.pc_error_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace gsr_render
@@ -1476,14 +1464,17 @@ extern "C" int gsr_debug_ticket_trace(uint32_t* out4, int n) {   // debug builds
 }
 #endif
 
-static uint32_t* pc_error_word() {   // pinned, device-visible; nullptr when it could not be allocated (then timeouts only show in g_pc_error)
-  static uint32_t* word = [] {
+static uint32_t* pc_error_word() {   // pinned, device-visible, ONE PER DEVICE (the current one); nullptr when it could not be allocated
+  static uint32_t* words = [] {      //   (then a timeout still shows as NaN gradients of its call and in g_pc_error)
     uint32_t* w = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&w), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return static_cast<uint32_t*>(nullptr);
-    *w = 0u;
+    if (hipHostMalloc(reinterpret_cast<void**>(&w), 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess)
+      return static_cast<uint32_t*>(nullptr);
+    for (int i = 0; i < 64; ++i) w[i] = 0u;
     return w;
   }();
-  return word;
+  int dev = 0;
+  if (!words || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return words + dev;
 }
 extern "C" int gsr_debug_pc_inject_error() {   // tests: pretend a wait of the last render_bwd_pc launch timed out (not part of include/gsr.h)
   uint32_t* w = pc_error_word();
@@ -1535,13 +1526,14 @@ int gsr_launch_render_bwd(const GsrRenderViews& tab_in, hipStream_t st) {
   // left at base priority 0 (192/256 raised) takes render_bwd 211.0 -> 207.9 us at four views and 379.1 -> 376.9 at eight; small raised
   // fractions (8..64/256: only the longest lists) and a second level for the longest did nothing -- the first round of tickets is ALL long.
   tab.prio_frac256 = tab.V <= 1 ? 160 : (tab.V >= 3 ? 192 : 0);
-  // render_bwd_pc's waits are bounded; one that ran out marks a pinned host word (the launch's gradients are garbage).  Nobody syncs here,
-  // so the report comes with the NEXT backward launch -- late, but loud (the word is cleared: the caller decides whether to go on).
+  // render_bwd_pc's waits are bounded; one that ran out marks its call's error word -- that call's dL/dmeans3D comes out as NaN -- and this
+  // device's pinned host word.  Nobody syncs here, so the host's report comes with the NEXT backward launch on the device (the word is
+  // cleared: the caller decides whether to go on); the NaNs do not wait for it.
   uint32_t* const pc_error = pc_error_word();
   if (pc_error && __atomic_load_n(pc_error, __ATOMIC_RELAXED) != 0u) {
     __atomic_store_n(pc_error, 0u, __ATOMIC_RELAXED);
     gsr_set_error("render_bwd_pc: a wait between the staging wave and the replaying waves timed out in an EARLIER backward launch; "
-                  "the gradients of that launch are invalid (set GSR_BWD_PC=0 to use the plain backward and report this)");
+                  "the gradients of that launch are invalid (its dL/dmeans3D is NaN; set GSR_BWD_PC=0 to use the plain backward and report this)");
     return -5;
   }
   tab.pc_error_out = pc_error;

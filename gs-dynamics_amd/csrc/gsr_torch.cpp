@@ -182,20 +182,22 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
     // P <= 512 Ki: every preprocess block stores {differs, its entry count} to pinned words -- the count is known when that kernel is through;
     // above: the tile-order kernel's count word
     const bool words = P <= kCompareMaxP;
-    if (words) for (int64_t b = 0; b < nblk; ++b) pin[2 + 2 * b] = -1;
+    // layout [count, pad, {differs, count} x nblk]: the pairs are 8-byte aligned (one 8-byte store each); BOTH words of a pair are reset --
+    // the count to the sentinel, the verdict to "differs" (the conservative value should a pair ever be seen half written)
+    if (words) for (int64_t b = 0; b < nblk; ++b) { pin[2 + 2 * b] = 1; pin[3 + 2 * b] = -1; }
     else pin[0] = -1;
     torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(cap, (int32_t)H, (int32_t)W)}, u8);
     check(gsr_forward_capacity(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
                                radii.data_ptr<int32_t>(), binning.data_ptr(), cap, image.data_ptr(), color.data_ptr<float>(),
                                depth.data_ptr<float>(), compare ? lc.geom.data_ptr() : nullptr,
-                               words ? reinterpret_cast<uint32_t*>(pin + 1) : nullptr, words ? nullptr : pin, fwd_flags, stream), "gsr_forward_capacity");
+                               words ? reinterpret_cast<uint32_t*>(pin + 2) : nullptr, words ? nullptr : pin, fwd_flags, stream), "gsr_forward_capacity");
     ++g_capacity_calls;
     int32_t any = 1;
-    int64_t count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 1), (int32_t)nblk, 500, 20 * 1000 * 1000, &any)
+    int64_t count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 2), (int32_t)nblk, 500, 20 * 1000 * 1000, &any)
                           : gsr_wait_counts(pin, 1, 500, 20 * 1000 * 1000);
     if (count < 0) {      // twenty seconds without the stores: let the runtime tell what happened to the stream
       C10_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-      count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 1), (int32_t)nblk, 0, 1000, &any) : (int64_t)pin[0];
+      count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 2), (int32_t)nblk, 0, 1000, &any) : (int64_t)pin[0];
       TORCH_CHECK(count >= 0, "gsr_forward_capacity: the entry count never arrived");
     }
     if ((uint64_t)count <= cap) {

@@ -833,10 +833,28 @@ def downsample_vertices(xyz: torch.Tensor, max_nobj: int, radius: float, start_i
     return xyz[idx], idx
 
 
+class RolloutNeedsHostSVD(RuntimeError):
+    """The graphed rollout met a bone whose rotation fit the device cannot decide (a rank-1 moment matrix with a vanishing first column:
+    the host's LAPACK decides those) AFTER frames / skinning packets had already been handed to a streaming consumer: the episode has
+    to be run again with ``graph_step=False``.  ``predict_episode`` does that by itself (all ranks of a pipelined episode together)."""
+
+
+def moving_steps(eef_xyz, n_steps: int, dist_thresh: float):
+    """Which steps repeat the previous frame (True): decided from the end-effector targets alone, on the host, with the arithmetic of the
+    reference's per-step test (fp32 norm of the difference to the last target that was acted on)."""
+    eef_host = eef_xyz.detach().to("cpu", torch.float32)
+    skip, last = [False] * n_steps, eef_host[0]
+    for i in range(1, n_steps):
+        skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
+        if not skip[i]:
+            last = eef_host[i]
+    return skip
+
+
 @torch.no_grad()
 def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_steps: int, inlier_idx_all, *, max_nobj: int,
             fps_radius_value: float, adj_thresh: float, topk: int, connect_all: bool, dist_thresh: float, n_fps_all: int = 1000,
-            thin_start_idx: int = 0, storage_device=None, after_step=None, on_skin=None, skin_source=None):
+            thin_start_idx: int = 0, storage_device=None, after_step=None, on_skin=None, skin_source=None, graph_step: bool = True):
     """The autoregressive loop of /root/reference/src/render/dynamics_module.py:53-172.  1000 (``n_fps_all``) farthest points of the
     inlier Gaussians carry the particle history; per step the bones are re-sampled from them, the GNN predicts the bones' next
     positions from the last ``n_his`` states and the end-effector motion, and all Gaussians follow the bones
@@ -848,7 +866,7 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     rotations, translations, quaternions, predicted bones) BEFORE ``after_step`` -- on a HIP device the packet is a static buffer the
     next step overwrites, to be consumed in stream order.  ``skin_source(i)`` -> packet: the RECEIVING side of that hand-over -- no
     network, no sampling, no graph: every moving step applies the packet it is given to the previous frame's Gaussians (the ranks of a
-    pipelined episode that only render; gsdyn/predict.py).  Same frames as the rank that rolled out: the skinning is per Gaussian.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
+    pipelined episode that only render; gsdyn/predict.py).  ``graph_step=False``: every step runs eagerly (what a streaming caller asks for after ``RolloutNeedsHostSVD``).  Same frames as the rank that rolled out: the skinning is per Gaussian.  Returns (xyz [S,P,3], rgb [S,P,3], quat [S,P,4], opa [S,P,1], xyz_bones [S,max_nobj,3],
     eef [S,1,3])."""
     dev = xyz_0.device
     store = dev if storage_device is None else torch.device(storage_device)
@@ -857,14 +875,7 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
     xyz_bones = torch.zeros((n_steps, max_nobj, 3), device=store)
     eef = rep(eef_xyz[0])
     arrays = (xyz, rgb, quat, opa, xyz_bones, eef)
-    # which steps repeat the previous frame: decided from the end-effector targets alone -- on the host, once, with the arithmetic of the
-    # reference's per-step test (fp32 norm of the difference to the last target that was acted on)
-    eef_host = eef_xyz.detach().to("cpu", torch.float32)
-    skip, last = [False] * n_steps, eef_host[0]
-    for i in range(1, n_steps):
-        skip[i] = float(torch.norm(eef_host[i] - last)) < dist_thresh
-        if not skip[i]:
-            last = eef_host[i]
+    skip = moving_steps(eef_xyz, n_steps, dist_thresh)
     if skin_source is not None:       # (no sampling here: frame 0's keypoints arrive as packet 0)
         if after_step is not None:    # frame 0's Gaussians need nothing from the rank that rolls out: a streaming consumer renders them
             after_step(0, arrays, False)   # while that rank is still sampling its tracked particles (4 ms at 500 k Gaussians)
@@ -891,7 +902,7 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
         after_step(0, arrays, False)
     c = model.model_config
     gs = None
-    if (dev.type == "cuda" and _GRAPH_ROLLOUT and _GRAPH_ROLLOUT_STEP and store == dev and not connect_all and n_fps_all <= 1024 and max_nobj <= 126
+    if (dev.type == "cuda" and graph_step and _GRAPH_ROLLOUT and _GRAPH_ROLLOUT_STEP and store == dev and not connect_all and n_fps_all <= 1024 and max_nobj <= 126
             and max_nobj <= fps_all_pos.shape[0]     # fewer tracked inliers than bones: fps_thin_padded needs npoints <= N -- the eager loop clamps
             and topk <= 16 and 0 <= thin_start_idx < min(max_nobj, n_fps_all) and c["state_dim"] in (0, 3) and c["action_dim"] == 3
             and c["rel_attr_dim"] > 0 and c["rel_group_dim"] > 0 and c["rel_distance_dim"] > 0 and c["attr_dim"] >= 2
@@ -913,9 +924,11 @@ def rollout(model: DynamicsPredictor, xyz_0, rgb_0, quat_0, opa_0, eef_xyz, n_st
                 after_step(i, arrays, skip[i])
         if int(gs.bad.item()) == 0:
             return xyz, rgb, quat, opa, xyz_bones, eef
-        # a rank-1 bone whose moment matrix has a vanishing first column (the host's LAPACK decides those): the eager loop redoes the episode
-        if after_step is not None:
-            raise RuntimeError("rollout: a bone needs the host's SVD; run with GSDYN_GRAPH_ROLLOUT_STEP=0 when streaming frames")
+        # a rank-1 bone whose moment matrix has a vanishing first column (the host's LAPACK decides those): the eager loop redoes the episode.
+        # A consumer that was handed frames or packets on the way must start over WITH it (and, in a pipelined episode, every rank with
+        # this one: the eager loop calls on_skin again for every step): that is the caller's to arrange
+        if after_step is not None or on_skin is not None:
+            raise RolloutNeedsHostSVD("rollout: a bone needs the host's SVD and frames / packets have already left; run again with graph_step=False")
     for i in range(1, n_steps):
         if skip[i]:
             for a in (quat, xyz, rgb, opa, xyz_bones, eef):

@@ -135,7 +135,7 @@ def gather_frames(local: dict, dst: int = 0, group=None) -> Optional[dict]:
 def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radius: float, adj_thresh: float, topk: int, connect_all: bool,
                        dist_thresh: float, n_fps_all: int = 1000, max_steps: int = 1000, low_opacity: float = 0.1,
                        remove_outliers: bool = True, thin_start_idx: int = 0, spatial_sort: bool = True, on_frame=None,
-                       on_skin=None, skin_source=None, tracked_only: bool = False):
+                       on_skin=None, skin_source=None, tracked_only: bool = False, graph_step: bool = True):
     """``DynamicsModule.collect_scene_data`` (/root/reference/src/render/dynamics_module.py:174-257) on the device: ``params`` is
     the tracking result (``params.npz``: means3D [T,P,3] or [P,3], rgb_colors, unnorm_rotations, logit_opacities, log_scales);
     frame 0 is activated, Gaussians with opacity < 0.1 are dropped (:187-192), statistical outliers are excluded from the bone
@@ -220,7 +220,7 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
         out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
                         adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
                         n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, after_step=after_step,
-                        on_skin=on_skin, skin_source=skin_source)
+                        on_skin=on_skin, skin_source=skin_source, graph_step=graph_step)
         emit(out, n_steps - 1)                      # trailing repeats of the last moving frame
         kp, tool = out[4].cpu().numpy(), out[5].cpu().numpy()
         vis = [{"kp": kp[t], "tool_kp": tool[t]} for t in range(n_steps)]
@@ -230,7 +230,8 @@ def collect_scene_data(model, params: dict, eef_xyz, *, max_nobj: int, fps_radiu
         return scene, vis, {"outlier_filter_ms": (t1 - t0) * 1e3, "rollout_ms": (t2 - t1) * 1e3, "frames": n_steps, "gaussians": int(xyz_0.shape[0])}
     out = D.rollout(model, xyz_0, rgb_0, quat_0, opa_0, eef, n_steps, inlier, max_nobj=max_nobj, fps_radius_value=fps_radius,
                     adj_thresh=adj_thresh, topk=topk, connect_all=connect_all, dist_thresh=dist_thresh,
-                    n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, on_skin=on_skin, skin_source=skin_source)
+                    n_fps_all=min(n_fps_all, int(inlier.shape[0])), thin_start_idx=thin_start_idx, on_skin=on_skin, skin_source=skin_source,
+                    graph_step=graph_step)
     out = D.smooth_frames(*out)
     scene, vis = D.pack_scene_data(out[0], out[1], out[2], out[3], scales_0, out[4], out[5])
     if dev.type == "cuda":
@@ -300,6 +301,7 @@ def _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg
     import queue
     import threading
     import time
+    from . import dynamics as _dyn
     dev = params["means3D"].device
     shard = FrameShard(dev, w, h, poses, rank, world, bg=bg)
     todo: "queue.Queue" = queue.Queue()
@@ -329,13 +331,20 @@ def _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, rollout_cfg
     t0 = time.perf_counter()
     th.start()
     # (a high-priority stream for the rollout's small launches was measured WORSE: 2.81 vs 2.38 ms per frame)
+    redo = False
     try:
         scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=lambda f, d, ev: todo.put((f, d, ev)), **rollout_cfg)
+    except _dyn.RolloutNeedsHostSVD:
+        redo = True
     finally:
         todo.put(None)
         th.join()
     if failure:
         raise failure[0]
+    if redo:        # the graphed rollout met a bone only the host's SVD decides after frames had left: drop them, run the eager rollout
+        torch.cuda.synchronize(dev)
+        return _predict_episode_overlapped(model, params, eef_xyz, poses, w, h, dict(rollout_cfg, graph_step=False), rank, world, gather_to, bg, rgba,
+                                           scene_out)
     torch.cuda.synchronize(dev)
     post = (lambda v: (compose_rgba(v[0], v[2]), v[1], v[2])) if rgba else None
     with torch.no_grad():
@@ -394,22 +403,69 @@ def _predict_episode_pipelined(model, params, eef_xyz, poses, w, h, rollout_cfg,
             for c, v in shard.render_frame(f, d).items():
                 frames[(f, c)] = (compose_rgba(v[0], v[2]), v[1], v[2]) if rgba else v
 
+    # Every rank knows how many packets an attempt carries (packet 0 + one per moving step: the end-effector targets decide that on the
+    # host), so a rank that fails on the way can still keep the broadcasts matched: the producer sends empty packets for the steps it did
+    # not reach, a render rank drains the ones it did not consume -- and the attempt ends with ONE status word from the producer:
+    #   0  the frames stand;
+    #   1  the graphed rollout met a bone only the host's SVD decides (dynamics.RolloutNeedsHostSVD) after its packets had left: every rank
+    #      drops its frames and the episode runs again with the eager rollout -- what the replicated form does silently on each rank;
+    #   2  the producer failed: every rank raises (instead of waiting for a broadcast that never comes).
+    eef_t = torch.as_tensor(eef_xyz, dtype=torch.float32)
+    eef_t = eef_t[:, None, :] if eef_t.dim() == 2 else eef_t
+    n_steps = min(int(eef_t.shape[0]), int(rollout_cfg.get("max_steps", 1000)))
+    n_packets = 1 + sum(1 for k in D.moving_steps(eef_t, n_steps, float(rollout_cfg["dist_thresh"]))[1:] if not k)
+    pdev = "cpu" if on_host else dev
+
+    def bcast(buf):
+        dist.broadcast(buf, src=src, group=group)
+        return buf
+
     t0 = time.perf_counter()
-    if rank == producer:
-        def on_skin(i, pk):
-            buf = pk.detach().to("cpu").contiguous() if on_host else pk      # (RCCL: the current stream waits for the broadcast: the next
-            dist.broadcast(buf, src=src, group=group)                          #  step's graph replay does not overwrite the packet under it)
-        # a producer that renders nothing and hands no scene back only needs its tracked particles (collect_scene_data)
-        light = shard is None and scene_out is None
-        scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=None if light else on_frame, on_skin=on_skin,
-                                            tracked_only=light, **rollout_cfg)
-        tm["producer_tracked_only"] = light
-    else:
-        def skin_source(i):
-            buf = torch.empty(plen, dtype=torch.float32, device="cpu" if on_host else dev)
-            dist.broadcast(buf, src=src, group=group)
-            return buf
-        scene, vis, tm = collect_scene_data(None, params, eef_xyz, on_frame=on_frame, skin_source=skin_source, **rollout_cfg)
+    attempts = 0
+    while True:
+        count, error, status = [0], None, 0
+        graph_step = attempts == 0
+        attempts += 1
+        if rank == producer:
+            def on_skin(i, pk):
+                bcast(pk.detach().to("cpu").contiguous() if on_host else pk)     # (RCCL: the current stream waits for the broadcast: the next
+                count[0] += 1                                                     #  step's graph replay does not overwrite the packet under it)
+            # a producer that renders nothing and hands no scene back only needs its tracked particles (collect_scene_data)
+            light = shard is None and scene_out is None
+            try:
+                scene, vis, tm = collect_scene_data(model, params, eef_xyz, on_frame=None if light else on_frame, on_skin=on_skin,
+                                                    tracked_only=light, **dict(rollout_cfg, graph_step=graph_step and rollout_cfg.get("graph_step", True)))
+                tm["producer_tracked_only"] = light
+            except D.RolloutNeedsHostSVD:
+                status = 1
+            except BaseException as e:      # noqa: BLE001 -- re-raised below, once the other ranks have been told
+                status, error = 2, e
+            while count[0] < n_packets:       # (only after a failure: the steps the rollout did not reach)
+                on_skin(-1, torch.zeros(plen, dtype=torch.float32, device=pdev))
+            bcast(torch.full((1,), float(status), dtype=torch.float32, device=pdev))
+        else:
+            def skin_source(i):
+                count[0] += 1
+                return bcast(torch.empty(plen, dtype=torch.float32, device=pdev))
+            try:
+                scene, vis, tm = collect_scene_data(None, params, eef_xyz, on_frame=on_frame, skin_source=skin_source, **rollout_cfg)
+            except BaseException as e:      # noqa: BLE001 -- re-raised below, once this rank's share of the broadcasts has been matched
+                error = e
+            while count[0] < n_packets:
+                skin_source(-1)
+            status = int(bcast(torch.empty(1, dtype=torch.float32, device=pdev)).item())
+        if error is not None:
+            raise error
+        if status == 2:
+            raise RuntimeError(f"pipelined episode: the rollout on rank {producer} failed (see that rank's traceback)")
+        if status == 0:
+            break
+        if attempts >= 2:
+            raise RuntimeError("pipelined episode: the eager rollout asked for a redo (cannot happen: it decides every bone on the host)")
+        frames.clear()                        # status 1: these frames came from packets of a rollout that has to be redone
+        if shard is not None:
+            shard = FrameShard(dev, w, h, poses, rr.index(rank), len(rr), bg=bg)
+    tm["rollout_attempts"] = attempts
     if shard is not None:
         post = (lambda v: (compose_rgba(v[0], v[2]), v[1], v[2])) if rgba else None
         with torch.no_grad():

@@ -120,7 +120,7 @@ int gsr_forward_render_shared(const gsr_settings* s, int32_t P, uint32_t num_ren
  * call's launches are queued.  count <= capacity_entries: the outputs and states are valid, and `capacity_entries` is the num_rendered
  * that gsr_backward, gsr_forward_render_shared and gsr_backward_scratch_bytes must be given for these states (it fixed their layout).
  * count > capacity_entries: nothing of the call may be used -- repeat with gsr_forward_preprocess + gsr_forward_render.
- * Earlier still (P <= 512 Ki): block_words_pinned -- pinned host memory, 2 * ceil(P / 256) words, the ODD words pre-set to 0xffffffff by the
+ * Earlier still (P <= 512 Ki): block_words_pinned -- pinned host memory, 8-BYTE ALIGNED, 2 * ceil(P / 256) words, the ODD words pre-set to 0xffffffff by the
  * caller.  Every preprocess block stores {differs, its entry count} there with one 8-byte store; gsr_wait_block_counts polls the words and
  * returns their sum as soon as the preprocess kernel's blocks are through -- typically before the host has finished queueing the rest of
  * the call -- so the host never waits and the GPU never idles.  count_pinned may then be NULL.  With prev_geom_state as well the blocks

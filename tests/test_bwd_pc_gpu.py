@@ -52,3 +52,35 @@ def test_timed_out_wait_is_reported_by_the_next_backward(dev):
     with pytest.raises(RuntimeError, match="render_bwd_pc"):
         step()
     assert torch.equal(step(), g0)
+
+
+@pytest.mark.gpu
+def test_aborted_blend_backward_poisons_its_own_call(dev):
+    """the host only hears of a timed-out wait at its NEXT backward launch.  The gradients of the launch that aborted must not be
+    consumed silently in between: the call's own error word (device memory, zeroed by its forward) makes the per-Gaussian backward queued
+    behind the blend write NaN for dL/dmeans3D -- and only for that call."""
+    import ctypes as C
+    import torch
+    from diff_gaussian_rasterization import _hip
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    params = synth_scene_params(2000, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, 128, 96, device=dev)[0]
+    with torch.no_grad():
+        rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+    args = (rv["means3D"], rv["opacities"], rv["colors_precomp"], None, rv["scales"], rv["rotations"], None)
+    dL = torch.ones((3, 96, 128), device=dev)
+
+    def run(mark):
+        _, radii, _, st = _hip.rasterize_forward(cam, *args)
+        if mark:
+            lib = _hip.load_library()
+            lib.gsr_debug_pc_mark_call_error.restype = C.c_int
+            lib.gsr_debug_pc_mark_call_error.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+            assert lib.gsr_debug_pc_mark_call_error(st.H, st.W, _hip._ptr(st.image), _hip._stream(dev)) == 0
+        g = _hip.rasterize_backward(st, dL, rv["means3D"], radii, rv["colors_precomp"], None, rv["scales"], rv["rotations"], None)
+        torch.cuda.synchronize()
+        return g[0]
+    g0 = run(False)
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    assert torch.isnan(run(True)).all()
+    assert torch.equal(run(False), g0)          # the next call's forward zeroes its own word

@@ -191,7 +191,7 @@ def test_predict_episode_is_rollout_then_sharded_renders(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------ the pipelined episode: one rank rolls out, the others skin + render
-def _pipelined_worker(rank, world, port, out_dir, producer_renders, light):
+def _pipelined_worker(rank, world, port, out_dir, producer_renders, light, fault=None):
     _setup()
     torch.set_num_threads(1)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -206,8 +206,36 @@ def _pipelined_worker(rank, world, port, out_dir, producer_renders, light):
     D.DynamicsPredictor.forward = lambda self, *a, **k: (ran.__setitem__("gnn", ran["gnn"] + 1), fwd0(self, *a, **k))[1]
     scene = []
     light = light and rank == 0        # the producer asks for no scene back: it rolls out its tracked particles only
-    frames, vis, tm = predict_episode(model if rank == 0 else None, params, eef, ring_poses(CAMS, W, H), W, H, rollout_cfg=ROLL, gather_to=0,
-                                      rgba=True, pipeline=True, producer_renders=producer_renders, scene_out=None if light else scene)
+    if fault and rank == 0:
+        # what a HIP producer's graphed rollout does when a bone needs the host's SVD: every packet has left, THEN it finds out
+        # ("redo"); and a rollout that dies half way ("die": after its third packet)
+        real = D.rollout
+
+        def faulty(*a, graph_step=True, on_skin=None, **k):
+            if fault == "die":
+                sent = [0]
+
+                def counting(i, pk):
+                    on_skin(i, pk)
+                    sent[0] += 1
+                    if sent[0] == 3:
+                        raise ValueError("injected rollout failure")
+                return real(*a, graph_step=graph_step, on_skin=counting, **k)
+            out = real(*a, graph_step=graph_step, on_skin=on_skin, **k)
+            if graph_step:
+                raise D.RolloutNeedsHostSVD("injected")
+            return out
+        D.rollout = faulty
+    try:
+        frames, vis, tm = predict_episode(model if rank == 0 else None, params, eef, ring_poses(CAMS, W, H), W, H, rollout_cfg=ROLL, gather_to=0,
+                                          rgba=True, pipeline=True, producer_renders=producer_renders, scene_out=None if light else scene)
+        assert fault != "die", "every rank must raise when the producer's rollout fails"
+    except (ValueError, RuntimeError) as e:
+        assert fault == "die" and ("injected" in str(e) if rank == 0 else "rollout on rank 0 failed" in str(e)), (rank, repr(e))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    assert tm["rollout_attempts"] == (2 if fault == "redo" else 1)
     rr = render_ranks_of(world, 0, producer_renders)
     assert tm["pipelined"] and tm["render_ranks"] == rr and tm["frames"] == EP_STEPS and len(vis) == EP_STEPS
     assert len(scene) == (0 if light else EP_STEPS) and (rank != 0 or tm["producer_tracked_only"] == light)
@@ -255,6 +283,37 @@ def test_pipelined_episode_equals_the_replicated_one(tmp_path, world, producer_r
     for (f, c), (im, depth, mask) in ref.items():
         assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
         assert np.array_equal(z[f"{f}_{c}_1"], depth.numpy()) and np.array_equal(z[f"{f}_{c}_2"], mask.numpy())
+
+
+@pytest.mark.timeout(600)
+def test_pipelined_episode_redoes_a_rollout_that_needs_the_host(tmp_path):
+    """a graphed rollout finds out AFTER its last packet that a bone needs the host's SVD.  The producer must not broadcast
+    the eager redo's packets into ranks that have consumed theirs (a hang): it ends the attempt with a status word, every rank drops its
+    frames, and the episode runs again eagerly -- the same frames as ever."""
+    _setup()
+    mp.spawn(_pipelined_worker, args=(3, _free_port(), str(tmp_path), False, False, "redo"), nprocs=3, join=True)
+    _install_double()
+    from gsdyn.predict import collect_scene_data, compose_rgba, FrameShard, ring_poses
+    model, params, eef = _episode_inputs()
+    scene, vis, _ = collect_scene_data(model, params, eef, **ROLL)
+    for r in range(3):
+        z = np.load(tmp_path / f"scene_{r}.npz")
+        for t, d in enumerate(scene):
+            for k, v in d.items():
+                assert np.array_equal(z[f"{t}_{k}"], v.numpy()), (r, t, k)
+    ref = FrameShard("cpu", W, H, ring_poses(CAMS, W, H), rank=0, world=1).render_episode(scene)
+    z = np.load(tmp_path / "episode.npz")
+    assert len(z.files) == 3 * EP_STEPS * CAMS
+    for (f, c), (im, depth, mask) in ref.items():
+        assert np.array_equal(z[f"{f}_{c}_0"], compose_rgba(im, mask).numpy()), (f, c)
+
+
+@pytest.mark.timeout(600)
+def test_pipelined_episode_fails_on_every_rank_when_the_rollout_dies(tmp_path):
+    """... and a producer whose rollout raises half way keeps the broadcasts matched (empty packets for the steps it did not reach) and
+    tells the others: they raise instead of waiting for a packet that never comes."""
+    _setup()
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), str(tmp_path), False, False, "die"), nprocs=2, join=True)
 
 
 def test_skin_packet_round_trip():

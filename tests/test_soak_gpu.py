@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from hipcheck import ROW_TOL_WORST_P5000, TOL, _check_against_oracle, _run_hip
-from util import mixed_err, oracle_camera, random_gaussians, look_at, rel_err, row_err
+from soak_cases import build_case, case_at, draw_case
+from util import mixed_err, rel_err, row_err
 from oracle import TiledOracle
 
 pytestmark = pytest.mark.gpu
@@ -70,29 +71,9 @@ def test_parity_soak(dev):
     with open(log, "a") as fh:
         fh.write(f"# parity soak: {n_cases} cases, seed {seed0}\n")
         for case in range(n_cases):
-            P = int(rng.choice([1, 5, 40, 150, 600, 1500, 4000]))
-            W, H = int(rng.integers(8, 260)), int(rng.integers(8, 200))
-            if big:        # GSR_SOAK_BIG=1: the same stream of choices at 10 - 40 x the Gaussians and ~3 x the image side (long lists, every sort build)
-                P, W, H = int(rng.choice([8000, 20000, 50000])), 3 * W + 5, 3 * H + 3
-            lo = float(rng.choice([0.003, 0.02, 0.08]))
-            hi = lo * float(rng.choice([1.5, 8.0, 30.0]))
-            kind = str(rng.choice(["rgb", "rgb", "sh", "cov3d"]))
-            deg = int(rng.integers(0, 4))
-            g = random_gaussians(P, seed=seed0 * 1000 + case, scale_lo=lo, scale_hi=hi, spread=float(rng.choice([0.4, 1.0, 2.0])),
-                                 sh_M=16 if kind == "sh" else 0)
-            shift = float(rng.choice([-2.5, 0.0, 2.0]))
-            g["opacities"] = (1.0 / (1.0 + np.exp(-(np.log(g["opacities"] / (1.0 - g["opacities"])) + shift)))).astype(np.float32)
-            ang, rad, hgt = float(rng.uniform(0, 6.28)), float(rng.choice([0.7, 2.0, 4.0, 8.0])), float(rng.choice([-0.6, 0.5, 2.5]))
-            f = float(rng.choice([0.6, 1.0, 1.8])) * W
-            cam = oracle_camera(W, H, look_at((rad * np.cos(ang), hgt, rad * np.sin(ang))), fx=f, fy=f * float(rng.choice([1.0, 1.2])),
-                                cx=W / 2 + float(rng.choice([0.0, 0.0, 0.13 * W])), cy=H / 2 - float(rng.choice([0.0, 0.09 * H])),
-                                bg=tuple(float(x) for x in rng.uniform(0, 1, 3)), sh_degree=deg if kind == "sh" else 0)
-            if kind == "sh":
-                del g["colors_precomp"]
-            elif kind == "cov3d":
-                probe = TiledOracle(cam, g["means3D"], g["opacities"], colors_precomp=g["colors_precomp"], scales=g["scales"], rotations=g["rotations"])
-                g = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=g["colors_precomp"], cov3D_precomp=probe.cov3D)
-            tag = f"case {case}: {kind}{deg if kind == 'sh' else ''} P={P} {W}x{H} scales {lo}..{hi:.3f} cam r={rad} h={hgt}"
+            c = draw_case(rng, big)
+            cam, g, tag = build_case(seed0, case, c)
+            hi, kind = c["hi"], c["kind"]
             tol_worst = 1e-3 if hi >= 1.0 else ROW_TOL_WORST_P5000
             try:
                 try:
@@ -138,3 +119,37 @@ def test_parity_soak(dev):
         fh.write(f"# passed {done} (of which {conditioned} through the fp64 referee), skipped {skipped}, bars missed in {len(missed)} scenes of Gaussians larger "
                  f"than the scene, a single row beyond the referee's rule in {len(row_missed)}, of {n_cases}; by colour model {kinds}\n")
     assert done >= 0.8 * n_cases and conditioned <= (0.3 if big else 0.1) * n_cases + 2 and len(missed) <= 0.02 * n_cases + 1 and len(row_missed) <= 0.01 * n_cases + 1, (done, skipped, conditioned, missed, row_missed)
+
+
+# Cases the long streams stopped at in round 5, as fixed regression cases of every -m gpu run.  Both were the blend kernels' conic rounded once
+# per Gaussian after scaling by log2 e, on a nearly singular conic (profiles/r05_conic_prescale_precision.txt); since round 6 the conic is
+# staged with its exact factors only (csrc/gsr_render.hip: gsr_power):
+#   seed 77 case 671      sh0, 40 Gaussians, 127x123: `scales` 1.17e-4 norm-wise from fp64 (fp32 oracle 2.5e-5)   -> 1.9e-5
+#   BIG seed 6 case 23    50 000 Gaussians of scale up to 0.6 on a 59x429 image: rotations 2.7e-4 (oracle 9.7e-5)   -> 9.7e-5
+# The bar here is the soak's own, with nothing tallied: the fp32 check, or the fp64 referee's norm-wise rule AND its row rule.
+@pytest.mark.parametrize("seed0,case,big", [(77, 671, False), (6, 23, True)])
+def test_soak_regression_cases(dev, seed0, case, big):
+    cam, g, tag, c = case_at(seed0, case, big)
+    tol_worst = 1e-3 if c["hi"] >= 1.0 else ROW_TOL_WORST_P5000
+    try:
+        _check_against_oracle(cam, g, dev, seed=case, min_ok=0.98, tol_worst=tol_worst)
+    except AssertionError as e:
+        if not (str(e).startswith(("grad ", "oracle P=", "final_T")) or str(e) in ("depth", "colour")):
+            raise
+        note, rows = _adjudicate(cam, g, dev, case, tol_worst)
+        assert not rows, (tag, rows, note)
+
+
+def test_soak_regression_case_against_fp64(dev):
+    """Seed 77 case 671 directly against the fp64 oracle: every gradient norm-wise inside 1e-4 (round 5: scales 1.17e-4)."""
+    cam, g, tag, c = case_at(77, 671)
+    kw = dict(colors_precomp=g.get("colors_precomp"), shs=g.get("shs"), scales=g.get("scales"), rotations=g.get("rotations"),
+              cov3D_precomp=g.get("cov3D_precomp"), nthreads=4)
+    o32 = TiledOracle(cam, g["means3D"], g["opacities"], **kw)
+    o64 = TiledOracle(cam, g["means3D"], g["opacities"], f64=True, decisions_of=o32, **kw)
+    dL = np.random.default_rng(671).uniform(-1, 1, (3, cam.image_height, cam.image_width)).astype(np.float32)
+    dL[:, o32.ambiguous] = 0.0
+    g64 = o64.backward(dL)
+    _, _, _, grads, _ = _run_hip(cam, g, dev, dL=dL)
+    for k, v in grads.items():
+        assert rel_err(v, g64[k]) <= TOL, (tag, k, rel_err(v, g64[k]))
