@@ -128,8 +128,17 @@ __device__ __forceinline__ PartialSum reduce_partials(const float4* __restrict__
   return ps;
 }
 
+// The per-Gaussian chain (3D covariance, conic -> cov2D -> cov3D / view-space mean, cov3D -> scale / rotation) runs in DOUBLE precision
+// (round 6).  It is a chain of differences of nearly equal products -- det = a c - b b, the inverse of the 2D covariance, the congruence
+// with T, the quaternion terms -- and for a Gaussian that is elongated on screen (a nearly singular conic) fp32 loses 1e-4 ... 6e-3 of that
+// Gaussian's gradient row THERE, in any operation order: the fp32 oracle's rows are as far from its fp64 build as this kernel's were.  Inputs
+// (the record sums of the blend backward, the parameters) and outputs stay fp32; in between, fp64 costs this latency-bound kernel 24 -> 29 us
+// at four views, +1 us at one (MI355X issues fp64 FMAs at the fp32 rate; the price is registers: 166 instead of 90 VGPRs), and puts the
+// parity soak's tail cases 3 - 40 x closer to the fp64 oracle than the fp32 oracle is (profiles/r06_fp64_chain.txt): seed 9 case 895
+// scales 1.03e-4 -> 1.2e-5, GSR_SOAK_BIG seed 6 case 156 worst row 6.2e-3 -> 7.4e-5.
+typedef double real;
 // Rotation matrix, scaled axes and 3D covariance of one Gaussian (view independent).
-struct Cov3 { float R[3][3]; float s[3]; float q[4]; float c[6]; };
+struct Cov3 { real R[3][3]; real s[3]; real q[4]; real c[6]; };
 __device__ __forceinline__ void build_cov3(int i, float mod, const float* __restrict__ scales,
                                            const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                                            Cov3& o) {
@@ -141,13 +150,13 @@ __device__ __forceinline__ void build_cov3(int i, float mod, const float* __rest
     o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f;
     return;
   }
-  const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+  const real r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
   o.q[0] = r; o.q[1] = x; o.q[2] = y; o.q[3] = z;
   o.R[0][0] = 1.f - 2.f * (y * y + z * z); o.R[0][1] = 2.f * (x * y - r * z); o.R[0][2] = 2.f * (x * z + r * y);
   o.R[1][0] = 2.f * (x * y + r * z); o.R[1][1] = 1.f - 2.f * (x * x + z * z); o.R[1][2] = 2.f * (y * z - r * x);
   o.R[2][0] = 2.f * (x * z - r * y); o.R[2][1] = 2.f * (y * z + r * x); o.R[2][2] = 1.f - 2.f * (x * x + y * y);
-  o.s[0] = mod * scales[3 * i]; o.s[1] = mod * scales[3 * i + 1]; o.s[2] = mod * scales[3 * i + 2];
-  float Mm[3][3];
+  o.s[0] = (real)mod * scales[3 * i]; o.s[1] = (real)mod * scales[3 * i + 1]; o.s[2] = (real)mod * scales[3 * i + 2];
+  real Mm[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -163,97 +172,99 @@ __device__ __forceinline__ void build_cov3(int i, float mod, const float* __rest
 // One view's chain: conic -> cov2D -> (cov3D, view-space mean) and 2D mean -> 3D mean.  ACCUMULATES into
 // gcov[6] and gm3[3]; returns this view's dL/d(NDC mean) in gm2.
 __device__ __forceinline__ void view_chain(const float* __restrict__ view, const float* __restrict__ proj, int W, int H,
-                                           float tanfovx, float tanfovy, float3 p, const float c[6],
+                                           float tanfovx, float tanfovy, float3 p, const real c[6],
                                            const PartialSum& ps, float gcov[6], float gm3[3], float gm2[2],
                                            float sx_first = 0.f, float sy_first = 0.f, float* gm2_first = nullptr) {
-  const float pvx = view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
-  const float pvy = view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
-  const float pvz = view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
-  const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-  const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-  const float tz = pvz;
-  const float txtz = pvx / tz, tytz = pvy / tz;
-  const float xm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-  const float ym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-  const float tx = clampf(txtz, -limx, limx) * tz, ty = clampf(tytz, -limy, limy) * tz;
-  const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
-  const float T0[3] = {J00 * view[0] + J02 * view[2], J00 * view[4] + J02 * view[6], J00 * view[8] + J02 * view[10]};
-  const float T1[3] = {J11 * view[1] + J12 * view[2], J11 * view[5] + J12 * view[6], J11 * view[9] + J12 * view[10]};
-  const float S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
-  float U0[3], U1[3];
+  const real pvx = (real)view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12];
+  const real pvy = (real)view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13];
+  const real pvz = (real)view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14];
+  const real fx = (real)W / (2.0f * (real)tanfovx), fy = (real)H / (2.0f * (real)tanfovy);
+  const real limx = 1.3f * (real)tanfovx, limy = 1.3f * (real)tanfovy;
+  const real tz = pvz;
+  const real txtz = pvx / tz, tytz = pvy / tz;
+  const real xm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  const real ym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const real tx = (txtz < -limx ? -limx : (txtz > limx ? limx : txtz)) * tz, ty = (tytz < -limy ? -limy : (tytz > limy ? limy : tytz)) * tz;
+  const real J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+  const real T0[3] = {J00 * view[0] + J02 * view[2], J00 * view[4] + J02 * view[6], J00 * view[8] + J02 * view[10]};
+  const real T1[3] = {J11 * view[1] + J12 * view[2], J11 * view[5] + J12 * view[6], J11 * view[9] + J12 * view[10]};
+  const real S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+  real U0[3], U1[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     U0[k] = S[k][0] * T0[0] + S[k][1] * T0[1] + S[k][2] * T0[2];
     U1[k] = S[k][0] * T1[0] + S[k][1] * T1[1] + S[k][2] * T1[2];
   }
-  const float a = U0[0] * T0[0] + U0[1] * T0[1] + U0[2] * T0[2] + 0.3f;
-  const float b = U0[0] * T1[0] + U0[1] * T1[1] + U0[2] * T1[2];
-  const float cc = U1[0] * T1[0] + U1[1] * T1[1] + U1[2] * T1[2] + 0.3f;
-  const float det = a * cc - b * b;
-  const float d2inv = 1.0f / (det * det + 0.0000001f);
-  const float gA = ps.gA, gB = ps.gB, gC = ps.gC;
-  const float dL_da = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
-  const float dL_dc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
-  const float dL_db = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
-  gcov[0] += T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
-  gcov[3] += T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
-  gcov[5] += T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
-  gcov[1] += 2.0f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.0f * T1[0] * T1[1] * dL_dc;
-  gcov[2] += 2.0f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.0f * T1[0] * T1[2] * dL_dc;
-  gcov[4] += 2.0f * T0[1] * T0[2] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.0f * T1[1] * T1[2] * dL_dc;
-  float dT0[3], dT1[3];
+  const real a = U0[0] * T0[0] + U0[1] * T0[1] + U0[2] * T0[2] + 0.3f;
+  const real b = U0[0] * T1[0] + U0[1] * T1[1] + U0[2] * T1[2];
+  const real cc = U1[0] * T1[0] + U1[1] * T1[1] + U1[2] * T1[2] + 0.3f;
+  const real det = a * cc - b * b;
+  const real d2inv = 1.0f / (det * det + 0.0000001f);
+  const real gA = ps.gA, gB = ps.gB, gC = ps.gC;
+  const real dL_da = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
+  const real dL_dc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
+  const real dL_db = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+  gcov[0] += (float)(T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+  gcov[3] += (float)(T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+  gcov[5] += (float)(T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+  gcov[1] += (float)(2.0f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.0f * T1[0] * T1[1] * dL_dc);
+  gcov[2] += (float)(2.0f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.0f * T1[0] * T1[2] * dL_dc);
+  gcov[4] += (float)(2.0f * T0[1] * T0[2] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.0f * T1[1] * T1[2] * dL_dc);
+  real dT0[3], dT1[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     dT0[j] = 2.0f * U0[j] * dL_da + U1[j] * dL_db;
     dT1[j] = 2.0f * U1[j] * dL_dc + U0[j] * dL_db;
   }
-  const float dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
-  const float dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
-  const float dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
-  const float dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
-  const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
-  const float dtx = xm * -fx * itz2 * dJ02;
-  const float dty = ym * -fy * itz2 * dJ12;
-  const float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
+  const real dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
+  const real dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
+  const real dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
+  const real dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
+  const real itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  const real dtx = xm * -fx * itz2 * dJ02;
+  const real dty = ym * -fy * itz2 * dJ12;
+  const real dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.0f * fx * tx) * itz3 * dJ02 + (2.0f * fy * ty) * itz3 * dJ12;
   // the blend backward hands over the raw sums of t*dx and t*dy (ps.gmx, ps.gmy); with the conic
   // (A, B, C) = (cc, -b, a) / det:  d/d mean2D.x = -(A sx + B sy),  d/d mean2D.y = -(C sy + B sx)
-  const float det_inv = 1.0f / det;
-  const float cA = cc * det_inv, cB = -b * det_inv, cC = a * det_inv;
-  gm2[0] = -(cA * ps.gmx + cB * ps.gmy) * 0.5f * (float)W;
-  gm2[1] = -(cC * ps.gmy + cB * ps.gmx) * 0.5f * (float)H;
+  const real det_inv = 1.0f / det;
+  const real cA = cc * det_inv, cB = -b * det_inv, cC = a * det_inv;
+  const real m2x = -(cA * ps.gmx + cB * ps.gmy) * 0.5f * (real)W;
+  gm2[0] = (float)m2x;
+  const real m2y = -(cC * ps.gmy + cB * ps.gmx) * 0.5f * (real)H;
+  gm2[1] = (float)m2y;
   if (gm2_first) {   // fused pair: the share of the first view of the pair (ps.gmx / gmy are the sums over both)
-    gm2_first[0] = -(cA * sx_first + cB * sy_first) * 0.5f * (float)W;
-    gm2_first[1] = -(cC * sy_first + cB * sx_first) * 0.5f * (float)H;
+    gm2_first[0] = (float)(-(cA * sx_first + cB * sy_first) * 0.5f * (real)W);
+    gm2_first[1] = (float)(-(cC * sy_first + cB * sx_first) * 0.5f * (real)H);
   }
-  const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
-  const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
-  const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
-  const float mw = 1.0f / (hw + 0.0000001f);
-  const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-  gm3[0] += view[0] * dtx + view[1] * dty + view[2] * dtz + (proj[0] * mw - proj[3] * mul1) * gm2[0] + (proj[1] * mw - proj[3] * mul2) * gm2[1];
-  gm3[1] += view[4] * dtx + view[5] * dty + view[6] * dtz + (proj[4] * mw - proj[7] * mul1) * gm2[0] + (proj[5] * mw - proj[7] * mul2) * gm2[1];
-  gm3[2] += view[8] * dtx + view[9] * dty + view[10] * dtz + (proj[8] * mw - proj[11] * mul1) * gm2[0] + (proj[9] * mw - proj[11] * mul2) * gm2[1];
+  const real hx = (real)proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
+  const real hy = (real)proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
+  const real hw = (real)proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
+  const real mw = 1.0f / (hw + 0.0000001f);
+  const real mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+  gm3[0] += (float)(view[0] * dtx + view[1] * dty + view[2] * dtz + (proj[0] * mw - proj[3] * mul1) * m2x + (proj[1] * mw - proj[3] * mul2) * m2y);
+  gm3[1] += (float)(view[4] * dtx + view[5] * dty + view[6] * dtz + (proj[4] * mw - proj[7] * mul1) * m2x + (proj[5] * mw - proj[7] * mul2) * m2y);
+  gm3[2] += (float)(view[8] * dtx + view[9] * dty + view[10] * dtz + (proj[8] * mw - proj[11] * mul1) * m2x + (proj[9] * mw - proj[11] * mul2) * m2y);
 }
 
 // dL/dcov3D -> dL/dscale, dL/drotation (linear in gcov: in the multi-view kernel it runs once on the sum).
 __device__ __forceinline__ void cov3_to_scale_rot(const Cov3& cv, float mod, const float gcov[6], float gs[3], float gq[4]) {
-  const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                          {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                          {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-  float G[3][3];
+  const real dS[3][3] = {{(real)gcov[0], 0.5f * (real)gcov[1], 0.5f * (real)gcov[2]},
+                          {0.5f * (real)gcov[1], (real)gcov[3], 0.5f * (real)gcov[4]},
+                          {0.5f * (real)gcov[2], 0.5f * (real)gcov[4], (real)gcov[5]}};
+  real G[3][3];
 #pragma unroll
   for (int jj = 0; jj < 3; ++jj) {
-    const float dM0 = 2.0f * (dS[0][0] * cv.R[0][jj] + dS[0][1] * cv.R[1][jj] + dS[0][2] * cv.R[2][jj]) * cv.s[jj];
-    const float dM1 = 2.0f * (dS[1][0] * cv.R[0][jj] + dS[1][1] * cv.R[1][jj] + dS[1][2] * cv.R[2][jj]) * cv.s[jj];
-    const float dM2 = 2.0f * (dS[2][0] * cv.R[0][jj] + dS[2][1] * cv.R[1][jj] + dS[2][2] * cv.R[2][jj]) * cv.s[jj];
-    gs[jj] = mod * (cv.R[0][jj] * dM0 + cv.R[1][jj] * dM1 + cv.R[2][jj] * dM2);
+    const real dM0 = 2.0f * (dS[0][0] * cv.R[0][jj] + dS[0][1] * cv.R[1][jj] + dS[0][2] * cv.R[2][jj]) * cv.s[jj];
+    const real dM1 = 2.0f * (dS[1][0] * cv.R[0][jj] + dS[1][1] * cv.R[1][jj] + dS[1][2] * cv.R[2][jj]) * cv.s[jj];
+    const real dM2 = 2.0f * (dS[2][0] * cv.R[0][jj] + dS[2][1] * cv.R[1][jj] + dS[2][2] * cv.R[2][jj]) * cv.s[jj];
+    gs[jj] = (float)((real)mod * (cv.R[0][jj] * dM0 + cv.R[1][jj] * dM1 + cv.R[2][jj] * dM2));
     G[0][jj] = dM0 * cv.s[jj]; G[1][jj] = dM1 * cv.s[jj]; G[2][jj] = dM2 * cv.s[jj];
   }
-  const float r = cv.q[0], x = cv.q[1], y = cv.q[2], z = cv.q[3];
-  gq[0] = 2.0f * (-z * G[0][1] + y * G[0][2] + z * G[1][0] - x * G[1][2] - y * G[2][0] + x * G[2][1]);
-  gq[1] = 2.0f * (y * G[0][1] + z * G[0][2] + y * G[1][0] - 2.0f * x * G[1][1] - r * G[1][2] + z * G[2][0] + r * G[2][1] - 2.0f * x * G[2][2]);
-  gq[2] = 2.0f * (-2.0f * y * G[0][0] + x * G[0][1] + r * G[0][2] + x * G[1][0] + z * G[1][2] - r * G[2][0] + z * G[2][1] - 2.0f * y * G[2][2]);
-  gq[3] = 2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]);
+  const real r = cv.q[0], x = cv.q[1], y = cv.q[2], z = cv.q[3];
+  gq[0] = (float)(2.0f * (-z * G[0][1] + y * G[0][2] + z * G[1][0] - x * G[1][2] - y * G[2][0] + x * G[2][1]));
+  gq[1] = (float)(2.0f * (y * G[0][1] + z * G[0][2] + y * G[1][0] - 2.0f * x * G[1][1] - r * G[1][2] + z * G[2][0] + r * G[2][1] - 2.0f * x * G[2][2]));
+  gq[2] = (float)(2.0f * (-2.0f * y * G[0][0] + x * G[0][1] + r * G[0][2] + x * G[1][0] + z * G[1][2] - r * G[2][0] + z * G[2][1] - 2.0f * y * G[2][2]));
+  gq[3] = (float)(2.0f * (-2.0f * z * G[0][0] - r * G[0][1] + x * G[0][2] + r * G[1][0] - 2.0f * z * G[1][1] + y * G[1][2] + x * G[2][0] + y * G[2][1]));
 }
 
 // The tracking forward marks the Gaussians some pixel of the view blended (GeomState::used; trusted when the view's `tracked` word is
@@ -387,10 +398,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_bwd_views_kernel(
 // additions as the loop, hence the same bits -- and finishes with the view-independent part (scale / rotation chain, activations).
 // V x more waves in flight, no second pass over HBM.
 #define PBW_VALUES 13      // gcov[6], gm3[3], gop, gcol[3]
-#ifndef PBW_MIN_WAVES
-#define PBW_MIN_WAVES 6   // 79 VGPRs: three 8-wave workgroups per CU instead of two (52 -> 48.5 us at 8 views; 8 waves per SIMD spills: 63.5)
-#endif
-__global__ __launch_bounds__(64 * GSR_MAX_BATCH, PBW_MIN_WAVES) void preprocess_bwd_views_waves_kernel(
+// (No occupancy bound: with the chain in fp64 the kernel needs 166 VGPRs; bounded to the fp32 build's 80 it spilled and took 70 us at four views.)
+template <int MAXW>      // waves per workgroup the instantiation is compiled for (= views it can take): its register budget follows
+__global__ __launch_bounds__(64 * MAXW) void preprocess_bwd_views_waves_kernel(
     GsrBwdViews vw, int P, float mod, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -518,9 +528,12 @@ int gsr_launch_preprocess_bwd_views(const GsrBwdViews& vw, int P, float scale_mo
   for (int v = 0; v < vw.V; ++v) nact += vw.v[v].fused_alias ? 0 : 1;
   if (nact >= 2) {      // one wave per view
     { GSR_PROF("preprocess_bwd_views", st);
-      hipLaunchKernelGGL(preprocess_bwd_views_waves_kernel, dim3((P + 63) / 64), dim3(64 * nact), sizeof(float) * (size_t)nact * (PBW_VALUES + 1) * 64,
-                         st, vw, P, scale_modifier, means3D, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity,
-                         dL_dscales, dL_drotations, dL_dcov3D); }
+#define PBW_LAUNCH(MAXW) hipLaunchKernelGGL(preprocess_bwd_views_waves_kernel<MAXW>, dim3((P + 63) / 64), dim3(64 * nact),              \
+                           sizeof(float) * (size_t)nact * (PBW_VALUES + 1) * 64, st, vw, P, scale_modifier, means3D, scales, rotations,       \
+                           cov3D_precomp, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D)
+      if (nact <= 4) PBW_LAUNCH(4); else if (nact <= 8) PBW_LAUNCH(8); else PBW_LAUNCH(GSR_MAX_BATCH);
+#undef PBW_LAUNCH
+    }
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
   }
