@@ -923,11 +923,11 @@ def run_extras(dev, params, cams, synth_ring_cameras, synth_scene_params):
                 GaussianRasterizer(raster_settings=cam)(**rv)
         import diff_gaussian_rasterization as dgr
         if dgr._C is not None:       # a FULL forward per call: the same frame rendered again would be served from the remembered tile lists
-            dgr._C.set_list_reuse(False)
+            dgr.layer_state(dev).list_reuse = False
         ms = _time_ms(fwd, 20, 5)
         ms_same = None
         if dgr._C is not None:
-            dgr._C.set_list_reuse(True)
+            dgr.layer_state(dev).list_reuse = True
             ms_same = _time_ms(fwd, 20, 5)
         out["forward_only_cfg2"] = {"ms_per_view": ms, "Mpix_per_s": H * W / ms / 1e3, "ms_per_view_same_geometry_again": ms_same,
                                     "what": "BASELINE.json configs[1]: 50k Gaussians, 1 view 800x800, forward only (tile-list reuse off: every call "

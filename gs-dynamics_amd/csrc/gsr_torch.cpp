@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 
@@ -82,29 +83,38 @@ struct ListCache {
   void* stream = nullptr;   // the stream the lists were produced on: a forward on ANOTHER stream is not ordered behind their writes -- it bins its own
   torch::Tensor geom, binning, image;
 };
-thread_local ListCache g_lists;
 
-// Capacity mode (include/gsr.h: gsr_forward_capacity; round 5).  Upstream's forward -- and this layer until now -- reads
+// Capacity mode (include/gsr.h: gsr_forward_capacity; round 5).  Upstream's forward -- and this layer until then -- reads
 // the entry count back between its two stages: the GPU idles while the host sizes the binning buffer and queues the remaining launches
 // (~20 us of a 98 us forward at 50 k Gaussians / 800^2).  The node's forward instead sizes the buffer from the previous call of the same
-// (device, P, H, W) plus 25 %, queues BOTH stages, and only then looks at the count (pinned words the preprocess blocks store: by then
+// (P, H, W) plus 25 %, queues BOTH stages, and only then looks at the count (pinned words the preprocess blocks store: by then
 // they have arrived -- the host does not wait and the GPU does not idle).  A count above the capacity -- the scene grew by more than a quarter between two calls -- repeats the forward
 // through the exact path before anything is returned.  The comparison with the previous forward's geometry (tile-list reuse) rides along:
-// its per-block verdict words go to pinned memory too, so this layer KNOWS after every call whether it was a twin of its predecessor, and
+// its per-block verdict words go to pinned memory too, so the layer KNOWS after every call whether it was a twin of its predecessor, and
 // sends a call through the comparing (synchronising, list-sharing) path when the call two before it was a twin -- the reference's
 // colour / seg and colour / mask alternation, or a static scene; mispredictions cost time (one readback, or one redundant binning), never results.
-struct CapacityState {
-  std::map<std::tuple<int, int64_t, int64_t, int64_t>, uint32_t> cap;   // remembered entry capacity per (device, P, H, W)
-  int32_t* pinned = nullptr;   // COHERENT pinned host words (lives for the process): [0] the tile-order kernel's count (P > 512 Ki), [1 ...] the preprocess blocks' {differs, entry count} words
-  bool twin[2] = {false, false};   // was the last forward / the one before it a twin of its predecessor
-};
-thread_local CapacityState g_capacity_state;
-bool g_capacity = true;
-int64_t g_capacity_calls = 0, g_capacity_overflows = 0, g_twins_seen_late = 0;
+//
+// EVERYTHING the layer remembers between two calls lives in ONE LayerState object (round 6; SURVEY.md section 8b: "no global state").  The
+// Python module owns the objects -- diff_gaussian_rasterization.layer_state(device): one per device, created on first use, inspectable
+// (stats()), resettable (reset()) -- and hands the device's to every GaussianRasterizer call.  Upstream's three entry points take it as an
+// optional last argument: WITHOUT one they are pure functions of their arguments, as upstream's are (exact path, nothing remembered).
 constexpr int64_t kCompareMaxP = 2048 * 256;     // the library compares up to this many Gaussians (GSR_HOST_SCAN_MAX_BLOCKS blocks)
-void note_twin(bool t) { auto& c = g_capacity_state; c.twin[1] = c.twin[0]; c.twin[0] = t; }
-bool g_reuse = [] { const char* e = getenv("GSR_NO_LIST_REUSE"); return !(e && *e && atoi(e) != 0); }();
-int64_t g_reuse_hits = 0;
+struct LayerState {
+  ListCache lists;                                              // the last forward's states (tile-list reuse)
+  std::map<std::tuple<int64_t, int64_t, int64_t>, uint32_t> cap;   // remembered entry capacity per (P, H, W)
+  int32_t* pinned = nullptr;   // COHERENT pinned host words: [0] the tile-order kernel's count (P > 512 Ki), [2 ...] the preprocess blocks' {differs, entry count} pairs
+  bool twin[2] = {false, false};   // was the last forward / the one before it a twin of its predecessor
+  bool capacity = true;        // switch: capacity-mode forwards
+  bool reuse = [] { const char* e = getenv("GSR_NO_LIST_REUSE"); return !(e && *e && atoi(e) != 0); }();   // switch: tile-list reuse
+  int64_t reuse_hits = 0, capacity_calls = 0, capacity_overflows = 0, twins_seen_late = 0;
+  LayerState() = default;
+  LayerState(const LayerState&) = delete;
+  LayerState& operator=(const LayerState&) = delete;
+  ~LayerState() { if (pinned) (void)hipHostFree(pinned); }
+  void note_twin(bool t) { twin[1] = twin[0]; twin[0] = t; }
+  void reset() { lists = ListCache(); cap.clear(); twin[0] = twin[1] = false; }     // forget everything learned; switches and counters stay
+};
+thread_local LayerState* t_call_state = nullptr;   // the state of the GaussianRasterizer call in flight on this thread (set around RasterizeFn::apply)
 
 // One forward (both stages) for the upstream-shaped binding and for the autograd node below.
 struct Forward {
@@ -117,7 +127,8 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
                           const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
                           int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
                           bool will_backward,       // false = no input requires a gradient -- the blend records nothing for a backward
-                          bool allow_capacity) {    // false = the caller hands num_rendered on (upstream's tuple): layout must equal the count
+                          bool allow_capacity,      // false = the caller hands num_rendered on (upstream's tuple): layout must equal the count
+                          LayerState* S) {          // what the layer may remember and reuse; nullptr = nothing (a pure function, as upstream's)
   TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build) runs on a HIP device only; there is no CPU fallback");
   const c10::Device dev = means3D.device();
@@ -150,8 +161,10 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
   }
   uint32_t D = 0;
   int32_t same = 0;
-  ListCache& lc = g_lists;
-  const bool candidate = g_reuse && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.stream == stream &&
+  ListCache none;
+  ListCache& lc = S ? S->lists : none;
+  const bool reuse = S && S->reuse;
+  const bool candidate = reuse && lc.valid && lc.dev == dev.index() && lc.P == P && lc.H == H && lc.W == W && lc.stream == stream &&
                          (allow_capacity || lc.layout == lc.D);
   const uint32_t fwd_flags = will_backward ? 0u : (uint32_t)GSR_FORWARD_ONLY;
   auto finish = [&](uint32_t count, uint32_t layout, const torch::Tensor& binning) {
@@ -160,18 +173,18 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
     return o;
   };
   auto remember = [&](uint32_t count, uint32_t layout, const torch::Tensor& binning) {
-    if (g_reuse && count > 0) {
+    if (!S) return;
+    if (reuse && count > 0) {
       lc.valid = true; lc.dev = dev.index(); lc.P = P; lc.H = H; lc.W = W; lc.D = count; lc.layout = layout; lc.stream = stream;
       lc.geom = geom; lc.binning = binning; lc.image = image;
     } else {
       lc = ListCache();
     }
   };
-  CapacityState& cs = g_capacity_state;
-  const auto key = std::make_tuple((int)dev.index(), P, H, W);
-  const auto known = cs.cap.find(key);
-  const bool predict_twin = candidate && cs.twin[1];
-  if (allow_capacity && g_capacity && known != cs.cap.end() && !predict_twin) {
+  const auto key = std::make_tuple(P, H, W);
+  if (S && allow_capacity && S->capacity && S->cap.count(key) && !(candidate && S->twin[1])) {
+    LayerState& cs = *S;
+    const auto known = cs.cap.find(key);
     // ---- both stages queued, then the count (see CapacityState)
     const uint32_t cap = known->second;
     const int64_t nblk = (P + 255) / 256;
@@ -191,7 +204,7 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
                                radii.data_ptr<int32_t>(), binning.data_ptr(), cap, image.data_ptr(), color.data_ptr<float>(),
                                depth.data_ptr<float>(), compare ? lc.geom.data_ptr() : nullptr,
                                words ? reinterpret_cast<uint32_t*>(pin + 2) : nullptr, words ? nullptr : pin, fwd_flags, stream), "gsr_forward_capacity");
-    ++g_capacity_calls;
+    ++cs.capacity_calls;
     int32_t any = 1;
     int64_t count = words ? gsr_wait_block_counts(reinterpret_cast<const volatile uint32_t*>(pin + 2), (int32_t)nblk, 500, 20 * 1000 * 1000, &any)
                           : gsr_wait_counts(pin, 1, 500, 20 * 1000 * 1000);
@@ -202,27 +215,27 @@ Forward rasterize_forward(const torch::Tensor& background, const torch::Tensor& 
     }
     if ((uint64_t)count <= cap) {
       const bool twin = compare && !any && lc.D == (uint32_t)count;
-      if (twin) ++g_twins_seen_late;       // its lists were built a second time: the predictor sends the next one of the pattern the sharing way
-      note_twin(twin);
+      if (twin) ++cs.twins_seen_late;       // its lists were built a second time: the predictor sends the next one of the pattern the sharing way
+      cs.note_twin(twin);
       cs.cap[key] = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)count + (uint64_t)count / 4 + 1024);
       remember((uint32_t)count, cap, binning);
       return finish((uint32_t)count, cap, binning);
     }
-    ++g_capacity_overflows;      // the scene outgrew the estimate: everything again, with the count known (the outputs above are overwritten)
+    ++cs.capacity_overflows;      // the scene outgrew the estimate: everything again, with the count known (the outputs above are overwritten)
   }
   check(gsr_forward_preprocess_same(&st.s, (int32_t)P, fptr(m3), fptr(sc), fptr(rot), fptr(op), fptr(col), fptr(shs), fptr(cov), geom.data_ptr(),
                                     radii.data_ptr<int32_t>(), &D, candidate ? lc.geom.data_ptr() : nullptr, candidate ? &same : nullptr, stream),
         "gsr_forward_preprocess");
-  cs.cap[key] = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)D + (uint64_t)D / 4 + 1024);
+  if (S) S->cap[key] = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)D + (uint64_t)D / 4 + 1024);
   if (candidate && same && D > 0 && lc.D == D) {
     // same geometry, same camera as the previous forward (compared on the device, bit for bit): its lists are this render's lists
     check(gsr_forward_render_shared_ex(&st.s, (int32_t)P, lc.layout, geom.data_ptr(), lc.binning.data_ptr(), lc.image.data_ptr(), image.data_ptr(),
                                        color.data_ptr<float>(), depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render_shared");
-    ++g_reuse_hits;
-    note_twin(true);
+    ++S->reuse_hits;
+    S->note_twin(true);
     return finish(D, lc.layout, lc.binning);
   }
-  note_twin(false);
+  if (S) S->note_twin(false);
   torch::Tensor binning = torch::empty({(int64_t)gsr_binning_bytes(D, (int32_t)H, (int32_t)W)}, u8);
   check(gsr_forward_render_ex(&st.s, (int32_t)P, D, geom.data_ptr(), binning.data_ptr(), image.data_ptr(), color.data_ptr<float>(),
                               depth.data_ptr<float>(), fwd_flags, stream), "gsr_forward_render");
@@ -239,9 +252,10 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
                     const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier, const torch::Tensor& cov3D_precomp,
                     const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
                     int64_t image_width, const torch::Tensor& sh, int64_t degree, const torch::Tensor& campos, bool prefiltered,
-                    bool will_backward) {     // extension over upstream (default true)
+                    bool will_backward,       // extension over upstream (default true)
+                    const std::shared_ptr<LayerState>& state) {   // extension (default none): tile-list reuse across calls (exact mode either way)
   Forward o = rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
-                                tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, will_backward, false);
+                                tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, will_backward, false, state.get());
   return std::make_tuple(o.D, o.color, o.depth, o.radii, o.geom, o.binning, o.image);
 }
 
@@ -312,7 +326,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     (void)means2D;
     ctx->set_materialize_grads(false);        // grad_depth is ignored: do not let autograd fill a zero image for it
     Forward r = rasterize_forward(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix, tanfovx,
-                                  tanfovy, H, W, sh, degree, campos, prefiltered, will_backward, true);
+                                  tanfovy, H, W, sh, degree, campos, prefiltered, will_backward, true, t_call_state);
     torch::Tensor color = r.color, depth = r.depth, radii = r.radii;
     ctx->saved_data["R"] = r.layout;      // what the states were laid out for (the count, or a capacity-mode forward's capacity)
     ctx->saved_data["tanfovx"] = tanfovx; ctx->saved_data["tanfovy"] = tanfovy; ctx->saved_data["scale_modifier"] = scale_modifier;
@@ -354,7 +368,8 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
 // forward the grad mode is always off and needs_input_grad reports requires_grad flags even under torch.no_grad() --
 // evaluation renders of trainable parameters under no_grad take the untracked forward (GSR_FORWARD_ONLY).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor>
-rasterize(const torch::Tensor& means3D, const torch::Tensor& means2D, const torch::Tensor& sh, const torch::Tensor& colors,
+rasterize(const std::shared_ptr<LayerState>& state,      // the calling module's state for the device (may be none: nothing remembered)
+          const torch::Tensor& means3D, const torch::Tensor& means2D, const torch::Tensor& sh, const torch::Tensor& colors,
           const torch::Tensor& opacities, const torch::Tensor& scales, const torch::Tensor& rotations, const torch::Tensor& cov3D,
           const torch::Tensor& bg, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const torch::Tensor& campos,
           double tanfovx, double tanfovy, int64_t H, int64_t W, double scale_modifier, int64_t degree, bool prefiltered) {
@@ -362,6 +377,11 @@ rasterize(const torch::Tensor& means3D, const torch::Tensor& means2D, const torc
   if (at::GradMode::is_enabled())
     for (const torch::Tensor* t : {&means3D, &means2D, &sh, &colors, &opacities, &scales, &rotations, &cov3D})
       will_backward = will_backward || (t->defined() && t->requires_grad());
+  struct Scope {      // the node's forward runs inside apply(), on this thread: it finds the state here
+    LayerState* prev;
+    explicit Scope(LayerState* s) : prev(t_call_state) { t_call_state = s; }
+    ~Scope() { t_call_state = prev; }
+  } scope(state.get());
   auto o = RasterizeFn::apply(means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, bg, viewmatrix, projmatrix, campos, tanfovx,
                               tanfovy, H, W, scale_modifier, degree, prefiltered, will_backward);
   return std::make_tuple(o[0], o[1], o[2]);
@@ -385,31 +405,34 @@ torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& vi
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  namespace py = pybind11;
   m.doc() = "MI355X rasterizer: torch layer over libgsr_hip.so (rasterize_gaussians / rasterize_gaussians_backward / mark_visible)";
-  m.def("rasterize_gaussians", &rasterize_gaussians);                      // 19 arguments: upstream's 18 + will_backward
-  m.def("rasterize_gaussians", [](const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
-                                  const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier,
-                                  const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
-                                  double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh,
-                                  int64_t degree, const torch::Tensor& campos, bool prefiltered) {        // upstream's exact argument list
-    return rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
-                               tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, true);
-  });
-  {
-    namespace py = pybind11;
-    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),
-          py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
-          py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"),
-          py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
-          py::arg("want_color_grad") = true);
-  }
-  m.def("rasterize", &rasterize);      // one GaussianRasterizer call: forward + the autograd node (C++)
+  py::class_<LayerState, std::shared_ptr<LayerState>>(m, "LayerState",
+      "What the layer remembers between calls on one device: the last forward's tile lists, entry capacities per (P, H, W), the twin predictor")
+      .def(py::init<>())
+      .def("reset", &LayerState::reset, "forget the cached lists, the capacities and the predictor (switches and counters stay)")
+      .def("drop_list_cache", [](LayerState& s) { s.lists = ListCache(); })
+      .def_property("list_reuse", [](const LayerState& s) { return s.reuse; }, [](LayerState& s, bool on) { s.reuse = on; s.lists = ListCache(); })
+      .def_property("capacity_mode", [](const LayerState& s) { return s.capacity; },
+                    [](LayerState& s, bool on) { s.capacity = on; s.twin[0] = s.twin[1] = false; })
+      .def("stats", [](const LayerState& s) {
+        py::dict d;
+        d["list_reuse_hits"] = s.reuse_hits; d["capacity_calls"] = s.capacity_calls; d["capacity_overflows"] = s.capacity_overflows;
+        d["twins_seen_late"] = s.twins_seen_late; d["cached_entries"] = s.lists.valid ? (int64_t)s.lists.D : (int64_t)0;
+        d["capacities"] = (int64_t)s.cap.size(); d["twin_history"] = py::make_tuple(s.twin[0], s.twin[1]);
+        return d;
+      });
+  // upstream's 18 arguments, then the two extensions (will_backward, state)
+  m.def("rasterize_gaussians", &rasterize_gaussians, py::arg("background"), py::arg("means3D"), py::arg("colors"), py::arg("opacity"),
+        py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"),
+        py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"), py::arg("degree"),
+        py::arg("campos"), py::arg("prefiltered"), py::arg("will_backward") = true, py::arg("state") = std::shared_ptr<LayerState>());
+  m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),
+        py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
+        py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"),
+        py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
+        py::arg("want_color_grad") = true);
+  m.def("rasterize", &rasterize);      // one GaussianRasterizer call: forward + the autograd node (C++); first argument: the LayerState or None
   m.def("mark_visible", &mark_visible);
-  m.def("set_list_reuse", [](bool on) { g_reuse = on; g_lists = ListCache(); });
-  m.def("list_reuse_hits", []() { return g_reuse_hits; });
-  m.def("drop_list_cache", []() { g_lists = ListCache(); });
-  m.def("set_capacity_mode", [](bool on) { g_capacity = on; g_capacity_state.twin[0] = g_capacity_state.twin[1] = false; });
-  m.def("capacity_stats", []() { return std::make_tuple(g_capacity_calls, g_capacity_overflows, g_twins_seen_late); });   // (calls, repeats after an overflow, twins noticed only afterwards)
-  m.def("forget_capacities", []() { g_capacity_state.cap.clear(); g_capacity_state.twin[0] = g_capacity_state.twin[1] = false; });
   m.def("abi_version", []() { return (int)GSR_VERSION; });   // the header this layer was COMPILED against (compare with the library's gsr_version())
 }

@@ -35,6 +35,29 @@ _CTYPES_FORWARD, _CTYPES_BACKWARD = _hip.rasterize_forward, _hip.rasterize_backw
 _PY_NODE = os.environ.get("GSR_PY_AUTOGRAD") == "1"   # A/B: the autograd node as a Python torch.autograd.Function (rounds 1 - 4) instead of _C.rasterize
 
 
+_LAYER_STATES = {}     # device index -> _C.LayerState: what the torch C++ layer remembers between GaussianRasterizer calls on that device
+
+
+def layer_state(device=None):
+    """The torch C++ layer's state for ``device`` (default: the current HIP device), created on first use: the last forward's tile lists
+    (the reference renders every camera twice with the same geometry), the entry capacities per (P, H, W) of the capacity-mode forward and
+    the twin predictor.  Owned HERE, not by the extension (no global state in the library or its torch layer):
+    ``layer_state().stats()`` inspects it, ``.reset()`` forgets everything learned, ``.list_reuse`` / ``.capacity_mode`` are the switches,
+    ``reset_layer_states()`` drops every device's.  None when the C++ layer is not loaded."""
+    if _C is None:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = torch.cuda.current_device() if dev.index is None else dev.index
+    st = _LAYER_STATES.get(idx)
+    if st is None:
+        st = _LAYER_STATES[idx] = _C.LayerState()
+    return st
+
+
+def reset_layer_states():
+    _LAYER_STATES.clear()
+
+
 def _native():
     """The torch C++ layer, unless a test double / spy has replaced the ctypes entry points (then those must be the ones called)."""
     if _C is not None and _hip.rasterize_forward is _CTYPES_FORWARD and _hip.rasterize_backward is _CTYPES_BACKWARD:
@@ -42,7 +65,8 @@ def _native():
     return None
 
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_views"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_views", "layer_state",
+           "reset_layer_states"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -99,7 +123,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             D, color, depth, radii, geom, binning, image = native.rasterize_gaussians(
                 rs.bg, m3, col_, opacities, sc_, rot_, float(rs.scale_modifier), cov_, rs.viewmatrix, rs.projmatrix, float(rs.tanfovx),
                 float(rs.tanfovy), int(rs.image_height), int(rs.image_width), sh_, int(rs.sh_degree), rs.campos, bool(rs.prefiltered),
-                bool(any(ctx.needs_input_grad)))       # (only reached through the Python node: test doubles; under torch.no_grad() this still says True -- the C++ node decides before it is built)
+                bool(any(ctx.needs_input_grad)), layer_state(m3.device))       # (only reached through the Python node: test doubles; under torch.no_grad() this still says True -- the C++ node decides before it is built)
             ctx.native, ctx.rs, ctx.num_rendered = native, rs, int(D)
             ctx.has = (sh_.numel() > 0, col_.numel() > 0, sc_.numel() > 0, cov_.numel() > 0)
             ctx.save_for_backward(m3, radii, col_, sh_, sc_, rot_, cov_, geom, binning, image)
@@ -224,7 +248,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     if native is not None and hasattr(native, "rasterize") and not _PY_NODE:
         # one crossing into the torch C++ layer: forward and the autograd node live there (csrc/gsr_torch.cpp: RasterizeFn)
         rs = raster_settings
-        return native.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg, rs.viewmatrix,
+        return native.rasterize(layer_state(means3D.device), means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg, rs.viewmatrix,
                                 rs.projmatrix, rs.campos, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height), int(rs.image_width),
                                 float(rs.scale_modifier), int(rs.sh_degree), bool(rs.prefiltered))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 123 /* 0.1.23: + gsr_arm_depth_cuts -- speculative per-tile depth cuts for forward-only frame sequences, validated by the blend; 0.1.22: + gsr_rollout_step_head, gsr_rollout_step_motion, gsr_construct_edges_rows, gsr_gnn_aggregate_res -- the torch glue of a graphed rollout step as kernels of this library (a replayed step is a chain of nodes: fewer nodes, shorter step); 0.1.21: + gsr_forward_capacity -- the single-view forward without a host wait inside; 0.1.20: gsr_gnn_propagate / gsr_gnn_workspace_bytes removed; gsr_forward_preprocess_same (an EXACT comparison with an earlier forward's geometry state) replaces the 64-bit fingerprint of gsr_forward_preprocess_fp; 0.1.19: + gsr_forward_render_ex / _shared_ex, gsr_gnn_propagate, gsr_gnn_aggregate, gsr_gnn_rel_inputs, gsr_construct_edges_dense, gsr_rollout_step_tail; 0.1.18: the list fingerprint covers the blend decisions; 0.1.17: + gsr_wait_counts; 0.1.16: + gsr_fit_bones, gsr_fps_thin, gsr_construct_edges, gsr_lbs_valid; the head of image_state (final_T) is readable; 0.1.15: gsr_forward_render_batch takes colors_views; 0.1.14: + gsr_forward_preprocess_fp / gsr_forward_render_shared; 0.1.13: `flags` of the batch forward; 0.1.12: gsr_fps scratch in bytes */
+#define GSR_VERSION 124 /* 0.1.24 -- the history of the ABI is in CHANGELOG.md ("ABI history") */
 #define GSR_TILE 16     /* tiles are 16x16 pixels, as in the reference extension */
 
 /* Mirror of GaussianRasterizationSettings (/root/reference/src/tracking/helpers.py:20-32).

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points_work_without_a_gpu():
     from diff_gaussian_rasterization import _hip
     lib = _hip.load_library()
-    assert lib.gsr_version() == 123
+    assert lib.gsr_version() == 124
     g1, g2 = lib.gsr_geom_bytes(1000), lib.gsr_geom_bytes(100000)
     assert 0 < g1 < g2 and g2 % 256 == 0
     assert lib.gsr_image_bytes(800, 800) >= 800 * 800 * 8 + 2500 * 8

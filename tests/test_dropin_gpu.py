@@ -11,6 +11,23 @@ from hipcheck import _check_against_oracle, _check_lists, _margin, _pin_tile_sor
 
 pytestmark = pytest.mark.gpu
 
+class _LayerSwitches:
+    """The switches / counters of the torch C++ layer's per-device state (diff_gaussian_rasterization.layer_state) under the names these
+    tests were written with (until round 6 they were module-level functions of _C acting on process globals)."""
+
+    def __init__(self, dgr, dev):
+        self.st = dgr.layer_state(dev)
+
+    def set_list_reuse(self, on): self.st.list_reuse = bool(on)
+    def set_capacity_mode(self, on): self.st.capacity_mode = bool(on)
+    def list_reuse_hits(self): return self.st.stats()["list_reuse_hits"]
+    def drop_list_cache(self): self.st.drop_list_cache()
+    def forget_capacities(self): self.st.reset()
+    def capacity_stats(self):
+        d = self.st.stats()
+        return d["capacity_calls"], d["capacity_overflows"], d["twins_seen_late"]
+
+
 
 def test_reference_call_pattern_get_loss(dev):
     """The literal call sequence of /root/reference/src/tracking/train_utils.py:174-192, 243-245 and
@@ -89,7 +106,7 @@ def test_unchanged_two_call_pattern_reuses_the_tile_lists(dev):
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
-    C_ = dgr._C
+    C_ = _LayerSwitches(dgr, dev)
     assert C_ is not None, "the torch C++ layer must be built on a GPU box"
     P, W, H = 40_000, 400, 304
     params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.05)
@@ -254,7 +271,7 @@ def test_capacity_mode_forward_is_the_exact_forward(dev):
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
-    C_ = dgr._C
+    C_ = _LayerSwitches(dgr, dev)
     P, W, H = 30_000, 400, 304
     cam = synth_ring_cameras(4, W, H, device=dev)[2]
     small = synth_scene_params(P, device=dev, scale_lo=0.005, scale_hi=0.02)
@@ -306,7 +323,7 @@ def test_capacity_mode_learns_the_two_render_pattern(dev):
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
-    C_ = dgr._C
+    C_ = _LayerSwitches(dgr, dev)
     P, W, H = 20_000, 320, 240
     cam = synth_ring_cameras(4, W, H, device=dev)[1]
     params = synth_scene_params(P, device=dev, scale_lo=0.01, scale_hi=0.04)
@@ -379,7 +396,7 @@ def test_random_call_sequences_through_the_stateful_layer(dev, seed):
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import GaussianRasterizer
     from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
-    C_ = dgr._C
+    C_ = _LayerSwitches(dgr, dev)
     rng = np.random.default_rng(2500 + seed)
     P, W, H = int(rng.choice([2000, 15000])), int(rng.integers(60, 330)), int(rng.integers(60, 260))
     cams = synth_ring_cameras(3, W, H, device=dev)[:2]
@@ -420,3 +437,38 @@ def test_random_call_sequences_through_the_stateful_layer(dev, seed):
     finally:
         C_.set_list_reuse(True)
         C_.set_capacity_mode(True)
+
+
+def test_layer_state_is_owned_by_the_module(dev):
+    """no global state.  What the torch C++ layer remembers between calls (tile lists of the last forward, capacities,
+    the twin predictor) lives in ONE object per device that the Python module owns: inspectable, resettable, droppable; upstream's entry
+    points called WITHOUT a state are pure functions of their arguments."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
+    assert dgr._C is not None
+    dgr.reset_layer_states()
+    st = dgr.layer_state(dev)
+    assert st is dgr.layer_state(dev) and st.stats()["cached_entries"] == 0 and st.stats()["capacities"] == 0
+    params = synth_scene_params(3000, device=dev, scale_lo=0.02, scale_hi=0.08)
+    cam = synth_ring_cameras(4, 160, 128, device=dev)[0]
+    with torch.no_grad():
+        rv = {k: v.detach() for k, v in params2rendervar(params).items()}
+        a = GaussianRasterizer(raster_settings=cam)(**rv)
+        s1 = st.stats()
+        assert s1["cached_entries"] > 0 and s1["capacities"] == 1
+        b = GaussianRasterizer(raster_settings=cam)(**rv)          # the same frame again: served from the remembered lists or re-binned -- same bits
+        st.reset()
+        assert st.stats()["cached_entries"] == 0 and st.stats()["capacities"] == 0
+        c = GaussianRasterizer(raster_settings=cam)(**rv)
+        e = rv["means3D"].new_empty(0)
+        h0 = st.stats()
+        up = dgr._C.rasterize_gaussians(cam.bg, rv["means3D"], rv["colors_precomp"], rv["opacities"], rv["scales"], rv["rotations"], 1.0, e,
+                                        cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, 128, 160, e, 0, cam.campos, False)
+        assert st.stats() == h0, "a call without a state must not touch any"
+    for x, y in ((a, b), (a, c)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    assert torch.equal(up[1], a[0]) and torch.equal(up[3], a[1]) and torch.equal(up[2], a[2])
+    dgr.reset_layer_states()
+    assert dgr.layer_state(dev) is not st

@@ -13,9 +13,9 @@ for P in (50_000, 100_000):
     cam = synth_ring_cameras(4, 800, 800, device=dev)[0]
     with torch.no_grad():
         rv = {k: v.detach() for k, v in params2rendervar(params).items()}
-    dgr._C.set_list_reuse(False)
+    dgr.layer_state(dev).list_reuse = False
     for cap in (True, False, True):
-        dgr._C.set_capacity_mode(cap)
+        dgr.layer_state(dev).capacity_mode = cap
         def fwd():
             with torch.no_grad():
                 GaussianRasterizer(raster_settings=cam)(**rv)

@@ -9,9 +9,9 @@ from diff_gaussian_rasterization import GaussianRasterizer
 from gsdyn import params2rendervar, synth_ring_cameras, synth_scene_params
 dev = torch.device("cuda:0")
 if os.environ.get("REUSE") == "0":
-    dgr._C.set_list_reuse(False)
+    dgr.layer_state(dev).list_reuse = False
 if os.environ.get("CAPACITY") == "0":
-    dgr._C.set_capacity_mode(False)
+    dgr.layer_state(dev).capacity_mode = False
 for P, S in ((2000, 128), (100_000, 800)):
     params = synth_scene_params(P, device=dev)
     cam = synth_ring_cameras(4, S, S, device=dev)[0]
