@@ -858,9 +858,8 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
     const GsrRenderView& vw = tab.v[__builtin_amdgcn_readfirstlane(ord.w)];  // uniform: scalar loads
     int pend;
     uint32_t pend_g;
-    // the longest tickets (the order is longest-first: rank = ticket) at a raised wave priority: see gsr_launch_render_fwd
-    const bool raised = ticket * 256u < n_busy * (uint32_t)tab.prio_frac256;
-    if (raised) __builtin_amdgcn_s_setprio(2);
+    // (Round 6: the longest 1/16 ... 1/2 of the tickets at wave priority 2 changed nothing at one, two or four views -- 49.5 / 66.8 / 109.5 us
+    //  either way, profiles/r06_v1_experiments.txt: a tile's walk is a dependent chain, not starved of issue slots.)
     if (PAIRS && vw.partner >= 0)
       pend = fwd_tile<PAIRS, TRACK>((int)ord.x, make_uint2(ord.y, ord.z), L, GSR_FWD_PASS(vw), fwd_partner(tab.v[vw.partner]), vw.contrib, vw.used, pend_g);
     else
@@ -869,7 +868,6 @@ __global__ __launch_bounds__(GSR_BLOCK, TRACK ? (PAIRS ? 5 : FWD_TRACK_WAVES) : 
 #ifdef GSR_TILE_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
-    if (raised) __builtin_amdgcn_s_setprio(0);
     if (threadIdx.x == 0) s_ticket = gridDim.x + atomicAdd(&queue[0], 1u);
     __syncthreads();
     ticket = s_ticket;
@@ -1501,11 +1499,8 @@ static bool has_pairs(const GsrRenderViews& tab) {
 // Launch parameters: workgroups per CU of the two blend kernels and the queue length from which the backward takes its small-batch build.
 // The defaults are the optimum of the round-5 sweep (tools/autotune.py -> profiles/r05_autotune.json: V = 1 .. 8 views x three densities);
 // the switches exist for that sweep.
-int gsr_launch_render_fwd(const GsrRenderViews& tab_in, hipStream_t st) {
-  if (tab_in.T <= 0 || tab_in.V <= 0) return 0;
-  GsrRenderViews tab = tab_in;
-  { static const int frac = env_int("GSR_FWD_PRIO_FRAC", -1);
-    tab.prio_frac256 = frac >= 0 ? frac : 0; }
+int gsr_launch_render_fwd(const GsrRenderViews& tab, hipStream_t st) {
+  if (tab.T <= 0 || tab.V <= 0) return 0;
   static const int wg_per_cu = env_int("GSR_FWD_WG_PER_CU", 6);
   const bool pairs = has_pairs(tab);
   const bool track = tab.track != 0;                // record the per-quad contribution bytes for a backward (not in forward-only calls)
