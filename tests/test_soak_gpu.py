@@ -153,3 +153,29 @@ def test_soak_regression_case_against_fp64(dev):
     _, _, _, grads, _ = _run_hip(cam, g, dev, dL=dL)
     for k, v in grads.items():
         assert rel_err(v, g64[k]) <= TOL, (tag, k, rel_err(v, g64[k]))
+
+
+# The cases the soak stopped at or tallied in round 6 BEFORE preprocess_bwd's chain moved to fp64 (profiles/r06_fp64_chain.txt): every one an
+# elongated Gaussian (a nearly singular conic) whose gradient row the fp32 chain put 1e-4 ... 6e-3 from fp64 -- in the HIP path and in the fp32
+# oracle alike.  With the chain in fp64 the HIP path must sit well INSIDE the fp32 oracle's distance on them: a regression of the chain's
+# precision (a float that crept back in, contraction, a reordered det) shows here, not in a bar that both fp32 evaluations miss together.
+_CHAIN_CASES = [(9, 895, False), (9, 778, False), (2025, 234, False), (123, 602, False), (4242, 790, False), (3, 1255, False)]
+
+
+@pytest.mark.parametrize("seed0,case,big", _CHAIN_CASES)
+def test_fp64_chain_is_closer_to_fp64_than_the_fp32_oracle(dev, seed0, case, big):
+    cam, g, tag, c = case_at(seed0, case, big)
+    kw = dict(colors_precomp=g.get("colors_precomp"), shs=g.get("shs"), scales=g.get("scales"), rotations=g.get("rotations"),
+              cov3D_precomp=g.get("cov3D_precomp"), nthreads=4)
+    o32 = TiledOracle(cam, g["means3D"], g["opacities"], **kw)
+    o64 = TiledOracle(cam, g["means3D"], g["opacities"], f64=True, decisions_of=o32, **kw)
+    dL = np.random.default_rng(case).uniform(-1, 1, (3, cam.image_height, cam.image_width)).astype(np.float32)
+    dL[:, o32.ambiguous] = 0.0
+    g32, g64 = o32.backward(dL), o64.backward(dL)
+    _, _, _, grads, _ = _run_hip(cam, g, dev, dL=dL)
+    for k in ("means3D", "scales", "rotations"):
+        e_h, e_o = rel_err(grads[k], g64[k]), rel_err(g32[k], g64[k])
+        r_h, r_o = row_err(grads[k], g64[k])[0], row_err(g32[k], g64[k])[0]
+        assert e_h <= TOL, (tag, k, e_h)
+        assert e_h <= 0.75 * e_o + 1e-5, (tag, k, "norm-wise", e_h, e_o)      # measured: 0.03 ... 0.6 x the oracle's distance on these cases
+        assert r_h <= 0.75 * r_o + 1e-4, (tag, k, "worst row", r_h, r_o)
