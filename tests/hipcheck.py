@@ -219,10 +219,14 @@ def _check_against_oracle(cam, g, dev, seed=0, nthreads=4, check_lists=True, min
         assert mixed_err(views["final_T"].cpu().numpy()[ok], o2.final_T[ok]) < TOL, "final_T"
     assert mixed_err(color[:, ok], o2.color[:, ok]) < TOL, "colour"
     assert mixed_err(depth[:, ok], o2.depth[:, ok]) < TOL, "depth"
-    if (~ok).any():     # threshold-ambiguous pixels: within what one flipped decision can move them
-        cs = max(1.0, float(np.abs(o2.color).max()))
+    if (~ok).any():     # threshold-ambiguous pixels: within what one flipped decision can move them -- (1 / 255) * T * the colour / depth OF THE GAUSSIAN whose
+        # alpha sat at the threshold.  (Until round 6 the scale was the OUTPUT image's maximum, which is smaller -- T alpha weights sum to < 1: the fresh
+        # soak seed 106 case 574 has ONE ambiguous pixel, a lone contribution of alpha = 1 / 255 at depth 3.72: 0.0145 against a bound of 4e-3 x 3.37.)
+        vis = o2.radii > 0
+        cs = max(1.0, float(np.abs(o2.color).max()), float(np.abs(o2.rgb[vis]).max()) if vis.any() else 0.0)
+        ds = max(1.0, float(o2.depth.max()), float(o2.depths[vis].max()) if vis.any() else 0.0)
         assert np.abs(color[:, ~ok] - o2.color[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * cs, "colour on ambiguous pixels"
-        assert np.abs(depth[:, ~ok] - o2.depth[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * max(1.0, float(o2.depth.max())), "depth on ambiguous pixels"
+        assert np.abs(depth[:, ~ok] - o2.depth[:, ~ok]).max() <= AMBIGUOUS_PIXEL_BOUND * ds, "depth on ambiguous pixels"
     rg = views["ranges"].cpu().numpy().astype(np.int64)
     o2.hip_max_list = int((rg[:, 1] - rg[:, 0]).max()) if o2.num_rendered else 0        # longest per-tile list the HIP path sorted
     if not backward:
