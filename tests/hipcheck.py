@@ -18,7 +18,7 @@ from oracle import OracleCamera, TiledOracle
 
 TOL = 1e-4
 def _margin(tag, err, scale):
-    """Relative error, printed with GSR_TEST_VERBOSE=1 (tools/test_margins.sh collects them from a GPU run)."""
+    """Relative error, printed with GSR_TEST_VERBOSE=1."""
     r = err / max(scale, 1e-300)
     if os.environ.get("GSR_TEST_VERBOSE"):
         print(f"margin {tag}: {r:.2e}")
